@@ -1,0 +1,48 @@
+"""Build libsurfel_hip.so (gfx950) in-tree with hipcc.  Usage: python build.py [--force]
+
+The .so is git-ignored but travels to the GPU box with the gpurun snapshot.
+"""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "lib", "libsurfel_hip.so")
+SOURCES = ["surfel_forward.hip", "surfel_backward.hip", "surfel_api.hip", "knn.hip"]
+HEADERS = ["surfel_common.h", "surfel_kernels.h", os.path.join("..", "..", "include", "surfel_hip.h")]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast", "-Wall", "-Wno-unused-result"]
+
+
+def _stale(out, deps):
+    if not os.path.exists(out):
+        return True
+    t = os.path.getmtime(out)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=False):
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    os.makedirs(os.path.join(HERE, "lib"), exist_ok=True)
+    os.makedirs(os.path.join(HERE, "build"), exist_ok=True)
+    hdrs = [os.path.join(CSRC, h) for h in HEADERS]
+    objs = []
+    for src in SOURCES:
+        sp = os.path.join(CSRC, src)
+        obj = os.path.join(HERE, "build", src + ".o")
+        objs.append(obj)
+        if force or _stale(obj, [sp] + hdrs):
+            cmd = [hipcc] + FLAGS + ["-c", sp, "-o", obj]
+            if verbose:
+                print(" ".join(cmd))
+            subprocess.check_call(cmd)
+    if force or _stale(LIB, objs):
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,370 @@
+// surfel_api.hip — C ABI (include/surfel_hip.h) of libsurfel_hip.so: stage orchestration, scratch
+// carving, rocPRIM scan / radix sort.  Host code only; kernels live in surfel_forward.hip,
+// surfel_backward.hip and knn.hip.
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include <hip/hip_runtime.h>
+#include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_scan.hpp>
+
+#include "../../include/surfel_hip.h"
+#include "surfel_common.h"
+#include "surfel_kernels.h"
+
+using namespace surfel;
+
+namespace {
+
+thread_local std::string g_err;
+thread_local float g_stage_ms[16];
+thread_local int g_stage_n = 0;
+thread_local int g_stage_id[16];
+
+const char* kStageNames[] = {"preprocess_fwd", "scan", "emit_instances", "radix_sort", "tile_ranges", "blend_fwd",
+                             "zero_grec", "blend_bwd", "preprocess_bwd", "knn"};
+enum Stage { ST_PRE = 0, ST_SCAN, ST_EMIT, ST_SORT, ST_RANGES, ST_BLEND, ST_ZERO, ST_BBWD, ST_PBWD, ST_KNN };
+
+int fail(int code, const char* what, hipError_t e = hipSuccess) {
+    g_err = what;
+    if (e != hipSuccess) { g_err += ": "; g_err += hipGetErrorString(e); }
+    return code;
+}
+
+#define HIP_TRY(expr)                                                    \
+    do {                                                                 \
+        hipError_t _e = (expr);                                          \
+        if (_e != hipSuccess) return fail(SURFEL_E_HIP, #expr, _e);      \
+    } while (0)
+
+inline size_t align_up(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }
+
+// Bump carving of an opaque buffer; with base == nullptr it only measures.
+struct Carver {
+    char* base; size_t off = 0;
+    explicit Carver(void* b) : base(static_cast<char*>(b)) {}
+    template <typename T> T* take(size_t count) {
+        off = align_up(off);
+        T* p = base ? reinterpret_cast<T*>(base + off) : nullptr;
+        off += count * sizeof(T);
+        return p;
+    }
+    size_t size() const { return align_up(off); }
+};
+
+struct GeomState {   // per-surfel state ("geomBuffer")
+    float* rec; float* depths; uint32_t* tiles_touched; uint32_t* offsets; uint8_t* clamped; char* scan_temp;
+    size_t scan_temp_bytes;
+    static GeomState carve(void* base, int P, size_t scan_bytes, size_t* total) {
+        Carver c(base); GeomState g;
+        g.rec = c.take<float>((size_t)P * REC_F);
+        g.depths = c.take<float>(P);
+        g.tiles_touched = c.take<uint32_t>(P);
+        g.offsets = c.take<uint32_t>(P);
+        g.clamped = c.take<uint8_t>(P);
+        g.scan_temp = c.take<char>(scan_bytes);
+        g.scan_temp_bytes = scan_bytes;
+        if (total) *total = c.size();
+        return g;
+    }
+};
+
+struct BinState {    // per-instance state ("binningBuffer"); point_list is always at a fixed offset
+    uint32_t* point_list; uint32_t* vals_alt; uint64_t* keys_a; uint64_t* keys_b; char* sort_temp; size_t sort_temp_bytes;
+    static BinState carve(void* base, size_t R, size_t sort_bytes, size_t* total) {
+        Carver c(base); BinState b;
+        b.point_list = c.take<uint32_t>(R);
+        b.vals_alt = c.take<uint32_t>(R);
+        b.keys_a = c.take<uint64_t>(R);
+        b.keys_b = c.take<uint64_t>(R);
+        b.sort_temp = c.take<char>(sort_bytes);
+        b.sort_temp_bytes = sort_bytes;
+        if (total) *total = c.size();
+        return b;
+    }
+};
+
+struct ImgState {    // per-pixel / per-tile state ("imgBuffer")
+    uint2* ranges; float* final_T; uint32_t* n_contrib;
+    static ImgState carve(void* base, int W, int H, size_t* total) {
+        Carver c(base); ImgState im;
+        const size_t tiles = (size_t)((W + TILE - 1) / TILE) * ((H + TILE - 1) / TILE);
+        im.ranges = c.take<uint2>(tiles);
+        im.final_T = c.take<float>((size_t)3 * W * H);
+        im.n_contrib = c.take<uint32_t>((size_t)2 * W * H);
+        if (total) *total = c.size();
+        return im;
+    }
+};
+
+// Stage timing on the caller's stream with HIP events.
+//   mode 1 (debug): synchronise + hipGetLastError after every stage (the reference's `debug` flag).
+//   mode 2 (profile): record events only; durations are resolved later by surfel_collect_stage_ms()
+//                     so a timed region is not perturbed by host synchronisation.
+struct PendingStage { int stage; hipEvent_t e0, e1; };
+thread_local std::vector<PendingStage> g_pending;
+
+struct StageTimer {
+    int mode; hipStream_t s; hipEvent_t e0 = nullptr, e1 = nullptr;
+    StageTimer(int mode_, hipStream_t s_) : mode(mode_), s(s_) {
+        if (mode == 1) { (void)hipEventCreate(&e0); (void)hipEventCreate(&e1); }
+    }
+    ~StageTimer() { if (mode == 1) { (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); } }
+    void begin() {
+        if (mode == 2) { (void)hipEventCreate(&e0); (void)hipEventCreate(&e1); }
+        if (mode) (void)hipEventRecord(e0, s);
+    }
+    int end(int stage) {   // returns hip error as int
+        if (!mode) return 0;
+        (void)hipEventRecord(e1, s);
+        if (mode == 2) { g_pending.push_back({stage, e0, e1}); return 0; }
+        hipError_t e = hipEventSynchronize(e1);
+        if (e != hipSuccess) return (int)e;
+        e = hipGetLastError();
+        if (e != hipSuccess) return (int)e;
+        float ms = 0.f; (void)hipEventElapsedTime(&ms, e0, e1);
+        if (g_stage_n < 16) { g_stage_ms[g_stage_n] = ms; g_stage_id[g_stage_n] = stage; g_stage_n++; }
+        return 0;
+    }
+};
+#define STAGE_END(timer, st)                                                               \
+    do {                                                                                   \
+        int _e = (timer).end(st);                                                          \
+        if (_e) return fail(SURFEL_E_HIP, kStageNames[st], (hipError_t)_e);                \
+    } while (0)
+
+uint32_t* pinned_u32() {
+    thread_local uint32_t* p = nullptr;
+    if (!p) { if (hipHostMalloc(reinterpret_cast<void**>(&p), 64, hipHostMallocDefault) != hipSuccess) p = nullptr; }
+    return p;
+}
+
+int higher_msb(uint32_t n) {   // number of bits needed to represent values < n
+    int b = 0;
+    while ((1ull << b) < (unsigned long long)n) b++;
+    return b < 1 ? 1 : b;
+}
+
+}  // namespace
+
+extern "C" {
+
+int surfel_abi_version(void) { return SURFEL_ABI_VERSION; }
+const char* surfel_last_error(void) { return g_err.c_str(); }
+const char* surfel_stage_name(int stage) { return (stage >= 0 && stage < 10) ? kStageNames[stage] : "?"; }
+int surfel_last_stage_ms(float* ms, int cap) {
+    int n = g_stage_n < cap ? g_stage_n : cap;
+    for (int i = 0; i < n; i++) ms[i] = g_stage_ms[i];
+    return n;
+}
+int surfel_last_stage_ids(int* ids, int cap) {
+    int n = g_stage_n < cap ? g_stage_n : cap;
+    for (int i = 0; i < n; i++) ids[i] = g_stage_id[i];
+    return n;
+}
+
+int surfel_collect_stage_ms(float* sum_ms, int* count, int cap) {
+    for (int i = 0; i < cap; i++) { sum_ms[i] = 0.f; count[i] = 0; }
+    for (auto& p : g_pending) {
+        float ms = 0.f;
+        if (hipEventSynchronize(p.e1) == hipSuccess && hipEventElapsedTime(&ms, p.e0, p.e1) == hipSuccess && p.stage < cap) {
+            sum_ms[p.stage] += ms; count[p.stage]++;
+        }
+        (void)hipEventDestroy(p.e0); (void)hipEventDestroy(p.e1);
+    }
+    g_pending.clear();
+    return 10;
+}
+
+int64_t surfel_rasterize_forward(surfel_alloc_fn geom_alloc, void* geom_user, surfel_alloc_fn binning_alloc, void* binning_user,
+                                 surfel_alloc_fn image_alloc, void* image_user, int P, int D, int M, const float* background,
+                                 int width, int height, const float* means3D, const float* shs, const float* colors_precomp,
+                                 const float* opacities, const float* scales, float scale_modifier, const float* rotations,
+                                 const float* transMat_precomp, const float* viewmatrix, const float* projmatrix,
+                                 const float* cam_pos, float tan_fovx, float tan_fovy, int prefiltered, float* out_color,
+                                 float* out_others, int* radii, int debug, void* stream) {
+    (void)tan_fovx; (void)tan_fovy; (void)prefiltered;
+    g_stage_n = 0;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (!geom_alloc || !binning_alloc || !image_alloc) return fail(SURFEL_E_INVALID, "allocator callback is NULL");
+    if (P < 0 || width <= 0 || height <= 0) return fail(SURFEL_E_INVALID, "bad sizes");
+    if ((shs == nullptr) == (colors_precomp == nullptr)) return fail(SURFEL_E_INVALID, "provide exactly one of shs / colors_precomp");
+    const bool has_sr = scales != nullptr && rotations != nullptr;
+    if (has_sr == (transMat_precomp != nullptr) || ((scales != nullptr) != (rotations != nullptr)))
+        return fail(SURFEL_E_INVALID, "provide exactly one of (scales, rotations) / transMat_precomp");
+    if (!background || !means3D || !opacities || !viewmatrix || !projmatrix || !cam_pos || !out_color || !out_others || !radii)
+        return fail(SURFEL_E_INVALID, "required pointer is NULL");
+    if (D < 0 || D > 3 || (shs && M < (D + 1) * (D + 1))) return fail(SURFEL_E_INVALID, "bad SH degree / coefficient count");
+    const int gx = (width + TILE - 1) / TILE, gy = (height + TILE - 1) / TILE;
+    if (gx > 1023 || gy > 1023) return fail(SURFEL_E_LIMIT, "image larger than 16368 px per side");
+    const size_t HW = (size_t)width * height;
+
+    size_t img_bytes = 0;
+    ImgState::carve(nullptr, width, height, &img_bytes);
+    void* img_base = image_alloc(image_user, img_bytes);
+    if (!img_base) return fail(SURFEL_E_ALLOC, "image buffer allocation failed");
+    ImgState img = ImgState::carve(img_base, width, height, nullptr);
+    HIP_TRY(hipMemsetAsync(img.ranges, 0, sizeof(uint2) * (size_t)gx * gy, s));
+
+    StageTimer tm(debug, s);
+    int64_t R = 0;
+    GeomState geom{};
+    if (P > 0) {
+        size_t scan_bytes = 0;
+        HIP_TRY(rocprim::inclusive_scan(nullptr, scan_bytes, (uint32_t*)nullptr, (uint32_t*)nullptr, (size_t)P,
+                                        rocprim::plus<uint32_t>(), s));
+        size_t geom_bytes = 0;
+        GeomState::carve(nullptr, P, scan_bytes, &geom_bytes);
+        void* geom_base = geom_alloc(geom_user, geom_bytes);
+        if (!geom_base) return fail(SURFEL_E_ALLOC, "geometry buffer allocation failed");
+        geom = GeomState::carve(geom_base, P, scan_bytes, nullptr);
+
+        PreprocessArgs pa{};
+        pa.P = P; pa.D = D; pa.M = M; pa.W = width; pa.H = height; pa.gx = gx; pa.gy = gy; pa.scale_modifier = scale_modifier;
+        pa.means3D = means3D; pa.opacities = opacities; pa.scales = scales; pa.rotations = rotations;
+        pa.transMat_precomp = transMat_precomp; pa.colors_precomp = colors_precomp; pa.shs = shs;
+        pa.viewmatrix = viewmatrix; pa.projmatrix = projmatrix; pa.campos = cam_pos;
+        pa.rec = geom.rec; pa.depths = geom.depths; pa.radii = radii; pa.tiles_touched = geom.tiles_touched; pa.clamped = geom.clamped;
+        tm.begin();
+        launch_preprocess_fwd(pa, s);
+        STAGE_END(tm, ST_PRE);
+
+        tm.begin();
+        HIP_TRY(rocprim::inclusive_scan(geom.scan_temp, scan_bytes, geom.tiles_touched, geom.offsets, (size_t)P,
+                                        rocprim::plus<uint32_t>(), s));
+        // The instance count sizes the binning buffers, so it has to reach the host (one 4-byte D2H).
+        uint32_t* hR = pinned_u32();
+        if (!hR) return fail(SURFEL_E_HIP, "hipHostMalloc failed");
+        HIP_TRY(hipMemcpyAsync(hR, geom.offsets + (P - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        R = (int64_t)*hR;
+        STAGE_END(tm, ST_SCAN);
+    } else {
+        void* geom_base = geom_alloc(geom_user, 256);
+        (void)geom_base;
+    }
+
+    BinState bin{};
+    {
+        size_t sort_bytes = 0;
+        const int end_bit = 32 + higher_msb((uint32_t)(gx * gy));
+        if (R > 0) {
+            rocprim::double_buffer<uint64_t> kq(nullptr, nullptr);
+            rocprim::double_buffer<uint32_t> vq(nullptr, nullptr);
+            HIP_TRY(rocprim::radix_sort_pairs(nullptr, sort_bytes, kq, vq, (size_t)R, 0, end_bit, s));
+        }
+        size_t bin_bytes = 0;
+        BinState::carve(nullptr, (size_t)R, sort_bytes, &bin_bytes);
+        void* bin_base = binning_alloc(binning_user, bin_bytes > 0 ? bin_bytes : 256);
+        if (!bin_base) return fail(SURFEL_E_ALLOC, "binning buffer allocation failed");
+        bin = BinState::carve(bin_base, (size_t)R, sort_bytes, nullptr);
+        if (R > 0) {
+            tm.begin();
+            launch_emit_instances(P, geom.rec, geom.depths, geom.offsets, radii, bin.keys_a, bin.vals_alt, gx, s);
+            STAGE_END(tm, ST_EMIT);
+            tm.begin();
+            rocprim::double_buffer<uint64_t> kq(bin.keys_a, bin.keys_b);
+            rocprim::double_buffer<uint32_t> vq(bin.vals_alt, bin.point_list);
+            HIP_TRY(rocprim::radix_sort_pairs(bin.sort_temp, sort_bytes, kq, vq, (size_t)R, 0, end_bit, s));
+            if (vq.current() != bin.point_list)
+                HIP_TRY(hipMemcpyAsync(bin.point_list, vq.current(), sizeof(uint32_t) * (size_t)R, hipMemcpyDeviceToDevice, s));
+            STAGE_END(tm, ST_SORT);
+            tm.begin();
+            launch_tile_ranges(R, kq.current(), img.ranges, s);
+            STAGE_END(tm, ST_RANGES);
+        }
+    }
+
+    BlendFwdArgs ba{};
+    ba.W = width; ba.H = height; ba.gx = gx; ba.gy = gy;
+    ba.ranges = img.ranges; ba.point_list = bin.point_list; ba.rec = geom.rec; ba.bg = background;
+    ba.out_color = out_color; ba.out_others = out_others; ba.final_T = img.final_T; ba.n_contrib = img.n_contrib;
+    tm.begin();
+    launch_blend_fwd(ba, s);
+    STAGE_END(tm, ST_BLEND);
+    HIP_TRY(hipGetLastError());
+    (void)HW;
+    return R;
+}
+
+int surfel_rasterize_backward(surfel_alloc_fn scratch_alloc, void* scratch_user, int P, int D, int M, int64_t R,
+                              const float* background, int width, int height, const float* means3D, const float* shs,
+                              const float* colors_precomp, const float* scales, float scale_modifier, const float* rotations,
+                              const float* transMat_precomp, const float* viewmatrix, const float* projmatrix,
+                              const float* cam_pos, float tan_fovx, float tan_fovy, const int* radii, const void* geom_buffer,
+                              const void* binning_buffer, const void* image_buffer, const float* dL_dout_color,
+                              const float* dL_dout_others, float* dL_dmeans2D, float* dL_dnormal, float* dL_dopacity,
+                              float* dL_dcolors, float* dL_dmeans3D, float* dL_dtransMat, float* dL_dsh, float* dL_dscales,
+                              float* dL_drots, int debug, void* stream) {
+    (void)tan_fovx; (void)tan_fovy; (void)colors_precomp;
+    g_stage_n = 0;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (P == 0 || R == 0) return 0;
+    if (!scratch_alloc || !geom_buffer || !binning_buffer || !image_buffer) return fail(SURFEL_E_INVALID, "buffer / allocator is NULL");
+    if (!dL_dout_color || !dL_dout_others || !dL_dmeans2D || !dL_dnormal || !dL_dopacity || !dL_dcolors || !dL_dmeans3D || !dL_dtransMat)
+        return fail(SURFEL_E_INVALID, "gradient pointer is NULL");
+    if (shs && !dL_dsh) return fail(SURFEL_E_INVALID, "dL_dsh is NULL");
+    if (!transMat_precomp && (!dL_dscales || !dL_drots || !scales || !rotations)) return fail(SURFEL_E_INVALID, "scale/rotation pointers are NULL");
+    const int gx = (width + TILE - 1) / TILE, gy = (height + TILE - 1) / TILE;
+
+    size_t scan_bytes = 0;
+    HIP_TRY(rocprim::inclusive_scan(nullptr, scan_bytes, (uint32_t*)nullptr, (uint32_t*)nullptr, (size_t)P, rocprim::plus<uint32_t>(), s));
+    GeomState geom = GeomState::carve(const_cast<void*>(geom_buffer), P, scan_bytes, nullptr);
+    BinState bin = BinState::carve(const_cast<void*>(binning_buffer), (size_t)R, 0, nullptr);
+    ImgState img = ImgState::carve(const_cast<void*>(image_buffer), width, height, nullptr);
+
+    const size_t grec_bytes = (size_t)R * GREC_F * sizeof(float);
+    float* grec = static_cast<float*>(scratch_alloc(scratch_user, grec_bytes));
+    if (!grec) return fail(SURFEL_E_ALLOC, "gradient record allocation failed");
+    StageTimer tm(debug, s);
+    tm.begin();
+    HIP_TRY(hipMemsetAsync(grec, 0, grec_bytes, s));
+    STAGE_END(tm, ST_ZERO);
+
+    BlendBwdArgs bb{};
+    bb.W = width; bb.H = height; bb.gx = gx; bb.gy = gy;
+    bb.ranges = img.ranges; bb.point_list = bin.point_list; bb.rec = geom.rec; bb.bg = background;
+    bb.final_T = img.final_T; bb.n_contrib = img.n_contrib; bb.dL_dpix = dL_dout_color; bb.dL_dothers = dL_dout_others;
+    bb.grec = grec;
+    tm.begin();
+    launch_blend_bwd(bb, s);
+    STAGE_END(tm, ST_BBWD);
+
+    PreprocessBwdArgs pb{};
+    pb.P = P; pb.D = D; pb.M = M; pb.W = width; pb.H = height; pb.scale_modifier = scale_modifier;
+    pb.means3D = means3D; pb.radii = radii; pb.shs = shs; pb.clamped = geom.clamped; pb.scales = scales; pb.rotations = rotations;
+    pb.transMat_precomp = transMat_precomp; pb.viewmatrix = viewmatrix; pb.projmatrix = projmatrix; pb.campos = cam_pos;
+    pb.rec = geom.rec; pb.offsets = geom.offsets; pb.grec = grec;
+    pb.dL_dtransMat = dL_dtransMat; pb.dL_dnormal = dL_dnormal; pb.dL_dopacity = dL_dopacity; pb.dL_dcolors = dL_dcolors;
+    pb.dL_dsh = dL_dsh; pb.dL_dmeans2D = dL_dmeans2D; pb.dL_dmeans3D = dL_dmeans3D; pb.dL_dscales = dL_dscales; pb.dL_drots = dL_drots;
+    tm.begin();
+    launch_preprocess_bwd(pb, s);
+    STAGE_END(tm, ST_PBWD);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int surfel_mark_visible(int P, const float* means3D, const float* viewmatrix, const float* projmatrix, uint8_t* present,
+                        void* stream) {
+    (void)projmatrix;
+    if (P < 0 || (P > 0 && (!means3D || !viewmatrix || !present))) return fail(SURFEL_E_INVALID, "bad arguments");
+    launch_mark_visible(P, means3D, viewmatrix, present, static_cast<hipStream_t>(stream));
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int surfel_knn_dist2(surfel_alloc_fn scratch_alloc, void* scratch_user, int P, const float* points, float* mean_dist2,
+                     void* stream) {
+    if (P < 0 || (P > 0 && (!points || !mean_dist2 || !scratch_alloc))) return fail(SURFEL_E_INVALID, "bad arguments");
+    if (P == 0) return 0;
+    const size_t bytes = knn_scratch_bytes(P);
+    void* scratch = scratch_alloc(scratch_user, bytes);
+    if (!scratch) return fail(SURFEL_E_ALLOC, "knn scratch allocation failed");
+    launch_knn(P, points, mean_dist2, scratch, bytes, static_cast<hipStream_t>(stream));
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+}  // extern "C"

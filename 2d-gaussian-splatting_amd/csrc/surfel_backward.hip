@@ -1,0 +1,395 @@
+// surfel_backward.hip — backward kernels of the gfx950 surfel rasterizer.
+//   blend_bwd       : per-tile back-to-front replay; per-surfel partial gradients are reduced
+//                     lane->wave with DPP adds, wave->tile through LDS, and written ONCE per
+//                     (tile, surfel) instance to a gradient record — no global atomics, so the
+//                     result is bit-reproducible and never crosses XCD L2s with device-scope RMWs.
+//   preprocess_bwd  : per-surfel sum of its instance records, then the chain rule into means,
+//                     scales, rotations, opacity and SH.
+// Semantics: oracle/surfel_oracle.c stages 4-5 (restating the absent diff-surfel-rasterization).
+#include "surfel_common.h"
+#include "surfel_kernels.h"
+
+namespace surfel {
+
+__device__ __constant__ float BSH_C0 = 0.28209479177387814f;
+__device__ __constant__ float BSH_C1 = 0.4886025119029199f;
+__device__ __constant__ float BSH_C2[5] = {1.0925484305920792f, -1.0925484305920792f, 0.31539156525252005f,
+                                           -1.0925484305920792f, 0.5462742152960396f};
+__device__ __constant__ float BSH_C3[7] = {-0.5900435899266435f, 2.890611442640554f, -0.4570457994644658f,
+                                           0.3731763325901154f, -0.4570457994644658f, 1.445305721320277f,
+                                           -0.5900435899266435f};
+
+// wave64 sum with DPP-fused adds; the total is valid in lane 63.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_add(float v) {
+    const int moved = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xf, false);
+    return v + __int_as_float(moved);
+}
+__device__ __forceinline__ float wave_sum_to_lane63(float v) {
+    v = dpp_add<0x111, 0xf>(v);   // row_shr:1
+    v = dpp_add<0x112, 0xf>(v);   // row_shr:2
+    v = dpp_add<0x114, 0xf>(v);   // row_shr:4   (lane 15 of each row: sum of lanes 8..15 pairs ...)
+    v = dpp_add<0x118, 0xf>(v);   // row_shr:8   -> lane 15 of every row holds the row total
+    v = dpp_add<0x142, 0xa>(v);   // row_bcast:15 into rows 1,3
+    v = dpp_add<0x143, 0xc>(v);   // row_bcast:31 into rows 2,3 -> lane 63 holds the wave total
+    return v;
+}
+
+constexpr int BB = 64;    // instances staged per batch in the backward
+constexpr int NV = 18;    // gradient values per instance
+
+// ---------------------------------------------------------------------------------------------
+// blend_bwd
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(BLOCK) blend_bwd_kernel(BlendBwdArgs a) {
+    __shared__ float4 s_rec[BB * 5];
+    __shared__ float s_acc[4][BB][NV];
+    __shared__ unsigned long long s_mask[4];
+    __shared__ int s_max;
+    const int tile = xcd_tile(blockIdx.x, a.gx * a.gy);
+    const int tx = tile % a.gx, ty = tile / a.gx;
+    int lx, ly;
+    thread_pixel(threadIdx.x, lx, ly);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int pxi = tx * TILE + lx, pyi = ty * TILE + ly;
+    const bool inside = pxi < a.W && pyi < a.H;
+    const float pxf = (float)pxi, pyf = (float)pyi;
+    const uint2 range = a.ranges[tile];
+    const size_t HW = (size_t)a.H * a.W;
+    const size_t pix = (size_t)pyi * a.W + pxi;
+
+    float T_final = 0.f, fM1 = 0.f, fM2 = 0.f;
+    int last = 0, medc = 0;
+    float gC0 = 0.f, gC1 = 0.f, gC2 = 0.f, g_depth = 0.f, g_alpha = 0.f, gN0 = 0.f, gN1 = 0.f, gN2 = 0.f, g_med = 0.f, g_dist = 0.f;
+    if (inside) {
+        T_final = a.final_T[pix]; fM1 = a.final_T[HW + pix]; fM2 = a.final_T[2 * HW + pix];
+        last = (int)a.n_contrib[pix]; medc = (int)a.n_contrib[HW + pix];
+        gC0 = a.dL_dpix[pix]; gC1 = a.dL_dpix[HW + pix]; gC2 = a.dL_dpix[2 * HW + pix];
+        g_depth = a.dL_dothers[pix]; g_alpha = a.dL_dothers[HW + pix];
+        gN0 = a.dL_dothers[2 * HW + pix]; gN1 = a.dL_dothers[3 * HW + pix]; gN2 = a.dL_dothers[4 * HW + pix];
+        g_med = a.dL_dothers[5 * HW + pix]; g_dist = a.dL_dothers[6 * HW + pix];
+    }
+    const float final_A = 1.f - T_final;
+    const float bg_dot = a.bg[0] * gC0 + a.bg[1] * gC1 + a.bg[2] * gC2;
+
+    if (threadIdx.x == 0) s_max = 0;
+    __syncthreads();
+    {
+        int m = last;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) m = max(m, __shfl_xor(m, o));
+        if (lane == 0) atomicMax(&s_max, m);
+    }
+    __syncthreads();
+    const int maxc = s_max;
+
+    float T = T_final;
+    float last_alpha = 0.f, lc0 = 0.f, lc1 = 0.f, lc2 = 0.f, ar0 = 0.f, ar1 = 0.f, ar2 = 0.f;
+    float last_depth = 0.f, accum_depth = 0.f, accum_alpha = 0.f;
+    float ln0 = 0.f, ln1 = 0.f, ln2 = 0.f, an0 = 0.f, an1 = 0.f, an2 = 0.f;
+    float last_dL_dT = 0.f;
+
+    for (int hi = maxc; hi > 0; hi -= BB) {
+        const int m = min(BB, hi);
+        __syncthreads();                      // previous batch's flush has finished with s_rec / s_acc
+        if ((int)threadIdx.x < m) {
+            const uint32_t id = a.point_list[range.x + (hi - threadIdx.x) - 1];
+            const float4* __restrict__ src = reinterpret_cast<const float4*>(a.rec + (size_t)id * REC_F);
+            const float4 v0 = src[0], v1 = src[1], v2 = src[2], v3 = src[3], v4 = src[4];
+            s_rec[threadIdx.x * 5 + 0] = v0; s_rec[threadIdx.x * 5 + 1] = v1; s_rec[threadIdx.x * 5 + 2] = v2;
+            s_rec[threadIdx.x * 5 + 3] = v3; s_rec[threadIdx.x * 5 + 4] = v4;
+        }
+        __syncthreads();
+        unsigned long long wmask = 0ull;
+        for (int j = 0; j < m; j++) {
+            const int pos = hi - j;           // 1-based position in the tile's list
+            float gv[NV];
+#pragma unroll
+            for (int q = 0; q < NV; q++) gv[q] = 0.f;
+            bool contrib = false;
+            if (pos <= last) {
+                const float4 q0 = s_rec[j * 5 + 0], q1 = s_rec[j * 5 + 1], q2 = s_rec[j * 5 + 2];
+                Hit h;
+                if (intersect(q0, q1, q2, pxf, pyf, h)) {
+                    contrib = true;
+                    const float4 q3 = s_rec[j * 5 + 3], q4 = s_rec[j * 5 + 4];
+                    const float alpha = h.alpha, G = h.G, opa = q2.w;
+                    const float Twx = q1.z, Twy = q1.w;
+                    T = T / (1.f - alpha);
+                    const float w = alpha * T;
+                    float dL_dalpha = 0.f;
+                    // colour
+                    ar0 = last_alpha * lc0 + (1.f - last_alpha) * ar0; lc0 = q3.w; dL_dalpha += (q3.w - ar0) * gC0;
+                    ar1 = last_alpha * lc1 + (1.f - last_alpha) * ar1; lc1 = q4.x; dL_dalpha += (q4.x - ar1) * gC1;
+                    ar2 = last_alpha * lc2 + (1.f - last_alpha) * ar2; lc2 = q4.y; dL_dalpha += (q4.y - ar2) * gC2;
+                    gv[15] = w * gC0; gv[16] = w * gC1; gv[17] = w * gC2;
+                    // distortion / depth / alpha / normal
+                    float dL_dz = 0.f;
+                    const float inv_d = __builtin_amdgcn_rcpf(h.depth);
+                    const float mm = FAR_N / (FAR_N - NEAR_N) * (1.f - NEAR_N * inv_d);
+                    const float dm_dd = (FAR_N * NEAR_N) / (FAR_N - NEAR_N) * inv_d * inv_d;
+                    if (pos == medc) dL_dz += g_med;
+                    const float dL_dweight = (fM2 + mm * mm * final_A - 2.f * mm * fM1) * g_dist;
+                    dL_dalpha += dL_dweight - last_dL_dT;
+                    last_dL_dT = dL_dweight * alpha + (1.f - alpha) * last_dL_dT;
+                    dL_dz += 2.f * w * (mm * final_A - fM1) * g_dist * dm_dd;
+                    accum_depth = last_alpha * last_depth + (1.f - last_alpha) * accum_depth;
+                    last_depth = h.depth;
+                    dL_dalpha += (h.depth - accum_depth) * g_depth;
+                    accum_alpha = last_alpha + (1.f - last_alpha) * accum_alpha;
+                    dL_dalpha += (1.f - accum_alpha) * g_alpha;
+                    an0 = last_alpha * ln0 + (1.f - last_alpha) * an0; ln0 = q3.x; dL_dalpha += (q3.x - an0) * gN0;
+                    an1 = last_alpha * ln1 + (1.f - last_alpha) * an1; ln1 = q3.y; dL_dalpha += (q3.y - an1) * gN1;
+                    an2 = last_alpha * ln2 + (1.f - last_alpha) * an2; ln2 = q3.z; dL_dalpha += (q3.z - an2) * gN2;
+                    gv[11] = w * gN0; gv[12] = w * gN1; gv[13] = w * gN2;
+                    dL_dalpha *= T;
+                    last_alpha = alpha;
+                    dL_dalpha += (-T_final / (1.f - alpha)) * bg_dot;
+                    const float dL_dG = opa * dL_dalpha;       // 0.99 clamp is pass-through
+                    dL_dz += w * g_depth;
+                    if (h.use3d) {
+                        const float dsx = dL_dG * -G * h.sx + dL_dz * Twx;
+                        const float dsy = dL_dG * -G * h.sy + dL_dz * Twy;
+                        const float ipz = __builtin_amdgcn_rcpf(h.pz);
+                        const float ax = dsx * ipz, ay = dsy * ipz;
+                        const float dp0 = ax, dp1 = ay, dp2 = -(ax * h.sx + ay * h.sy);
+                        const float dk0 = h.ly * dp2 - h.lz * dp1, dk1 = h.lz * dp0 - h.lx * dp2, dk2 = h.lx * dp1 - h.ly * dp0;
+                        const float dl0 = dp1 * h.kz - dp2 * h.ky, dl1 = dp2 * h.kx - dp0 * h.kz, dl2 = dp0 * h.ky - dp1 * h.kx;
+                        gv[0] = -dk0; gv[1] = -dk1; gv[2] = -dk2;
+                        gv[3] = -dl0; gv[4] = -dl1; gv[5] = -dl2;
+                        gv[6] = pxf * dk0 + pyf * dl0 + dL_dz * h.sx;
+                        gv[7] = pxf * dk1 + pyf * dl1 + dL_dz * h.sy;
+                        gv[8] = pxf * dk2 + pyf * dl2 + dL_dz;
+                    } else {
+                        gv[9] = dL_dG * (-G * FILTER_INV_SQUARE * h.dx);
+                        gv[10] = dL_dG * (-G * FILTER_INV_SQUARE * h.dy);
+                        gv[8] = dL_dz;
+                    }
+                    gv[14] = G * dL_dalpha;
+                }
+            }
+            if (__ballot(contrib) == 0ull) continue;      // wave-uniform: nobody in this 8x8 quad touched it
+#pragma unroll
+            for (int q = 0; q < NV; q++) gv[q] = wave_sum_to_lane63(gv[q]);
+            if (lane == 63) {
+#pragma unroll
+                for (int q = 0; q < NV; q++) s_acc[wave][j][q] = gv[q];
+            }
+            wmask |= 1ull << j;
+        }
+        if (lane == 0) s_mask[wave] = wmask;
+        __syncthreads();
+        // flush: one thread per staged instance sums the four wave partials in fixed order
+        if ((int)threadIdx.x < m) {
+            const int j = threadIdx.x;
+            const unsigned long long bit = 1ull << j;
+            const bool h0 = s_mask[0] & bit, h1 = s_mask[1] & bit, h2 = s_mask[2] & bit, h3 = s_mask[3] & bit;
+            if (h0 | h1 | h2 | h3) {
+                float out[GREC_F];
+#pragma unroll
+                for (int q = 0; q < NV; q++) {
+                    float sacc = 0.f;
+                    if (h0) sacc += s_acc[0][j][q];
+                    if (h1) sacc += s_acc[1][j][q];
+                    if (h2) sacc += s_acc[2][j][q];
+                    if (h3) sacc += s_acc[3][j][q];
+                    out[q] = sacc;
+                }
+                out[18] = 0.f; out[19] = 0.f;
+                const float4 q4 = s_rec[j * 5 + 4];
+                const uint32_t basei = __float_as_uint(q4.z), rectbits = __float_as_uint(q4.w);
+                const int x0 = rectbits & 1023, y0 = (rectbits >> 10) & 1023, rw = rectbits >> 20;
+                const size_t dest = (size_t)basei + (size_t)((ty - y0) * rw + (tx - x0));
+                float4* __restrict__ dst = reinterpret_cast<float4*>(a.grec + dest * GREC_F);
+#pragma unroll
+                for (int q = 0; q < 5; q++) dst[q] = make_float4(out[4 * q], out[4 * q + 1], out[4 * q + 2], out[4 * q + 3]);
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// preprocess_bwd: one thread per surfel.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) preprocess_bwd_kernel(PreprocessBwdArgs a) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.P) return;
+    if (!(a.radii[i] > 0)) return;
+    // 1. gather-sum this surfel's instance gradient records (contiguous, fixed order)
+    float g[NV];
+#pragma unroll
+    for (int q = 0; q < NV; q++) g[q] = 0.f;
+    const uint32_t beg = (i == 0) ? 0u : a.offsets[i - 1], end = a.offsets[i];
+    for (uint32_t k = beg; k < end; k++) {
+        const float4* __restrict__ src = reinterpret_cast<const float4*>(a.grec + (size_t)k * GREC_F);
+        const float4 v0 = src[0], v1 = src[1], v2 = src[2], v3 = src[3], v4 = src[4];
+        g[0] += v0.x; g[1] += v0.y; g[2] += v0.z; g[3] += v0.w;
+        g[4] += v1.x; g[5] += v1.y; g[6] += v1.z; g[7] += v1.w;
+        g[8] += v2.x; g[9] += v2.y; g[10] += v2.z; g[11] += v2.w;
+        g[12] += v3.x; g[13] += v3.y; g[14] += v3.z; g[15] += v3.w;
+        g[16] += v4.x; g[17] += v4.y;
+    }
+    a.dL_dopacity[i] = g[14];
+    a.dL_dnormal[3 * (size_t)i] = g[11]; a.dL_dnormal[3 * (size_t)i + 1] = g[12]; a.dL_dnormal[3 * (size_t)i + 2] = g[13];
+    a.dL_dcolors[3 * (size_t)i] = g[15]; a.dL_dcolors[3 * (size_t)i + 1] = g[16]; a.dL_dcolors[3 * (size_t)i + 2] = g[17];
+
+    const float4* __restrict__ rq = reinterpret_cast<const float4*>(a.rec + (size_t)i * REC_F);
+    const float4 r0 = rq[0], r1 = rq[1], r2 = rq[2];
+    const float T[9] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w, r2.x};
+    // densification statistic from the blend-stage dL/dT (before the centre term is folded in)
+    const float stat_x = g[2] * T[8] * 0.5f * (float)a.W;
+    const float stat_y = g[5] * T[8] * 0.5f * (float)a.H;
+
+    float gT[9];
+#pragma unroll
+    for (int q = 0; q < 9; q++) gT[q] = g[q];
+    const float gx2 = g[9], gy2 = g[10];
+    if (gx2 != 0.f || gy2 != 0.f) {
+        const float t[3] = {CUTOFF * CUTOFF, CUTOFF * CUTOFF, -1.f};
+        const float d = t[0] * T[6] * T[6] + t[1] * T[7] * T[7] + t[2] * T[8] * T[8];
+        const float id = 1.f / d;
+        float f[3], dd = 0.f;
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            f[k] = t[k] * id;
+            dd += (gx2 * T[k] * T[6 + k] + gy2 * T[3 + k] * T[6 + k]) * f[k];
+        }
+        dd *= -id;
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            gT[k] += gx2 * f[k] * T[6 + k];
+            gT[3 + k] += gy2 * f[k] * T[6 + k];
+            gT[6 + k] += gx2 * f[k] * T[k] + gy2 * f[k] * T[3 + k] + dd * t[k] * T[6 + k] * 2.f;
+        }
+    }
+    const float px = a.means3D[3 * (size_t)i], py = a.means3D[3 * (size_t)i + 1], pz = a.means3D[3 * (size_t)i + 2];
+    float dmx = 0.f, dmy = 0.f, dmz = 0.f;
+    if (a.transMat_precomp != nullptr) {
+        // statistic uses the folded gradient in this mode (matches the oracle / upstream ordering)
+#pragma unroll
+        for (int q = 0; q < 9; q++) a.dL_dtransMat[9 * (size_t)i + q] = gT[q];
+        a.dL_dmeans2D[3 * (size_t)i] = gT[2] * T[8] * 0.5f * (float)a.W;
+        a.dL_dmeans2D[3 * (size_t)i + 1] = gT[5] * T[8] * 0.5f * (float)a.H;
+    } else {
+#pragma unroll
+        for (int q = 0; q < 9; q++) a.dL_dtransMat[9 * (size_t)i + q] = g[q];
+        a.dL_dmeans2D[3 * (size_t)i] = stat_x;
+        a.dL_dmeans2D[3 * (size_t)i + 1] = stat_y;
+        const float* __restrict__ vm = a.viewmatrix;
+        float Pm[12];
+        world2pix(a.projmatrix, a.W, a.H, Pm);
+        const float4 q = reinterpret_cast<const float4*>(a.rotations)[i];
+        const float2 sc = reinterpret_cast<const float2*>(a.scales)[i];
+        const float s = rsqrtf(q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w);
+        const float w = q.x * s, x = q.y * s, y = q.z * s, z = q.w * s;
+        const float sx = a.scale_modifier * sc.x, sy = a.scale_modifier * sc.y;
+        const float R00 = 1.f - 2.f * (y * y + z * z), R01 = 2.f * (x * y - w * z), R02 = 2.f * (x * z + w * y);
+        const float R10 = 2.f * (x * y + w * z), R11 = 1.f - 2.f * (x * x + z * z), R12 = 2.f * (y * z - w * x);
+        const float R20 = 2.f * (x * z - w * y), R21 = 2.f * (y * z + w * x), R22 = 1.f - 2.f * (x * x + y * y);
+        // dL/dA[r][j] = sum_c gT[3c+r] * Pm[j][c]
+        float dA[3][3];
+#pragma unroll
+        for (int r = 0; r < 3; r++)
+#pragma unroll
+            for (int j = 0; j < 3; j++) dA[r][j] = gT[r] * Pm[3 * j] + gT[3 + r] * Pm[3 * j + 1] + gT[6 + r] * Pm[3 * j + 2];
+        // normal path
+        const float nx = vm[0] * R02 + vm[4] * R12 + vm[8] * R22;
+        const float ny = vm[1] * R02 + vm[5] * R12 + vm[9] * R22;
+        const float nz = vm[2] * R02 + vm[6] * R12 + vm[10] * R22;
+        const float vx = vm[0] * px + vm[4] * py + vm[8] * pz + vm[12];
+        const float vy = vm[1] * px + vm[5] * py + vm[9] * pz + vm[13];
+        const float vz = vm[2] * px + vm[6] * py + vm[10] * pz + vm[14];
+        const float flip = (-(vx * nx + vy * ny + vz * nz)) > 0.f ? 1.f : -1.f;
+        const float dtn0 = flip * (vm[0] * g[11] + vm[1] * g[12] + vm[2] * g[13]);
+        const float dtn1 = flip * (vm[4] * g[11] + vm[5] * g[12] + vm[6] * g[13]);
+        const float dtn2 = flip * (vm[8] * g[11] + vm[9] * g[12] + vm[10] * g[13]);
+        // dL/dR[r][c]
+        const float d00 = dA[0][0] * sx, d10 = dA[0][1] * sx, d20 = dA[0][2] * sx;
+        const float d01 = dA[1][0] * sy, d11 = dA[1][1] * sy, d21 = dA[1][2] * sy;
+        const float d02 = dtn0, d12 = dtn1, d22 = dtn2;
+        a.dL_dscales[2 * (size_t)i] = a.scale_modifier * (dA[0][0] * R00 + dA[0][1] * R10 + dA[0][2] * R20);
+        a.dL_dscales[2 * (size_t)i + 1] = a.scale_modifier * (dA[1][0] * R01 + dA[1][1] * R11 + dA[1][2] * R21);
+        dmx = dA[2][0]; dmy = dA[2][1]; dmz = dA[2][2];
+        float4 gq;
+        gq.x = 2.f * (x * (d21 - d12) + y * (d02 - d20) + z * (d10 - d01));
+        gq.y = 2.f * (-2.f * x * (d11 + d22) + y * (d01 + d10) + z * (d02 + d20) + w * (d21 - d12));
+        gq.z = 2.f * (x * (d01 + d10) - 2.f * y * (d00 + d22) + z * (d12 + d21) + w * (d02 - d20));
+        gq.w = 2.f * (x * (d02 + d20) + y * (d12 + d21) - 2.f * z * (d00 + d11) + w * (d10 - d01));
+        reinterpret_cast<float4*>(a.dL_drots)[i] = gq;
+    }
+
+    if (a.shs != nullptr) {
+        const float* __restrict__ sh = a.shs + (size_t)i * a.M * 3;
+        float* __restrict__ gsh = a.dL_dsh + (size_t)i * a.M * 3;
+        const float dox = px - a.campos[0], doy = py - a.campos[1], doz = pz - a.campos[2];
+        const float sum2 = dox * dox + doy * doy + doz * doz;
+        const float il = rsqrtf(sum2);
+        const float x = dox * il, y = doy * il, z = doz * il;
+        const uint8_t cb = a.clamped[i];
+        float gR[3] = {(cb & 1) ? 0.f : g[15], (cb & 2) ? 0.f : g[16], (cb & 4) ? 0.f : g[17]};
+        float ddx[3] = {0.f, 0.f, 0.f}, ddy[3] = {0.f, 0.f, 0.f}, ddz[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+        for (int c = 0; c < 3; c++) gsh[c] = BSH_C0 * gR[c];
+        if (a.D > 0) {
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                gsh[3 + c] = -BSH_C1 * y * gR[c];
+                gsh[6 + c] = BSH_C1 * z * gR[c];
+                gsh[9 + c] = -BSH_C1 * x * gR[c];
+                ddx[c] = -BSH_C1 * sh[9 + c]; ddy[c] = -BSH_C1 * sh[3 + c]; ddz[c] = BSH_C1 * sh[6 + c];
+            }
+            if (a.D > 1) {
+                const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+#pragma unroll
+                for (int c = 0; c < 3; c++) {
+                    gsh[12 + c] = BSH_C2[0] * xy * gR[c];
+                    gsh[15 + c] = BSH_C2[1] * yz * gR[c];
+                    gsh[18 + c] = BSH_C2[2] * (2.f * zz - xx - yy) * gR[c];
+                    gsh[21 + c] = BSH_C2[3] * xz * gR[c];
+                    gsh[24 + c] = BSH_C2[4] * (xx - yy) * gR[c];
+                    ddx[c] += BSH_C2[0] * y * sh[12 + c] + BSH_C2[2] * 2.f * -x * sh[18 + c] + BSH_C2[3] * z * sh[21 + c] + BSH_C2[4] * 2.f * x * sh[24 + c];
+                    ddy[c] += BSH_C2[0] * x * sh[12 + c] + BSH_C2[1] * z * sh[15 + c] + BSH_C2[2] * 2.f * -y * sh[18 + c] + BSH_C2[4] * 2.f * -y * sh[24 + c];
+                    ddz[c] += BSH_C2[1] * y * sh[15 + c] + BSH_C2[2] * 4.f * z * sh[18 + c] + BSH_C2[3] * x * sh[21 + c];
+                }
+                if (a.D > 2) {
+#pragma unroll
+                    for (int c = 0; c < 3; c++) {
+                        gsh[27 + c] = BSH_C3[0] * y * (3.f * xx - yy) * gR[c];
+                        gsh[30 + c] = BSH_C3[1] * xy * z * gR[c];
+                        gsh[33 + c] = BSH_C3[2] * y * (4.f * zz - xx - yy) * gR[c];
+                        gsh[36 + c] = BSH_C3[3] * z * (2.f * zz - 3.f * xx - 3.f * yy) * gR[c];
+                        gsh[39 + c] = BSH_C3[4] * x * (4.f * zz - xx - yy) * gR[c];
+                        gsh[42 + c] = BSH_C3[5] * z * (xx - yy) * gR[c];
+                        gsh[45 + c] = BSH_C3[6] * x * (xx - 3.f * yy) * gR[c];
+                        ddx[c] += BSH_C3[0] * sh[27 + c] * 6.f * xy + BSH_C3[1] * sh[30 + c] * yz + BSH_C3[2] * sh[33 + c] * -2.f * xy +
+                                  BSH_C3[3] * sh[36 + c] * -6.f * xz + BSH_C3[4] * sh[39 + c] * (-3.f * xx + 4.f * zz - yy) +
+                                  BSH_C3[5] * sh[42 + c] * 2.f * xz + BSH_C3[6] * sh[45 + c] * 3.f * (xx - yy);
+                        ddy[c] += BSH_C3[0] * sh[27 + c] * 3.f * (xx - yy) + BSH_C3[1] * sh[30 + c] * xz +
+                                  BSH_C3[2] * sh[33 + c] * (-3.f * yy + 4.f * zz - xx) + BSH_C3[3] * sh[36 + c] * -6.f * yz +
+                                  BSH_C3[4] * sh[39 + c] * -2.f * xy + BSH_C3[5] * sh[42 + c] * -2.f * yz + BSH_C3[6] * sh[45 + c] * -6.f * xy;
+                        ddz[c] += BSH_C3[1] * sh[30 + c] * xy + BSH_C3[2] * sh[33 + c] * 8.f * yz +
+                                  BSH_C3[3] * sh[36 + c] * 3.f * (2.f * zz - xx - yy) + BSH_C3[4] * sh[39 + c] * 8.f * xz +
+                                  BSH_C3[5] * sh[42 + c] * (xx - yy);
+                    }
+                }
+            }
+        }
+        const float gdx = ddx[0] * gR[0] + ddx[1] * gR[1] + ddx[2] * gR[2];
+        const float gdy = ddy[0] * gR[0] + ddy[1] * gR[1] + ddy[2] * gR[2];
+        const float gdz = ddz[0] * gR[0] + ddz[1] * gR[1] + ddz[2] * gR[2];
+        const float il3 = il * il * il;
+        dmx += ((sum2 - dox * dox) * gdx - doy * dox * gdy - doz * dox * gdz) * il3;
+        dmy += (-dox * doy * gdx + (sum2 - doy * doy) * gdy - doz * doy * gdz) * il3;
+        dmz += (-dox * doz * gdx - doy * doz * gdy + (sum2 - doz * doz) * gdz) * il3;
+    }
+    a.dL_dmeans3D[3 * (size_t)i] = dmx; a.dL_dmeans3D[3 * (size_t)i + 1] = dmy; a.dL_dmeans3D[3 * (size_t)i + 2] = dmz;
+}
+
+void launch_blend_bwd(const BlendBwdArgs& a, hipStream_t s) {
+    hipLaunchKernelGGL(blend_bwd_kernel, dim3(a.gx * a.gy), dim3(BLOCK), 0, s, a);
+}
+void launch_preprocess_bwd(const PreprocessBwdArgs& a, hipStream_t s) {
+    if (a.P > 0) hipLaunchKernelGGL(preprocess_bwd_kernel, dim3((a.P + 255) / 256), dim3(256), 0, s, a);
+}
+
+}  // namespace surfel

@@ -1,0 +1,304 @@
+// surfel_forward.hip — forward kernels of the gfx950 surfel rasterizer.
+//   preprocess_fwd   : per-surfel homography, AABB, SH colour  -> packed 80-B records
+//   emit_instances   : (tile, depth) keys for every touched tile
+//   tile_ranges      : [start,end) of every tile in the sorted instance list
+//   blend_fwd        : per-tile front-to-back alpha blend, 10 output channels
+// Reference interfaces replaced: the native half of diff_surfel_rasterization (absent submodule,
+// /root/reference/.gitmodules:1-3); semantics as stated in oracle/surfel_oracle.c.
+#include "surfel_common.h"
+#include "surfel_kernels.h"
+
+namespace surfel {
+
+__device__ __constant__ float SH_C0 = 0.28209479177387814f;
+__device__ __constant__ float SH_C1 = 0.4886025119029199f;
+__device__ __constant__ float SH_C2[5] = {1.0925484305920792f, -1.0925484305920792f, 0.31539156525252005f,
+                                          -1.0925484305920792f, 0.5462742152960396f};
+__device__ __constant__ float SH_C3[7] = {-0.5900435899266435f, 2.890611442640554f, -0.4570457994644658f,
+                                          0.3731763325901154f, -0.4570457994644658f, 1.445305721320277f,
+                                          -0.5900435899266435f};
+
+// ---------------------------------------------------------------------------------------------
+// preprocess_fwd: one thread per surfel.  Camera matrices are wave-uniform (scalar loads).
+// HBM traffic per surfel: reads 40 B geometry (+192 B SH only when the surfel survives culling),
+// writes 80 B record + 13 B bookkeeping.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) preprocess_fwd_kernel(PreprocessArgs a) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.P) return;
+    int rad_out = 0;
+    uint32_t tiles = 0;
+    const float* __restrict__ vm = a.viewmatrix;
+    const float px = a.means3D[3 * i], py = a.means3D[3 * i + 1], pz = a.means3D[3 * i + 2];
+    const float vx = vm[0] * px + vm[4] * py + vm[8] * pz + vm[12];
+    const float vy = vm[1] * px + vm[5] * py + vm[9] * pz + vm[13];
+    const float vz = vm[2] * px + vm[6] * py + vm[10] * pz + vm[14];
+    do {
+        if (vz <= 0.2f) break;
+        float T[9];
+        float nx, ny, nz;
+        if (a.transMat_precomp == nullptr) {
+            const float4 q = reinterpret_cast<const float4*>(a.rotations)[i];
+            const float2 sc = reinterpret_cast<const float2*>(a.scales)[i];
+            const float s = rsqrtf(q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w);
+            const float w = q.x * s, x = q.y * s, y = q.z * s, z = q.w * s;
+            const float sx = a.scale_modifier * sc.x, sy = a.scale_modifier * sc.y;
+            // columns of R (world axes of the disc): L0 = R[:,0]*sx, L1 = R[:,1]*sy, L2 = R[:,2]
+            const float L0x = (1.f - 2.f * (y * y + z * z)) * sx, L0y = (2.f * (x * y + w * z)) * sx, L0z = (2.f * (x * z - w * y)) * sx;
+            const float L1x = (2.f * (x * y - w * z)) * sy, L1y = (1.f - 2.f * (x * x + z * z)) * sy, L1z = (2.f * (y * z + w * x)) * sy;
+            const float L2x = 2.f * (x * z + w * y), L2y = 2.f * (y * z - w * x), L2z = 1.f - 2.f * (x * x + y * y);
+            // Pm = world2ndc * ndc2pix (4x3): wave-uniform, built from scalar loads of projmatrix
+            float Pm[12];
+            world2pix(a.projmatrix, a.W, a.H, Pm);
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                T[3 * c + 0] = L0x * Pm[0 * 3 + c] + L0y * Pm[1 * 3 + c] + L0z * Pm[2 * 3 + c];
+                T[3 * c + 1] = L1x * Pm[0 * 3 + c] + L1y * Pm[1 * 3 + c] + L1z * Pm[2 * 3 + c];
+                T[3 * c + 2] = px * Pm[0 * 3 + c] + py * Pm[1 * 3 + c] + pz * Pm[2 * 3 + c] + Pm[3 * 3 + c];
+            }
+            nx = vm[0] * L2x + vm[4] * L2y + vm[8] * L2z;
+            ny = vm[1] * L2x + vm[5] * L2y + vm[9] * L2z;
+            nz = vm[2] * L2x + vm[6] * L2y + vm[10] * L2z;
+        } else {
+#pragma unroll
+            for (int k = 0; k < 9; k++) T[k] = a.transMat_precomp[9 * (size_t)i + k];
+            nx = 0.f; ny = 0.f; nz = 1.f;
+        }
+        const float cosv = -(vx * nx + vy * ny + vz * nz);
+        if (cosv == 0.f) break;
+        const float flip = cosv > 0.f ? 1.f : -1.f;
+        nx *= flip; ny *= flip; nz *= flip;
+
+        const float t0 = CUTOFF * CUTOFF, t2 = -1.0f;
+        const float dist = t0 * T[6] * T[6] + t0 * T[7] * T[7] + t2 * T[8] * T[8];
+        if (dist == 0.f) break;
+        const float f0 = t0 / dist, f2 = t2 / dist;
+        const float cx = f0 * T[0] * T[6] + f0 * T[1] * T[7] + f2 * T[2] * T[8];
+        const float cy = f0 * T[3] * T[6] + f0 * T[4] * T[7] + f2 * T[5] * T[8];
+        const float hx = cx * cx - (f0 * T[0] * T[0] + f0 * T[1] * T[1] + f2 * T[2] * T[2]);
+        const float hy = cy * cy - (f0 * T[3] * T[3] + f0 * T[4] * T[4] + f2 * T[5] * T[5]);
+        const float ex = sqrtf(fmaxf(1e-4f, hx)), ey = sqrtf(fmaxf(1e-4f, hy));
+        const float radius = ceilf(fmaxf(fmaxf(ex, ey), CUTOFF * FILTER_SIZE));
+        const int irad = (int)radius;
+        const Rect rc = tile_rect(cx, cy, irad, a.gx, a.gy);
+        const int ntiles = (rc.x1 - rc.x0) * (rc.y1 - rc.y0);
+        if (ntiles == 0) break;
+
+        float r = 0.f, g = 0.f, b = 0.f;
+        uint8_t clampbits = 0;
+        if (a.colors_precomp == nullptr) {
+            const float4* __restrict__ shq = reinterpret_cast<const float4*>(a.shs + (size_t)i * a.M * 3);
+            float dx = px - a.campos[0], dy = py - a.campos[1], dz = pz - a.campos[2];
+            const float il = rsqrtf(dx * dx + dy * dy + dz * dz);
+            dx *= il; dy *= il; dz *= il;
+            // basis values for the active degree
+            float B[16];
+            B[0] = SH_C0;
+            int nb = 1;
+            if (a.D > 0) {
+                B[1] = -SH_C1 * dy; B[2] = SH_C1 * dz; B[3] = -SH_C1 * dx; nb = 4;
+                if (a.D > 1) {
+                    const float xx = dx * dx, yy = dy * dy, zz = dz * dz, xy = dx * dy, yz = dy * dz, xz = dx * dz;
+                    B[4] = SH_C2[0] * xy; B[5] = SH_C2[1] * yz; B[6] = SH_C2[2] * (2.f * zz - xx - yy);
+                    B[7] = SH_C2[3] * xz; B[8] = SH_C2[4] * (xx - yy); nb = 9;
+                    if (a.D > 2) {
+                        B[9] = SH_C3[0] * dy * (3.f * xx - yy); B[10] = SH_C3[1] * xy * dz;
+                        B[11] = SH_C3[2] * dy * (4.f * zz - xx - yy); B[12] = SH_C3[3] * dz * (2.f * zz - 3.f * xx - 3.f * yy);
+                        B[13] = SH_C3[4] * dx * (4.f * zz - xx - yy); B[14] = SH_C3[5] * dz * (xx - yy);
+                        B[15] = SH_C3[6] * dx * (xx - 3.f * yy); nb = 16;
+                    }
+                }
+            }
+            // coefficients are [M][3] floats = 12 float4 for M = 16; walk them as float4 (16-B loads),
+            // statically indexed (a runtime-indexed B[] would live in scratch), skipping the float4s
+            // that hold only inactive coefficients (wave-uniform branch)
+            if (a.M == 16) {
+                float acc[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+                for (int v = 0; v < 12; v++) {
+                    if (4 * v < 3 * nb) {
+                        const float4 c4 = shq[v];
+                        const float cv[4] = {c4.x, c4.y, c4.z, c4.w};
+#pragma unroll
+                        for (int e = 0; e < 4; e++) {
+                            const int flat = 4 * v + e;          // = 3*coef + channel
+                            if (flat / 3 < 16) acc[flat % 3] += (flat / 3 < nb ? B[flat / 3] : 0.f) * cv[e];
+                        }
+                    }
+                }
+                r = acc[0]; g = acc[1]; b = acc[2];
+            } else {
+                const float* __restrict__ sh = a.shs + (size_t)i * a.M * 3;
+                r = SH_C0 * sh[0]; g = SH_C0 * sh[1]; b = SH_C0 * sh[2];
+                if (nb > 1) {
+#pragma unroll
+                    for (int k = 1; k < 16; k++) {
+                        if (k < nb && k < a.M) { r += B[k] * sh[3 * k]; g += B[k] * sh[3 * k + 1]; b += B[k] * sh[3 * k + 2]; }
+                    }
+                }
+            }
+            r += 0.5f; g += 0.5f; b += 0.5f;
+            clampbits = (r < 0.f ? 1 : 0) | (g < 0.f ? 2 : 0) | (b < 0.f ? 4 : 0);
+            r = fmaxf(r, 0.f); g = fmaxf(g, 0.f); b = fmaxf(b, 0.f);
+        } else {
+            r = a.colors_precomp[3 * (size_t)i]; g = a.colors_precomp[3 * (size_t)i + 1]; b = a.colors_precomp[3 * (size_t)i + 2];
+        }
+        float4* __restrict__ rec = reinterpret_cast<float4*>(a.rec + (size_t)i * REC_F);
+        rec[0] = make_float4(T[0], T[1], T[2], T[3]);
+        rec[1] = make_float4(T[4], T[5], T[6], T[7]);
+        rec[2] = make_float4(T[8], cx, cy, a.opacities[i]);
+        rec[3] = make_float4(nx, ny, nz, r);
+        const uint32_t rectbits = (uint32_t)rc.x0 | ((uint32_t)rc.y0 << 10) | ((uint32_t)(rc.x1 - rc.x0) << 20);
+        rec[4] = make_float4(g, b, 0.f /* inst_base patched by emit_instances */, __uint_as_float(rectbits));
+        a.depths[i] = vz;
+        a.clamped[i] = clampbits;
+        rad_out = irad;
+        tiles = (uint32_t)ntiles;
+    } while (false);
+    a.radii[i] = rad_out;
+    a.tiles_touched[i] = tiles;
+}
+
+// ---------------------------------------------------------------------------------------------
+// emit_instances: one thread per surfel writes its (tile<<32 | depth bits) keys and surfel index.
+// Also patches the record's inst_base (first instance slot of this surfel) used by the
+// atomic-free backward.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) emit_instances_kernel(int P, float* rec, const float* __restrict__ depths, const uint32_t* __restrict__ offsets,
+                                                             const int* __restrict__ radii, uint64_t* __restrict__ keys,
+                                                             uint32_t* __restrict__ vals, int gx) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P) return;
+    if (radii[i] <= 0) return;
+    uint32_t off = (i == 0) ? 0u : offsets[i - 1];
+    const uint32_t rectbits = __float_as_uint(rec[(size_t)i * REC_F + 19]);
+    const int x0 = rectbits & 1023, y0 = (rectbits >> 10) & 1023, w = rectbits >> 20;
+    const int n = (int)(offsets[i] - off);
+    rec[(size_t)i * REC_F + 18] = __uint_as_float(off);
+    const uint32_t dbits = __float_as_uint(depths[i]);
+    int x = 0, y = 0;
+    for (int k = 0; k < n; k++) {
+        const uint64_t key = ((uint64_t)(uint32_t)((y0 + y) * gx + (x0 + x)) << 32) | dbits;
+        keys[off + k] = key;
+        vals[off + k] = (uint32_t)i;
+        if (++x == w) { x = 0; ++y; }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// tile_ranges: boundaries of each tile's run in the sorted key list (ranges pre-zeroed).
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) tile_ranges_kernel(int64_t R, const uint64_t* __restrict__ keys, uint2* __restrict__ ranges) {
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= R) return;
+    const uint32_t tile = (uint32_t)(keys[k] >> 32);
+    if (k == 0) ranges[tile].x = 0;
+    else {
+        const uint32_t prev = (uint32_t)(keys[k - 1] >> 32);
+        if (prev != tile) { ranges[prev].y = (uint32_t)k; ranges[tile].x = (uint32_t)k; }
+    }
+    if (k == R - 1) ranges[tile].y = (uint32_t)R;
+}
+
+// ---------------------------------------------------------------------------------------------
+// blend_fwd: one workgroup (4 waves) per 16x16 tile; each wave owns an 8x8 pixel quad.
+// Surfel records of the tile's sorted list are staged through LDS 256 at a time (20 KB, one
+// coalesced-as-possible 80-B gather per thread); the inner loop reads them back as wave-uniform
+// broadcasts (conflict-free).  A wave whose 64 pixels are all saturated skips the batch.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(BLOCK) blend_fwd_kernel(BlendFwdArgs a) {
+    __shared__ float4 s_rec[BLOCK * 5];
+    const int tile = xcd_tile(blockIdx.x, a.gx * a.gy);
+    const int tx = tile % a.gx, ty = tile / a.gx;
+    int lx, ly;
+    thread_pixel(threadIdx.x, lx, ly);
+    const int pxi = tx * TILE + lx, pyi = ty * TILE + ly;
+    const bool inside = pxi < a.W && pyi < a.H;
+    const float pxf = (float)pxi, pyf = (float)pyi;
+    const uint2 range = a.ranges[tile];
+    const int n = (int)(range.y - range.x);
+
+    bool done = !inside;
+    float T = 1.f, C0 = 0.f, C1 = 0.f, C2 = 0.f, N0 = 0.f, N1 = 0.f, N2 = 0.f;
+    float D = 0.f, M1 = 0.f, M2 = 0.f, dist = 0.f, med = 0.f;
+    uint32_t contributor = 0, last = 0, medc = 0;
+
+    for (int base = 0; base < n; base += BLOCK) {
+        if (__syncthreads_count(done) == BLOCK) break;
+        const int m = min(BLOCK, n - base);
+        if ((int)threadIdx.x < m) {
+            const uint32_t id = a.point_list[range.x + base + threadIdx.x];
+            const float4* __restrict__ src = reinterpret_cast<const float4*>(a.rec + (size_t)id * REC_F);
+            const float4 v0 = src[0], v1 = src[1], v2 = src[2], v3 = src[3], v4 = src[4];
+            s_rec[threadIdx.x * 5 + 0] = v0; s_rec[threadIdx.x * 5 + 1] = v1; s_rec[threadIdx.x * 5 + 2] = v2;
+            s_rec[threadIdx.x * 5 + 3] = v3; s_rec[threadIdx.x * 5 + 4] = v4;
+        }
+        __syncthreads();
+        if (!__all(done)) {
+            for (int j = 0; j < m; j++) {
+                if (done) break;   // lanes finish independently
+                contributor = base + j + 1;
+                const float4 q0 = s_rec[j * 5 + 0], q1 = s_rec[j * 5 + 1], q2 = s_rec[j * 5 + 2];
+                Hit h;
+                if (!intersect(q0, q1, q2, pxf, pyf, h)) continue;
+                const float testT = T * (1.f - h.alpha);
+                if (testT < T_EPS) { done = true; continue; }
+                const float4 q3 = s_rec[j * 5 + 3], q4 = s_rec[j * 5 + 4];
+                const float w = h.alpha * T;
+                const float A = 1.f - T;
+                const float mm = FAR_N / (FAR_N - NEAR_N) * (1.f - NEAR_N / h.depth);
+                dist += (mm * mm * A + M2 - 2.f * mm * M1) * w;
+                D += h.depth * w;
+                M1 += mm * w;
+                M2 += mm * mm * w;
+                if (T > 0.5f) { med = h.depth; medc = contributor; }
+                N0 += q3.x * w; N1 += q3.y * w; N2 += q3.z * w;
+                C0 += q3.w * w; C1 += q4.x * w; C2 += q4.y * w;
+                T = testT;
+                last = contributor;
+            }
+        }
+    }
+    if (inside) {
+        const size_t HW = (size_t)a.H * a.W;
+        const size_t pix = (size_t)pyi * a.W + pxi;
+        a.final_T[pix] = T; a.final_T[HW + pix] = M1; a.final_T[2 * HW + pix] = M2;
+        a.n_contrib[pix] = last; a.n_contrib[HW + pix] = medc;
+        a.out_color[pix] = C0 + T * a.bg[0];
+        a.out_color[HW + pix] = C1 + T * a.bg[1];
+        a.out_color[2 * HW + pix] = C2 + T * a.bg[2];
+        a.out_others[pix] = D;
+        a.out_others[HW + pix] = 1.f - T;
+        a.out_others[2 * HW + pix] = N0; a.out_others[3 * HW + pix] = N1; a.out_others[4 * HW + pix] = N2;
+        a.out_others[5 * HW + pix] = med;
+        a.out_others[6 * HW + pix] = dist;
+    }
+}
+
+__global__ void __launch_bounds__(256) mark_visible_kernel(int P, const float* __restrict__ means3D, const float* __restrict__ vm,
+                                                           uint8_t* __restrict__ present) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P) return;
+    const float vz = vm[2] * means3D[3 * i] + vm[6] * means3D[3 * i + 1] + vm[10] * means3D[3 * i + 2] + vm[14];
+    present[i] = vz > 0.2f ? 1 : 0;
+}
+
+// ------------------------------------------------------------------------------- launchers
+void launch_preprocess_fwd(const PreprocessArgs& a, hipStream_t s) {
+    if (a.P > 0) hipLaunchKernelGGL(preprocess_fwd_kernel, dim3((a.P + 255) / 256), dim3(256), 0, s, a);
+}
+void launch_emit_instances(int P, float* rec, const float* depths, const uint32_t* offsets, const int* radii, uint64_t* keys,
+                           uint32_t* vals, int gx, hipStream_t s) {
+    if (P > 0) hipLaunchKernelGGL(emit_instances_kernel, dim3((P + 255) / 256), dim3(256), 0, s, P, rec, depths, offsets, radii, keys, vals, gx);
+}
+void launch_tile_ranges(int64_t R, const uint64_t* keys, uint2* ranges, hipStream_t s) {
+    if (R > 0) hipLaunchKernelGGL(tile_ranges_kernel, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, s, R, keys, ranges);
+}
+void launch_blend_fwd(const BlendFwdArgs& a, hipStream_t s) {
+    hipLaunchKernelGGL(blend_fwd_kernel, dim3(a.gx * a.gy), dim3(BLOCK), 0, s, a);
+}
+void launch_mark_visible(int P, const float* means3D, const float* vm, uint8_t* present, hipStream_t s) {
+    if (P > 0) hipLaunchKernelGGL(mark_visible_kernel, dim3((P + 255) / 256), dim3(256), 0, s, P, means3D, vm, present);
+}
+
+}  // namespace surfel

@@ -1,0 +1,53 @@
+// surfel_kernels.h — argument blocks and launchers shared between the kernel files and the C ABI.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace surfel {
+
+struct PreprocessArgs {
+    int P, D, M, W, H, gx, gy;
+    float scale_modifier;
+    const float* means3D; const float* opacities; const float* scales; const float* rotations;
+    const float* transMat_precomp; const float* colors_precomp; const float* shs;
+    const float* viewmatrix; const float* projmatrix; const float* campos;
+    float* rec; float* depths; int* radii; uint32_t* tiles_touched; uint8_t* clamped;
+};
+
+struct BlendFwdArgs {
+    int W, H, gx, gy;
+    const uint2* ranges; const uint32_t* point_list; const float* rec; const float* bg;
+    float* out_color; float* out_others; float* final_T; uint32_t* n_contrib;
+};
+
+struct BlendBwdArgs {
+    int W, H, gx, gy;
+    const uint2* ranges; const uint32_t* point_list; const float* rec; const float* bg;
+    const float* final_T; const uint32_t* n_contrib;
+    const float* dL_dpix; const float* dL_dothers;
+    float* grec;      // [R][GREC_F] per-instance gradient records (pre-zeroed)
+};
+
+struct PreprocessBwdArgs {
+    int P, D, M, W, H;
+    float scale_modifier;
+    const float* means3D; const int* radii; const float* shs; const uint8_t* clamped;
+    const float* scales; const float* rotations; const float* transMat_precomp;
+    const float* viewmatrix; const float* projmatrix; const float* campos;
+    const float* rec; const uint32_t* offsets; const float* grec;
+    float* dL_dtransMat; float* dL_dnormal; float* dL_dopacity; float* dL_dcolors; float* dL_dsh;
+    float* dL_dmeans2D; float* dL_dmeans3D; float* dL_dscales; float* dL_drots;
+};
+
+void launch_preprocess_fwd(const PreprocessArgs& a, hipStream_t s);
+void launch_emit_instances(int P, float* rec, const float* depths, const uint32_t* offsets, const int* radii, uint64_t* keys,
+                           uint32_t* vals, int gx, hipStream_t s);
+void launch_tile_ranges(int64_t R, const uint64_t* keys, uint2* ranges, hipStream_t s);
+void launch_blend_fwd(const BlendFwdArgs& a, hipStream_t s);
+void launch_mark_visible(int P, const float* means3D, const float* vm, uint8_t* present, hipStream_t s);
+void launch_blend_bwd(const BlendBwdArgs& a, hipStream_t s);
+void launch_preprocess_bwd(const PreprocessBwdArgs& a, hipStream_t s);
+void launch_knn(int P, const float* points, float* out, void* scratch, size_t scratch_bytes, hipStream_t s);
+size_t knn_scratch_bytes(int P);
+
+}  // namespace surfel

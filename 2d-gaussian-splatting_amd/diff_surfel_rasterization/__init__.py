@@ -1,0 +1,154 @@
+"""Drop-in replacement for the `diff_surfel_rasterization` Python package of hbb1/2d-gaussian-splatting.
+
+The reference imports these two names literally (/root/reference/gaussian_renderer/__init__.py:14) and
+uses them at :37-53 and :97-106; the original package is an absent submodule
+(/root/reference/.gitmodules:1-3).  Same names, argument meaning and error behaviour; the native half
+is libsurfel_hip.so (hand-written HIP for gfx950) reached through the C ABI in include/surfel_hip.h.
+No CPU / PyTorch fallback exists: importing this without the built library raises ImportError.
+"""
+from typing import NamedTuple
+
+import torch
+import torch.nn as nn
+
+import surfel_native as _n
+
+_n.load()  # fail loudly at import time if the HIP extension is missing
+
+last_num_rendered = 0   # instance count R of the most recent forward (introspection for bench / tests)
+
+
+class GaussianRasterizationSettings(NamedTuple):
+    image_height: int
+    image_width: int
+    tanfovx: float
+    tanfovy: float
+    bg: torch.Tensor
+    scale_modifier: float
+    viewmatrix: torch.Tensor
+    projmatrix: torch.Tensor
+    sh_degree: int
+    campos: torch.Tensor
+    prefiltered: bool
+    debug: bool
+
+
+def _c(t):
+    """contiguous fp32 view (or None for the reference's 'empty tensor' placeholders)."""
+    if t is None or t.numel() == 0:
+        return None
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t.contiguous()
+
+
+def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, raster_settings):
+    return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
+                                     raster_settings)
+
+
+class _RasterizeGaussians(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, raster_settings):
+        rs = raster_settings
+        lib = _n.load()
+        dev = means3D.device
+        if dev.type != "cuda":
+            raise RuntimeError("diff_surfel_rasterization: tensors must live on a HIP device (got %s)" % dev)
+        means3D = _c(means3D); sh = _c(sh); colors_precomp = _c(colors_precomp); opacities = _c(opacities)
+        scales = _c(scales); rotations = _c(rotations); cov3Ds_precomp = _c(cov3Ds_precomp)
+        bg = _c(rs.bg); viewmatrix = _c(rs.viewmatrix); projmatrix = _c(rs.projmatrix); campos = _c(rs.campos)
+        P = 0 if means3D is None else means3D.shape[0]
+        H, W = int(rs.image_height), int(rs.image_width)
+        M = 0 if sh is None else sh.shape[1]
+        out_color = torch.empty((3, H, W), dtype=torch.float32, device=dev)
+        out_others = torch.empty((7, H, W), dtype=torch.float32, device=dev)
+        radii = torch.zeros((P,), dtype=torch.int32, device=dev)
+        ga, ba, ia = _n.TorchAllocator(dev), _n.TorchAllocator(dev), _n.TorchAllocator(dev)
+        with torch.cuda.device(dev):
+            R = lib.surfel_rasterize_forward(ga.cb, None, ba.cb, None, ia.cb, None, P, int(rs.sh_degree), M, _n.ptr(bg), W, H,
+                                             _n.ptr(means3D), _n.ptr(sh), _n.ptr(colors_precomp), _n.ptr(opacities),
+                                             _n.ptr(scales), float(rs.scale_modifier), _n.ptr(rotations),
+                                             _n.ptr(cov3Ds_precomp), _n.ptr(viewmatrix), _n.ptr(projmatrix), _n.ptr(campos),
+                                             float(rs.tanfovx), float(rs.tanfovy), int(bool(rs.prefiltered)),
+                                             _n.ptr(out_color), _n.ptr(out_others), _n.ptr(radii), int(rs.debug),
+                                             _n.current_stream_ptr(dev))
+        if R < 0:
+            raise RuntimeError("surfel_rasterize_forward failed (%d): %s" % (R, _n.last_error()))
+        global last_num_rendered
+        last_num_rendered = int(R)
+        ctx.raster_settings = rs
+        ctx.num_rendered = int(R)
+        ctx.dims = (P, M, H, W)
+        ctx.has = (sh is not None, colors_precomp is not None, scales is not None, cov3Ds_precomp is not None)
+        geomBuffer, binningBuffer, imgBuffer = ga.last(), ba.last(), ia.last()
+        none = torch.empty(0, device=dev)
+        ctx.save_for_backward(*(x if x is not None else none for x in
+                                (colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geomBuffer,
+                                 binningBuffer, imgBuffer, bg, viewmatrix, projmatrix, campos)))
+        ctx.mark_non_differentiable(radii)
+        return out_color, radii, out_others
+
+    @staticmethod
+    def backward(ctx, grad_out_color, grad_radii, grad_depth):
+        rs = ctx.raster_settings
+        lib = _n.load()
+        (colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geomBuffer, binningBuffer, imgBuffer, bg,
+         viewmatrix, projmatrix, campos) = ctx.saved_tensors
+        has_sh, has_col, has_sr, has_cov = ctx.has
+        P, M, H, W = ctx.dims
+        dev = means3D.device
+        z = lambda *shape: torch.zeros(shape, dtype=torch.float32, device=dev)
+        g_means2D, g_normal, g_opac, g_colors = z(P, 3), z(P, 3), z(P, 1), z(P, 3)
+        g_means3D, g_trans = z(P, 3), z(P, 9)
+        g_sh = z(P, M, 3) if has_sh else None
+        g_scales = z(P, 2) if has_sr else None
+        g_rots = z(P, 4) if has_sr else None
+        gc = grad_out_color.contiguous().float() if grad_out_color is not None else z(3, H, W)
+        gd = grad_depth.contiguous().float() if grad_depth is not None else z(7, H, W)
+        sa = _n.TorchAllocator(dev)
+        opt = lambda t, ok: _n.ptr(t) if ok else None
+        with torch.cuda.device(dev):
+            rc = lib.surfel_rasterize_backward(sa.cb, None, P, int(rs.sh_degree), M, ctx.num_rendered, _n.ptr(bg), W, H,
+                                               _n.ptr(means3D), opt(sh, has_sh), opt(colors_precomp, has_col),
+                                               opt(scales, has_sr), float(rs.scale_modifier), opt(rotations, has_sr),
+                                               opt(cov3Ds_precomp, has_cov), _n.ptr(viewmatrix), _n.ptr(projmatrix),
+                                               _n.ptr(campos), float(rs.tanfovx), float(rs.tanfovy), _n.ptr(radii),
+                                               _n.ptr(geomBuffer), _n.ptr(binningBuffer), _n.ptr(imgBuffer), _n.ptr(gc),
+                                               _n.ptr(gd), _n.ptr(g_means2D), _n.ptr(g_normal), _n.ptr(g_opac),
+                                               _n.ptr(g_colors), _n.ptr(g_means3D), _n.ptr(g_trans), _n.ptr(g_sh),
+                                               _n.ptr(g_scales), _n.ptr(g_rots), int(rs.debug),
+                                               _n.current_stream_ptr(dev))
+        if rc < 0:
+            raise RuntimeError("surfel_rasterize_backward failed (%d): %s" % (rc, _n.last_error()))
+        return (g_means3D, g_means2D, g_sh, g_colors if has_col else None, g_opac, g_scales, g_rots,
+                g_trans if has_cov else None, None)
+
+
+class GaussianRasterizer(nn.Module):
+    def __init__(self, raster_settings):
+        super().__init__()
+        self.raster_settings = raster_settings
+
+    def markVisible(self, positions):
+        rs = self.raster_settings
+        with torch.no_grad():
+            positions = _c(positions)
+            P = positions.shape[0]
+            present = torch.zeros((P,), dtype=torch.uint8, device=positions.device)
+            with torch.cuda.device(positions.device):
+                rc = _n.load().surfel_mark_visible(P, _n.ptr(positions), _n.ptr(_c(rs.viewmatrix)), _n.ptr(_c(rs.projmatrix)),
+                                                   _n.ptr(present), _n.current_stream_ptr(positions.device))
+            if rc < 0:
+                raise RuntimeError("surfel_mark_visible failed: %s" % _n.last_error())
+        return present.bool()
+
+    def forward(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,
+                cov3D_precomp=None):
+        rs = self.raster_settings
+        if (shs is None and colors_precomp is None) or (shs is not None and colors_precomp is not None):
+            raise Exception('Please provide excatly one of either SHs or precomputed colors!')
+        if ((scales is None or rotations is None) and cov3D_precomp is None) or \
+                ((scales is not None or rotations is not None) and cov3D_precomp is not None):
+            raise Exception('Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!')
+        return rasterize_gaussians(means3D, means2D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, rs)

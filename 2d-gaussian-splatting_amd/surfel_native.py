@@ -1,0 +1,114 @@
+"""ctypes loader for libsurfel_hip.so — the C-ABI boundary declared in include/surfel_hip.h.
+
+There is NO fallback: if the HIP library is missing or cannot be loaded this module raises, so a
+GPU box can never silently run some other path.  torch is imported first so that the HIP runtime
+already mapped by PyTorch-ROCm (same SONAME libamdhip64.so.7) is the one our library binds to; torch
+here is plumbing only (device memory through its caching allocator, current stream).
+"""
+import ctypes as C
+import os
+import threading
+
+import torch  # noqa: F401  (must precede the CDLL below, see module doc)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libsurfel_hip.so")
+
+ALLOC_FN = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_size_t)
+
+EXPORTS = ["surfel_abi_version", "surfel_last_error", "surfel_rasterize_forward", "surfel_rasterize_backward",
+           "surfel_mark_visible", "surfel_knn_dist2", "surfel_last_stage_ms", "surfel_last_stage_ids", "surfel_stage_name",
+           "surfel_collect_stage_ms"]
+
+_lib = None
+_lock = threading.Lock()
+
+
+def load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                "libsurfel_hip.so not found at %s — build it with `python 2d-gaussian-splatting_amd/build.py` "
+                "(hipcc --offload-arch=gfx950). There is no CPU / PyTorch fallback for the rasterizer." % LIB_PATH)
+        lib = C.CDLL(LIB_PATH)
+        vp, f, i, i64 = C.c_void_p, C.c_float, C.c_int, C.c_int64
+        lib.surfel_abi_version.restype = i
+        lib.surfel_last_error.restype = C.c_char_p
+        lib.surfel_rasterize_forward.restype = i64
+        lib.surfel_rasterize_forward.argtypes = [ALLOC_FN, vp, ALLOC_FN, vp, ALLOC_FN, vp, i, i, i, vp, i, i,
+                                                 vp, vp, vp, vp, vp, f, vp, vp, vp, vp, vp, f, f, i, vp, vp, vp, i, vp]
+        lib.surfel_rasterize_backward.restype = i
+        lib.surfel_rasterize_backward.argtypes = [ALLOC_FN, vp, i, i, i, i64, vp, i, i, vp, vp, vp, vp, f, vp, vp, vp, vp, vp,
+                                                  f, f, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i, vp]
+        lib.surfel_mark_visible.restype = i
+        lib.surfel_mark_visible.argtypes = [i, vp, vp, vp, vp, vp]
+        lib.surfel_knn_dist2.restype = i
+        lib.surfel_knn_dist2.argtypes = [ALLOC_FN, vp, i, vp, vp, vp]
+        lib.surfel_last_stage_ms.restype = i
+        lib.surfel_last_stage_ms.argtypes = [C.POINTER(C.c_float), i]
+        lib.surfel_last_stage_ids.restype = i
+        lib.surfel_last_stage_ids.argtypes = [C.POINTER(C.c_int), i]
+        lib.surfel_collect_stage_ms.restype = i
+        lib.surfel_collect_stage_ms.argtypes = [C.POINTER(C.c_float), C.POINTER(C.c_int), i]
+        lib.surfel_stage_name.restype = C.c_char_p
+        lib.surfel_stage_name.argtypes = [i]
+        if lib.surfel_abi_version() != 1:
+            raise ImportError("libsurfel_hip.so ABI version mismatch")
+        _lib = lib
+    return _lib
+
+
+def last_error():
+    return load().surfel_last_error().decode()
+
+
+class TorchAllocator:
+    """Allocator callbacks backed by torch's caching allocator (uint8 tensors kept alive in `held`)."""
+
+    def __init__(self, device):
+        self.device = device
+        self.held = []
+        self.cb = ALLOC_FN(self._alloc)
+
+    def _alloc(self, user, nbytes):
+        try:
+            t = torch.empty(max(int(nbytes), 1), dtype=torch.uint8, device=self.device)
+        except Exception:  # out of memory -> NULL -> SURFEL_E_ALLOC
+            return None
+        self.held.append(t)
+        return t.data_ptr()
+
+    def last(self):
+        return self.held[-1]
+
+
+def ptr(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def current_stream_ptr(device):
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def stage_times():
+    """[(stage_name, ms)] of the last debug-mode forward/backward on this thread."""
+    lib = load()
+    ms = (C.c_float * 16)()
+    ids = (C.c_int * 16)()
+    n = lib.surfel_last_stage_ms(ms, 16)
+    lib.surfel_last_stage_ids(ids, 16)
+    return [(lib.surfel_stage_name(ids[k]).decode(), float(ms[k])) for k in range(n)]
+
+
+def collect_stage_times():
+    """{stage_name: (total_ms, launches)} for all debug==2 calls since the previous collect (synchronises)."""
+    lib = load()
+    ms = (C.c_float * 16)()
+    cnt = (C.c_int * 16)()
+    n = lib.surfel_collect_stage_ms(ms, cnt, 16)
+    return {lib.surfel_stage_name(k).decode(): (float(ms[k]), int(cnt[k])) for k in range(n) if cnt[k] > 0}

@@ -60,7 +60,7 @@ def _rot(axis, ang):
     return np.eye(3) + math.sin(ang) * K + (1 - math.cos(ang)) * K @ K
 
 
-def make_scene(P, W, H, seed=0, z_near=2.0, z_far=12.0, px_radius=None, tilt=True, sh_degree=3):
+def make_scene(P, W, H, seed=0, z_near=2.0, z_far=12.0, px_radius=None, tilt=True, sh_degree=3, view_index=0):
     """Random surfels filling 110 % of the frustum slab z in [z_near, z_far] (≈9 % culled off-screen).
     Scales are chosen so the median projected 1-sigma radius is `px_radius` px (default: 4 px at 1080p,
     scaled with resolution). Camera is slightly rotated/translated so no matrix entry is trivially 0."""
@@ -72,12 +72,19 @@ def make_scene(P, W, H, seed=0, z_near=2.0, z_far=12.0, px_radius=None, tilt=Tru
         Rcw, t = np.eye(3), np.zeros(3)
     cam = look_at_camera(W, H, Rcw=Rcw, t=t)
     f = 1.2 * W
+    cam0 = cam
+    if view_index:
+        # another training view of the SAME surfels (view-parallel ranks): small extra rotation + shift
+        Rv = _rot([0.1, 1.0, 0.0], 0.02 * view_index) @ Rcw
+        tv = t + np.array([0.05 * view_index, 0.0, 0.02 * view_index])
+        cam = look_at_camera(W, H, Rcw=Rv, t=tv)
+    cam0 = cam0  # surfels are laid out in the base camera's frustum
     if px_radius is None:
         px_radius = 4.0 * W / 1920.0 * 1.0
         px_radius = max(px_radius, 1.5)
     z = rng.uniform(z_near, z_far, P)
-    xv = rng.uniform(-1.1, 1.1, P) * cam["tanfovx"] * z
-    yv = rng.uniform(-1.1, 1.1, P) * cam["tanfovy"] * z
+    xv = rng.uniform(-1.1, 1.1, P) * cam0["tanfovx"] * z
+    yv = rng.uniform(-1.1, 1.1, P) * cam0["tanfovy"] * z
     pv = np.stack([xv, yv, z], 1)                                   # view space
     pw = (pv - t) @ Rcw                                             # world = R^T (p_view - t)
     s0 = px_radius * z / f                                          # world size for px_radius at depth z

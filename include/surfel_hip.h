@@ -1,0 +1,124 @@
+/*
+ * surfel_hip.h — C ABI of libsurfel_hip.so: the MI355X (gfx950) differentiable surfel rasterizer
+ * and the simple-knn initialisation kernel.
+ *
+ * This is the drop-in boundary for the hot path of hbb1/2d-gaussian-splatting.  The reference binds
+ * the same functionality through two pybind11 modules that are absent (un-vendored submodules,
+ * /root/reference/.gitmodules:1-6):
+ *     diff_surfel_rasterization._C : rasterize_gaussians / rasterize_gaussians_backward / mark_visible
+ *     simple_knn._C                : distCUDA2
+ * Their call sites in the reference are cited per function below.  Plain pointers and sizes only —
+ * no torch types; every pointer is a DEVICE pointer unless stated; `stream` is a hipStream_t passed
+ * as void* (NULL = default stream).  The library never calls hipMalloc: scratch memory is obtained
+ * through caller-supplied allocator callbacks (the reference's std::function<char*(size_t)> "resize"
+ * functors), so PyTorch's caching allocator owns all memory.
+ *
+ * Error convention: functions return a value >= 0 on success and a negative SURFEL_E_* code on
+ * failure; surfel_last_error() returns a thread-local message.  With debug == 1 every stage is
+ * followed by a stream synchronise + hipGetLastError (the reference's `debug` flag,
+ * /root/reference/gaussian_renderer/__init__.py:49); debug == 2 only records timing events.
+ */
+#ifndef SURFEL_HIP_H
+#define SURFEL_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SURFEL_ABI_VERSION 1
+
+#define SURFEL_E_INVALID (-1)   /* bad argument combination / null pointer */
+#define SURFEL_E_ALLOC   (-2)   /* allocator callback returned NULL */
+#define SURFEL_E_HIP     (-3)   /* a HIP call or kernel failed (message has the hipError string) */
+#define SURFEL_E_LIMIT   (-4)   /* size exceeds an internal limit (e.g. > 2^32-1 tile instances) */
+
+/* Allocator callback: return a device pointer to `bytes` bytes, 256-byte aligned, valid until the
+ * caller frees it.  Replaces the resize functors the reference's binding hands to the native
+ * rasterizer (geometry / binning / image buffers; SURVEY.md §8b "ownership"). */
+typedef void* (*surfel_alloc_fn)(void* user, size_t bytes);
+
+int surfel_abi_version(void);
+const char* surfel_last_error(void);
+
+/*
+ * Forward rasterisation.  Replaces `_C.rasterize_gaussians` (reference call site:
+ * /root/reference/gaussian_renderer/__init__.py:97-106 through GaussianRasterizer.forward).
+ *
+ *   P surfels, D active SH degree (0..3), M SH coefficients stored per surfel (16).
+ *   background[3]; means3D[P,3]; shs[P,M,3] or NULL; colors_precomp[P,3] or NULL (exactly one);
+ *   opacities[P]; scales[P,2] + rotations[P,4] (w,x,y,z)  or  transMat_precomp[P,9] (exactly one);
+ *   viewmatrix[16] = world_view_transform, projmatrix[16] = full_proj_transform, both as torch
+ *   stores them (transposed, /root/reference/scene/cameras.py:56-58); cam_pos[3].
+ * Outputs (caller-allocated): out_color[3,H,W], out_others[7,H,W] (channels: 0 sum w*depth, 1 alpha,
+ *   2-4 view-space normal, 5 median depth, 6 distortion — contract pinned by
+ *   /root/reference/gaussian_renderer/__init__.py:118-135), radii[P] (int32).
+ * The three opaque buffers obtained through the callbacks must be kept by the caller and handed to
+ * surfel_rasterize_backward unchanged.
+ * Returns num_rendered (number of (tile, surfel) instances, >= 0) or a negative error code.
+ */
+int64_t surfel_rasterize_forward(
+    surfel_alloc_fn geom_alloc, void* geom_user,
+    surfel_alloc_fn binning_alloc, void* binning_user,
+    surfel_alloc_fn image_alloc, void* image_user,
+    int P, int D, int M,
+    const float* background, int width, int height,
+    const float* means3D, const float* shs, const float* colors_precomp, const float* opacities,
+    const float* scales, float scale_modifier, const float* rotations, const float* transMat_precomp,
+    const float* viewmatrix, const float* projmatrix, const float* cam_pos,
+    float tan_fovx, float tan_fovy, int prefiltered,
+    float* out_color, float* out_others, int* radii,
+    int debug, void* stream);
+
+/*
+ * Backward.  Replaces `_C.rasterize_gaussians_backward` (reached from loss.backward(),
+ * /root/reference/train.py:90).  R = value returned by the matching forward; geom/binning/image
+ * buffers = the pointers the forward's callbacks returned.  dL_dout_color[3,H,W],
+ * dL_dout_others[7,H,W].  All dL_d* outputs are caller-allocated and MUST be zero-filled:
+ *   dL_dmeans2D[P,3] (densification statistic consumed at /root/reference/scene/gaussian_model.py:405-407),
+ *   dL_dnormal[P,3], dL_dopacity[P], dL_dcolors[P,3], dL_dmeans3D[P,3], dL_dtransMat[P,9],
+ *   dL_dsh[P,M,3], dL_dscales[P,2], dL_drots[P,4].
+ * `scratch_alloc` provides the per-instance gradient records (R * 80 bytes); gradients are
+ * accumulated without atomics, so results are bit-reproducible run to run.
+ */
+int surfel_rasterize_backward(
+    surfel_alloc_fn scratch_alloc, void* scratch_user,
+    int P, int D, int M, int64_t R,
+    const float* background, int width, int height,
+    const float* means3D, const float* shs, const float* colors_precomp,
+    const float* scales, float scale_modifier, const float* rotations, const float* transMat_precomp,
+    const float* viewmatrix, const float* projmatrix, const float* cam_pos,
+    float tan_fovx, float tan_fovy, const int* radii,
+    const void* geom_buffer, const void* binning_buffer, const void* image_buffer,
+    const float* dL_dout_color, const float* dL_dout_others,
+    float* dL_dmeans2D, float* dL_dnormal, float* dL_dopacity, float* dL_dcolors,
+    float* dL_dmeans3D, float* dL_dtransMat, float* dL_dsh, float* dL_dscales, float* dL_drots,
+    int debug, void* stream);
+
+/* Replaces `_C.mark_visible` (GaussianRasterizer.markVisible): present[P] (uint8) = view depth > 0.2. */
+int surfel_mark_visible(int P, const float* means3D, const float* viewmatrix, const float* projmatrix,
+                        uint8_t* present, void* stream);
+
+/*
+ * Replaces `simple_knn._C.distCUDA2` (/root/reference/scene/gaussian_model.py:20,134):
+ * mean_dist2[P] = mean squared distance of every point to its 3 nearest neighbours.
+ */
+int surfel_knn_dist2(surfel_alloc_fn scratch_alloc, void* scratch_user, int P, const float* points,
+                     float* mean_dist2, void* stream);
+
+/* Introspection used by tests / bench: per-stage device timings (ms) of the last forward / backward
+ * call made with debug != 0 on this thread; returns the number of stages written (<= cap). */
+int surfel_last_stage_ms(float* ms, int cap);
+int surfel_last_stage_ids(int* ids, int cap);
+/* debug == 2 ("profile"): stages are bracketed with HIP events on `stream` WITHOUT synchronising;
+ * this resolves every pending pair, adds the durations into sum_ms[stage] / count[stage]
+ * (arrays of `cap` >= 10 entries, indexed by stage id) and returns the number of stage ids. */
+int surfel_collect_stage_ms(float* sum_ms, int* count, int cap);
+const char* surfel_stage_name(int stage);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SURFEL_HIP_H */
