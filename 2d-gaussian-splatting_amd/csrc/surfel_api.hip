@@ -3,6 +3,7 @@
 // surfel_backward.hip and knn.hip.
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -104,7 +105,8 @@ struct ImgState {    // per-pixel / per-tile state ("imgBuffer")
 //   mode 2 (profile): record events only; durations are resolved later by surfel_collect_stage_ms()
 //                     so a timed region is not perturbed by host synchronisation.
 struct PendingStage { int stage; hipEvent_t e0, e1; };
-thread_local std::vector<PendingStage> g_pending;
+std::vector<PendingStage> g_pending;   // process-wide: autograd runs backward on its own thread
+std::mutex g_pending_mu;
 
 struct StageTimer {
     int mode; hipStream_t s; hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -119,7 +121,7 @@ struct StageTimer {
     int end(int stage) {   // returns hip error as int
         if (!mode) return 0;
         (void)hipEventRecord(e1, s);
-        if (mode == 2) { g_pending.push_back({stage, e0, e1}); return 0; }
+        if (mode == 2) { std::lock_guard<std::mutex> lk(g_pending_mu); g_pending.push_back({stage, e0, e1}); return 0; }
         hipError_t e = hipEventSynchronize(e1);
         if (e != hipSuccess) return (int)e;
         e = hipGetLastError();
@@ -167,6 +169,7 @@ int surfel_last_stage_ids(int* ids, int cap) {
 
 int surfel_collect_stage_ms(float* sum_ms, int* count, int cap) {
     for (int i = 0; i < cap; i++) { sum_ms[i] = 0.f; count[i] = 0; }
+    std::lock_guard<std::mutex> lk(g_pending_mu);
     for (auto& p : g_pending) {
         float ms = 0.f;
         if (hipEventSynchronize(p.e1) == hipSuccess && hipEventElapsedTime(&ms, p.e0, p.e1) == hipSuccess && p.stage < cap) {
@@ -190,13 +193,15 @@ int64_t surfel_rasterize_forward(surfel_alloc_fn geom_alloc, void* geom_user, su
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (!geom_alloc || !binning_alloc || !image_alloc) return fail(SURFEL_E_INVALID, "allocator callback is NULL");
     if (P < 0 || width <= 0 || height <= 0) return fail(SURFEL_E_INVALID, "bad sizes");
-    if ((shs == nullptr) == (colors_precomp == nullptr)) return fail(SURFEL_E_INVALID, "provide exactly one of shs / colors_precomp");
-    const bool has_sr = scales != nullptr && rotations != nullptr;
-    if (has_sr == (transMat_precomp != nullptr) || ((scales != nullptr) != (rotations != nullptr)))
-        return fail(SURFEL_E_INVALID, "provide exactly one of (scales, rotations) / transMat_precomp");
-    if (!background || !means3D || !opacities || !viewmatrix || !projmatrix || !cam_pos || !out_color || !out_others || !radii)
-        return fail(SURFEL_E_INVALID, "required pointer is NULL");
-    if (D < 0 || D > 3 || (shs && M < (D + 1) * (D + 1))) return fail(SURFEL_E_INVALID, "bad SH degree / coefficient count");
+    if (P > 0) {   // an empty scene (P == 0) renders the background; per-surfel pointers may then be NULL
+        if ((shs == nullptr) == (colors_precomp == nullptr)) return fail(SURFEL_E_INVALID, "provide exactly one of shs / colors_precomp");
+        const bool has_sr = scales != nullptr && rotations != nullptr;
+        if (has_sr == (transMat_precomp != nullptr) || ((scales != nullptr) != (rotations != nullptr)))
+            return fail(SURFEL_E_INVALID, "provide exactly one of (scales, rotations) / transMat_precomp");
+        if (!means3D || !opacities || !viewmatrix || !projmatrix || !cam_pos || !radii) return fail(SURFEL_E_INVALID, "required pointer is NULL");
+        if (D < 0 || D > 3 || (shs && M < (D + 1) * (D + 1))) return fail(SURFEL_E_INVALID, "bad SH degree / coefficient count");
+    }
+    if (!background || !out_color || !out_others) return fail(SURFEL_E_INVALID, "required pointer is NULL");
     const int gx = (width + TILE - 1) / TILE, gy = (height + TILE - 1) / TILE;
     if (gx > 1023 || gy > 1023) return fail(SURFEL_E_LIMIT, "image larger than 16368 px per side");
     const size_t HW = (size_t)width * height;
