@@ -45,6 +45,7 @@ __global__ void __launch_bounds__(BLOCK) blend_bwd_kernel(BlendBwdArgs a) {
     __shared__ float4 s_rec[BB * 5];
     __shared__ float s_acc[4][BB][NV];
     __shared__ unsigned long long s_mask[4];
+    __shared__ unsigned long long s_qmask[4];
     __shared__ int s_max;
     const int tile = xcd_tile(blockIdx.x, a.gx * a.gy);
     const int tx = tile % a.gx, ty = tile / a.gx;
@@ -92,16 +93,25 @@ __global__ void __launch_bounds__(BLOCK) blend_bwd_kernel(BlendBwdArgs a) {
     for (int hi = maxc; hi > 0; hi -= BB) {
         const int m = min(BB, hi);
         __syncthreads();                      // previous batch's flush has finished with s_rec / s_acc
-        if ((int)threadIdx.x < m) {
-            const uint32_t id = a.point_list[range.x + (hi - threadIdx.x) - 1];
-            const float4* __restrict__ src = reinterpret_cast<const float4*>(a.rec + (size_t)id * REC_F);
-            const float4 v0 = src[0], v1 = src[1], v2 = src[2], v3 = src[3], v4 = src[4];
-            s_rec[threadIdx.x * 5 + 0] = v0; s_rec[threadIdx.x * 5 + 1] = v1; s_rec[threadIdx.x * 5 + 2] = v2;
-            s_rec[threadIdx.x * 5 + 3] = v3; s_rec[threadIdx.x * 5 + 4] = v4;
+        if (wave == 0) {
+            unsigned ov = 0;
+            if (lane < m) {
+                const uint32_t id = a.point_list[range.x + (hi - lane) - 1];
+                const float4* __restrict__ src = reinterpret_cast<const float4*>(a.rec + (size_t)id * REC_F);
+                const float4 v0 = src[0], v1 = src[1], v2 = src[2], v3 = src[3], v4 = src[4], v5 = src[5];
+                s_rec[lane * 5 + 0] = v0; s_rec[lane * 5 + 1] = v1; s_rec[lane * 5 + 2] = v2;
+                s_rec[lane * 5 + 3] = v3; s_rec[lane * 5 + 4] = v4;
+                ov = quad_overlap(v5, tx * TILE, ty * TILE);
+            }
+            const unsigned long long b0 = __ballot(ov & 1u), b1 = __ballot(ov & 2u), b2 = __ballot(ov & 4u), b3 = __ballot(ov & 8u);
+            if (lane == 0) { s_qmask[0] = b0; s_qmask[1] = b1; s_qmask[2] = b2; s_qmask[3] = b3; }
         }
         __syncthreads();
         unsigned long long wmask = 0ull;
-        for (int j = 0; j < m; j++) {
+        unsigned long long qm = uniform_u64(s_qmask[wave]);
+        while (qm) {
+            const int j = __builtin_ctzll(qm);
+            qm &= qm - 1;
             const int pos = hi - j;           // 1-based position in the tile's list
             float gv[NV];
 #pragma unroll

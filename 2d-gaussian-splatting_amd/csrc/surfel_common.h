@@ -20,14 +20,16 @@ constexpr float ALPHA_MIN = 1.0f / 255.0f;
 constexpr float ALPHA_MAX = 0.99f;
 constexpr float T_EPS = 0.0001f;
 
-// Per-surfel packed record, 80 B = 5 x float4, written by preprocess, gathered by the blend kernels.
-// One record touches at most two 128-B lines (vs. six separate arrays in an SoA layout).
+// Per-surfel packed record, 96 B = 6 x float4, written by preprocess, gathered by the blend kernels.
+// One record touches at most two 128-B lines (vs. seven separate arrays in an SoA layout).
 //   q0 = Tu.x Tu.y Tu.z Tv.x
 //   q1 = Tv.y Tv.z Tw.x Tw.y
 //   q2 = Tw.z xy.x xy.y opacity
 //   q3 = n.x  n.y  n.z  r
 //   q4 = g    b    inst_base(u32 bits)  rect(u32 bits: x0 | y0<<10 | w<<20)
-constexpr int REC_F = 20;
+//   q5 = xmin xmax ymin ymax : conservative pixel bbox of {alpha >= 1/255} (cull only, never changes results)
+constexpr int REC_F = 24;
+constexpr int REC_Q = REC_F / 4;
 // Per-(tile,surfel) gradient record written by blend-backward, summed by preprocess-backward:
 //   [0..8] dL/dT (Tu,Tv,Tw)  [9..10] dL/dxy (low-pass branch)  [11..13] dL/dnormal  [14] dL/dopacity
 //   [15..17] dL/drgb  [18..19] pad
@@ -51,6 +53,20 @@ __device__ __forceinline__ int xcd_tile(int b, int n) {
     const int q = n >> 3, r = n & 7;
     const int xcd = b & 7, i = b >> 3;
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + i;
+}
+
+// Which of the tile's four 8x8 quads (= waves) can a surfel with pixel bbox (xmin,xmax,ymin,ymax) touch?
+__device__ __forceinline__ unsigned quad_overlap(const float4 bb, int tile_x0, int tile_y0) {
+    const float x0 = (float)tile_x0, y0 = (float)tile_y0;
+    const bool xl = bb.x <= x0 + 7.f && bb.y >= x0, xr = bb.x <= x0 + 15.f && bb.y >= x0 + 8.f;
+    const bool yt = bb.z <= y0 + 7.f && bb.w >= y0, yb = bb.z <= y0 + 15.f && bb.w >= y0 + 8.f;
+    return (xl && yt ? 1u : 0u) | (xr && yt ? 2u : 0u) | (xl && yb ? 4u : 0u) | (xr && yb ? 8u : 0u);
+}
+
+__device__ __forceinline__ unsigned long long uniform_u64(unsigned long long v) {
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v);
+    const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return ((unsigned long long)hi << 32) | lo;
 }
 
 // pixel owned by a thread: wave w -> 8x8 quad (w&1, w>>1); lane -> (lane&7, lane>>3)

@@ -143,6 +143,37 @@ __global__ void __launch_bounds__(256) preprocess_fwd_kernel(PreprocessArgs a) {
         } else {
             r = a.colors_precomp[3 * (size_t)i]; g = a.colors_precomp[3 * (size_t)i + 1]; b = a.colors_precomp[3 * (size_t)i + 2];
         }
+        // Conservative pixel bbox of the region where this surfel can reach alpha >= 1/255:
+        //   alpha = min(.99, o*exp(-rho/2)) >= 1/255  =>  rho = min(rho3d, rho2d) <= rmax = 2 ln(255 o)
+        //   {rho2d <= rmax}: disc of radius sqrt(rmax/2) about (cx,cy);  {rho3d <= rmax}: the projected
+        //   sqrt(rmax)-sigma ellipse, bounded by the same AABB formula as above with cutoff^2 = rmax.
+        // Inflated for fp32 cancellation; unbounded (whole image) when the ellipse meets the camera plane.
+        float bx0 = 1.f, bx1 = 0.f, by0 = 1.f, by1 = 0.f;       // empty
+        {
+            const float opa = a.opacities[i];
+            if (opa * 255.f >= 0.999f) {
+                const float rmax = 2.f * __logf(fmaxf(opa * 255.f, 1.f)) * 1.0001f + 1e-3f;
+                const float r2 = sqrtf(0.5f * rmax) + 0.05f;
+                bx0 = cx - r2; bx1 = cx + r2; by0 = cy - r2; by1 = cy + r2;
+                const float tw2 = T[8] * T[8];
+                const float dc = rmax * (T[6] * T[6] + T[7] * T[7]) - tw2;
+                if (dc < -1e-3f * tw2) {
+                    const float g0 = rmax / dc, g2 = -1.f / dc;
+                    const float ccx = g0 * T[0] * T[6] + g0 * T[1] * T[7] + g2 * T[2] * T[8];
+                    const float ccy = g0 * T[3] * T[6] + g0 * T[4] * T[7] + g2 * T[5] * T[8];
+                    const float sxx = g0 * T[0] * T[0] + g0 * T[1] * T[1] + g2 * T[2] * T[2];
+                    const float syy = g0 * T[3] * T[3] + g0 * T[4] * T[4] + g2 * T[5] * T[5];
+                    const float ehx = sqrtf(fmaxf(ccx * ccx - sxx, 0.f) + 2e-6f * (ccx * ccx + fabsf(sxx)));
+                    const float ehy = sqrtf(fmaxf(ccy * ccy - syy, 0.f) + 2e-6f * (ccy * ccy + fabsf(syy)));
+                    const float mx = ehx * 1.001f + 1e-4f * fabsf(ccx) + 0.3f, my = ehy * 1.001f + 1e-4f * fabsf(ccy) + 0.3f;
+                    bx0 = fminf(bx0, ccx - mx); bx1 = fmaxf(bx1, ccx + mx);
+                    by0 = fminf(by0, ccy - my); by1 = fmaxf(by1, ccy + my);
+                    if (!(ehx == ehx) || !(ehy == ehy) || !(ccx == ccx) || !(ccy == ccy)) { bx0 = by0 = -3.0e38f; bx1 = by1 = 3.0e38f; }
+                } else {
+                    bx0 = by0 = -3.0e38f; bx1 = by1 = 3.0e38f;
+                }
+            }
+        }
         float4* __restrict__ rec = reinterpret_cast<float4*>(a.rec + (size_t)i * REC_F);
         rec[0] = make_float4(T[0], T[1], T[2], T[3]);
         rec[1] = make_float4(T[4], T[5], T[6], T[7]);
@@ -150,6 +181,7 @@ __global__ void __launch_bounds__(256) preprocess_fwd_kernel(PreprocessArgs a) {
         rec[3] = make_float4(nx, ny, nz, r);
         const uint32_t rectbits = (uint32_t)rc.x0 | ((uint32_t)rc.y0 << 10) | ((uint32_t)(rc.x1 - rc.x0) << 20);
         rec[4] = make_float4(g, b, 0.f /* inst_base patched by emit_instances */, __uint_as_float(rectbits));
+        rec[5] = make_float4(bx0, bx1, by0, by1);
         a.depths[i] = vz;
         a.clamped[i] = clampbits;
         rad_out = irad;
@@ -208,10 +240,12 @@ __global__ void __launch_bounds__(256) tile_ranges_kernel(int64_t R, const uint6
 // ---------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(BLOCK) blend_fwd_kernel(BlendFwdArgs a) {
     __shared__ float4 s_rec[BLOCK * 5];
+    __shared__ unsigned long long s_qmask[4][4];     // [consumer quad][staging wave]
     const int tile = xcd_tile(blockIdx.x, a.gx * a.gy);
     const int tx = tile % a.gx, ty = tile / a.gx;
     int lx, ly;
     thread_pixel(threadIdx.x, lx, ly);
+    const int wave = threadIdx.x >> 6;
     const int pxi = tx * TILE + lx, pyi = ty * TILE + ly;
     const bool inside = pxi < a.W && pyi < a.H;
     const float pxf = (float)pxi, pyf = (float)pyi;
@@ -221,41 +255,55 @@ __global__ void __launch_bounds__(BLOCK) blend_fwd_kernel(BlendFwdArgs a) {
     bool done = !inside;
     float T = 1.f, C0 = 0.f, C1 = 0.f, C2 = 0.f, N0 = 0.f, N1 = 0.f, N2 = 0.f;
     float D = 0.f, M1 = 0.f, M2 = 0.f, dist = 0.f, med = 0.f;
-    uint32_t contributor = 0, last = 0, medc = 0;
+    uint32_t last = 0, medc = 0;
 
     for (int base = 0; base < n; base += BLOCK) {
         if (__syncthreads_count(done) == BLOCK) break;
         const int m = min(BLOCK, n - base);
+        unsigned ov = 0;
         if ((int)threadIdx.x < m) {
             const uint32_t id = a.point_list[range.x + base + threadIdx.x];
             const float4* __restrict__ src = reinterpret_cast<const float4*>(a.rec + (size_t)id * REC_F);
-            const float4 v0 = src[0], v1 = src[1], v2 = src[2], v3 = src[3], v4 = src[4];
+            const float4 v0 = src[0], v1 = src[1], v2 = src[2], v3 = src[3], v4 = src[4], v5 = src[5];
             s_rec[threadIdx.x * 5 + 0] = v0; s_rec[threadIdx.x * 5 + 1] = v1; s_rec[threadIdx.x * 5 + 2] = v2;
             s_rec[threadIdx.x * 5 + 3] = v3; s_rec[threadIdx.x * 5 + 4] = v4;
+            ov = quad_overlap(v5, tx * TILE, ty * TILE);
+        }
+        // per-quad bitmasks of the instances this staging wave holds: the consumer waves then walk set
+        // bits only (scalar s_ff1 loop) — culled instances cost nothing.
+        {
+            const unsigned long long b0 = __ballot(ov & 1u), b1 = __ballot(ov & 2u), b2 = __ballot(ov & 4u), b3 = __ballot(ov & 8u);
+            if ((threadIdx.x & 63) == 0) { s_qmask[0][wave] = b0; s_qmask[1][wave] = b1; s_qmask[2][wave] = b2; s_qmask[3][wave] = b3; }
         }
         __syncthreads();
         if (!__all(done)) {
-            for (int j = 0; j < m; j++) {
-                if (done) break;   // lanes finish independently
-                contributor = base + j + 1;
-                const float4 q0 = s_rec[j * 5 + 0], q1 = s_rec[j * 5 + 1], q2 = s_rec[j * 5 + 2];
-                Hit h;
-                if (!intersect(q0, q1, q2, pxf, pyf, h)) continue;
-                const float testT = T * (1.f - h.alpha);
-                if (testT < T_EPS) { done = true; continue; }
-                const float4 q3 = s_rec[j * 5 + 3], q4 = s_rec[j * 5 + 4];
-                const float w = h.alpha * T;
-                const float A = 1.f - T;
-                const float mm = FAR_N / (FAR_N - NEAR_N) * (1.f - NEAR_N / h.depth);
-                dist += (mm * mm * A + M2 - 2.f * mm * M1) * w;
-                D += h.depth * w;
-                M1 += mm * w;
-                M2 += mm * mm * w;
-                if (T > 0.5f) { med = h.depth; medc = contributor; }
-                N0 += q3.x * w; N1 += q3.y * w; N2 += q3.z * w;
-                C0 += q3.w * w; C1 += q4.x * w; C2 += q4.y * w;
-                T = testT;
-                last = contributor;
+            for (int sw = 0; sw < 4; sw++) {
+                unsigned long long mask = uniform_u64(s_qmask[wave][sw]);
+                while (mask) {
+                    const int j = sw * 64 + __builtin_ctzll(mask);
+                    mask &= mask - 1;
+                    if (done) continue;
+                    const uint32_t contributor = base + j + 1;
+                    const float4 q0 = s_rec[j * 5 + 0], q1 = s_rec[j * 5 + 1], q2 = s_rec[j * 5 + 2];
+                    Hit h;
+                    if (!intersect(q0, q1, q2, pxf, pyf, h)) continue;
+                    const float testT = T * (1.f - h.alpha);
+                    if (testT < T_EPS) { done = true; continue; }
+                    const float4 q3 = s_rec[j * 5 + 3], q4 = s_rec[j * 5 + 4];
+                    const float w = h.alpha * T;
+                    const float A = 1.f - T;
+                    const float mm = FAR_N / (FAR_N - NEAR_N) * (1.f - NEAR_N / h.depth);
+                    dist += (mm * mm * A + M2 - 2.f * mm * M1) * w;
+                    D += h.depth * w;
+                    M1 += mm * w;
+                    M2 += mm * mm * w;
+                    if (T > 0.5f) { med = h.depth; medc = contributor; }
+                    N0 += q3.x * w; N1 += q3.y * w; N2 += q3.z * w;
+                    C0 += q3.w * w; C1 += q4.x * w; C2 += q4.y * w;
+                    T = testT;
+                    last = contributor;
+                }
+                if (__all(done)) break;
             }
         }
     }
