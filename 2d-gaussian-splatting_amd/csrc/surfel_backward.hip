@@ -19,33 +19,55 @@ __device__ __constant__ float BSH_C3[7] = {-0.5900435899266435f, 2.8906114426405
                                            0.3731763325901154f, -0.4570457994644658f, 1.445305721320277f,
                                            -0.5900435899266435f};
 
-// wave64 sum with DPP-fused adds; the total is valid in lane 63.
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ float dpp_add(float v) {
-    const int moved = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xf, false);
-    return v + __int_as_float(moved);
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+
+// v + (v rotated right by N lanes inside each 16-lane row): fuses into one v_add_f32_dpp.
+template <int CTRL>
+__device__ __forceinline__ float row_ror_add(float v) {
+    return v + __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), CTRL, 0xf, 0xf, true));
 }
-__device__ __forceinline__ float wave_sum_to_lane63(float v) {
-    v = dpp_add<0x111, 0xf>(v);   // row_shr:1
-    v = dpp_add<0x112, 0xf>(v);   // row_shr:2
-    v = dpp_add<0x114, 0xf>(v);   // row_shr:4   (lane 15 of each row: sum of lanes 8..15 pairs ...)
-    v = dpp_add<0x118, 0xf>(v);   // row_shr:8   -> lane 15 of every row holds the row total
-    v = dpp_add<0x142, 0xa>(v);   // row_bcast:15 into rows 1,3
-    v = dpp_add<0x143, 0xc>(v);   // row_bcast:31 into rows 2,3 -> lane 63 holds the wave total
-    return v;
+// a,b -> [a.lo+a.hi | b.lo+b.hi] over the two 32-lane halves (v_permlane32_swap + add)
+__device__ __forceinline__ float fold32(float a, float b) {
+    const u32x2 r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    return __uint_as_float(r.x) + __uint_as_float(r.y);
+}
+// x=[x0 x1 x2 x3], y=[y0 y1 y2 y3] (16-lane rows) -> [x0+x1, y0+y1, x2+x3, y2+y3] (v_permlane16_swap + add)
+__device__ __forceinline__ float fold16(float x, float y) {
+    const u32x2 r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(y), false, false);
+    return __uint_as_float(r.x) + __uint_as_float(r.y);
 }
 
-constexpr int BB = 64;    // instances staged per batch in the backward
+constexpr int BS = 256;   // instances staged per outer batch (one 80-B gather per thread)
+constexpr int BB = 64;    // instances per accumulate/flush sub-batch
 constexpr int NV = 18;    // gradient values per instance
+constexpr int NVP = 20;   // padded to 5 registers x 4 rows for the wave reduction
+
+// Wave-wide sum of 20 per-lane values in 50 instructions (vs 6 DPP adds per value = 120):
+//   10 x fold32 -> 10 regs, 5 x fold16 -> 5 regs, 5 x 4 row_ror adds.  Afterwards register j holds,
+//   in every lane of row q (= lane>>4), the total of value 4j + {0,2,1,3}[q].
+__device__ __forceinline__ void wave_reduce20(const float (&v)[NVP], float (&z)[5]) {
+    float x[10];
+#pragma unroll
+    for (int i = 0; i < 10; i++) x[i] = fold32(v[2 * i], v[2 * i + 1]);
+#pragma unroll
+    for (int j = 0; j < 5; j++) {
+        float t = fold16(x[2 * j], x[2 * j + 1]);
+        t = row_ror_add<0x128>(t);
+        t = row_ror_add<0x124>(t);
+        t = row_ror_add<0x122>(t);
+        t = row_ror_add<0x121>(t);
+        z[j] = t;
+    }
+}
 
 // ---------------------------------------------------------------------------------------------
 // blend_bwd
 // ---------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(BLOCK) blend_bwd_kernel(BlendBwdArgs a) {
-    __shared__ float4 s_rec[BB * 5];
-    __shared__ float s_acc[4][BB][NV];
-    __shared__ unsigned long long s_mask[4];
-    __shared__ unsigned long long s_qmask[4];
+    __shared__ float4 s_rec[BS * 5];                 // 20 KB
+    __shared__ float s_acc[4][BB][NVP];              // 20 KB: per-wave partial sums of the current sub-batch
+    __shared__ unsigned long long s_mask[4];         // which sub-batch slots each wave wrote
+    __shared__ unsigned long long s_qmask[4][4];     // [quad][staging wave] overlap bitmasks of the staged batch
     __shared__ int s_max;
     const int tile = xcd_tile(blockIdx.x, a.gx * a.gy);
     const int tx = tile % a.gx, ty = tile / a.gx;
@@ -71,7 +93,7 @@ __global__ void __launch_bounds__(BLOCK) blend_bwd_kernel(BlendBwdArgs a) {
         g_med = a.dL_dothers[5 * HW + pix]; g_dist = a.dL_dothers[6 * HW + pix];
     }
     const float final_A = 1.f - T_final;
-    const float bg_dot = a.bg[0] * gC0 + a.bg[1] * gC1 + a.bg[2] * gC2;
+    const float bgT = -T_final * (a.bg[0] * gC0 + a.bg[1] * gC1 + a.bg[2] * gC2);
 
     if (threadIdx.x == 0) s_max = 0;
     __syncthreads();
@@ -89,131 +111,147 @@ __global__ void __launch_bounds__(BLOCK) blend_bwd_kernel(BlendBwdArgs a) {
     float last_depth = 0.f, accum_depth = 0.f, accum_alpha = 0.f;
     float ln0 = 0.f, ln1 = 0.f, ln2 = 0.f, an0 = 0.f, an1 = 0.f, an2 = 0.f;
     float last_dL_dT = 0.f;
+    constexpr float MC1 = FAR_N / (FAR_N - NEAR_N), MC2 = (FAR_N * NEAR_N) / (FAR_N - NEAR_N);
+    // LDS slot address pattern of the reduced values: lane (row q, first lane) stores value 4j + {0,2,1,3}[q]
+    const int row = lane >> 4;
+    const int vslot = ((row & 1) << 1) | (row >> 1);
+    const bool writer = (lane & 15) == 0;
 
-    for (int hi = maxc; hi > 0; hi -= BB) {
-        const int m = min(BB, hi);
-        __syncthreads();                      // previous batch's flush has finished with s_rec / s_acc
-        if (wave == 0) {
+    for (int hi = maxc; hi > 0; hi -= BS) {
+        const int mb = min(BS, hi);
+        __syncthreads();                      // previous batch fully flushed
+        {
             unsigned ov = 0;
-            if (lane < m) {
-                const uint32_t id = a.point_list[range.x + (hi - lane) - 1];
+            if ((int)threadIdx.x < mb) {
+                const uint32_t id = a.point_list[range.x + (hi - threadIdx.x) - 1];
                 const float4* __restrict__ src = reinterpret_cast<const float4*>(a.rec + (size_t)id * REC_F);
                 const float4 v0 = src[0], v1 = src[1], v2 = src[2], v3 = src[3], v4 = src[4], v5 = src[5];
-                s_rec[lane * 5 + 0] = v0; s_rec[lane * 5 + 1] = v1; s_rec[lane * 5 + 2] = v2;
-                s_rec[lane * 5 + 3] = v3; s_rec[lane * 5 + 4] = v4;
+                s_rec[threadIdx.x * 5 + 0] = v0; s_rec[threadIdx.x * 5 + 1] = v1; s_rec[threadIdx.x * 5 + 2] = v2;
+                s_rec[threadIdx.x * 5 + 3] = v3; s_rec[threadIdx.x * 5 + 4] = v4;
                 ov = quad_overlap(v5, tx * TILE, ty * TILE);
             }
             const unsigned long long b0 = __ballot(ov & 1u), b1 = __ballot(ov & 2u), b2 = __ballot(ov & 4u), b3 = __ballot(ov & 8u);
-            if (lane == 0) { s_qmask[0] = b0; s_qmask[1] = b1; s_qmask[2] = b2; s_qmask[3] = b3; }
+            if (lane == 0) { s_qmask[0][wave] = b0; s_qmask[1][wave] = b1; s_qmask[2][wave] = b2; s_qmask[3][wave] = b3; }
         }
         __syncthreads();
-        unsigned long long wmask = 0ull;
-        unsigned long long qm = uniform_u64(s_qmask[wave]);
-        while (qm) {
-            const int j = __builtin_ctzll(qm);
-            qm &= qm - 1;
-            const int pos = hi - j;           // 1-based position in the tile's list
-            float gv[NV];
-#pragma unroll
-            for (int q = 0; q < NV; q++) gv[q] = 0.f;
-            bool contrib = false;
-            if (pos <= last) {
+        for (int sb = 0; sb * BB < mb; sb++) {        // sub-batch sb = staged instances [64 sb, 64 sb + 64)
+            unsigned long long wmask = 0ull;
+            unsigned long long qm = uniform_u64(s_qmask[wave][sb]);
+            while (qm) {
+                const int jj = __builtin_ctzll(qm);
+                qm &= qm - 1;
+                const int j = sb * BB + jj;
+                const int pos = hi - j;           // 1-based position in the tile's list
                 const float4 q0 = s_rec[j * 5 + 0], q1 = s_rec[j * 5 + 1], q2 = s_rec[j * 5 + 2];
-                Hit h;
-                if (intersect(q0, q1, q2, pxf, pyf, h)) {
-                    contrib = true;
+                // ---- ray-splat intersection, branch-free
+                const float Tux = q0.x, Tuy = q0.y, Tuz = q0.z, Tvx = q0.w, Tvy = q1.x, Tvz = q1.y;
+                const float Twx = q1.z, Twy = q1.w, Twz = q2.x, opa = q2.w;
+                const float kx = pxf * Twx - Tux, ky = pxf * Twy - Tuy, kz = pxf * Twz - Tuz;
+                const float lx_ = pyf * Twx - Tvx, ly_ = pyf * Twy - Tvy, lz_ = pyf * Twz - Tvz;
+                const float p0 = ky * lz_ - kz * ly_, p1 = kz * lx_ - kx * lz_, p2 = kx * ly_ - ky * lx_;
+                const float ip = __builtin_amdgcn_rcpf(p2);
+                const float sx = p0 * ip, sy = p1 * ip;
+                const float rho3d = sx * sx + sy * sy;
+                const float dx = q2.y - pxf, dy = q2.z - pyf;
+                const float rho2d = FILTER_INV_SQUARE * (dx * dx + dy * dy);
+                const bool use3d = rho3d <= rho2d;
+                const float rho = fminf(rho3d, rho2d);
+                const float depth = use3d ? (sx * Twx + sy * Twy) + Twz : Twz;
+                const float G = __expf(-0.5f * rho);
+                const float alpha = fminf(ALPHA_MAX, opa * G);
+                const bool ok = (pos <= last) & (p2 != 0.f) & (depth >= NEAR_N) & (alpha >= ALPHA_MIN);
+                if (__ballot(ok) == 0ull) continue;      // wave-uniform
+                float gv[NVP];
+#pragma unroll
+                for (int q = 0; q < NVP; q++) gv[q] = 0.f;
+                if (ok) {
                     const float4 q3 = s_rec[j * 5 + 3], q4 = s_rec[j * 5 + 4];
-                    const float alpha = h.alpha, G = h.G, opa = q2.w;
-                    const float Twx = q1.z, Twy = q1.w;
-                    T = T / (1.f - alpha);
+                    const float i1a = __builtin_amdgcn_rcpf(1.f - alpha);
+                    T = T * i1a;
                     const float w = alpha * T;
-                    float dL_dalpha = 0.f;
+                    const float om = 1.f - last_alpha;
+                    float dL_dalpha;
                     // colour
-                    ar0 = last_alpha * lc0 + (1.f - last_alpha) * ar0; lc0 = q3.w; dL_dalpha += (q3.w - ar0) * gC0;
-                    ar1 = last_alpha * lc1 + (1.f - last_alpha) * ar1; lc1 = q4.x; dL_dalpha += (q4.x - ar1) * gC1;
-                    ar2 = last_alpha * lc2 + (1.f - last_alpha) * ar2; lc2 = q4.y; dL_dalpha += (q4.y - ar2) * gC2;
+                    ar0 = last_alpha * lc0 + om * ar0; lc0 = q3.w; dL_dalpha = (q3.w - ar0) * gC0;
+                    ar1 = last_alpha * lc1 + om * ar1; lc1 = q4.x; dL_dalpha += (q4.x - ar1) * gC1;
+                    ar2 = last_alpha * lc2 + om * ar2; lc2 = q4.y; dL_dalpha += (q4.y - ar2) * gC2;
                     gv[15] = w * gC0; gv[16] = w * gC1; gv[17] = w * gC2;
-                    // distortion / depth / alpha / normal
-                    float dL_dz = 0.f;
-                    const float inv_d = __builtin_amdgcn_rcpf(h.depth);
-                    const float mm = FAR_N / (FAR_N - NEAR_N) * (1.f - NEAR_N * inv_d);
-                    const float dm_dd = (FAR_N * NEAR_N) / (FAR_N - NEAR_N) * inv_d * inv_d;
-                    if (pos == medc) dL_dz += g_med;
-                    const float dL_dweight = (fM2 + mm * mm * final_A - 2.f * mm * fM1) * g_dist;
+                    // distortion
+                    const float inv_d = __builtin_amdgcn_rcpf(depth);
+                    const float mm = MC1 - (MC1 * NEAR_N) * inv_d;
+                    const float dm_dd = MC2 * inv_d * inv_d;
+                    const float dL_dweight = (fM2 + mm * (mm * final_A - 2.f * fM1)) * g_dist;
                     dL_dalpha += dL_dweight - last_dL_dT;
                     last_dL_dT = dL_dweight * alpha + (1.f - alpha) * last_dL_dT;
-                    dL_dz += 2.f * w * (mm * final_A - fM1) * g_dist * dm_dd;
-                    accum_depth = last_alpha * last_depth + (1.f - last_alpha) * accum_depth;
-                    last_depth = h.depth;
-                    dL_dalpha += (h.depth - accum_depth) * g_depth;
-                    accum_alpha = last_alpha + (1.f - last_alpha) * accum_alpha;
+                    float dL_dz = (2.f * w * g_dist) * (mm * final_A - fM1) * dm_dd + w * g_depth;
+                    dL_dz += (pos == medc) ? g_med : 0.f;
+                    // depth / alpha
+                    accum_depth = last_alpha * last_depth + om * accum_depth; last_depth = depth;
+                    dL_dalpha += (depth - accum_depth) * g_depth;
+                    accum_alpha = last_alpha + om * accum_alpha;
                     dL_dalpha += (1.f - accum_alpha) * g_alpha;
-                    an0 = last_alpha * ln0 + (1.f - last_alpha) * an0; ln0 = q3.x; dL_dalpha += (q3.x - an0) * gN0;
-                    an1 = last_alpha * ln1 + (1.f - last_alpha) * an1; ln1 = q3.y; dL_dalpha += (q3.y - an1) * gN1;
-                    an2 = last_alpha * ln2 + (1.f - last_alpha) * an2; ln2 = q3.z; dL_dalpha += (q3.z - an2) * gN2;
+                    // normals
+                    an0 = last_alpha * ln0 + om * an0; ln0 = q3.x; dL_dalpha += (q3.x - an0) * gN0;
+                    an1 = last_alpha * ln1 + om * an1; ln1 = q3.y; dL_dalpha += (q3.y - an1) * gN1;
+                    an2 = last_alpha * ln2 + om * an2; ln2 = q3.z; dL_dalpha += (q3.z - an2) * gN2;
                     gv[11] = w * gN0; gv[12] = w * gN1; gv[13] = w * gN2;
-                    dL_dalpha *= T;
+                    dL_dalpha = dL_dalpha * T + bgT * i1a;
                     last_alpha = alpha;
-                    dL_dalpha += (-T_final / (1.f - alpha)) * bg_dot;
                     const float dL_dG = opa * dL_dalpha;       // 0.99 clamp is pass-through
-                    dL_dz += w * g_depth;
-                    if (h.use3d) {
-                        const float dsx = dL_dG * -G * h.sx + dL_dz * Twx;
-                        const float dsy = dL_dG * -G * h.sy + dL_dz * Twy;
-                        const float ipz = __builtin_amdgcn_rcpf(h.pz);
-                        const float ax = dsx * ipz, ay = dsy * ipz;
-                        const float dp0 = ax, dp1 = ay, dp2 = -(ax * h.sx + ay * h.sy);
-                        const float dk0 = h.ly * dp2 - h.lz * dp1, dk1 = h.lz * dp0 - h.lx * dp2, dk2 = h.lx * dp1 - h.ly * dp0;
-                        const float dl0 = dp1 * h.kz - dp2 * h.ky, dl1 = dp2 * h.kx - dp0 * h.kz, dl2 = dp0 * h.ky - dp1 * h.kx;
-                        gv[0] = -dk0; gv[1] = -dk1; gv[2] = -dk2;
-                        gv[3] = -dl0; gv[4] = -dl1; gv[5] = -dl2;
-                        gv[6] = pxf * dk0 + pyf * dl0 + dL_dz * h.sx;
-                        gv[7] = pxf * dk1 + pyf * dl1 + dL_dz * h.sy;
-                        gv[8] = pxf * dk2 + pyf * dl2 + dL_dz;
-                    } else {
-                        gv[9] = dL_dG * (-G * FILTER_INV_SQUARE * h.dx);
-                        gv[10] = dL_dG * (-G * FILTER_INV_SQUARE * h.dy);
-                        gv[8] = dL_dz;
-                    }
                     gv[14] = G * dL_dalpha;
+                    // geometry: 3-D branch -> homography, low-pass branch -> centre (+ Tw.z for depth)
+                    const float nGG = -G * dL_dG;
+                    const float dz3 = use3d ? dL_dz : 0.f;
+                    const float g3 = use3d ? nGG : 0.f;
+                    const float dsx = g3 * sx + dz3 * Twx, dsy = g3 * sy + dz3 * Twy;
+                    const float ax = dsx * ip, ay = dsy * ip;
+                    const float dp2 = -(ax * sx + ay * sy);
+                    const float dk0 = ly_ * dp2 - lz_ * ay, dk1 = lz_ * ax - lx_ * dp2, dk2 = lx_ * ay - ly_ * ax;
+                    const float dl0 = ay * kz - dp2 * ky, dl1 = dp2 * kx - ax * kz, dl2 = ax * ky - ay * kx;
+                    gv[0] = -dk0; gv[1] = -dk1; gv[2] = -dk2;
+                    gv[3] = -dl0; gv[4] = -dl1; gv[5] = -dl2;
+                    gv[6] = pxf * dk0 + pyf * dl0 + dz3 * sx;
+                    gv[7] = pxf * dk1 + pyf * dl1 + dz3 * sy;
+                    gv[8] = pxf * dk2 + pyf * dl2 + dL_dz;
+                    const float g2 = use3d ? 0.f : nGG * FILTER_INV_SQUARE;
+                    gv[9] = g2 * dx; gv[10] = g2 * dy;
+                }
+                float z[5];
+                wave_reduce20(gv, z);
+                if (writer) {
+#pragma unroll
+                    for (int q = 0; q < 5; q++) s_acc[wave][jj][4 * q + vslot] = z[q];
+                }
+                wmask |= 1ull << jj;
+            }
+            if (lane == 0) s_mask[wave] = wmask;
+            __syncthreads();
+            // flush: one thread per sub-batch instance sums the four wave partials in fixed order
+            if ((int)threadIdx.x < BB) {
+                const int jj = threadIdx.x;
+                const unsigned long long bit = 1ull << jj;
+                const bool h0 = s_mask[0] & bit, h1 = s_mask[1] & bit, h2 = s_mask[2] & bit, h3 = s_mask[3] & bit;
+                if (h0 | h1 | h2 | h3) {
+                    float4 out[5];
+#pragma unroll
+                    for (int q = 0; q < 5; q++) {
+                        float4 sacc = make_float4(0.f, 0.f, 0.f, 0.f);
+                        if (h0) { const float4 t4 = *reinterpret_cast<const float4*>(&s_acc[0][jj][4 * q]); sacc.x += t4.x; sacc.y += t4.y; sacc.z += t4.z; sacc.w += t4.w; }
+                        if (h1) { const float4 t4 = *reinterpret_cast<const float4*>(&s_acc[1][jj][4 * q]); sacc.x += t4.x; sacc.y += t4.y; sacc.z += t4.z; sacc.w += t4.w; }
+                        if (h2) { const float4 t4 = *reinterpret_cast<const float4*>(&s_acc[2][jj][4 * q]); sacc.x += t4.x; sacc.y += t4.y; sacc.z += t4.z; sacc.w += t4.w; }
+                        if (h3) { const float4 t4 = *reinterpret_cast<const float4*>(&s_acc[3][jj][4 * q]); sacc.x += t4.x; sacc.y += t4.y; sacc.z += t4.z; sacc.w += t4.w; }
+                        out[q] = sacc;
+                    }
+                    const float4 q4 = s_rec[(sb * BB + jj) * 5 + 4];
+                    const uint32_t basei = __float_as_uint(q4.z), rectbits = __float_as_uint(q4.w);
+                    const int x0 = rectbits & 1023, y0 = (rectbits >> 10) & 1023, rw = rectbits >> 20;
+                    const size_t dest = (size_t)basei + (size_t)((ty - y0) * rw + (tx - x0));
+                    float4* __restrict__ dst = reinterpret_cast<float4*>(a.grec + dest * GREC_F);
+#pragma unroll
+                    for (int q = 0; q < 5; q++) dst[q] = out[q];
                 }
             }
-            if (__ballot(contrib) == 0ull) continue;      // wave-uniform: nobody in this 8x8 quad touched it
-#pragma unroll
-            for (int q = 0; q < NV; q++) gv[q] = wave_sum_to_lane63(gv[q]);
-            if (lane == 63) {
-#pragma unroll
-                for (int q = 0; q < NV; q++) s_acc[wave][j][q] = gv[q];
-            }
-            wmask |= 1ull << j;
-        }
-        if (lane == 0) s_mask[wave] = wmask;
-        __syncthreads();
-        // flush: one thread per staged instance sums the four wave partials in fixed order
-        if ((int)threadIdx.x < m) {
-            const int j = threadIdx.x;
-            const unsigned long long bit = 1ull << j;
-            const bool h0 = s_mask[0] & bit, h1 = s_mask[1] & bit, h2 = s_mask[2] & bit, h3 = s_mask[3] & bit;
-            if (h0 | h1 | h2 | h3) {
-                float out[GREC_F];
-#pragma unroll
-                for (int q = 0; q < NV; q++) {
-                    float sacc = 0.f;
-                    if (h0) sacc += s_acc[0][j][q];
-                    if (h1) sacc += s_acc[1][j][q];
-                    if (h2) sacc += s_acc[2][j][q];
-                    if (h3) sacc += s_acc[3][j][q];
-                    out[q] = sacc;
-                }
-                out[18] = 0.f; out[19] = 0.f;
-                const float4 q4 = s_rec[j * 5 + 4];
-                const uint32_t basei = __float_as_uint(q4.z), rectbits = __float_as_uint(q4.w);
-                const int x0 = rectbits & 1023, y0 = (rectbits >> 10) & 1023, rw = rectbits >> 20;
-                const size_t dest = (size_t)basei + (size_t)((ty - y0) * rw + (tx - x0));
-                float4* __restrict__ dst = reinterpret_cast<float4*>(a.grec + dest * GREC_F);
-#pragma unroll
-                for (int q = 0; q < 5; q++) dst[q] = make_float4(out[4 * q], out[4 * q + 1], out[4 * q + 2], out[4 * q + 3]);
-            }
+            __syncthreads();                  // s_acc / s_mask reusable
         }
     }
 }
