@@ -179,13 +179,28 @@ __global__ void __launch_bounds__(256) preprocess_fwd_kernel(PreprocessArgs a) {
         rec[1] = make_float4(T[4], T[5], T[6], T[7]);
         rec[2] = make_float4(T[8], cx, cy, a.opacities[i]);
         rec[3] = make_float4(nx, ny, nz, r);
-        const uint32_t rectbits = (uint32_t)rc.x0 | ((uint32_t)rc.y0 << 10) | ((uint32_t)(rc.x1 - rc.x0) << 20);
+        // Instances are emitted only for the tiles of the reference rect that the alpha>=1/255 bbox can
+        // reach (a pure cull: skipped (tile, surfel) pairs contribute to no pixel, so images and gradients
+        // are unchanged; `radii` keeps the reference definition).
+        int ex0 = rc.x0, ex1 = rc.x1, ey0 = rc.y0, ey1 = rc.y1;
+        {
+            const float lo_x = ceilf(fmaxf(bx0, 0.f)), hi_x = floorf(fminf(bx1, (float)(a.gx * TILE)));
+            const float lo_y = ceilf(fmaxf(by0, 0.f)), hi_y = floorf(fminf(by1, (float)(a.gy * TILE)));
+            if (!(lo_x <= hi_x) || !(lo_y <= hi_y)) { ex1 = ex0; ey1 = ey0; }
+            else {
+                ex0 = max(ex0, (int)lo_x >> 4); ex1 = min(ex1, ((int)hi_x >> 4) + 1);
+                ey0 = max(ey0, (int)lo_y >> 4); ey1 = min(ey1, ((int)hi_y >> 4) + 1);
+                if (ex1 < ex0) ex1 = ex0;
+                if (ey1 < ey0) ey1 = ey0;
+            }
+        }
+        const uint32_t rectbits = (uint32_t)ex0 | ((uint32_t)ey0 << 10) | ((uint32_t)(ex1 - ex0) << 20);
         rec[4] = make_float4(g, b, 0.f /* inst_base patched by emit_instances */, __uint_as_float(rectbits));
         rec[5] = make_float4(bx0, bx1, by0, by1);
         a.depths[i] = vz;
         a.clamped[i] = clampbits;
         rad_out = irad;
-        tiles = (uint32_t)ntiles;
+        tiles = (uint32_t)((ex1 - ex0) * (ey1 - ey0));
     } while (false);
     a.radii[i] = rad_out;
     a.tiles_touched[i] = tiles;
