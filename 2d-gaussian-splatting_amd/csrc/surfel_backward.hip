@@ -37,7 +37,7 @@ __device__ __forceinline__ float fold16(float x, float y) {
     return __uint_as_float(r.x) + __uint_as_float(r.y);
 }
 
-constexpr int BS = 256;   // instances staged per outer batch (one 80-B gather per thread)
+constexpr int BS = 128;   // instances staged per outer batch (one 80-B gather per thread of waves 0-1)
 constexpr int BB = 64;    // instances per accumulate/flush sub-batch
 constexpr int NV = 18;    // gradient values per instance
 constexpr int NVP = 20;   // padded to 5 registers x 4 rows for the wave reduction
@@ -161,59 +161,57 @@ __global__ void __launch_bounds__(BLOCK) blend_bwd_kernel(BlendBwdArgs a) {
                 const float alpha = fminf(ALPHA_MAX, opa * G);
                 const bool ok = (pos <= last) & (p2 != 0.f) & (depth >= NEAR_N) & (alpha >= ALPHA_MIN);
                 if (__ballot(ok) == 0ull) continue;      // wave-uniform
-                float gv[NVP];
-#pragma unroll
-                for (int q = 0; q < NVP; q++) gv[q] = 0.f;
+                // Sequential per-pixel state lives in the divergent region (in-place, no copies); it hands
+                // three scalars (w, dL_dalpha, dL_dz) — zero for lanes that skip — to the branch-free
+                // gradient expansion below.
+                const float4 q3 = s_rec[j * 5 + 3], q4 = s_rec[j * 5 + 4];
+                float w = 0.f, dL_dalpha = 0.f, dL_dz = 0.f;
                 if (ok) {
-                    const float4 q3 = s_rec[j * 5 + 3], q4 = s_rec[j * 5 + 4];
                     const float i1a = __builtin_amdgcn_rcpf(1.f - alpha);
                     T = T * i1a;
-                    const float w = alpha * T;
+                    w = alpha * T;
                     const float om = 1.f - last_alpha;
-                    float dL_dalpha;
-                    // colour
-                    ar0 = last_alpha * lc0 + om * ar0; lc0 = q3.w; dL_dalpha = (q3.w - ar0) * gC0;
-                    ar1 = last_alpha * lc1 + om * ar1; lc1 = q4.x; dL_dalpha += (q4.x - ar1) * gC1;
-                    ar2 = last_alpha * lc2 + om * ar2; lc2 = q4.y; dL_dalpha += (q4.y - ar2) * gC2;
-                    gv[15] = w * gC0; gv[16] = w * gC1; gv[17] = w * gC2;
-                    // distortion
+                    float da;
+                    ar0 = last_alpha * lc0 + om * ar0; lc0 = q3.w; da = (q3.w - ar0) * gC0;
+                    ar1 = last_alpha * lc1 + om * ar1; lc1 = q4.x; da += (q4.x - ar1) * gC1;
+                    ar2 = last_alpha * lc2 + om * ar2; lc2 = q4.y; da += (q4.y - ar2) * gC2;
                     const float inv_d = __builtin_amdgcn_rcpf(depth);
                     const float mm = MC1 - (MC1 * NEAR_N) * inv_d;
-                    const float dm_dd = MC2 * inv_d * inv_d;
                     const float dL_dweight = (fM2 + mm * (mm * final_A - 2.f * fM1)) * g_dist;
-                    dL_dalpha += dL_dweight - last_dL_dT;
+                    da += dL_dweight - last_dL_dT;
                     last_dL_dT = dL_dweight * alpha + (1.f - alpha) * last_dL_dT;
-                    float dL_dz = (2.f * w * g_dist) * (mm * final_A - fM1) * dm_dd + w * g_depth;
+                    dL_dz = (2.f * w * g_dist) * (mm * final_A - fM1) * (MC2 * inv_d * inv_d) + w * g_depth;
                     dL_dz += (pos == medc) ? g_med : 0.f;
-                    // depth / alpha
                     accum_depth = last_alpha * last_depth + om * accum_depth; last_depth = depth;
-                    dL_dalpha += (depth - accum_depth) * g_depth;
+                    da += (depth - accum_depth) * g_depth;
                     accum_alpha = last_alpha + om * accum_alpha;
-                    dL_dalpha += (1.f - accum_alpha) * g_alpha;
-                    // normals
-                    an0 = last_alpha * ln0 + om * an0; ln0 = q3.x; dL_dalpha += (q3.x - an0) * gN0;
-                    an1 = last_alpha * ln1 + om * an1; ln1 = q3.y; dL_dalpha += (q3.y - an1) * gN1;
-                    an2 = last_alpha * ln2 + om * an2; ln2 = q3.z; dL_dalpha += (q3.z - an2) * gN2;
-                    gv[11] = w * gN0; gv[12] = w * gN1; gv[13] = w * gN2;
-                    dL_dalpha = dL_dalpha * T + bgT * i1a;
+                    da += (1.f - accum_alpha) * g_alpha;
+                    an0 = last_alpha * ln0 + om * an0; ln0 = q3.x; da += (q3.x - an0) * gN0;
+                    an1 = last_alpha * ln1 + om * an1; ln1 = q3.y; da += (q3.y - an1) * gN1;
+                    an2 = last_alpha * ln2 + om * an2; ln2 = q3.z; da += (q3.z - an2) * gN2;
+                    dL_dalpha = da * T + bgT * i1a;
                     last_alpha = alpha;
-                    const float dL_dG = opa * dL_dalpha;       // 0.99 clamp is pass-through
-                    gv[14] = G * dL_dalpha;
-                    // geometry: 3-D branch -> homography, low-pass branch -> centre (+ Tw.z for depth)
-                    const float nGG = -G * dL_dG;
+                }
+                float gv[NVP];
+                gv[15] = w * gC0; gv[16] = w * gC1; gv[17] = w * gC2;
+                gv[11] = w * gN0; gv[12] = w * gN1; gv[13] = w * gN2;
+                gv[14] = G * dL_dalpha;
+                gv[18] = 0.f; gv[19] = 0.f;
+                {
+                    const float nGG = -G * (opa * dL_dalpha);      // dL/dG * dG/drho*2 ; 0.99 clamp is pass-through
                     const float dz3 = use3d ? dL_dz : 0.f;
                     const float g3 = use3d ? nGG : 0.f;
-                    const float dsx = g3 * sx + dz3 * Twx, dsy = g3 * sy + dz3 * Twy;
-                    const float ax = dsx * ip, ay = dsy * ip;
-                    const float dp2 = -(ax * sx + ay * sy);
-                    const float dk0 = ly_ * dp2 - lz_ * ay, dk1 = lz_ * ax - lx_ * dp2, dk2 = lx_ * ay - ly_ * ax;
-                    const float dl0 = ay * kz - dp2 * ky, dl1 = dp2 * kx - ax * kz, dl2 = ax * ky - ay * kx;
-                    gv[0] = -dk0; gv[1] = -dk1; gv[2] = -dk2;
-                    gv[3] = -dl0; gv[4] = -dl1; gv[5] = -dl2;
-                    gv[6] = pxf * dk0 + pyf * dl0 + dz3 * sx;
-                    gv[7] = pxf * dk1 + pyf * dl1 + dz3 * sy;
-                    gv[8] = pxf * dk2 + pyf * dl2 + dL_dz;
                     const float g2 = use3d ? 0.f : nGG * FILTER_INV_SQUARE;
+                    const float ax = (g3 * sx + dz3 * Twx) * ip, ay = (g3 * sy + dz3 * Twy) * ip;
+                    const float dp2 = -(ax * sx + ay * sy);
+                    // -dk = dp x l ,  -dl = k x dp
+                    const float nk0 = ay * lz_ - dp2 * ly_, nk1 = dp2 * lx_ - ax * lz_, nk2 = ax * ly_ - ay * lx_;
+                    const float nl0 = ky * dp2 - kz * ay, nl1 = kz * ax - kx * dp2, nl2 = kx * ay - ky * ax;
+                    gv[0] = nk0; gv[1] = nk1; gv[2] = nk2;
+                    gv[3] = nl0; gv[4] = nl1; gv[5] = nl2;
+                    gv[6] = dz3 * sx - (pxf * nk0 + pyf * nl0);
+                    gv[7] = dz3 * sy - (pxf * nk1 + pyf * nl1);
+                    gv[8] = dL_dz - (pxf * nk2 + pyf * nl2);
                     gv[9] = g2 * dx; gv[10] = g2 * dy;
                 }
                 float z[5];
