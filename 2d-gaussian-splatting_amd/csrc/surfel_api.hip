@@ -10,6 +10,8 @@
 #include <hip/hip_runtime.h>
 #include <rocprim/device/device_radix_sort.hpp>
 #include <rocprim/device/device_scan.hpp>
+#include <rocprim/iterator/counting_iterator.hpp>
+#include <rocprim/iterator/transform_iterator.hpp>
 
 #include "../../include/surfel_hip.h"
 #include "surfel_common.h"
@@ -24,7 +26,7 @@ thread_local float g_stage_ms[16];
 thread_local int g_stage_n = 0;
 thread_local int g_stage_id[16];
 
-const char* kStageNames[] = {"preprocess_fwd", "scan", "emit_instances", "radix_sort", "tile_ranges", "blend_fwd",
+const char* kStageNames[] = {"preprocess_fwd", "depth_sort_scan", "emit_instances", "tile_sort", "tile_ranges", "blend_fwd",
                              "zero_grec", "blend_bwd", "preprocess_bwd", "knn"};
 enum Stage { ST_PRE = 0, ST_SCAN, ST_EMIT, ST_SORT, ST_RANGES, ST_BLEND, ST_ZERO, ST_BBWD, ST_PBWD, ST_KNN };
 
@@ -56,30 +58,40 @@ struct Carver {
 };
 
 struct GeomState {   // per-surfel state ("geomBuffer")
-    float* rec; float* depths; uint32_t* tiles_touched; uint32_t* offsets; uint8_t* clamped; char* scan_temp;
-    size_t scan_temp_bytes;
-    static GeomState carve(void* base, int P, size_t scan_bytes, size_t* total) {
+    float* rec; float* depths; uint32_t* tiles_touched; uint8_t* clamped;
+    uint32_t *dkey_a, *dkey_b, *ord_a, *ord_b;   // depth-bit keys / surfel order (double buffers of the P-sized sort)
+    uint32_t* offsets;                            // inclusive scan of tiles_touched in depth order
+    char* temp; size_t temp_bytes;                // rocPRIM scratch (max of scan / P-sized sort)
+    static GeomState carve(void* base, int P, size_t temp_bytes, size_t* total) {
         Carver c(base); GeomState g;
         g.rec = c.take<float>((size_t)P * REC_F);
-        g.depths = c.take<float>(P);
+        g.depths = c.take<float>(P);           // float32 view depth per surfel (sort key source; kept for inspection)
         g.tiles_touched = c.take<uint32_t>(P);
-        g.offsets = c.take<uint32_t>(P);
         g.clamped = c.take<uint8_t>(P);
-        g.scan_temp = c.take<char>(scan_bytes);
-        g.scan_temp_bytes = scan_bytes;
+        g.dkey_a = c.take<uint32_t>(P); g.dkey_b = c.take<uint32_t>(P);
+        g.ord_a = c.take<uint32_t>(P); g.ord_b = c.take<uint32_t>(P);
+        g.offsets = c.take<uint32_t>(P);
+        g.temp = c.take<char>(temp_bytes);
+        g.temp_bytes = temp_bytes;
         if (total) *total = c.size();
         return g;
     }
 };
 
+// tiles_touched gathered through the depth order, as a rocPRIM input iterator for the scan
+struct GatherTiles {
+    const uint32_t* tiles; const uint32_t* order;
+    __host__ __device__ uint32_t operator()(uint32_t k) const { return tiles[order[k]]; }
+};
+
 struct BinState {    // per-instance state ("binningBuffer"); point_list is always at a fixed offset
-    uint32_t* point_list; uint32_t* vals_alt; uint64_t* keys_a; uint64_t* keys_b; char* sort_temp; size_t sort_temp_bytes;
+    uint32_t* point_list; uint32_t* vals_alt; uint32_t* keys_a; uint32_t* keys_b; char* sort_temp; size_t sort_temp_bytes;
     static BinState carve(void* base, size_t R, size_t sort_bytes, size_t* total) {
         Carver c(base); BinState b;
         b.point_list = c.take<uint32_t>(R);
         b.vals_alt = c.take<uint32_t>(R);
-        b.keys_a = c.take<uint64_t>(R);
-        b.keys_b = c.take<uint64_t>(R);
+        b.keys_a = c.take<uint32_t>(R);
+        b.keys_b = c.take<uint32_t>(R);
         b.sort_temp = c.take<char>(sort_bytes);
         b.sort_temp_bytes = sort_bytes;
         if (total) *total = c.size();
@@ -216,29 +228,46 @@ int64_t surfel_rasterize_forward(surfel_alloc_fn geom_alloc, void* geom_user, su
     StageTimer tm(debug, s);
     int64_t R = 0;
     GeomState geom{};
+    BinState bin{};
     if (P > 0) {
-        size_t scan_bytes = 0;
-        HIP_TRY(rocprim::inclusive_scan(nullptr, scan_bytes, (uint32_t*)nullptr, (uint32_t*)nullptr, (size_t)P,
-                                        rocprim::plus<uint32_t>(), s));
+        // rocPRIM scratch sizes (host-side queries only)
+        size_t scan_bytes = 0, psort_bytes = 0;
+        GatherTiles gq{nullptr, nullptr};
+        auto gin0 = rocprim::make_transform_iterator(rocprim::make_counting_iterator<uint32_t>(0u), gq);
+        HIP_TRY(rocprim::inclusive_scan(nullptr, scan_bytes, gin0, (uint32_t*)nullptr, (size_t)P, rocprim::plus<uint32_t>(), s));
+        {
+            rocprim::double_buffer<uint32_t> kq(nullptr, nullptr), vq(nullptr, nullptr);
+            HIP_TRY(rocprim::radix_sort_pairs(nullptr, psort_bytes, kq, vq, (size_t)P, 0, 32, s));
+        }
+        const size_t temp_bytes = scan_bytes > psort_bytes ? scan_bytes : psort_bytes;
         size_t geom_bytes = 0;
-        GeomState::carve(nullptr, P, scan_bytes, &geom_bytes);
+        GeomState::carve(nullptr, P, temp_bytes, &geom_bytes);
         void* geom_base = geom_alloc(geom_user, geom_bytes);
         if (!geom_base) return fail(SURFEL_E_ALLOC, "geometry buffer allocation failed");
-        geom = GeomState::carve(geom_base, P, scan_bytes, nullptr);
+        geom = GeomState::carve(geom_base, P, temp_bytes, nullptr);
 
         PreprocessArgs pa{};
         pa.P = P; pa.D = D; pa.M = M; pa.W = width; pa.H = height; pa.gx = gx; pa.gy = gy; pa.scale_modifier = scale_modifier;
         pa.means3D = means3D; pa.opacities = opacities; pa.scales = scales; pa.rotations = rotations;
         pa.transMat_precomp = transMat_precomp; pa.colors_precomp = colors_precomp; pa.shs = shs;
         pa.viewmatrix = viewmatrix; pa.projmatrix = projmatrix; pa.campos = cam_pos;
-        pa.rec = geom.rec; pa.depths = geom.depths; pa.radii = radii; pa.tiles_touched = geom.tiles_touched; pa.clamped = geom.clamped;
+        pa.rec = geom.rec; pa.depths = geom.depths; pa.depth_keys = geom.dkey_a; pa.ident = geom.ord_a; pa.radii = radii;
+        pa.tiles_touched = geom.tiles_touched; pa.clamped = geom.clamped;
         tm.begin();
         launch_preprocess_fwd(pa, s);
         STAGE_END(tm, ST_PRE);
 
         tm.begin();
-        HIP_TRY(rocprim::inclusive_scan(geom.scan_temp, scan_bytes, geom.tiles_touched, geom.offsets, (size_t)P,
-                                        rocprim::plus<uint32_t>(), s));
+        // (1) surfel order by view depth (stable; culled surfels carry key 0xffffffff and sort last)
+        rocprim::double_buffer<uint32_t> dk(geom.dkey_a, geom.dkey_b), od(geom.ord_a, geom.ord_b);
+        size_t tb = temp_bytes;
+        HIP_TRY(rocprim::radix_sort_pairs(geom.temp, tb, dk, od, (size_t)P, 0, 32, s));
+        const uint32_t* order = od.current();
+        // (2) instance offsets in depth order
+        GatherTiles gt{geom.tiles_touched, order};
+        auto gin = rocprim::make_transform_iterator(rocprim::make_counting_iterator<uint32_t>(0u), gt);
+        tb = temp_bytes;
+        HIP_TRY(rocprim::inclusive_scan(geom.temp, tb, gin, geom.offsets, (size_t)P, rocprim::plus<uint32_t>(), s));
         // The instance count sizes the binning buffers, so it has to reach the host (one 4-byte D2H).
         uint32_t* hR = pinned_u32();
         if (!hR) return fail(SURFEL_E_HIP, "hipHostMalloc failed");
@@ -246,18 +275,11 @@ int64_t surfel_rasterize_forward(surfel_alloc_fn geom_alloc, void* geom_user, su
         HIP_TRY(hipStreamSynchronize(s));
         R = (int64_t)*hR;
         STAGE_END(tm, ST_SCAN);
-    } else {
-        void* geom_base = geom_alloc(geom_user, 256);
-        (void)geom_base;
-    }
 
-    BinState bin{};
-    {
         size_t sort_bytes = 0;
-        const int end_bit = 32 + higher_msb((uint32_t)(gx * gy));
+        const int end_bit = higher_msb((uint32_t)(gx * gy));
         if (R > 0) {
-            rocprim::double_buffer<uint64_t> kq(nullptr, nullptr);
-            rocprim::double_buffer<uint32_t> vq(nullptr, nullptr);
+            rocprim::double_buffer<uint32_t> kq(nullptr, nullptr), vq(nullptr, nullptr);
             HIP_TRY(rocprim::radix_sort_pairs(nullptr, sort_bytes, kq, vq, (size_t)R, 0, end_bit, s));
         }
         size_t bin_bytes = 0;
@@ -267,11 +289,11 @@ int64_t surfel_rasterize_forward(surfel_alloc_fn geom_alloc, void* geom_user, su
         bin = BinState::carve(bin_base, (size_t)R, sort_bytes, nullptr);
         if (R > 0) {
             tm.begin();
-            launch_emit_instances(P, geom.rec, geom.depths, geom.offsets, radii, bin.keys_a, bin.vals_alt, gx, s);
+            launch_emit_instances(P, geom.rec, order, geom.offsets, bin.keys_a, bin.vals_alt, gx, s);
             STAGE_END(tm, ST_EMIT);
             tm.begin();
-            rocprim::double_buffer<uint64_t> kq(bin.keys_a, bin.keys_b);
-            rocprim::double_buffer<uint32_t> vq(bin.vals_alt, bin.point_list);
+            // (3) stable sort on the tile-id bits only: depth order inside every tile is preserved
+            rocprim::double_buffer<uint32_t> kq(bin.keys_a, bin.keys_b), vq(bin.vals_alt, bin.point_list);
             HIP_TRY(rocprim::radix_sort_pairs(bin.sort_temp, sort_bytes, kq, vq, (size_t)R, 0, end_bit, s));
             if (vq.current() != bin.point_list)
                 HIP_TRY(hipMemcpyAsync(bin.point_list, vq.current(), sizeof(uint32_t) * (size_t)R, hipMemcpyDeviceToDevice, s));
@@ -280,6 +302,11 @@ int64_t surfel_rasterize_forward(surfel_alloc_fn geom_alloc, void* geom_user, su
             launch_tile_ranges(R, kq.current(), img.ranges, s);
             STAGE_END(tm, ST_RANGES);
         }
+    } else {
+        (void)geom_alloc(geom_user, 256);
+        void* bin_base = binning_alloc(binning_user, 256);
+        if (!bin_base) return fail(SURFEL_E_ALLOC, "binning buffer allocation failed");
+        bin = BinState::carve(bin_base, 0, 0, nullptr);
     }
 
     BlendFwdArgs ba{};
@@ -314,9 +341,7 @@ int surfel_rasterize_backward(surfel_alloc_fn scratch_alloc, void* scratch_user,
     if (!transMat_precomp && (!dL_dscales || !dL_drots || !scales || !rotations)) return fail(SURFEL_E_INVALID, "scale/rotation pointers are NULL");
     const int gx = (width + TILE - 1) / TILE, gy = (height + TILE - 1) / TILE;
 
-    size_t scan_bytes = 0;
-    HIP_TRY(rocprim::inclusive_scan(nullptr, scan_bytes, (uint32_t*)nullptr, (uint32_t*)nullptr, (size_t)P, rocprim::plus<uint32_t>(), s));
-    GeomState geom = GeomState::carve(const_cast<void*>(geom_buffer), P, scan_bytes, nullptr);
+    GeomState geom = GeomState::carve(const_cast<void*>(geom_buffer), P, 0, nullptr);   // rocPRIM scratch is last: layout of the rest is size-independent
     BinState bin = BinState::carve(const_cast<void*>(binning_buffer), (size_t)R, 0, nullptr);
     ImgState img = ImgState::carve(const_cast<void*>(image_buffer), width, height, nullptr);
 
@@ -341,7 +366,7 @@ int surfel_rasterize_backward(surfel_alloc_fn scratch_alloc, void* scratch_user,
     pb.P = P; pb.D = D; pb.M = M; pb.W = width; pb.H = height; pb.scale_modifier = scale_modifier;
     pb.means3D = means3D; pb.radii = radii; pb.shs = shs; pb.clamped = geom.clamped; pb.scales = scales; pb.rotations = rotations;
     pb.transMat_precomp = transMat_precomp; pb.viewmatrix = viewmatrix; pb.projmatrix = projmatrix; pb.campos = cam_pos;
-    pb.rec = geom.rec; pb.offsets = geom.offsets; pb.grec = grec;
+    pb.rec = geom.rec; pb.tiles_touched = geom.tiles_touched; pb.grec = grec;
     pb.dL_dtransMat = dL_dtransMat; pb.dL_dnormal = dL_dnormal; pb.dL_dopacity = dL_dopacity; pb.dL_dcolors = dL_dcolors;
     pb.dL_dsh = dL_dsh; pb.dL_dmeans2D = dL_dmeans2D; pb.dL_dmeans3D = dL_dmeans3D; pb.dL_dscales = dL_dscales; pb.dL_drots = dL_drots;
     tm.begin();

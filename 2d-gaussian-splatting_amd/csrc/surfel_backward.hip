@@ -265,7 +265,10 @@ __global__ void __launch_bounds__(256) preprocess_bwd_kernel(PreprocessBwdArgs a
     float g[NV];
 #pragma unroll
     for (int q = 0; q < NV; q++) g[q] = 0.f;
-    const uint32_t beg = (i == 0) ? 0u : a.offsets[i - 1], end = a.offsets[i];
+    const float4* __restrict__ rq = reinterpret_cast<const float4*>(a.rec + (size_t)i * REC_F);
+    const float4 r4 = rq[4];
+    const uint32_t beg = __float_as_uint(r4.z);          // inst_base patched by emit_instances
+    const uint32_t end = beg + a.tiles_touched[i];       // its instances are contiguous in emission order
     for (uint32_t k = beg; k < end; k++) {
         const float4* __restrict__ src = reinterpret_cast<const float4*>(a.grec + (size_t)k * GREC_F);
         const float4 v0 = src[0], v1 = src[1], v2 = src[2], v3 = src[3], v4 = src[4];
@@ -279,7 +282,6 @@ __global__ void __launch_bounds__(256) preprocess_bwd_kernel(PreprocessBwdArgs a
     a.dL_dnormal[3 * (size_t)i] = g[11]; a.dL_dnormal[3 * (size_t)i + 1] = g[12]; a.dL_dnormal[3 * (size_t)i + 2] = g[13];
     a.dL_dcolors[3 * (size_t)i] = g[15]; a.dL_dcolors[3 * (size_t)i + 1] = g[16]; a.dL_dcolors[3 * (size_t)i + 2] = g[17];
 
-    const float4* __restrict__ rq = reinterpret_cast<const float4*>(a.rec + (size_t)i * REC_F);
     const float4 r0 = rq[0], r1 = rq[1], r2 = rq[2];
     const float T[9] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w, r2.x};
     // densification statistic from the blend-stage dL/dT (before the centre term is folded in)

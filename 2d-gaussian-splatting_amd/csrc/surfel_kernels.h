@@ -11,7 +11,7 @@ struct PreprocessArgs {
     const float* means3D; const float* opacities; const float* scales; const float* rotations;
     const float* transMat_precomp; const float* colors_precomp; const float* shs;
     const float* viewmatrix; const float* projmatrix; const float* campos;
-    float* rec; float* depths; int* radii; uint32_t* tiles_touched; uint8_t* clamped;
+    float* rec; float* depths; uint32_t* depth_keys; uint32_t* ident; int* radii; uint32_t* tiles_touched; uint8_t* clamped;
 };
 
 struct BlendFwdArgs {
@@ -34,15 +34,15 @@ struct PreprocessBwdArgs {
     const float* means3D; const int* radii; const float* shs; const uint8_t* clamped;
     const float* scales; const float* rotations; const float* transMat_precomp;
     const float* viewmatrix; const float* projmatrix; const float* campos;
-    const float* rec; const uint32_t* offsets; const float* grec;
+    const float* rec; const uint32_t* tiles_touched; const float* grec;
     float* dL_dtransMat; float* dL_dnormal; float* dL_dopacity; float* dL_dcolors; float* dL_dsh;
     float* dL_dmeans2D; float* dL_dmeans3D; float* dL_dscales; float* dL_drots;
 };
 
 void launch_preprocess_fwd(const PreprocessArgs& a, hipStream_t s);
-void launch_emit_instances(int P, float* rec, const float* depths, const uint32_t* offsets, const int* radii, uint64_t* keys,
+void launch_emit_instances(int P, float* rec, const uint32_t* order, const uint32_t* offsets_sorted, uint32_t* keys,
                            uint32_t* vals, int gx, hipStream_t s);
-void launch_tile_ranges(int64_t R, const uint64_t* keys, uint2* ranges, hipStream_t s);
+void launch_tile_ranges(int64_t R, const uint32_t* keys, uint2* ranges, hipStream_t s);
 void launch_blend_fwd(const BlendFwdArgs& a, hipStream_t s);
 void launch_mark_visible(int P, const float* means3D, const float* vm, uint8_t* present, hipStream_t s);
 void launch_blend_bwd(const BlendBwdArgs& a, hipStream_t s);
