@@ -333,7 +333,7 @@ int surfel_rasterize_backward(surfel_alloc_fn scratch_alloc, void* scratch_user,
     (void)tan_fovx; (void)tan_fovy; (void)colors_precomp;
     g_stage_n = 0;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (P == 0 || R == 0) return 0;
+    if (P == 0) return 0;
     if (!scratch_alloc || !geom_buffer || !binning_buffer || !image_buffer) return fail(SURFEL_E_INVALID, "buffer / allocator is NULL");
     if (!dL_dout_color || !dL_dout_others || !dL_dmeans2D || !dL_dnormal || !dL_dopacity || !dL_dcolors || !dL_dmeans3D || !dL_dtransMat)
         return fail(SURFEL_E_INVALID, "gradient pointer is NULL");
@@ -345,22 +345,22 @@ int surfel_rasterize_backward(surfel_alloc_fn scratch_alloc, void* scratch_user,
     BinState bin = BinState::carve(const_cast<void*>(binning_buffer), (size_t)R, 0, nullptr);
     ImgState img = ImgState::carve(const_cast<void*>(image_buffer), width, height, nullptr);
 
-    const size_t grec_bytes = (size_t)R * GREC_F * sizeof(float);
+    // per-instance gradient records: every record is written exactly once by blend_bwd (no memset, no atomics)
+    const size_t grec_bytes = (size_t)(R > 0 ? R : 1) * GREC_F * sizeof(float);
     float* grec = static_cast<float*>(scratch_alloc(scratch_user, grec_bytes));
     if (!grec) return fail(SURFEL_E_ALLOC, "gradient record allocation failed");
     StageTimer tm(debug, s);
-    tm.begin();
-    HIP_TRY(hipMemsetAsync(grec, 0, grec_bytes, s));
-    STAGE_END(tm, ST_ZERO);
 
     BlendBwdArgs bb{};
     bb.W = width; bb.H = height; bb.gx = gx; bb.gy = gy;
     bb.ranges = img.ranges; bb.point_list = bin.point_list; bb.rec = geom.rec; bb.bg = background;
     bb.final_T = img.final_T; bb.n_contrib = img.n_contrib; bb.dL_dpix = dL_dout_color; bb.dL_dothers = dL_dout_others;
     bb.grec = grec;
-    tm.begin();
-    launch_blend_bwd(bb, s);
-    STAGE_END(tm, ST_BBWD);
+    if (R > 0) {
+        tm.begin();
+        launch_blend_bwd(bb, s);
+        STAGE_END(tm, ST_BBWD);
+    }
 
     PreprocessBwdArgs pb{};
     pb.P = P; pb.D = D; pb.M = M; pb.W = width; pb.H = height; pb.scale_modifier = scale_modifier;

@@ -224,51 +224,88 @@ __global__ void __launch_bounds__(BLOCK) blend_bwd_kernel(BlendBwdArgs a) {
             }
             if (lane == 0) s_mask[wave] = wmask;
             __syncthreads();
-            // flush: one thread per sub-batch instance sums the four wave partials in fixed order
-            if ((int)threadIdx.x < BB) {
+            // flush: one thread per sub-batch instance sums the four wave partials in fixed order and writes the
+            // instance's gradient record — always (zeros when nobody touched it), so grec needs no memset
+            if ((int)threadIdx.x < min(BB, mb - sb * BB)) {
                 const int jj = threadIdx.x;
                 const unsigned long long bit = 1ull << jj;
                 const bool h0 = s_mask[0] & bit, h1 = s_mask[1] & bit, h2 = s_mask[2] & bit, h3 = s_mask[3] & bit;
-                if (h0 | h1 | h2 | h3) {
-                    float4 out[5];
+                float4 out[5];
 #pragma unroll
-                    for (int q = 0; q < 5; q++) {
-                        float4 sacc = make_float4(0.f, 0.f, 0.f, 0.f);
-                        if (h0) { const float4 t4 = *reinterpret_cast<const float4*>(&s_acc[0][jj][4 * q]); sacc.x += t4.x; sacc.y += t4.y; sacc.z += t4.z; sacc.w += t4.w; }
-                        if (h1) { const float4 t4 = *reinterpret_cast<const float4*>(&s_acc[1][jj][4 * q]); sacc.x += t4.x; sacc.y += t4.y; sacc.z += t4.z; sacc.w += t4.w; }
-                        if (h2) { const float4 t4 = *reinterpret_cast<const float4*>(&s_acc[2][jj][4 * q]); sacc.x += t4.x; sacc.y += t4.y; sacc.z += t4.z; sacc.w += t4.w; }
-                        if (h3) { const float4 t4 = *reinterpret_cast<const float4*>(&s_acc[3][jj][4 * q]); sacc.x += t4.x; sacc.y += t4.y; sacc.z += t4.z; sacc.w += t4.w; }
-                        out[q] = sacc;
-                    }
-                    const float4 q4 = s_rec[(sb * BB + jj) * 5 + 4];
-                    const uint32_t basei = __float_as_uint(q4.z), rectbits = __float_as_uint(q4.w);
-                    const int x0 = rectbits & 1023, y0 = (rectbits >> 10) & 1023, rw = rectbits >> 20;
-                    const size_t dest = (size_t)basei + (size_t)((ty - y0) * rw + (tx - x0));
-                    float4* __restrict__ dst = reinterpret_cast<float4*>(a.grec + dest * GREC_F);
-#pragma unroll
-                    for (int q = 0; q < 5; q++) dst[q] = out[q];
+                for (int q = 0; q < 5; q++) {
+                    float4 sacc = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (h0) { const float4 t4 = *reinterpret_cast<const float4*>(&s_acc[0][jj][4 * q]); sacc.x += t4.x; sacc.y += t4.y; sacc.z += t4.z; sacc.w += t4.w; }
+                    if (h1) { const float4 t4 = *reinterpret_cast<const float4*>(&s_acc[1][jj][4 * q]); sacc.x += t4.x; sacc.y += t4.y; sacc.z += t4.z; sacc.w += t4.w; }
+                    if (h2) { const float4 t4 = *reinterpret_cast<const float4*>(&s_acc[2][jj][4 * q]); sacc.x += t4.x; sacc.y += t4.y; sacc.z += t4.z; sacc.w += t4.w; }
+                    if (h3) { const float4 t4 = *reinterpret_cast<const float4*>(&s_acc[3][jj][4 * q]); sacc.x += t4.x; sacc.y += t4.y; sacc.z += t4.z; sacc.w += t4.w; }
+                    out[q] = sacc;
                 }
+                const float4 q4 = s_rec[(sb * BB + jj) * 5 + 4];
+                const uint32_t basei = __float_as_uint(q4.z), rectbits = __float_as_uint(q4.w);
+                const int x0 = rectbits & 1023, y0 = (rectbits >> 10) & 1023, rw = rectbits >> 20;
+                const size_t dest = (size_t)basei + (size_t)((ty - y0) * rw + (tx - x0));
+                float4* __restrict__ dst = reinterpret_cast<float4*>(a.grec + dest * GREC_F);
+#pragma unroll
+                for (int q = 0; q < 5; q++) dst[q] = out[q];
             }
             __syncthreads();                  // s_acc / s_mask reusable
         }
+    }
+    // instances behind every pixel's last contributor were never staged: their records are zero
+    for (int pos = maxc + 1 + (int)threadIdx.x; pos <= (int)(range.y - range.x); pos += BLOCK) {
+        const uint32_t id = a.point_list[range.x + pos - 1];
+        const float4 q4 = reinterpret_cast<const float4*>(a.rec + (size_t)id * REC_F)[4];
+        const uint32_t basei = __float_as_uint(q4.z), rectbits = __float_as_uint(q4.w);
+        const int x0 = rectbits & 1023, y0 = (rectbits >> 10) & 1023, rw = rectbits >> 20;
+        const size_t dest = (size_t)basei + (size_t)((ty - y0) * rw + (tx - x0));
+        float4* __restrict__ dst = reinterpret_cast<float4*>(a.grec + dest * GREC_F);
+        const float4 zz = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int q = 0; q < 5; q++) dst[q] = zz;
     }
 }
 
 // ---------------------------------------------------------------------------------------------
 // preprocess_bwd: one thread per surfel.
 // ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void store3(float* p, size_t i, float x, float y, float z) { p[3 * i] = x; p[3 * i + 1] = y; p[3 * i + 2] = z; }
+
+// Every output element of every surfel is written here (zeros for culled surfels and inactive SH degrees),
+// so the caller does not have to zero-fill nine gradient tensors per step.
 __global__ void __launch_bounds__(256) preprocess_bwd_kernel(PreprocessBwdArgs a) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= a.P) return;
-    if (!(a.radii[i] > 0)) return;
-    // 1. gather-sum this surfel's instance gradient records (contiguous, fixed order)
+    const bool precomp = a.transMat_precomp != nullptr;
+    const bool vis = a.radii[i] > 0;
+    float4* __restrict__ gshq = a.shs ? reinterpret_cast<float4*>(a.dL_dsh + (size_t)i * a.M * 3) : nullptr;
+    if (!vis) {
+        a.dL_dopacity[i] = 0.f;
+        store3(a.dL_dnormal, i, 0.f, 0.f, 0.f); store3(a.dL_dcolors, i, 0.f, 0.f, 0.f);
+        store3(a.dL_dmeans2D, i, 0.f, 0.f, 0.f); store3(a.dL_dmeans3D, i, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int q = 0; q < 9; q++) a.dL_dtransMat[9 * (size_t)i + q] = 0.f;
+        if (!precomp) {
+            reinterpret_cast<float2*>(a.dL_dscales)[i] = make_float2(0.f, 0.f);
+            reinterpret_cast<float4*>(a.dL_drots)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        if (gshq) {
+            if (a.M == 16) {
+#pragma unroll
+                for (int v = 0; v < 12; v++) gshq[v] = make_float4(0.f, 0.f, 0.f, 0.f);
+            } else {
+                for (int v = 0; v < a.M * 3; v++) a.dL_dsh[(size_t)i * a.M * 3 + v] = 0.f;
+            }
+        }
+        return;
+    }
+    // 1. gather-sum this surfel's instance gradient records (contiguous in emission order, fixed order)
     float g[NV];
 #pragma unroll
     for (int q = 0; q < NV; q++) g[q] = 0.f;
     const float4* __restrict__ rq = reinterpret_cast<const float4*>(a.rec + (size_t)i * REC_F);
     const float4 r4 = rq[4];
     const uint32_t beg = __float_as_uint(r4.z);          // inst_base patched by emit_instances
-    const uint32_t end = beg + a.tiles_touched[i];       // its instances are contiguous in emission order
+    const uint32_t end = beg + a.tiles_touched[i];
     for (uint32_t k = beg; k < end; k++) {
         const float4* __restrict__ src = reinterpret_cast<const float4*>(a.grec + (size_t)k * GREC_F);
         const float4 v0 = src[0], v1 = src[1], v2 = src[2], v3 = src[3], v4 = src[4];
@@ -279,15 +316,11 @@ __global__ void __launch_bounds__(256) preprocess_bwd_kernel(PreprocessBwdArgs a
         g[16] += v4.x; g[17] += v4.y;
     }
     a.dL_dopacity[i] = g[14];
-    a.dL_dnormal[3 * (size_t)i] = g[11]; a.dL_dnormal[3 * (size_t)i + 1] = g[12]; a.dL_dnormal[3 * (size_t)i + 2] = g[13];
-    a.dL_dcolors[3 * (size_t)i] = g[15]; a.dL_dcolors[3 * (size_t)i + 1] = g[16]; a.dL_dcolors[3 * (size_t)i + 2] = g[17];
+    store3(a.dL_dnormal, i, g[11], g[12], g[13]);
+    store3(a.dL_dcolors, i, g[15], g[16], g[17]);
 
     const float4 r0 = rq[0], r1 = rq[1], r2 = rq[2];
     const float T[9] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w, r2.x};
-    // densification statistic from the blend-stage dL/dT (before the centre term is folded in)
-    const float stat_x = g[2] * T[8] * 0.5f * (float)a.W;
-    const float stat_y = g[5] * T[8] * 0.5f * (float)a.H;
-
     float gT[9];
 #pragma unroll
     for (int q = 0; q < 9; q++) gT[q] = g[q];
@@ -312,17 +345,16 @@ __global__ void __launch_bounds__(256) preprocess_bwd_kernel(PreprocessBwdArgs a
     }
     const float px = a.means3D[3 * (size_t)i], py = a.means3D[3 * (size_t)i + 1], pz = a.means3D[3 * (size_t)i + 2];
     float dmx = 0.f, dmy = 0.f, dmz = 0.f;
-    if (a.transMat_precomp != nullptr) {
-        // statistic uses the folded gradient in this mode (matches the oracle / upstream ordering)
+    if (precomp) {
+        // the centre term is folded into dL/dtransMat, and the densification statistic uses the folded value
 #pragma unroll
         for (int q = 0; q < 9; q++) a.dL_dtransMat[9 * (size_t)i + q] = gT[q];
-        a.dL_dmeans2D[3 * (size_t)i] = gT[2] * T[8] * 0.5f * (float)a.W;
-        a.dL_dmeans2D[3 * (size_t)i + 1] = gT[5] * T[8] * 0.5f * (float)a.H;
+        store3(a.dL_dmeans2D, i, gT[2] * T[8] * 0.5f * (float)a.W, gT[5] * T[8] * 0.5f * (float)a.H, 0.f);
     } else {
 #pragma unroll
         for (int q = 0; q < 9; q++) a.dL_dtransMat[9 * (size_t)i + q] = g[q];
-        a.dL_dmeans2D[3 * (size_t)i] = stat_x;
-        a.dL_dmeans2D[3 * (size_t)i + 1] = stat_y;
+        // densification statistic from the blend-stage dL/dT (before the centre term is folded in)
+        store3(a.dL_dmeans2D, i, g[2] * T[8] * 0.5f * (float)a.W, g[5] * T[8] * 0.5f * (float)a.H, 0.f);
         const float* __restrict__ vm = a.viewmatrix;
         float Pm[12];
         world2pix(a.projmatrix, a.W, a.H, Pm);
@@ -355,8 +387,8 @@ __global__ void __launch_bounds__(256) preprocess_bwd_kernel(PreprocessBwdArgs a
         const float d00 = dA[0][0] * sx, d10 = dA[0][1] * sx, d20 = dA[0][2] * sx;
         const float d01 = dA[1][0] * sy, d11 = dA[1][1] * sy, d21 = dA[1][2] * sy;
         const float d02 = dtn0, d12 = dtn1, d22 = dtn2;
-        a.dL_dscales[2 * (size_t)i] = a.scale_modifier * (dA[0][0] * R00 + dA[0][1] * R10 + dA[0][2] * R20);
-        a.dL_dscales[2 * (size_t)i + 1] = a.scale_modifier * (dA[1][0] * R01 + dA[1][1] * R11 + dA[1][2] * R21);
+        reinterpret_cast<float2*>(a.dL_dscales)[i] = make_float2(a.scale_modifier * (dA[0][0] * R00 + dA[0][1] * R10 + dA[0][2] * R20),
+                                                                 a.scale_modifier * (dA[1][0] * R01 + dA[1][1] * R11 + dA[1][2] * R21));
         dmx = dA[2][0]; dmy = dA[2][1]; dmz = dA[2][2];
         float4 gq;
         gq.x = 2.f * (x * (d21 - d12) + y * (d02 - d20) + z * (d10 - d01));
@@ -367,70 +399,79 @@ __global__ void __launch_bounds__(256) preprocess_bwd_kernel(PreprocessBwdArgs a
     }
 
     if (a.shs != nullptr) {
-        const float* __restrict__ sh = a.shs + (size_t)i * a.M * 3;
-        float* __restrict__ gsh = a.dL_dsh + (size_t)i * a.M * 3;
         const float dox = px - a.campos[0], doy = py - a.campos[1], doz = pz - a.campos[2];
         const float sum2 = dox * dox + doy * doy + doz * doz;
         const float il = rsqrtf(sum2);
         const float x = dox * il, y = doy * il, z = doz * il;
         const uint8_t cb = a.clamped[i];
-        float gR[3] = {(cb & 1) ? 0.f : g[15], (cb & 2) ? 0.f : g[16], (cb & 4) ? 0.f : g[17]};
-        float ddx[3] = {0.f, 0.f, 0.f}, ddy[3] = {0.f, 0.f, 0.f}, ddz[3] = {0.f, 0.f, 0.f};
+        const float gR[3] = {(cb & 1) ? 0.f : g[15], (cb & 2) ? 0.f : g[16], (cb & 4) ? 0.f : g[17]};
+        // SH basis B[k] and its direction derivatives dB[k]/d{x,y,z} for the active degree (zero above it)
+        float B[16], Bx[16], By[16], Bz[16];
 #pragma unroll
-        for (int c = 0; c < 3; c++) gsh[c] = BSH_C0 * gR[c];
+        for (int k = 0; k < 16; k++) { B[k] = 0.f; Bx[k] = 0.f; By[k] = 0.f; Bz[k] = 0.f; }
+        B[0] = BSH_C0;
         if (a.D > 0) {
-#pragma unroll
-            for (int c = 0; c < 3; c++) {
-                gsh[3 + c] = -BSH_C1 * y * gR[c];
-                gsh[6 + c] = BSH_C1 * z * gR[c];
-                gsh[9 + c] = -BSH_C1 * x * gR[c];
-                ddx[c] = -BSH_C1 * sh[9 + c]; ddy[c] = -BSH_C1 * sh[3 + c]; ddz[c] = BSH_C1 * sh[6 + c];
-            }
+            B[1] = -BSH_C1 * y; By[1] = -BSH_C1;
+            B[2] = BSH_C1 * z;  Bz[2] = BSH_C1;
+            B[3] = -BSH_C1 * x; Bx[3] = -BSH_C1;
             if (a.D > 1) {
                 const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
-#pragma unroll
-                for (int c = 0; c < 3; c++) {
-                    gsh[12 + c] = BSH_C2[0] * xy * gR[c];
-                    gsh[15 + c] = BSH_C2[1] * yz * gR[c];
-                    gsh[18 + c] = BSH_C2[2] * (2.f * zz - xx - yy) * gR[c];
-                    gsh[21 + c] = BSH_C2[3] * xz * gR[c];
-                    gsh[24 + c] = BSH_C2[4] * (xx - yy) * gR[c];
-                    ddx[c] += BSH_C2[0] * y * sh[12 + c] + BSH_C2[2] * 2.f * -x * sh[18 + c] + BSH_C2[3] * z * sh[21 + c] + BSH_C2[4] * 2.f * x * sh[24 + c];
-                    ddy[c] += BSH_C2[0] * x * sh[12 + c] + BSH_C2[1] * z * sh[15 + c] + BSH_C2[2] * 2.f * -y * sh[18 + c] + BSH_C2[4] * 2.f * -y * sh[24 + c];
-                    ddz[c] += BSH_C2[1] * y * sh[15 + c] + BSH_C2[2] * 4.f * z * sh[18 + c] + BSH_C2[3] * x * sh[21 + c];
-                }
+                B[4] = BSH_C2[0] * xy; Bx[4] = BSH_C2[0] * y; By[4] = BSH_C2[0] * x;
+                B[5] = BSH_C2[1] * yz; By[5] = BSH_C2[1] * z; Bz[5] = BSH_C2[1] * y;
+                B[6] = BSH_C2[2] * (2.f * zz - xx - yy); Bx[6] = BSH_C2[2] * -2.f * x; By[6] = BSH_C2[2] * -2.f * y; Bz[6] = BSH_C2[2] * 4.f * z;
+                B[7] = BSH_C2[3] * xz; Bx[7] = BSH_C2[3] * z; Bz[7] = BSH_C2[3] * x;
+                B[8] = BSH_C2[4] * (xx - yy); Bx[8] = BSH_C2[4] * 2.f * x; By[8] = BSH_C2[4] * -2.f * y;
                 if (a.D > 2) {
-#pragma unroll
-                    for (int c = 0; c < 3; c++) {
-                        gsh[27 + c] = BSH_C3[0] * y * (3.f * xx - yy) * gR[c];
-                        gsh[30 + c] = BSH_C3[1] * xy * z * gR[c];
-                        gsh[33 + c] = BSH_C3[2] * y * (4.f * zz - xx - yy) * gR[c];
-                        gsh[36 + c] = BSH_C3[3] * z * (2.f * zz - 3.f * xx - 3.f * yy) * gR[c];
-                        gsh[39 + c] = BSH_C3[4] * x * (4.f * zz - xx - yy) * gR[c];
-                        gsh[42 + c] = BSH_C3[5] * z * (xx - yy) * gR[c];
-                        gsh[45 + c] = BSH_C3[6] * x * (xx - 3.f * yy) * gR[c];
-                        ddx[c] += BSH_C3[0] * sh[27 + c] * 6.f * xy + BSH_C3[1] * sh[30 + c] * yz + BSH_C3[2] * sh[33 + c] * -2.f * xy +
-                                  BSH_C3[3] * sh[36 + c] * -6.f * xz + BSH_C3[4] * sh[39 + c] * (-3.f * xx + 4.f * zz - yy) +
-                                  BSH_C3[5] * sh[42 + c] * 2.f * xz + BSH_C3[6] * sh[45 + c] * 3.f * (xx - yy);
-                        ddy[c] += BSH_C3[0] * sh[27 + c] * 3.f * (xx - yy) + BSH_C3[1] * sh[30 + c] * xz +
-                                  BSH_C3[2] * sh[33 + c] * (-3.f * yy + 4.f * zz - xx) + BSH_C3[3] * sh[36 + c] * -6.f * yz +
-                                  BSH_C3[4] * sh[39 + c] * -2.f * xy + BSH_C3[5] * sh[42 + c] * -2.f * yz + BSH_C3[6] * sh[45 + c] * -6.f * xy;
-                        ddz[c] += BSH_C3[1] * sh[30 + c] * xy + BSH_C3[2] * sh[33 + c] * 8.f * yz +
-                                  BSH_C3[3] * sh[36 + c] * 3.f * (2.f * zz - xx - yy) + BSH_C3[4] * sh[39 + c] * 8.f * xz +
-                                  BSH_C3[5] * sh[42 + c] * (xx - yy);
-                    }
+                    B[9] = BSH_C3[0] * y * (3.f * xx - yy); Bx[9] = BSH_C3[0] * 6.f * xy; By[9] = BSH_C3[0] * 3.f * (xx - yy);
+                    B[10] = BSH_C3[1] * xy * z; Bx[10] = BSH_C3[1] * yz; By[10] = BSH_C3[1] * xz; Bz[10] = BSH_C3[1] * xy;
+                    B[11] = BSH_C3[2] * y * (4.f * zz - xx - yy); Bx[11] = BSH_C3[2] * -2.f * xy; By[11] = BSH_C3[2] * (-3.f * yy + 4.f * zz - xx); Bz[11] = BSH_C3[2] * 8.f * yz;
+                    B[12] = BSH_C3[3] * z * (2.f * zz - 3.f * xx - 3.f * yy); Bx[12] = BSH_C3[3] * -6.f * xz; By[12] = BSH_C3[3] * -6.f * yz; Bz[12] = BSH_C3[3] * 3.f * (2.f * zz - xx - yy);
+                    B[13] = BSH_C3[4] * x * (4.f * zz - xx - yy); Bx[13] = BSH_C3[4] * (-3.f * xx + 4.f * zz - yy); By[13] = BSH_C3[4] * -2.f * xy; Bz[13] = BSH_C3[4] * 8.f * xz;
+                    B[14] = BSH_C3[5] * z * (xx - yy); Bx[14] = BSH_C3[5] * 2.f * xz; By[14] = BSH_C3[5] * -2.f * yz; Bz[14] = BSH_C3[5] * (xx - yy);
+                    B[15] = BSH_C3[6] * x * (xx - 3.f * yy); Bx[15] = BSH_C3[6] * 3.f * (xx - yy); By[15] = BSH_C3[6] * -6.f * xy;
                 }
             }
         }
-        const float gdx = ddx[0] * gR[0] + ddx[1] * gR[1] + ddx[2] * gR[2];
-        const float gdy = ddy[0] * gR[0] + ddy[1] * gR[1] + ddy[2] * gR[2];
-        const float gdz = ddz[0] * gR[0] + ddz[1] * gR[1] + ddz[2] * gR[2];
+        float gdx = 0.f, gdy = 0.f, gdz = 0.f;
+        if (a.M == 16) {
+            // one pass over the 48 coefficients as 12 float4: read sh (for the direction gradient), write dL/dsh
+            const float4* __restrict__ shq = reinterpret_cast<const float4*>(a.shs + (size_t)i * 48);
+#pragma unroll
+            for (int v = 0; v < 12; v++) {
+                const float4 c4 = shq[v];
+                const float cv[4] = {c4.x, c4.y, c4.z, c4.w};
+                float o[4];
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    const int flat = 4 * v + e, k = flat / 3, c = flat % 3;
+                    o[e] = B[k] * gR[c];
+                    const float t = cv[e] * gR[c];
+                    gdx += Bx[k] * t; gdy += By[k] * t; gdz += Bz[k] * t;
+                }
+                gshq[v] = make_float4(o[0], o[1], o[2], o[3]);
+            }
+        } else {
+            const float* __restrict__ sh = a.shs + (size_t)i * a.M * 3;
+            float* __restrict__ gsh = a.dL_dsh + (size_t)i * a.M * 3;
+#pragma unroll
+            for (int k = 0; k < 16; k++) {
+                if (k < a.M) {
+#pragma unroll
+                    for (int c = 0; c < 3; c++) {
+                        gsh[3 * k + c] = B[k] * gR[c];
+                        const float t = sh[3 * k + c] * gR[c];
+                        gdx += Bx[k] * t; gdy += By[k] * t; gdz += Bz[k] * t;
+                    }
+                }
+            }
+            for (int k = 16; k < a.M; k++) { gsh[3 * k] = 0.f; gsh[3 * k + 1] = 0.f; gsh[3 * k + 2] = 0.f; }
+        }
         const float il3 = il * il * il;
         dmx += ((sum2 - dox * dox) * gdx - doy * dox * gdy - doz * dox * gdz) * il3;
         dmy += (-dox * doy * gdx + (sum2 - doy * doy) * gdy - doz * doy * gdz) * il3;
         dmz += (-dox * doz * gdx - doy * doz * gdy + (sum2 - doz * doz) * gdz) * il3;
     }
-    a.dL_dmeans3D[3 * (size_t)i] = dmx; a.dL_dmeans3D[3 * (size_t)i + 1] = dmy; a.dL_dmeans3D[3 * (size_t)i + 2] = dmz;
+    store3(a.dL_dmeans3D, i, dmx, dmy, dmz);
 }
 
 void launch_blend_bwd(const BlendBwdArgs& a, hipStream_t s) {

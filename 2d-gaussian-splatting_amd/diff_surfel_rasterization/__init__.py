@@ -63,7 +63,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         M = 0 if sh is None else sh.shape[1]
         out_color = torch.empty((3, H, W), dtype=torch.float32, device=dev)
         out_others = torch.empty((7, H, W), dtype=torch.float32, device=dev)
-        radii = torch.zeros((P,), dtype=torch.int32, device=dev)
+        radii = torch.empty((P,), dtype=torch.int32, device=dev)
         ga, ba, ia = _n.TorchAllocator(dev), _n.TorchAllocator(dev), _n.TorchAllocator(dev)
         with torch.cuda.device(dev):
             R = lib.surfel_rasterize_forward(ga.cb, None, ba.cb, None, ia.cb, None, P, int(rs.sh_degree), M, _n.ptr(bg), W, H,
@@ -98,14 +98,14 @@ class _RasterizeGaussians(torch.autograd.Function):
         has_sh, has_col, has_sr, has_cov = ctx.has
         P, M, H, W = ctx.dims
         dev = means3D.device
-        z = lambda *shape: torch.zeros(shape, dtype=torch.float32, device=dev)
+        z = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)   # the kernels write every element
         g_means2D, g_normal, g_opac, g_colors = z(P, 3), z(P, 3), z(P, 1), z(P, 3)
         g_means3D, g_trans = z(P, 3), z(P, 9)
         g_sh = z(P, M, 3) if has_sh else None
         g_scales = z(P, 2) if has_sr else None
         g_rots = z(P, 4) if has_sr else None
-        gc = grad_out_color.contiguous().float() if grad_out_color is not None else z(3, H, W)
-        gd = grad_depth.contiguous().float() if grad_depth is not None else z(7, H, W)
+        gc = grad_out_color.contiguous().float() if grad_out_color is not None else torch.zeros((3, H, W), device=dev)
+        gd = grad_depth.contiguous().float() if grad_depth is not None else torch.zeros((7, H, W), device=dev)
         sa = _n.TorchAllocator(dev)
         opt = lambda t, ok: _n.ptr(t) if ok else None
         with torch.cuda.device(dev):

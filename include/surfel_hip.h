@@ -76,12 +76,13 @@ int64_t surfel_rasterize_forward(
  * Backward.  Replaces `_C.rasterize_gaussians_backward` (reached from loss.backward(),
  * /root/reference/train.py:90).  R = value returned by the matching forward; geom/binning/image
  * buffers = the pointers the forward's callbacks returned.  dL_dout_color[3,H,W],
- * dL_dout_others[7,H,W].  All dL_d* outputs are caller-allocated and MUST be zero-filled:
+ * dL_dout_others[7,H,W].  All dL_d* outputs are caller-allocated; every element is written (zeros for culled
+ * surfels), so they need NOT be zero-filled:
  *   dL_dmeans2D[P,3] (densification statistic consumed at /root/reference/scene/gaussian_model.py:405-407),
  *   dL_dnormal[P,3], dL_dopacity[P], dL_dcolors[P,3], dL_dmeans3D[P,3], dL_dtransMat[P,9],
  *   dL_dsh[P,M,3], dL_dscales[P,2], dL_drots[P,4].
- * `scratch_alloc` provides the per-instance gradient records (R * 80 bytes); gradients are
- * accumulated without atomics, so results are bit-reproducible run to run.
+ * `scratch_alloc` provides the per-instance gradient records (R * 80 bytes, each written exactly once);
+ * gradients are accumulated without atomics, so results are bit-reproducible run to run.
  */
 int surfel_rasterize_backward(
     surfel_alloc_fn scratch_alloc, void* scratch_user,

@@ -47,7 +47,7 @@ class HipRun:
         torch, n = self.torch, self.n
         self.color = torch.empty((3, self.H, self.W), device=self.dev)
         self.others = torch.empty((7, self.H, self.W), device=self.dev)
-        self.radii = torch.zeros((self.P,), dtype=torch.int32, device=self.dev)
+        self.radii = torch.full((self.P,), -7, dtype=torch.int32, device=self.dev)
         self.ga, self.ba, self.ia = n.TorchAllocator(self.dev), n.TorchAllocator(self.dev), n.TorchAllocator(self.dev)
         a = self.a
         R = self.lib.surfel_rasterize_forward(self.ga.cb, None, self.ba.cb, None, self.ia.cb, None, self.P, self.D, self.M,
@@ -68,7 +68,7 @@ class HipRun:
 
     def backward(self, gC, gO):
         torch, n = self.torch, self.n
-        z = lambda *s: torch.zeros(s, device=self.dev)
+        z = lambda *s: torch.full(s, float('nan'), device=self.dev)   # poison: the kernels must write every element
         P, M = self.P, self.M
         self.g = dict(means2D=z(P, 3), normal=z(P, 3), opacity=z(P, 1), colors=z(P, 3), means3D=z(P, 3), transMat=z(P, 9),
                       sh=z(P, max(M, 1), 3), scales=z(P, 2), rots=z(P, 4))
