@@ -9,7 +9,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "lib", "libsurfel_hip.so")
-SOURCES = ["surfel_forward.hip", "surfel_backward.hip", "surfel_api.hip", "knn.hip"]
+SOURCES = ["surfel_forward.hip", "surfel_backward.hip", "surfel_sort.hip", "surfel_api.hip", "knn.hip"]
 HEADERS = ["surfel_common.h", "surfel_kernels.h", os.path.join("..", "..", "include", "surfel_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast", "-Wall", "-Wno-unused-result"]
 

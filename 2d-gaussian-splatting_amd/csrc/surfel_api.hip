@@ -8,7 +8,6 @@
 #include <vector>
 
 #include <hip/hip_runtime.h>
-#include <rocprim/device/device_radix_sort.hpp>
 #include <rocprim/device/device_scan.hpp>
 #include <rocprim/iterator/counting_iterator.hpp>
 #include <rocprim/iterator/transform_iterator.hpp>
@@ -230,15 +229,12 @@ int64_t surfel_rasterize_forward(surfel_alloc_fn geom_alloc, void* geom_user, su
     GeomState geom{};
     BinState bin{};
     if (P > 0) {
-        // rocPRIM scratch sizes (host-side queries only)
-        size_t scan_bytes = 0, psort_bytes = 0;
+        // scratch sizes (host-side queries only)
+        size_t scan_bytes = 0;
         GatherTiles gq{nullptr, nullptr};
         auto gin0 = rocprim::make_transform_iterator(rocprim::make_counting_iterator<uint32_t>(0u), gq);
         HIP_TRY(rocprim::inclusive_scan(nullptr, scan_bytes, gin0, (uint32_t*)nullptr, (size_t)P, rocprim::plus<uint32_t>(), s));
-        {
-            rocprim::double_buffer<uint32_t> kq(nullptr, nullptr), vq(nullptr, nullptr);
-            HIP_TRY(rocprim::radix_sort_pairs(nullptr, psort_bytes, kq, vq, (size_t)P, 0, 32, s));
-        }
+        const size_t psort_bytes = radix_sort_scratch_bytes((size_t)P);
         const size_t temp_bytes = scan_bytes > psort_bytes ? scan_bytes : psort_bytes;
         size_t geom_bytes = 0;
         GeomState::carve(nullptr, P, temp_bytes, &geom_bytes);
@@ -259,10 +255,9 @@ int64_t surfel_rasterize_forward(surfel_alloc_fn geom_alloc, void* geom_user, su
 
         tm.begin();
         // (1) surfel order by view depth (stable; culled surfels carry key 0xffffffff and sort last)
-        rocprim::double_buffer<uint32_t> dk(geom.dkey_a, geom.dkey_b), od(geom.ord_a, geom.ord_b);
+        const int which = radix_sort_pairs_u32(geom.dkey_a, geom.ord_a, geom.dkey_b, geom.ord_b, (size_t)P, 0, 32, geom.temp, s);
+        const uint32_t* order = which ? geom.ord_b : geom.ord_a;
         size_t tb = temp_bytes;
-        HIP_TRY(rocprim::radix_sort_pairs(geom.temp, tb, dk, od, (size_t)P, 0, 32, s));
-        const uint32_t* order = od.current();
         // (2) instance offsets in depth order
         GatherTiles gt{geom.tiles_touched, order};
         auto gin = rocprim::make_transform_iterator(rocprim::make_counting_iterator<uint32_t>(0u), gt);
@@ -276,30 +271,28 @@ int64_t surfel_rasterize_forward(surfel_alloc_fn geom_alloc, void* geom_user, su
         R = (int64_t)*hR;
         STAGE_END(tm, ST_SCAN);
 
-        size_t sort_bytes = 0;
         const int end_bit = higher_msb((uint32_t)(gx * gy));
-        if (R > 0) {
-            rocprim::double_buffer<uint32_t> kq(nullptr, nullptr), vq(nullptr, nullptr);
-            HIP_TRY(rocprim::radix_sort_pairs(nullptr, sort_bytes, kq, vq, (size_t)R, 0, end_bit, s));
-        }
+        const size_t sort_bytes = radix_sort_scratch_bytes((size_t)R);
         size_t bin_bytes = 0;
         BinState::carve(nullptr, (size_t)R, sort_bytes, &bin_bytes);
         void* bin_base = binning_alloc(binning_user, bin_bytes > 0 ? bin_bytes : 256);
         if (!bin_base) return fail(SURFEL_E_ALLOC, "binning buffer allocation failed");
         bin = BinState::carve(bin_base, (size_t)R, sort_bytes, nullptr);
         if (R > 0) {
+            // (3) stable sort on the tile-id bits only: depth order inside every tile is preserved.  The value buffers
+            // are assigned so that the ping-pong ends in bin.point_list.
+            const bool odd = radix_sort_passes(0, end_bit) & 1;
+            uint32_t* va = odd ? bin.vals_alt : bin.point_list;
+            uint32_t* vb = odd ? bin.point_list : bin.vals_alt;
             tm.begin();
-            launch_emit_instances(P, geom.rec, order, geom.offsets, bin.keys_a, bin.vals_alt, gx, s);
+            launch_emit_instances(P, geom.rec, order, geom.offsets, bin.keys_a, va, gx, s);
             STAGE_END(tm, ST_EMIT);
             tm.begin();
-            // (3) stable sort on the tile-id bits only: depth order inside every tile is preserved
-            rocprim::double_buffer<uint32_t> kq(bin.keys_a, bin.keys_b), vq(bin.vals_alt, bin.point_list);
-            HIP_TRY(rocprim::radix_sort_pairs(bin.sort_temp, sort_bytes, kq, vq, (size_t)R, 0, end_bit, s));
-            if (vq.current() != bin.point_list)
-                HIP_TRY(hipMemcpyAsync(bin.point_list, vq.current(), sizeof(uint32_t) * (size_t)R, hipMemcpyDeviceToDevice, s));
+            const int wk = radix_sort_pairs_u32(bin.keys_a, va, bin.keys_b, vb, (size_t)R, 0, end_bit, bin.sort_temp, s);
+            const uint32_t* sorted_keys = wk ? bin.keys_b : bin.keys_a;
             STAGE_END(tm, ST_SORT);
             tm.begin();
-            launch_tile_ranges(R, kq.current(), img.ranges, s);
+            launch_tile_ranges(R, sorted_keys, img.ranges, s);
             STAGE_END(tm, ST_RANGES);
         }
     } else {

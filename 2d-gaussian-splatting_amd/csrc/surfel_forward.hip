@@ -281,6 +281,7 @@ __global__ void __launch_bounds__(BLOCK) blend_fwd_kernel(BlendFwdArgs a) {
     float T = 1.f, C0 = 0.f, C1 = 0.f, C2 = 0.f, N0 = 0.f, N1 = 0.f, N2 = 0.f;
     float D = 0.f, M1 = 0.f, M2 = 0.f, dist = 0.f, med = 0.f;
     uint32_t last = 0, medc = 0;
+    constexpr float MC1 = FAR_N / (FAR_N - NEAR_N);
 
     for (int base = 0; base < n; base += BLOCK) {
         if (__syncthreads_count(done) == BLOCK) break;
@@ -307,26 +308,40 @@ __global__ void __launch_bounds__(BLOCK) blend_fwd_kernel(BlendFwdArgs a) {
                 while (mask) {
                     const int j = sw * 64 + __builtin_ctzll(mask);
                     mask &= mask - 1;
-                    if (done) continue;
-                    const uint32_t contributor = base + j + 1;
                     const float4 q0 = s_rec[j * 5 + 0], q1 = s_rec[j * 5 + 1], q2 = s_rec[j * 5 + 2];
-                    Hit h;
-                    if (!intersect(q0, q1, q2, pxf, pyf, h)) continue;
-                    const float testT = T * (1.f - h.alpha);
-                    if (testT < T_EPS) { done = true; continue; }
-                    const float4 q3 = s_rec[j * 5 + 3], q4 = s_rec[j * 5 + 4];
-                    const float w = h.alpha * T;
-                    const float A = 1.f - T;
-                    const float mm = FAR_N / (FAR_N - NEAR_N) * (1.f - NEAR_N / h.depth);
-                    dist += (mm * mm * A + M2 - 2.f * mm * M1) * w;
-                    D += h.depth * w;
-                    M1 += mm * w;
-                    M2 += mm * mm * w;
-                    if (T > 0.5f) { med = h.depth; medc = contributor; }
-                    N0 += q3.x * w; N1 += q3.y * w; N2 += q3.z * w;
-                    C0 += q3.w * w; C1 += q4.x * w; C2 += q4.y * w;
-                    T = testT;
-                    last = contributor;
+                    // ray-splat intersection, branch-free (same arithmetic as surfel::intersect)
+                    const float Twx = q1.z, Twy = q1.w, Twz = q2.x;
+                    const float kx = pxf * Twx - q0.x, ky = pxf * Twy - q0.y, kz = pxf * Twz - q0.z;
+                    const float lx_ = pyf * Twx - q0.w, ly_ = pyf * Twy - q1.x, lz_ = pyf * Twz - q1.y;
+                    const float p0 = ky * lz_ - kz * ly_, p1 = kz * lx_ - kx * lz_, p2 = kx * ly_ - ky * lx_;
+                    const float ip = __builtin_amdgcn_rcpf(p2);
+                    const float sx = p0 * ip, sy = p1 * ip;
+                    const float rho3d = sx * sx + sy * sy;
+                    const float dx = q2.y - pxf, dy = q2.z - pyf;
+                    const float rho2d = FILTER_INV_SQUARE * (dx * dx + dy * dy);
+                    const float depth = (rho3d <= rho2d) ? (sx * Twx + sy * Twy) + Twz : Twz;
+                    const float alpha = fminf(ALPHA_MAX, q2.w * __expf(-0.5f * fminf(rho3d, rho2d)));
+                    const bool ok = (!done) & (p2 != 0.f) & (depth >= NEAR_N) & (alpha >= ALPHA_MIN);
+                    if (__ballot(ok) == 0ull) continue;
+                    if (ok) {
+                        const float testT = T * (1.f - alpha);
+                        if (testT < T_EPS) done = true;       // the terminating surfel is not composited
+                        else {
+                            const uint32_t contributor = base + j + 1;
+                            const float4 q3 = s_rec[j * 5 + 3], q4 = s_rec[j * 5 + 4];
+                            const float w = alpha * T;
+                            const float mm = MC1 - (MC1 * NEAR_N) * __builtin_amdgcn_rcpf(depth);
+                            dist += (mm * (mm * (1.f - T) - 2.f * M1) + M2) * w;
+                            D += depth * w;
+                            M1 += mm * w;
+                            M2 += mm * mm * w;
+                            if (T > 0.5f) { med = depth; medc = contributor; }
+                            N0 += q3.x * w; N1 += q3.y * w; N2 += q3.z * w;
+                            C0 += q3.w * w; C1 += q4.x * w; C2 += q4.y * w;
+                            T = testT;
+                            last = contributor;
+                        }
+                    }
                 }
                 if (__all(done)) break;
             }
