@@ -1,0 +1,114 @@
+"""Multi-GPU shim beside the render boundary: one process per GPU, torch.distributed over RCCL/xGMI.
+
+The reference has no distributed code at all; its training loop renders ONE view per
+iteration on cuda:0 (/root/reference/train.py:54-69, utils/general_utils.py:133).  Two shardings are
+provided, both with exactly one data-path collective per step and nothing else crossing GPUs:
+
+  * view-parallel (BASELINE config 4): every rank holds a replica of the surfel parameters, renders a
+    DIFFERENT training view, and the per-surfel gradients are summed with ONE all-reduce over a flat fp32
+    bucket of 58 floats / surfel (xyz 3, f_dc 3, f_rest 45, opacity 1, scaling 2, rotation 4 — the Adam
+    groups of /root/reference/scene/gaussian_model.py:153-160) = 232 B/surfel.  The densification statistics
+    the reference keeps per view (train.py:126-128, gaussian_model.py:405-407) are reduced alongside:
+    sum of per-view ||means2D.grad||, sum of visibility, max of radii.
+  * tile-band sharding (BASELINE config 5): rank r renders image rows [y0, y1) (multiples of 16, so tile
+    boundaries coincide) by giving the unchanged rasterizer a shifted projection (`band_settings`); bands are
+    independent (no halo), the loss is a sum over pixels, so the per-surfel gradients of the bands add up —
+    the same single all-reduce.
+
+The backward kernels accumulate without atomics, so every rank's gradients are bit-reproducible and an
+identical all-reduced bucket + identical Adam step keeps the replicas bit-identical.
+xGMI note: 8 GPUs are fully connected (7 links x ~153 GB/s per GPU); one large bucket lets RCCL pick a
+direct reduce-scatter + all-gather over all links — do not split it into per-tensor collectives.
+"""
+import math
+from typing import Dict, List, Optional, Sequence
+
+import torch
+import torch.distributed as dist
+
+BUCKET_LAYOUT = (("xyz", 3), ("f_dc", 3), ("f_rest", 45), ("opacity", 1), ("scaling", 2), ("rotation", 4))
+BUCKET_FLOATS = sum(n for _, n in BUCKET_LAYOUT)      # 58 floats = 232 B per surfel
+
+
+def view_indices(n_views: int, world: int, rank: int, iteration: int, seed: int = 0) -> int:
+    """The training view of `rank` at global step `iteration`: all ranks walk the SAME seeded permutation of the
+    views (re-drawn every epoch like the reference's pop-from-shuffled-stack, train.py:64-67), rank-strided, so a
+    step consumes `world` distinct views."""
+    per_epoch = max(1, n_views // world)
+    epoch, k = divmod(iteration, per_epoch)
+    g = torch.Generator().manual_seed(seed * 1_000_003 + epoch)
+    perm = torch.randperm(n_views, generator=g)
+    return int(perm[(k * world + rank) % n_views])
+
+
+class GradBucket:
+    """Flat [P, 58] fp32 gradient bucket: pack -> ONE all-reduce(SUM) -> unpack."""
+
+    def __init__(self, P: int, device, group=None):
+        self.P, self.group = P, group
+        self.buf = torch.empty((P, BUCKET_FLOATS), dtype=torch.float32, device=device)
+
+    def pack(self, grads: Dict[str, torch.Tensor]):
+        views = [grads[name].reshape(self.P, n) for name, n in BUCKET_LAYOUT]
+        torch.cat(views, dim=1, out=self.buf)
+        return self.buf
+
+    def all_reduce(self, average: bool = True, async_op: bool = False):
+        work = dist.all_reduce(self.buf, op=dist.ReduceOp.SUM, group=self.group, async_op=async_op)
+        if average and not async_op:
+            self.buf.div_(dist.get_world_size(self.group))
+        return work
+
+    def unpack(self, like: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+        out, c = {}, 0
+        for name, n in BUCKET_LAYOUT:
+            out[name] = self.buf[:, c:c + n].reshape(like[name].shape)
+            c += n
+        return out
+
+
+def reduce_densification_stats(grad_norm: torch.Tensor, visible: torch.Tensor, radii: torch.Tensor, group=None):
+    """Per-view statistics -> job-wide: grad_norm [P,1] = ||means2D.grad|| of THIS rank's view (norm taken locally,
+    before reducing: gaussian_model.py:406), visible [P] bool, radii [P].  Returns (sum_norm, denom, max_radii)."""
+    vis = visible.to(torch.float32).reshape(-1, 1)
+    packed = torch.cat([grad_norm.reshape(-1, 1) * vis, vis], dim=1).contiguous()
+    dist.all_reduce(packed, op=dist.ReduceOp.SUM, group=group)
+    mr = torch.where(visible.reshape(-1), radii.reshape(-1).to(torch.float32), torch.zeros((), device=radii.device)).contiguous()
+    dist.all_reduce(mr, op=dist.ReduceOp.MAX, group=group)
+    return packed[:, :1], packed[:, 1:2], mr
+
+
+def broadcast_parameters(params: Sequence[torch.Tensor], src: int = 0, group=None):
+    """Start / resume: make every replica bit-identical to rank `src`."""
+    for p in params:
+        dist.broadcast(p.data if hasattr(p, "data") else p, src=src, group=group)
+
+
+# ------------------------------------------------------------------------------------------- tile bands
+def band_bounds(H: int, world: int, weights: Optional[Sequence[float]] = None) -> List[tuple]:
+    """Split image rows into `world` contiguous bands whose edges are multiples of 16 (tile rows).  `weights`
+    (one per tile row, e.g. last frame's instance counts) balances the bands; default = equal tile rows."""
+    rows = (H + 15) // 16
+    w = [1.0] * rows if weights is None else [float(x) + 1e-6 for x in weights]
+    assert len(w) == rows and world >= 1
+    total = sum(w)
+    cuts, acc, r = [0], 0.0, 0
+    for k in range(1, world):
+        while r < rows and acc + w[r] <= total * k / world + 1e-9:
+            acc += w[r]; r += 1
+        cuts.append(max(r, cuts[-1]))
+    cuts.append(rows)
+    return [(min(cuts[i] * 16, H), min(cuts[i + 1] * 16, H)) for i in range(world)]
+
+
+def band_settings(raster_settings, y0: int, y1: int):
+    """Raster settings that make the UNCHANGED rasterizer render rows [y0, y1) of the full image.
+    Pixel rows shift by y0 and the image height shrinks, which in the kernel's convention
+    y_pix = ((y_ndc + 1) * H - 1) / 2 is the clip-space map  y_clip' = y_clip * H/Hb + w_clip * (H - Hb - 2*y0)/Hb ;
+    with row-vector matrices (scene/cameras.py:56-58) that is a change of column 1 of the projection matrix."""
+    H = int(raster_settings.image_height)
+    Hb = int(y1 - y0)
+    assert y0 % 16 == 0 and 0 < Hb and y1 <= H
+    pm = raster_settings.projmatrix.clone()
+    pm[:, 1] = raster_settings.projmatrix[:, 1] * (H / Hb) + raster_settings.projmatrix[:, 3] * ((H - Hb - 2.0 * y0) / Hb)
+    return raster_settings._replace(image_height=Hb, projmatrix=pm, tanfovy=raster_settings.tanfovy * Hb / H)

@@ -76,7 +76,8 @@ def main():
     means3D, shs, opac, scales, rots = params
     g = torch.Generator(device="cpu").manual_seed(1234 + rank)
     gC = torch.randn((3, H, W), generator=g).to(dev); gO = torch.randn((7, H, W), generator=g).to(dev)
-    bucket = torch.empty((P, 58), device=dev) if world > 1 else None
+    import surfel_dist
+    bucket = surfel_dist.GradBucket(P, dev) if world > 1 else None
     state = {}
 
     def step():
@@ -85,8 +86,10 @@ def main():
                                     scales=scales, rotations=rots, cov3D_precomp=None)
         torch.autograd.backward([color, allmap], [gC, gO])
         if world > 1:
-            torch.cat([means3D.grad, shs.grad.view(P, 48), opac.grad, scales.grad, rots.grad], dim=1, out=bucket)
-            dist.all_reduce(bucket)
+            sg = shs.grad
+            bucket.pack(dict(xyz=means3D.grad, f_dc=sg[:, :1], f_rest=sg[:, 1:], opacity=opac.grad, scaling=scales.grad,
+                             rotation=rots.grad))
+            bucket.all_reduce(average=True)
         state["radii"] = radii
         for p_ in params:
             p_.grad = None

@@ -1,0 +1,116 @@
+"""CPU tests of the multi-GPU shim: world_size-2 gloo processes for the collectives; the tile-band projection trick
+is checked against the fp64 oracle (band images concatenate to the full image, band gradients sum to the full gradient)."""
+import os
+import socket
+from collections import namedtuple
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _fake_grads(P, rank):
+    g = torch.Generator().manual_seed(100 + rank)
+    shapes = dict(xyz=(P, 3), f_dc=(P, 1, 3), f_rest=(P, 15, 3), opacity=(P, 1), scaling=(P, 2), rotation=(P, 4))
+    return {k: torch.randn(s, generator=g) for k, s in shapes.items()}
+
+
+def _worker(rank, world, port, P, q):
+    import sys
+    here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(here, "2d-gaussian-splatting_amd"))
+    import surfel_dist as sd
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        grads = _fake_grads(P, rank)
+        b = sd.GradBucket(P, "cpu")
+        b.pack(grads); b.all_reduce(average=False)
+        out = b.unpack(grads)
+        expect = {k: sum(_fake_grads(P, r)[k] for r in range(world)) for k in grads}
+        ok = all(torch.allclose(out[k], expect[k], atol=1e-6) for k in grads)
+        b.pack(grads); b.all_reduce(average=True)
+        ok &= torch.allclose(b.unpack(grads)["xyz"], expect["xyz"] / world, atol=1e-6)
+        # densification statistics
+        g = torch.Generator().manual_seed(7 + rank)
+        gn = torch.rand((P, 1), generator=g); vis = torch.rand(P, generator=g) > 0.5; rad = torch.randint(0, 30, (P,), generator=g)
+        sn, dn, mr = sd.reduce_densification_stats(gn, vis, rad)
+        e_sn = torch.zeros(P, 1); e_dn = torch.zeros(P, 1); e_mr = torch.zeros(P)
+        for r in range(world):
+            g2 = torch.Generator().manual_seed(7 + r)
+            gn2 = torch.rand((P, 1), generator=g2); vis2 = torch.rand(P, generator=g2) > 0.5; rad2 = torch.randint(0, 30, (P,), generator=g2)
+            e_sn += gn2 * vis2[:, None]; e_dn += vis2[:, None].float(); e_mr = torch.maximum(e_mr, torch.where(vis2, rad2.float(), torch.zeros(())))
+        ok &= torch.allclose(sn, e_sn, atol=1e-6) and torch.equal(dn, e_dn) and torch.equal(mr, e_mr)
+        # parameter broadcast
+        p = torch.full((4, 3), float(rank))
+        sd.broadcast_parameters([p], src=0)
+        ok &= bool((p == 0).all())
+        # view schedule: the ranks of one step get distinct views; every rank computes the same schedule
+        mine = [sd.view_indices(10, world, rank, it, seed=3) for it in range(12)]
+        other = [sd.view_indices(10, world, 1 - rank, it, seed=3) for it in range(12)]
+        ok &= all(a != b_ for a, b_ in zip(mine, other))
+        q.put((rank, bool(ok)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_gloo_world2_collectives():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, 257, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+    assert res == [(0, True), (1, True)]
+
+
+def test_band_bounds():
+    import surfel_dist as sd
+    b = sd.band_bounds(2160, 8)
+    assert b[0][0] == 0 and b[-1][1] == 2160 and all(b[i][1] == b[i + 1][0] for i in range(7)) and all(y0 % 16 == 0 for y0, _ in b)
+    assert max(y1 - y0 for y0, y1 in b) - min(y1 - y0 for y0, y1 in b) <= 32
+    w = [1.0] * 10 + [9.0] * 5            # heavy bottom rows -> the bottom band is shorter
+    b2 = sd.band_bounds(240, 2, w)
+    assert b2[0][1] > 120 and b2[1][1] == 240
+
+
+def test_tile_band_sharding_matches_full_render():
+    """Rendering rows [y0,y1) through band_settings' shifted projection == the same rows of the full render, and the
+    per-surfel gradients of the bands add up to the full-image gradients (fp64 oracle)."""
+    import surfel_dist as sd
+    import synthetic
+    from helpers import oracle_forward, scene_args
+    from oracle.surfel_oracle import Oracle
+    RS = namedtuple("RS", "image_height image_width tanfovx tanfovy bg scale_modifier viewmatrix projmatrix sh_degree campos prefiltered debug")
+    W, H, P = 96, 80, 700
+    sc = synthetic.make_scene(P, W, H, seed=5, px_radius=5.0)
+    a = scene_args(sc)
+    o = Oracle("f64")
+    R, col, oth, radii, st = oracle_forward(o, a)
+    rng = np.random.default_rng(1)
+    gC = rng.normal(size=col.shape); gO = rng.normal(size=oth.shape)
+    gO[5] = 0     # median-depth channel is piecewise constant; keep its gradient out of the additivity check
+    g_full = o.rasterize_backward(st, gC, gO)
+    rs = RS(H, W, a["tanfovx"], a["tanfovy"], torch.tensor(a["bg"]), 1.0, torch.tensor(a["viewmatrix"]), torch.tensor(a["projmatrix"]), 3,
+            torch.tensor(a["campos"]), False, False)
+    acc = None
+    for (y0, y1) in sd.band_bounds(H, 2):
+        rb = sd.band_settings(rs, y0, y1)
+        ab = dict(a); ab["H"] = rb.image_height; ab["projmatrix"] = rb.projmatrix.numpy(); ab["tanfovy"] = rb.tanfovy
+        Rb, colb, othb, radb, stb = oracle_forward(o, ab)
+        assert np.abs(colb - col[:, y0:y1]).max() < 1e-5            # projection matrices are fp32: 1e-7-relative shift
+        assert np.abs(othb[[0, 1, 2, 3, 4, 6]] - oth[[0, 1, 2, 3, 4, 6], y0:y1]).max() < 1e-4
+        gb = o.rasterize_backward(stb, gC[:, y0:y1], gO[:, y0:y1])
+        part = [gb.dL_dmeans3D, gb.dL_dscales, gb.dL_drots, gb.dL_dopacity, gb.dL_dsh]
+        acc = part if acc is None else [x + y for x, y in zip(acc, part)]
+    for got, ref in zip(acc, [g_full.dL_dmeans3D, g_full.dL_dscales, g_full.dL_drots, g_full.dL_dopacity, g_full.dL_dsh]):
+        assert np.abs(got - ref).max() <= 2e-3 * np.abs(ref).max()
