@@ -297,3 +297,38 @@ def test_knn_exact():
     d, _ = cKDTree(pts.astype(np.float64)).query(pts.astype(np.float64), k=4)
     ref = (d[:, 1:] ** 2).mean(1)
     assert np.allclose(got, ref, rtol=1e-4, atol=1e-9)
+
+
+def test_tile_band_sharding_on_device():
+    """surfel_dist.band_settings on the HIP path: bands concatenate to the full image and band gradients add up."""
+    import torch
+    import surfel_dist as sd
+    from diff_surfel_rasterization import GaussianRasterizationSettings, GaussianRasterizer
+    sc = _scene((4000, 160, 128), seed=8, px_radius=5.0)
+    a = scene_args(sc)
+    dev = torch.device("cuda:0")
+    t = lambda x: torch.tensor(x, device=dev)
+    rs = GaussianRasterizationSettings(image_height=a["H"], image_width=a["W"], tanfovx=a["tanfovx"], tanfovy=a["tanfovy"],
+                                       bg=t(a["bg"]), scale_modifier=1.0, viewmatrix=t(a["viewmatrix"]),
+                                       projmatrix=t(a["projmatrix"]), sh_degree=3, campos=t(a["campos"]), prefiltered=False, debug=False)
+    rng = np.random.default_rng(4)
+    gC = t(rng.normal(size=(3, a["H"], a["W"])).astype(np.float32)); gO = t(rng.normal(size=(7, a["H"], a["W"])).astype(np.float32))
+    gO[5] = 0
+
+    def run(settings, gc, go):
+        leaves = [t(a[k]).requires_grad_(True) for k in ("means3D", "shs", "opacities", "scales", "rotations")]
+        m2 = torch.zeros_like(leaves[0], requires_grad=True)
+        color, radii, allmap = GaussianRasterizer(settings)(means3D=leaves[0], means2D=m2, shs=leaves[1], colors_precomp=None,
+                                                           opacities=leaves[2], scales=leaves[3], rotations=leaves[4], cov3D_precomp=None)
+        torch.autograd.backward([color, allmap], [gc, go])
+        return color.detach(), allmap.detach(), [l.grad for l in leaves]
+
+    col, oth, g_full = run(rs, gC, gO)
+    acc = None
+    for (y0, y1) in sd.band_bounds(a["H"], 4):
+        cb, ob, gb = run(sd.band_settings(rs, y0, y1), gC[:, y0:y1].contiguous(), gO[:, y0:y1].contiguous())
+        assert frac_close(cb.cpu().numpy(), col[:, y0:y1].cpu().numpy(), 2e-4, 2e-4) > 0.999
+        assert frac_close(ob[:5].cpu().numpy(), oth[:5, y0:y1].cpu().numpy(), 2e-4, 2e-4) > 0.999
+        acc = gb if acc is None else [x + y for x, y in zip(acc, gb)]
+    for got, ref in zip(acc, g_full):
+        assert cosine(got.cpu().numpy(), ref.cpu().numpy()) > 0.9999
