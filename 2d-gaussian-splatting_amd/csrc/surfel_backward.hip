@@ -93,7 +93,6 @@ __global__ void __launch_bounds__(BLOCK) blend_bwd_kernel(BlendBwdArgs a) {
         g_med = a.dL_dothers[5 * HW + pix]; g_dist = a.dL_dothers[6 * HW + pix];
     }
     const float final_A = 1.f - T_final;
-    const float bgT = -T_final * (a.bg[0] * gC0 + a.bg[1] * gC1 + a.bg[2] * gC2);
 
     if (threadIdx.x == 0) s_max = 0;
     __syncthreads();
@@ -107,10 +106,7 @@ __global__ void __launch_bounds__(BLOCK) blend_bwd_kernel(BlendBwdArgs a) {
     const int maxc = s_max;
 
     float T = T_final;
-    float last_alpha = 0.f, lc0 = 0.f, lc1 = 0.f, lc2 = 0.f, ar0 = 0.f, ar1 = 0.f, ar2 = 0.f;
-    float last_depth = 0.f, accum_depth = 0.f, accum_alpha = 0.f;
-    float ln0 = 0.f, ln1 = 0.f, ln2 = 0.f, an0 = 0.f, an1 = 0.f, an2 = 0.f;
-    float last_dL_dT = 0.f;
+    float X = T_final * (a.bg[0] * gC0 + a.bg[1] * gC1 + a.bg[2] * gC2);     // suffix sum, seeded with the background term
     constexpr float MC1 = FAR_N / (FAR_N - NEAR_N), MC2 = (FAR_N * NEAR_N) / (FAR_N - NEAR_N);
     // LDS slot address pattern of the reduced values: lane (row q, first lane) stores value 4j + {0,2,1,3}[q]
     const int row = lane >> 4;
@@ -161,36 +157,28 @@ __global__ void __launch_bounds__(BLOCK) blend_bwd_kernel(BlendBwdArgs a) {
                 const float alpha = fminf(ALPHA_MAX, opa * G);
                 const bool ok = (pos <= last) & (p2 != 0.f) & (depth >= NEAR_N) & (alpha >= ALPHA_MIN);
                 if (__ballot(ok) == 0ull) continue;      // wave-uniform
-                // Sequential per-pixel state lives in the divergent region (in-place, no copies); it hands
-                // three scalars (w, dL_dalpha, dL_dz) — zero for lanes that skip — to the branch-free
-                // gradient expansion below.
+                // Sequential per-pixel state.  Every upstream gradient enters dL/dalpha only through its dot product
+                // with this surfel's attributes, so the back-to-front recurrences (colour, depth, alpha, normal,
+                // distortion, background) collapse into ONE scalar suffix sum
+                //     X_k = T_final*bg.gC + sum_{i>k} w_i u_i ,  u_i = c_i.gC + d_i g_D + g_A + n_i.gN + dDist/dw_i
+                //     dL/dalpha_k = T_k u_k - X_k / (1 - alpha_k)
+                // (algebraically identical to the per-channel "accum_rec" recurrences, 2 state floats instead of 17).
                 const float4 q3 = s_rec[j * 5 + 3], q4 = s_rec[j * 5 + 4];
                 float w = 0.f, dL_dalpha = 0.f, dL_dz = 0.f;
                 if (ok) {
                     const float i1a = __builtin_amdgcn_rcpf(1.f - alpha);
                     T = T * i1a;
                     w = alpha * T;
-                    const float om = 1.f - last_alpha;
-                    float da;
-                    ar0 = last_alpha * lc0 + om * ar0; lc0 = q3.w; da = (q3.w - ar0) * gC0;
-                    ar1 = last_alpha * lc1 + om * ar1; lc1 = q4.x; da += (q4.x - ar1) * gC1;
-                    ar2 = last_alpha * lc2 + om * ar2; lc2 = q4.y; da += (q4.y - ar2) * gC2;
                     const float inv_d = __builtin_amdgcn_rcpf(depth);
                     const float mm = MC1 - (MC1 * NEAR_N) * inv_d;
-                    const float dL_dweight = (fM2 + mm * (mm * final_A - 2.f * fM1)) * g_dist;
-                    da += dL_dweight - last_dL_dT;
-                    last_dL_dT = dL_dweight * alpha + (1.f - alpha) * last_dL_dT;
+                    float u = (fM2 + mm * (mm * final_A - 2.f * fM1)) * g_dist + g_alpha;
+                    u += q3.w * gC0; u += q4.x * gC1; u += q4.y * gC2;
+                    u += depth * g_depth;
+                    u += q3.x * gN0; u += q3.y * gN1; u += q3.z * gN2;
+                    dL_dalpha = T * u - X * i1a;
+                    X += w * u;
                     dL_dz = (2.f * w * g_dist) * (mm * final_A - fM1) * (MC2 * inv_d * inv_d) + w * g_depth;
                     dL_dz += (pos == medc) ? g_med : 0.f;
-                    accum_depth = last_alpha * last_depth + om * accum_depth; last_depth = depth;
-                    da += (depth - accum_depth) * g_depth;
-                    accum_alpha = last_alpha + om * accum_alpha;
-                    da += (1.f - accum_alpha) * g_alpha;
-                    an0 = last_alpha * ln0 + om * an0; ln0 = q3.x; da += (q3.x - an0) * gN0;
-                    an1 = last_alpha * ln1 + om * an1; ln1 = q3.y; da += (q3.y - an1) * gN1;
-                    an2 = last_alpha * ln2 + om * an2; ln2 = q3.z; da += (q3.z - an2) * gN2;
-                    dL_dalpha = da * T + bgT * i1a;
-                    last_alpha = alpha;
                 }
                 float gv[NVP];
                 gv[15] = w * gC0; gv[16] = w * gC1; gv[17] = w * gC2;
