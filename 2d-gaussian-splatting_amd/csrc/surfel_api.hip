@@ -125,14 +125,18 @@ struct StageTimer {
         if (mode == 1) { (void)hipEventCreate(&e0); (void)hipEventCreate(&e1); }
     }
     ~StageTimer() { if (mode == 1) { (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); } }
-    void begin() {
-        if (mode == 2) { (void)hipEventCreate(&e0); (void)hipEventCreate(&e1); }
-        if (mode) (void)hipEventRecord(e0, s);
+    bool armed = false;
+    void begin(int stage = -1) {
+        armed = mode == 1 || mode == 2 || (mode == 3 && stage == ST_BBWD);
+        if (!armed) return;
+        if (mode >= 2) { (void)hipEventCreate(&e0); (void)hipEventCreate(&e1); }
+        (void)hipEventRecord(e0, s);
     }
     int end(int stage) {   // returns hip error as int
-        if (!mode) return 0;
+        if (!armed) return 0;
+        armed = false;
         (void)hipEventRecord(e1, s);
-        if (mode == 2) { std::lock_guard<std::mutex> lk(g_pending_mu); g_pending.push_back({stage, e0, e1}); return 0; }
+        if (mode >= 2) { std::lock_guard<std::mutex> lk(g_pending_mu); g_pending.push_back({stage, e0, e1}); return 0; }
         hipError_t e = hipEventSynchronize(e1);
         if (e != hipSuccess) return (int)e;
         e = hipGetLastError();
@@ -281,7 +285,7 @@ int64_t surfel_rasterize_forward(surfel_alloc_fn geom_alloc, void* geom_user, su
         if (R > 0) {
             // (3) stable sort on the tile-id bits only: depth order inside every tile is preserved.  The value buffers
             // are assigned so that the ping-pong ends in bin.point_list.
-            const bool odd = radix_sort_passes(0, end_bit) & 1;
+            const bool odd = radix_sort_passes((size_t)R, 0, end_bit) & 1;
             uint32_t* va = odd ? bin.vals_alt : bin.point_list;
             uint32_t* vb = odd ? bin.point_list : bin.vals_alt;
             tm.begin();
@@ -350,7 +354,7 @@ int surfel_rasterize_backward(surfel_alloc_fn scratch_alloc, void* scratch_user,
     bb.final_T = img.final_T; bb.n_contrib = img.n_contrib; bb.dL_dpix = dL_dout_color; bb.dL_dothers = dL_dout_others;
     bb.grec = grec;
     if (R > 0) {
-        tm.begin();
+        tm.begin(ST_BBWD);
         launch_blend_bwd(bb, s);
         STAGE_END(tm, ST_BBWD);
     }

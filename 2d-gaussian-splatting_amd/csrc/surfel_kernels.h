@@ -50,7 +50,7 @@ void launch_preprocess_bwd(const PreprocessBwdArgs& a, hipStream_t s);
 void launch_knn(int P, const float* points, float* out, void* scratch, size_t scratch_bytes, hipStream_t s);
 size_t knn_scratch_bytes(int P);
 size_t radix_sort_scratch_bytes(size_t n);
-int radix_sort_passes(int begin_bit, int end_bit);
+int radix_sort_passes(size_t n, int begin_bit, int end_bit);
 int radix_sort_pairs_u32(uint32_t* keys_a, uint32_t* vals_a, uint32_t* keys_b, uint32_t* vals_b, size_t n, int begin_bit, int end_bit,
                          void* scratch, hipStream_t s);
 

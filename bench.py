@@ -70,7 +70,7 @@ def main():
     t = lambda x: torch.as_tensor(np.ascontiguousarray(x)).to(dev)
     rs = GaussianRasterizationSettings(image_height=H, image_width=W, tanfovx=sc["tanfovx"], tanfovy=sc["tanfovy"], bg=t(sc["bg"]),
                                        scale_modifier=1.0, viewmatrix=t(sc["viewmatrix"]), projmatrix=t(sc["projmatrix"]),
-                                       sh_degree=3, campos=t(sc["campos"]), prefiltered=False, debug=2)   # 2 = event timing, no sync
+                                       sh_degree=3, campos=t(sc["campos"]), prefiltered=False, debug=3)   # 3 = HIP events around the dominant kernel only, no sync
     rast = GaussianRasterizer(raster_settings=rs)
     params = [t(sc[k]).requires_grad_(True) for k in ("means3D", "shs", "opacities", "scales", "rotations")]
     means3D, shs, opac, scales, rots = params
@@ -109,7 +109,15 @@ def main():
         step()
     fence()
     dt = time.perf_counter() - t0
+    dom_stage = surfel_native.collect_stage_times()        # {"blend_bwd": (total_ms, launches)} from the timed region itself
+    # per-stage breakdown: a second, untimed pass of the same steps with every stage bracketed by events
+    # (bracketing all ~9 stages costs ~10 us each, which would perturb the timed region by ~9 % at this size)
+    rast.raster_settings = rs._replace(debug=2)
+    for _ in range(max(5, args.steps // 2)):
+        step()
+    fence()
     stages = surfel_native.collect_stage_times()
+    stages.update(dom_stage)
     if world > 1:
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
