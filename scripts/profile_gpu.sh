@@ -1,0 +1,27 @@
+#!/bin/bash
+# Run ON THE GPU BOX from the repo root (via gpurun):  bash scripts/profile_gpu.sh <tag> [workload]
+# Produces under gpurun_out/prof_<tag>/ :
+#   kt/      rocprofv3 --kernel-trace --stats of the default `python bench.py` command
+#   fetch/   --pmc FETCH_SIZE   (own pass: FETCH_SIZE takes 3 of the 4 TCC slots)
+#   write/   --pmc WRITE_SIZE   (own pass)
+#   sq/      --pmc SQ_* issue/wait counters
+# PMC passes never combine with sys/hip/hsa trace domains (only --kernel-trace is implied by rocprofv3 itself).
+# scripts/profile_summary.py then condenses these into profiles/.
+TAG=${1:-r01}
+WL=${2:-C2}
+ROOT=$(pwd)
+OUT=$ROOT/gpurun_out/prof_$TAG
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -o kt -- python $ROOT/bench.py --workload $WL > $OUT/bench_kt.log 2>&1
+SHORT="--workload $WL --steps 8 --warmup 2 --no-cpu-baseline --no-1080p"
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -o p -- python $ROOT/bench.py $SHORT > $OUT/bench_fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/write -o p -- python $ROOT/bench.py $SHORT > $OUT/bench_write.log 2>&1
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_INST_ANY SQ_LDS_BANK_CONFLICT \
+    --output-format csv -d $OUT/sq -o p -- python $ROOT/bench.py $SHORT > $OUT/bench_sq.log 2>&1
+cd $ROOT
+# keep what comes back small: kernel_trace of the PMC passes is not needed
+find $OUT -name '*.db' -delete
+find $OUT/fetch $OUT/write $OUT/sq -name '*kernel_trace.csv' -delete
+tail -n 1 $OUT/bench_kt.log
+ls -R $OUT | head -40

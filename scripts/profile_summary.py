@@ -1,0 +1,93 @@
+"""Condense gpurun_out/prof_<tag>/ (scripts/profile_gpu.sh) into the tracked profiles/ directory.
+
+    python scripts/profile_summary.py <tag> [workload]
+
+Writes
+    profiles/<tag>_<workload>_kernel_stats.csv      rocprofv3 --kernel-trace --stats of `python bench.py` (kernel names shortened)
+    profiles/<tag>_<workload>_bench_under_rocprof.json   the JSON line bench.py printed in that run
+    profiles/<tag>_<workload>_pmc.json              per-kernel mean FETCH_SIZE / WRITE_SIZE / SQ counters per launch
+    profiles/pmc_traffic.json                        {workload: {stage: HBM bytes per launch}}  (read by bench.py -> roofline.traffic)
+
+HBM traffic per launch = 2 x FETCH_SIZE[KiB] x 1024 + WRITE_SIZE[KiB] x 1024: on gfx950 FETCH_SIZE tallies
+128-B read requests at 64 B (MI355X_MICROARCH.md "HBM"), so it is doubled; WRITE_SIZE is taken as reported
+(uncalibrated per the guide).  Counters are collected in separate rocprofv3 passes.
+"""
+import collections
+import csv
+import glob
+import json
+import os
+import re
+import sys
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+STAGE_OF = {"preprocess_fwd_kernel": "preprocess_fwd", "emit_instances_kernel": "emit_instances", "tile_ranges_kernel": "tile_ranges",
+            "blend_fwd_kernel": "blend_fwd", "blend_bwd_kernel": "blend_bwd", "preprocess_bwd_kernel": "preprocess_bwd"}
+
+
+def short(name):
+    n = name.split("(")[0].replace("surfel::", "").replace("void ", "")
+    n = re.sub(r"<.*", "", n)
+    return n[:80]
+
+
+def one(pattern):
+    g = glob.glob(pattern, recursive=True)
+    return g[0] if g else None
+
+
+def pmc_means(d):
+    f = one(os.path.join(d, "**", "*counter_collection.csv"))
+    acc = collections.defaultdict(lambda: collections.defaultdict(list))
+    if not f:
+        return {}
+    for r in csv.DictReader(open(f)):
+        acc[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    return {k: {c: sum(v) / len(v) for c, v in cs.items()} for k, cs in acc.items()}
+
+
+def main():
+    tag = sys.argv[1]
+    wl = sys.argv[2] if len(sys.argv) > 2 else "C2"
+    src = os.path.join(REPO, "gpurun_out", "prof_" + tag)
+    dst = os.path.join(REPO, "profiles")
+    os.makedirs(dst, exist_ok=True)
+    # 1. kernel stats
+    ks = one(os.path.join(src, "kt", "**", "*kernel_stats.csv"))
+    if ks:
+        rows = list(csv.DictReader(open(ks)))
+        with open(os.path.join(dst, "%s_%s_kernel_stats.csv" % (tag, wl)), "w", newline="") as fo:
+            w = csv.writer(fo)
+            w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs", "StdDev"])
+            for r in rows:
+                w.writerow([short(r["Name"]), r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"], r["MinNs"], r["MaxNs"], r["StdDev"]])
+    log = os.path.join(src, "bench_kt.log")
+    if os.path.exists(log):
+        lines = [l for l in open(log) if l.startswith("{")]
+        if lines:
+            open(os.path.join(dst, "%s_%s_bench_under_rocprof.json" % (tag, wl)), "w").write(lines[-1])
+    # 2. PMC
+    merged = collections.defaultdict(dict)
+    for sub in ("fetch", "write", "sq"):
+        for k, cs in pmc_means(os.path.join(src, sub)).items():
+            merged[k].update(cs)
+    merged = {k: v for k, v in merged.items() if k in STAGE_OF or k.startswith("rs_") or "knn" in k}
+    traffic = {}
+    for k, cs in merged.items():
+        if "FETCH_SIZE" in cs and "WRITE_SIZE" in cs:
+            cs["HBM_bytes_per_launch"] = int(2 * cs["FETCH_SIZE"] * 1024 + cs["WRITE_SIZE"] * 1024)
+            if k in STAGE_OF:
+                traffic[STAGE_OF[k]] = cs["HBM_bytes_per_launch"]
+    json.dump(merged, open(os.path.join(dst, "%s_%s_pmc.json" % (tag, wl)), "w"), indent=1, sort_keys=True)
+    tf = os.path.join(dst, "pmc_traffic.json")
+    allt = json.load(open(tf)) if os.path.exists(tf) else {}
+    allt[wl] = traffic
+    allt.setdefault("_note", "HBM bytes per launch = (2*FETCH_SIZE + WRITE_SIZE) KiB, separate --pmc passes, gfx950 FETCH_SIZE x2 "
+                             "correction (MI355X_MICROARCH.md); produced by scripts/profile_summary.py")
+    json.dump(allt, open(tf, "w"), indent=1, sort_keys=True)
+    for k, cs in sorted(merged.items()):
+        print(k, {c: round(v, 1) for c, v in cs.items()})
+
+
+if __name__ == "__main__":
+    main()
