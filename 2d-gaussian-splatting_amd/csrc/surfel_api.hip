@@ -21,6 +21,7 @@ using namespace surfel;
 namespace {
 
 thread_local std::string g_err;
+int g_opt_cull = 1;        // surfel_set_option("cull", .)
 thread_local float g_stage_ms[16];
 thread_local int g_stage_n = 0;
 thread_local int g_stage_id[16];
@@ -182,6 +183,11 @@ int surfel_last_stage_ids(int* ids, int cap) {
     return n;
 }
 
+int surfel_set_option(const char* name, int value) {
+    if (name && std::strcmp(name, "cull") == 0) { g_opt_cull = value ? 1 : 0; return 0; }
+    return fail(SURFEL_E_INVALID, "unknown option");
+}
+
 int surfel_collect_stage_ms(float* sum_ms, int* count, int cap) {
     for (int i = 0; i < cap; i++) { sum_ms[i] = 0.f; count[i] = 0; }
     std::lock_guard<std::mutex> lk(g_pending_mu);
@@ -248,6 +254,7 @@ int64_t surfel_rasterize_forward(surfel_alloc_fn geom_alloc, void* geom_user, su
 
         PreprocessArgs pa{};
         pa.P = P; pa.D = D; pa.M = M; pa.W = width; pa.H = height; pa.gx = gx; pa.gy = gy; pa.scale_modifier = scale_modifier;
+        pa.cull = g_opt_cull;
         pa.means3D = means3D; pa.opacities = opacities; pa.scales = scales; pa.rotations = rotations;
         pa.transMat_precomp = transMat_precomp; pa.colors_precomp = colors_precomp; pa.shs = shs;
         pa.viewmatrix = viewmatrix; pa.projmatrix = projmatrix; pa.campos = cam_pos;

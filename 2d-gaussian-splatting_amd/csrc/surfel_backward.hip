@@ -1,8 +1,10 @@
 // surfel_backward.hip — backward kernels of the gfx950 surfel rasterizer.
 //   blend_bwd       : per-tile back-to-front replay; per-surfel partial gradients are reduced
-//                     lane->wave with DPP adds, wave->tile through LDS, and written ONCE per
+//                     lane->wave with permlane-swap / DPP adds, wave->tile through LDS, and written ONCE per
 //                     (tile, surfel) instance to a gradient record — no global atomics, so the
 //                     result is bit-reproducible and never crosses XCD L2s with device-scope RMWs.
+//                     (A per-DPP-row walk like the forward's was measured slower here: its per-row partial
+//                     sums need LDS float atomics, ~45 LDS cycles each, and the kernel turns LDS-bound.)
 //   preprocess_bwd  : per-surfel sum of its instance records, then the chain rule into means,
 //                     scales, rotations, opacity and SH.
 // Semantics: oracle/surfel_oracle.c stages 4-5 (restating the absent diff-surfel-rasterization).
@@ -71,8 +73,9 @@ __global__ void __launch_bounds__(BLOCK) blend_bwd_kernel(BlendBwdArgs a) {
     __shared__ int s_max;
     const int tile = xcd_tile(blockIdx.x, a.gx * a.gy);
     const int tx = tile % a.gx, ty = tile / a.gx;
-    int lx, ly;
-    thread_pixel(threadIdx.x, lx, ly);
+    int lx, ly, sub;
+    thread_pixel(threadIdx.x, lx, ly, sub);
+    (void)sub;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int pxi = tx * TILE + lx, pyi = ty * TILE + ly;
     const bool inside = pxi < a.W && pyi < a.H;
@@ -121,10 +124,10 @@ __global__ void __launch_bounds__(BLOCK) blend_bwd_kernel(BlendBwdArgs a) {
             if ((int)threadIdx.x < mb) {
                 const uint32_t id = a.point_list[range.x + (hi - threadIdx.x) - 1];
                 const float4* __restrict__ src = reinterpret_cast<const float4*>(a.rec + (size_t)id * REC_F);
-                const float4 v0 = src[0], v1 = src[1], v2 = src[2], v3 = src[3], v4 = src[4], v5 = src[5];
+                const float4 v0 = src[0], v1 = src[1], v2 = src[2], v3 = src[3], v4 = src[4], v5 = src[5], v6 = src[6];
                 s_rec[threadIdx.x * 5 + 0] = v0; s_rec[threadIdx.x * 5 + 1] = v1; s_rec[threadIdx.x * 5 + 2] = v2;
                 s_rec[threadIdx.x * 5 + 3] = v3; s_rec[threadIdx.x * 5 + 4] = v4;
-                ov = quad_overlap(v5, tx * TILE, ty * TILE);
+                ov = quad_overlap(make_foot(v2, v5, v6), tx * TILE, ty * TILE);
             }
             const unsigned long long b0 = __ballot(ov & 1u), b1 = __ballot(ov & 2u), b2 = __ballot(ov & 4u), b3 = __ballot(ov & 8u);
             if (lane == 0) { s_qmask[0][wave] = b0; s_qmask[1][wave] = b1; s_qmask[2][wave] = b2; s_qmask[3][wave] = b3; }
@@ -187,18 +190,19 @@ __global__ void __launch_bounds__(BLOCK) blend_bwd_kernel(BlendBwdArgs a) {
                 gv[18] = 0.f; gv[19] = 0.f;
                 {
                     const float nGG = -G * (opa * dL_dalpha);      // dL/dG * dG/drho*2 ; 0.99 clamp is pass-through
-                    const float dz3 = use3d ? dL_dz : 0.f;
-                    const float g3 = use3d ? nGG : 0.f;
+                    // low-pass branch: no gradient reaches the intersection.  The selects zero (s, 1/p2) themselves —
+                    // they may be inf there (p2 ~ 0 on edge-on discs) and 0 * inf must not enter the sums.
+                    const float sxg = use3d ? sx : 0.f, syg = use3d ? sy : 0.f, ipg = use3d ? ip : 0.f;
                     const float g2 = use3d ? 0.f : nGG * FILTER_INV_SQUARE;
-                    const float ax = (g3 * sx + dz3 * Twx) * ip, ay = (g3 * sy + dz3 * Twy) * ip;
-                    const float dp2 = -(ax * sx + ay * sy);
+                    const float ax = (nGG * sxg + dL_dz * Twx) * ipg, ay = (nGG * syg + dL_dz * Twy) * ipg;
+                    const float dp2 = -(ax * sxg + ay * syg);
                     // -dk = dp x l ,  -dl = k x dp
                     const float nk0 = ay * lz_ - dp2 * ly_, nk1 = dp2 * lx_ - ax * lz_, nk2 = ax * ly_ - ay * lx_;
                     const float nl0 = ky * dp2 - kz * ay, nl1 = kz * ax - kx * dp2, nl2 = kx * ay - ky * ax;
                     gv[0] = nk0; gv[1] = nk1; gv[2] = nk2;
                     gv[3] = nl0; gv[4] = nl1; gv[5] = nl2;
-                    gv[6] = dz3 * sx - (pxf * nk0 + pyf * nl0);
-                    gv[7] = dz3 * sy - (pxf * nk1 + pyf * nl1);
+                    gv[6] = dL_dz * sxg - (pxf * nk0 + pyf * nl0);
+                    gv[7] = dL_dz * syg - (pxf * nk1 + pyf * nl1);
                     gv[8] = dL_dz - (pxf * nk2 + pyf * nl2);
                     gv[9] = g2 * dx; gv[10] = g2 * dy;
                 }

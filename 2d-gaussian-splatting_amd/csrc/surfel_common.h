@@ -20,15 +20,17 @@ constexpr float ALPHA_MIN = 1.0f / 255.0f;
 constexpr float ALPHA_MAX = 0.99f;
 constexpr float T_EPS = 0.0001f;
 
-// Per-surfel packed record, 96 B = 6 x float4, written by preprocess, gathered by the blend kernels.
-// One record touches at most two 128-B lines (vs. seven separate arrays in an SoA layout).
+// Per-surfel packed record, 112 B = 7 x float4, written by preprocess, gathered by the blend kernels
+// (q0-q4 are staged in LDS for the blend loop; q5-q6 feed the staging-time culling only).
 //   q0 = Tu.x Tu.y Tu.z Tv.x
 //   q1 = Tv.y Tv.z Tw.x Tw.y
 //   q2 = Tw.z xy.x xy.y opacity
 //   q3 = n.x  n.y  n.z  r
 //   q4 = g    b    inst_base(u32 bits)  rect(u32 bits: x0 | y0<<10 | w<<20)
-//   q5 = xmin xmax ymin ymax : conservative pixel bbox of {alpha >= 1/255} (cull only, never changes results)
-constexpr int REC_F = 24;
+//   q5 = ecx  ecy  Sxx  Sxy     conservative footprint of {alpha >= 1/255} (cull only, never changes results):
+//   q6 = Syy  r2^2 det  -       ellipse {d^T S^-1 d <= 1} about (ecx,ecy)  U  disc of radius r2 about xy
+constexpr int REC_F = 28;
+constexpr float FOOT_UNBOUNDED = 1.0e30f;   // Sxx >= this: the footprint is the whole image
 constexpr int REC_Q = REC_F / 4;
 // Per-(tile,surfel) gradient record written by blend-backward, summed by preprocess-backward:
 //   [0..8] dL/dT (Tu,Tv,Tw)  [9..10] dL/dxy (low-pass branch)  [11..13] dL/dnormal  [14] dL/dopacity
@@ -55,12 +57,72 @@ __device__ __forceinline__ int xcd_tile(int b, int n) {
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + i;
 }
 
-// Which of the tile's four 8x8 quads (= waves) can a surfel with pixel bbox (xmin,xmax,ymin,ymax) touch?
-__device__ __forceinline__ unsigned quad_overlap(const float4 bb, int tile_x0, int tile_y0) {
-    const float x0 = (float)tile_x0, y0 = (float)tile_y0;
-    const bool xl = bb.x <= x0 + 7.f && bb.y >= x0, xr = bb.x <= x0 + 15.f && bb.y >= x0 + 8.f;
-    const bool yt = bb.z <= y0 + 7.f && bb.w >= y0, yb = bb.z <= y0 + 15.f && bb.w >= y0 + 8.f;
-    return (xl && yt ? 1u : 0u) | (xr && yt ? 2u : 0u) | (xl && yb ? 4u : 0u) | (xr && yb ? 8u : 0u);
+// ---- footprint culling ---------------------------------------------------------------------------
+// The pixels a surfel can touch with alpha >= 1/255 lie inside  E U D :  E = the projected sqrt(rmax)-sigma ellipse
+// {d = p - e : d^T S^-1 d <= 1} (rho3d <= rmax), D = the low-pass disc (rho2d <= rmax), both inflated for fp32
+// (preprocess_fwd).  Culling is done ONCE per (tile, instance) by the staging thread, i.e. at 1/64 of the price of
+// a blend visit, so it can afford the exact geometry: for a horizontal strip of pixel rows the x-interval of
+// (E U D) /\ strip is closed-form (the extreme points of an ellipse inside a strip are its global extreme points
+// clamped to the strip), and a block of pixel columns is hit iff it meets that interval.
+struct Foot {
+    float ecx, ecy, syy, det, k, isyy, hy, yR;   // ellipse
+    float dcx, dcy, r2sq;                        // disc
+    bool unbounded;
+};
+__device__ __forceinline__ Foot make_foot(const float4 q2, const float4 q5, const float4 q6) {
+    Foot f;
+    f.ecx = q5.x; f.ecy = q5.y; f.syy = q6.x; f.det = q6.z;
+    f.unbounded = q5.z >= FOOT_UNBOUNDED;
+    f.isyy = __builtin_amdgcn_rcpf(q6.x);
+    f.k = q5.w * f.isyy;                         // dx/dy of the ellipse's centre line
+    f.hy = sqrtf(q6.x);
+    f.yR = q5.w * __builtin_amdgcn_rsqf(q5.z);   // y of the rightmost point (leftmost: -yR)
+    f.dcx = q2.y; f.dcy = q2.z; f.r2sq = q6.y;
+    return f;
+}
+// x-interval [xmin, xmax] of (E U D) within the closed strip y in [Y0, Y1] (empty: xmin > xmax)
+__device__ __forceinline__ void foot_strip(const Foot& f, float Y0, float Y1, float& xmin, float& xmax) {
+    xmin = 3.0e38f; xmax = -3.0e38f;
+    const float a0 = fmaxf(Y0 - f.ecy, -f.hy), a1 = fminf(Y1 - f.ecy, f.hy);
+    if (a0 <= a1) {
+        const float yr = fminf(fmaxf(f.yR, a0), a1), yl = fminf(fmaxf(-f.yR, a0), a1);
+        xmax = f.ecx + f.k * yr + sqrtf(fmaxf(f.det * (f.syy - yr * yr), 0.f)) * f.isyy + 1e-3f;
+        xmin = f.ecx + f.k * yl - sqrtf(fmaxf(f.det * (f.syy - yl * yl), 0.f)) * f.isyy - 1e-3f;
+    }
+    const float dy = fmaxf(fmaxf(Y0 - f.dcy, f.dcy - Y1), 0.f);
+    const float h2 = f.r2sq - dy * dy;
+    if (h2 >= 0.f) {
+        const float h = sqrtf(h2);
+        xmin = fminf(xmin, f.dcx - h); xmax = fmaxf(xmax, f.dcx + h);
+    }
+    if (f.unbounded) { xmin = -3.0e38f; xmax = 3.0e38f; }
+}
+// Sub-tiles: a 16x16 tile is a 4x4 grid of 4x4-pixel sub-tiles (id = 4*(y block) + (x block)); one DPP row of a
+// forward wave owns one sub-tile.  16-bit mask of the sub-tiles the footprint can touch.
+__device__ __forceinline__ unsigned subtile_overlap(const Foot& f, int tile_x0, int tile_y0) {
+    unsigned ov = 0;
+#pragma unroll
+    for (int by = 0; by < 4; by++) {
+        float xmin, xmax;
+        foot_strip(f, (float)(tile_y0 + 4 * by), (float)(tile_y0 + 4 * by + 3), xmin, xmax);
+        xmin -= (float)tile_x0; xmax -= (float)tile_x0;
+#pragma unroll
+        for (int bx = 0; bx < 4; bx++) ov |= (xmin <= (float)(4 * bx + 3) && xmax >= (float)(4 * bx)) ? (1u << (4 * by + bx)) : 0u;
+    }
+    return ov;
+}
+// 4-bit mask of the tile's 8x8 quads (= backward waves; quad id = 2*(y half) + (x half)) the footprint can touch.
+__device__ __forceinline__ unsigned quad_overlap(const Foot& f, int tile_x0, int tile_y0) {
+    unsigned ov = 0;
+#pragma unroll
+    for (int by = 0; by < 2; by++) {
+        float xmin, xmax;
+        foot_strip(f, (float)(tile_y0 + 8 * by), (float)(tile_y0 + 8 * by + 7), xmin, xmax);
+        xmin -= (float)tile_x0; xmax -= (float)tile_x0;
+#pragma unroll
+        for (int bx = 0; bx < 2; bx++) ov |= (xmin <= (float)(8 * bx + 7) && xmax >= (float)(8 * bx)) ? (1u << (2 * by + bx)) : 0u;
+    }
+    return ov;
 }
 
 __device__ __forceinline__ unsigned long long uniform_u64(unsigned long long v) {
@@ -69,43 +131,14 @@ __device__ __forceinline__ unsigned long long uniform_u64(unsigned long long v) 
     return ((unsigned long long)hi << 32) | lo;
 }
 
-// pixel owned by a thread: wave w -> 8x8 quad (w&1, w>>1); lane -> (lane&7, lane>>3)
-__device__ __forceinline__ void thread_pixel(int tid, int& lx, int& ly) {
-    const int w = tid >> 6, l = tid & 63;
-    lx = ((w & 1) << 3) + (l & 7);
-    ly = ((w >> 1) << 3) + (l >> 3);
-}
-
-struct Hit {
-    float sx, sy, pz, kx, ky, kz, lx, ly, lz, dx, dy, depth, G, alpha;
-    bool use3d;
-};
-
-// Ray–splat intersection and alpha for one (pixel, surfel) pair; false = pair skipped.
-__device__ __forceinline__ bool intersect(const float4 q0, const float4 q1, const float4 q2, float pxf, float pyf, Hit& h) {
-    const float Tux = q0.x, Tuy = q0.y, Tuz = q0.z, Tvx = q0.w, Tvy = q1.x, Tvz = q1.y;
-    const float Twx = q1.z, Twy = q1.w, Twz = q2.x;
-    h.kx = pxf * Twx - Tux; h.ky = pxf * Twy - Tuy; h.kz = pxf * Twz - Tuz;
-    h.lx = pyf * Twx - Tvx; h.ly = pyf * Twy - Tvy; h.lz = pyf * Twz - Tvz;
-    const float p0 = h.ky * h.lz - h.kz * h.ly;
-    const float p1 = h.kz * h.lx - h.kx * h.lz;
-    const float p2 = h.kx * h.ly - h.ky * h.lx;
-    if (p2 == 0.0f) return false;
-    h.pz = p2;
-    const float ip = __builtin_amdgcn_rcpf(p2);
-    h.sx = p0 * ip; h.sy = p1 * ip;
-    const float rho3d = h.sx * h.sx + h.sy * h.sy;
-    h.dx = q2.y - pxf; h.dy = q2.z - pyf;
-    const float rho2d = FILTER_INV_SQUARE * (h.dx * h.dx + h.dy * h.dy);
-    h.use3d = rho3d <= rho2d;
-    const float rho = fminf(rho3d, rho2d);
-    h.depth = h.use3d ? (h.sx * Twx + h.sy * Twy) + Twz : Twz;
-    if (h.depth < NEAR_N) return false;
-    const float power = -0.5f * rho;
-    if (power > 0.0f) return false;
-    h.G = __expf(power);
-    h.alpha = fminf(ALPHA_MAX, q2.w * h.G);
-    return h.alpha >= ALPHA_MIN;
+// pixel owned by a thread: wave w -> 8x8 quad (w&1, w>>1); DPP row r = lane>>4 -> 4x4 sub-tile (r&1, r>>1) of the
+// quad; lane i = lane&15 -> pixel (i&3, i>>2) of the sub-tile.  `sub` = the sub-tile's id (subtile_overlap bit).
+__device__ __forceinline__ void thread_pixel(int tid, int& lx, int& ly, int& sub) {
+    const int w = tid >> 6, r = (tid >> 4) & 3, i = tid & 15;
+    const int bx = ((w & 1) << 1) | (r & 1), by = (w & 2) | (r >> 1);
+    lx = (bx << 2) + (i & 3);
+    ly = (by << 2) + (i >> 2);
+    sub = (by << 2) | bx;
 }
 
 }  // namespace surfel

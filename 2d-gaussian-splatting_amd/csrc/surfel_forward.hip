@@ -21,7 +21,7 @@ __device__ __constant__ float SH_C3[7] = {-0.5900435899266435f, 2.89061144264055
 // ---------------------------------------------------------------------------------------------
 // preprocess_fwd: one thread per surfel.  Camera matrices are wave-uniform (scalar loads).
 // HBM traffic per surfel: reads 40 B geometry (+192 B SH only when the surfel survives culling),
-// writes 80 B record + 13 B bookkeeping.
+// writes 112 B record + 21 B bookkeeping.
 // ---------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) preprocess_fwd_kernel(PreprocessArgs a) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -144,36 +144,50 @@ __global__ void __launch_bounds__(256) preprocess_fwd_kernel(PreprocessArgs a) {
         } else {
             r = a.colors_precomp[3 * (size_t)i]; g = a.colors_precomp[3 * (size_t)i + 1]; b = a.colors_precomp[3 * (size_t)i + 2];
         }
-        // Conservative pixel bbox of the region where this surfel can reach alpha >= 1/255:
+        // Conservative footprint of the region where this surfel can reach alpha >= 1/255:
         //   alpha = min(.99, o*exp(-rho/2)) >= 1/255  =>  rho = min(rho3d, rho2d) <= rmax = 2 ln(255 o)
-        //   {rho2d <= rmax}: disc of radius sqrt(rmax/2) about (cx,cy);  {rho3d <= rmax}: the projected
-        //   sqrt(rmax)-sigma ellipse, bounded by the same AABB formula as above with cutoff^2 = rmax.
-        // Inflated for fp32 cancellation; unbounded (whole image) when the ellipse meets the camera plane.
-        float bx0 = 1.f, bx1 = 0.f, by0 = 1.f, by1 = 0.f;       // empty
+        //   {rho2d <= rmax}: disc of radius sqrt(rmax/2) about (cx,cy);
+        //   {rho3d <= rmax}: the projected sqrt(rmax)-sigma ellipse = the conic whose dual is M diag(rmax,rmax,-1) M^T
+        //   (M = rows Tu,Tv,Tw), i.e. centre e = (D02,D12)/D22 and "covariance" S = e e^T - D[0:2,0:2]/D22.
+        // S is evaluated in a frame shifted to (cx,cy) so that e e^T - D/D22 does not cancel ~1e6-sized terms, then
+        // inflated (x1.002 + 0.3 px on the diagonal) for fp32; unbounded when the ellipse meets the camera plane.
+        float bx0 = 1.f, bx1 = 0.f, by0 = 1.f, by1 = 0.f;       // bbox of the footprint (tile-level cull); empty
+        float ecx = cx, ecy = cy, Sxx = FOOT_UNBOUNDED, Sxy = 0.f, Syy = FOOT_UNBOUNDED, r2sq = 0.f, Sdet = 1.f;
         {
             const float opa = a.opacities[i];
             if (opa * 255.f >= 0.999f) {
                 const float rmax = 2.f * __logf(fmaxf(opa * 255.f, 1.f)) * 1.0001f + 1e-3f;
                 const float r2 = sqrtf(0.5f * rmax) + 0.05f;
+                r2sq = r2 * r2;
                 bx0 = cx - r2; bx1 = cx + r2; by0 = cy - r2; by1 = cy + r2;
                 const float tw2 = T[8] * T[8];
                 const float dc = rmax * (T[6] * T[6] + T[7] * T[7]) - tw2;
-                if (dc < -1e-3f * tw2) {
+                bool bounded = dc < -1e-3f * tw2;
+                if (bounded) {
                     const float g0 = rmax / dc, g2 = -1.f / dc;
-                    const float ccx = g0 * T[0] * T[6] + g0 * T[1] * T[7] + g2 * T[2] * T[8];
-                    const float ccy = g0 * T[3] * T[6] + g0 * T[4] * T[7] + g2 * T[5] * T[8];
-                    const float sxx = g0 * T[0] * T[0] + g0 * T[1] * T[1] + g2 * T[2] * T[2];
-                    const float syy = g0 * T[3] * T[3] + g0 * T[4] * T[4] + g2 * T[5] * T[5];
-                    const float ehx = sqrtf(fmaxf(ccx * ccx - sxx, 0.f) + 2e-6f * (ccx * ccx + fabsf(sxx)));
-                    const float ehy = sqrtf(fmaxf(ccy * ccy - syy, 0.f) + 2e-6f * (ccy * ccy + fabsf(syy)));
-                    const float mx = ehx * 1.001f + 1e-4f * fabsf(ccx) + 0.3f, my = ehy * 1.001f + 1e-4f * fabsf(ccy) + 0.3f;
-                    bx0 = fminf(bx0, ccx - mx); bx1 = fmaxf(bx1, ccx + mx);
-                    by0 = fminf(by0, ccy - my); by1 = fmaxf(by1, ccy + my);
-                    if (!(ehx == ehx) || !(ehy == ehy) || !(ccx == ccx) || !(ccy == ccy)) { bx0 = by0 = -3.0e38f; bx1 = by1 = 3.0e38f; }
-                } else {
-                    bx0 = by0 = -3.0e38f; bx1 = by1 = 3.0e38f;
+                    const float U0 = T[0] - cx * T[6], U1 = T[1] - cx * T[7], U2 = T[2] - cx * T[8];
+                    const float V0 = T[3] - cy * T[6], V1 = T[4] - cy * T[7], V2 = T[5] - cy * T[8];
+                    const float ex_ = g0 * U0 * T[6] + g0 * U1 * T[7] + g2 * U2 * T[8];
+                    const float ey_ = g0 * V0 * T[6] + g0 * V1 * T[7] + g2 * V2 * T[8];
+                    const float sxx = ex_ * ex_ - (g0 * U0 * U0 + g0 * U1 * U1 + g2 * U2 * U2);
+                    const float sxy = ex_ * ey_ - (g0 * U0 * V0 + g0 * U1 * V1 + g2 * U2 * V2);
+                    const float syy = ey_ * ey_ - (g0 * V0 * V0 + g0 * V1 * V1 + g2 * V2 * V2);
+                    constexpr float EPS = 0.09f;
+                    const float ixx = fmaxf(sxx, 0.f) * 1.002f + EPS, iyy = fmaxf(syy, 0.f) * 1.002f + EPS;
+                    // det(S0*1.002 + EPS*I) >= EPS*tr(S0)*1.002: the analytic floor survives the cancellation in
+                    // ixx*iyy - sxy^2 for long thin diagonal footprints; the last term over-covers its rounding error
+                    const float det = fmaxf(ixx * iyy - sxy * sxy, EPS * (ixx + iyy - 2.f * EPS)) + 4e-7f * ixx * iyy;
+                    bounded = (ex_ == ex_) && (ey_ == ey_) && (det == det) && (ixx < 1e12f) && (iyy < 1e12f) && (fabsf(sxy) < 1e12f);
+                    if (bounded) {
+                        ecx = cx + ex_; ecy = cy + ey_; Sxx = ixx; Sxy = sxy; Syy = iyy; Sdet = det;
+                        const float mx = sqrtf(ixx) + 1e-4f * fabsf(ecx) + 0.01f, my = sqrtf(iyy) + 1e-4f * fabsf(ecy) + 0.01f;
+                        bx0 = fminf(bx0, ecx - mx); bx1 = fmaxf(bx1, ecx + mx);
+                        by0 = fminf(by0, ecy - my); by1 = fmaxf(by1, ecy + my);
+                    }
                 }
+                if (!bounded) { bx0 = by0 = -3.0e38f; bx1 = by1 = 3.0e38f; Sxx = Syy = FOOT_UNBOUNDED; Sxy = 0.f; Sdet = 1.f; }
             }
+            if (!a.cull) { bx0 = by0 = -3.0e38f; bx1 = by1 = 3.0e38f; ecx = cx; ecy = cy; Sxx = Syy = FOOT_UNBOUNDED; Sxy = 0.f; Sdet = 1.f; }
         }
         float4* __restrict__ rec = reinterpret_cast<float4*>(a.rec + (size_t)i * REC_F);
         rec[0] = make_float4(T[0], T[1], T[2], T[3]);
@@ -197,7 +211,8 @@ __global__ void __launch_bounds__(256) preprocess_fwd_kernel(PreprocessArgs a) {
         }
         const uint32_t rectbits = (uint32_t)ex0 | ((uint32_t)ey0 << 10) | ((uint32_t)(ex1 - ex0) << 20);
         rec[4] = make_float4(g, b, 0.f /* inst_base patched by emit_instances */, __uint_as_float(rectbits));
-        rec[5] = make_float4(bx0, bx1, by0, by1);
+        rec[5] = make_float4(ecx, ecy, Sxx, Sxy);
+        rec[6] = make_float4(Syy, r2sq, Sdet, 0.f);
         dkey = __float_as_uint(vz);
         a.clamped[i] = clampbits;
         rad_out = irad;
@@ -258,30 +273,36 @@ __global__ void __launch_bounds__(256) tile_ranges_kernel(int64_t R, const uint3
 }
 
 // ---------------------------------------------------------------------------------------------
-// blend_fwd: one workgroup (4 waves) per 16x16 tile; each wave owns an 8x8 pixel quad.
-// Surfel records of the tile's sorted list are staged through LDS 256 at a time (20 KB, one
-// coalesced-as-possible 80-B gather per thread); the inner loop reads them back as wave-uniform
-// broadcasts (conflict-free).  A wave whose 64 pixels are all saturated skips the batch.
+// blend_fwd: one workgroup (4 waves) per 16x16 tile.  Surfel records of the tile's sorted list are staged through
+// LDS 256 at a time (20 KB, one 80-B gather per thread).  Each DPP row of 16 lanes owns a 4x4-pixel sub-tile and
+// walks its own bitmask of the staged instances whose alpha>=1/255 bbox reaches that sub-tile: a wave therefore
+// blends FOUR different instances per pass of the loop body, and a small surfel occupies issue slots only where
+// it can contribute.  Per-pixel order is the staged (depth) order, so results equal the whole-tile walk.
 // ---------------------------------------------------------------------------------------------
+constexpr int MW = 8;             // 32-bit mask words per staged batch of 256
+constexpr int MSTRIDE = MW + 2;   // + zero sentinel word, padded so each sub-tile's words start 8-B aligned
+
 __global__ void __launch_bounds__(BLOCK) blend_fwd_kernel(BlendFwdArgs a) {
     __shared__ float4 s_rec[BLOCK * 5];
-    __shared__ unsigned long long s_qmask[4][4];     // [consumer quad][staging wave]
+    __shared__ __attribute__((aligned(8))) uint32_t s_mask[16 * MSTRIDE];    // [sub-tile][word]
     const int tile = xcd_tile(blockIdx.x, a.gx * a.gy);
     const int tx = tile % a.gx, ty = tile / a.gx;
-    int lx, ly;
-    thread_pixel(threadIdx.x, lx, ly);
-    const int wave = threadIdx.x >> 6;
+    int lx, ly, sub;
+    thread_pixel(threadIdx.x, lx, ly, sub);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int pxi = tx * TILE + lx, pyi = ty * TILE + ly;
     const bool inside = pxi < a.W && pyi < a.H;
     const float pxf = (float)pxi, pyf = (float)pyi;
     const uint2 range = a.ranges[tile];
     const int n = (int)(range.y - range.x);
+    const uint32_t* mrow = &s_mask[sub * MSTRIDE];
 
     bool done = !inside;
     float T = 1.f, C0 = 0.f, C1 = 0.f, C2 = 0.f, N0 = 0.f, N1 = 0.f, N2 = 0.f;
     float D = 0.f, M1 = 0.f, M2 = 0.f, dist = 0.f, med = 0.f;
     uint32_t last = 0, medc = 0;
     constexpr float MC1 = FAR_N / (FAR_N - NEAR_N);
+    if (threadIdx.x < 16) s_mask[threadIdx.x * MSTRIDE + MW] = 0u;     // sentinel
 
     for (int base = 0; base < n; base += BLOCK) {
         if (__syncthreads_count(done) == BLOCK) break;
@@ -290,61 +311,68 @@ __global__ void __launch_bounds__(BLOCK) blend_fwd_kernel(BlendFwdArgs a) {
         if ((int)threadIdx.x < m) {
             const uint32_t id = a.point_list[range.x + base + threadIdx.x];
             const float4* __restrict__ src = reinterpret_cast<const float4*>(a.rec + (size_t)id * REC_F);
-            const float4 v0 = src[0], v1 = src[1], v2 = src[2], v3 = src[3], v4 = src[4], v5 = src[5];
+            const float4 v0 = src[0], v1 = src[1], v2 = src[2], v3 = src[3], v4 = src[4], v5 = src[5], v6 = src[6];
             s_rec[threadIdx.x * 5 + 0] = v0; s_rec[threadIdx.x * 5 + 1] = v1; s_rec[threadIdx.x * 5 + 2] = v2;
             s_rec[threadIdx.x * 5 + 3] = v3; s_rec[threadIdx.x * 5 + 4] = v4;
-            ov = quad_overlap(v5, tx * TILE, ty * TILE);
+            ov = subtile_overlap(make_foot(v2, v5, v6), tx * TILE, ty * TILE);
         }
-        // per-quad bitmasks of the instances this staging wave holds: the consumer waves then walk set
-        // bits only (scalar s_ff1 loop) — culled instances cost nothing.
-        {
-            const unsigned long long b0 = __ballot(ov & 1u), b1 = __ballot(ov & 2u), b2 = __ballot(ov & 4u), b3 = __ballot(ov & 8u);
-            if ((threadIdx.x & 63) == 0) { s_qmask[0][wave] = b0; s_qmask[1][wave] = b1; s_qmask[2][wave] = b2; s_qmask[3][wave] = b3; }
+        // per-sub-tile bitmasks of the 64 instances this staging wave holds (words 2*wave, 2*wave+1)
+#pragma unroll
+        for (int s = 0; s < 16; s++) {
+            const unsigned long long b = __ballot((ov >> s) & 1u);
+            if (lane == 0) *reinterpret_cast<unsigned long long*>(&s_mask[s * MSTRIDE + 2 * wave]) = b;
         }
         __syncthreads();
-        if (!__all(done)) {
-            for (int sw = 0; sw < 4; sw++) {
-                unsigned long long mask = uniform_u64(s_qmask[wave][sw]);
-                while (mask) {
-                    const int j = sw * 64 + __builtin_ctzll(mask);
-                    mask &= mask - 1;
-                    const float4 q0 = s_rec[j * 5 + 0], q1 = s_rec[j * 5 + 1], q2 = s_rec[j * 5 + 2];
-                    // ray-splat intersection, branch-free (same arithmetic as surfel::intersect)
-                    const float Twx = q1.z, Twy = q1.w, Twz = q2.x;
-                    const float kx = pxf * Twx - q0.x, ky = pxf * Twy - q0.y, kz = pxf * Twz - q0.z;
-                    const float lx_ = pyf * Twx - q0.w, ly_ = pyf * Twy - q1.x, lz_ = pyf * Twz - q1.y;
-                    const float p0 = ky * lz_ - kz * ly_, p1 = kz * lx_ - kx * lz_, p2 = kx * ly_ - ky * lx_;
-                    const float ip = __builtin_amdgcn_rcpf(p2);
-                    const float sx = p0 * ip, sy = p1 * ip;
-                    const float rho3d = sx * sx + sy * sy;
-                    const float dx = q2.y - pxf, dy = q2.z - pyf;
-                    const float rho2d = FILTER_INV_SQUARE * (dx * dx + dy * dy);
-                    const float depth = (rho3d <= rho2d) ? (sx * Twx + sy * Twy) + Twz : Twz;
-                    const float alpha = fminf(ALPHA_MAX, q2.w * __expf(-0.5f * fminf(rho3d, rho2d)));
-                    const bool ok = (!done) & (p2 != 0.f) & (depth >= NEAR_N) & (alpha >= ALPHA_MIN);
-                    if (__ballot(ok) == 0ull) continue;
-                    if (ok) {
-                        const float testT = T * (1.f - alpha);
-                        if (testT < T_EPS) done = true;       // the terminating surfel is not composited
-                        else {
-                            const uint32_t contributor = base + j + 1;
-                            const float4 q3 = s_rec[j * 5 + 3], q4 = s_rec[j * 5 + 4];
-                            const float w = alpha * T;
-                            const float mm = MC1 - (MC1 * NEAR_N) * __builtin_amdgcn_rcpf(depth);
-                            dist += (mm * (mm * (1.f - T) - 2.f * M1) + M2) * w;
-                            D += depth * w;
-                            M1 += mm * w;
-                            M2 += mm * mm * w;
-                            if (T > 0.5f) { med = depth; medc = contributor; }
-                            N0 += q3.x * w; N1 += q3.y * w; N2 += q3.z * w;
-                            C0 += q3.w * w; C1 += q4.x * w; C2 += q4.y * w;
-                            T = testT;
-                            last = contributor;
-                        }
+        const int nw = (m + 31) >> 5;                 // mask words in use
+        // row walk state: cur = unvisited instances of word widx, next = word widx+1 (prefetched)
+        int widx = 0;
+        uint32_t cur = mrow[0], next = mrow[1];
+        {   // a row whose 16 pixels are all saturated skips the batch
+            const unsigned long long db = __ballot(done);
+            if ((((unsigned)(db >> (lane & 48))) & 0xffffu) == 0xffffu) { cur = 0u; widx = nw; }
+        }
+        for (;;) {
+            if (!__any((cur != 0u) | (widx < nw - 1))) break;
+            const bool act = cur != 0u;
+            const int j = (widx << 5) + __builtin_ctz(cur | 0x80000000u);
+            cur &= cur - 1u;
+            const float4 q0 = s_rec[j * 5 + 0], q1 = s_rec[j * 5 + 1], q2 = s_rec[j * 5 + 2];
+            // ray-splat intersection, branch-free
+            const float Twx = q1.z, Twy = q1.w, Twz = q2.x;
+            const float kx = pxf * Twx - q0.x, ky = pxf * Twy - q0.y, kz = pxf * Twz - q0.z;
+            const float lx_ = pyf * Twx - q0.w, ly_ = pyf * Twy - q1.x, lz_ = pyf * Twz - q1.y;
+            const float p0 = ky * lz_ - kz * ly_, p1 = kz * lx_ - kx * lz_, p2 = kx * ly_ - ky * lx_;
+            const float ip = __builtin_amdgcn_rcpf(p2);
+            const float sx = p0 * ip, sy = p1 * ip;
+            const float rho3d = sx * sx + sy * sy;
+            const float dx = q2.y - pxf, dy = q2.z - pyf;
+            const float rho2d = FILTER_INV_SQUARE * (dx * dx + dy * dy);
+            const float depth = (rho3d <= rho2d) ? (sx * Twx + sy * Twy) + Twz : Twz;
+            const float alpha = fminf(ALPHA_MAX, q2.w * __expf(-0.5f * fminf(rho3d, rho2d)));
+            const bool ok = act & (!done) & (p2 != 0.f) & (depth >= NEAR_N) & (alpha >= ALPHA_MIN);
+            if (__any(ok)) {
+                if (ok) {
+                    const float testT = T * (1.f - alpha);
+                    if (testT < T_EPS) done = true;       // the terminating surfel is not composited
+                    else {
+                        const uint32_t contributor = base + j + 1;
+                        const float4 q3 = s_rec[j * 5 + 3], q4 = s_rec[j * 5 + 4];
+                        const float w = alpha * T;
+                        const float mm = MC1 - (MC1 * NEAR_N) * __builtin_amdgcn_rcpf(depth);
+                        dist += (mm * (mm * (1.f - T) - 2.f * M1) + M2) * w;
+                        D += depth * w;
+                        M1 += mm * w;
+                        M2 += mm * mm * w;
+                        if (T > 0.5f) { med = depth; medc = contributor; }
+                        N0 += q3.x * w; N1 += q3.y * w; N2 += q3.z * w;
+                        C0 += q3.w * w; C1 += q4.x * w; C2 += q4.y * w;
+                        T = testT;
+                        last = contributor;
                     }
                 }
                 if (__all(done)) break;
             }
+            if (cur == 0u && widx < nw - 1) { widx++; cur = next; next = mrow[widx + 1]; }
         }
     }
     if (inside) {

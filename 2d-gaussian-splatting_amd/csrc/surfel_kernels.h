@@ -7,6 +7,7 @@ namespace surfel {
 
 struct PreprocessArgs {
     int P, D, M, W, H, gx, gy;
+    int cull;                 // 0: emit the full reference rect, footprints unbounded (test switch)
     float scale_modifier;
     const float* means3D; const float* opacities; const float* scales; const float* rotations;
     const float* transMat_precomp; const float* colors_precomp; const float* shs;

@@ -119,6 +119,13 @@ int surfel_last_stage_ids(int* ids, int cap);
 int surfel_collect_stage_ms(float* sum_ms, int* count, int cap);
 const char* surfel_stage_name(int stage);
 
+/* Process-wide tuning / test switches; returns 0, or SURFEL_E_INVALID for an unknown name.
+ *   "cull" (default 1): 0 disables every exact-preserving cull (tile emission restricted to the surfel's
+ *          alpha>=1/255 footprint, per-quad / per-sub-tile instance masks) so the blend kernels visit every
+ *          (pixel, surfel) pair of the reference's tile rectangles.  Results are bit-identical either way —
+ *          that is what tests/test_gpu_parity.py::test_culling_is_exact checks. */
+int surfel_set_option(const char* name, int value);
+
 #ifdef __cplusplus
 }
 #endif

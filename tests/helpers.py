@@ -62,8 +62,8 @@ class HipRun:
         return self
 
     def depths(self):
-        """float32 view depths the device sorted on (white-box: geom buffer = [rec P*96 B | depths ...])."""
-        off = (self.P * 96 + 255) // 256 * 256
+        """float32 view depths the device sorted on (white-box: geom buffer = [rec P*112 B | depths ...])."""
+        off = (self.P * 112 + 255) // 256 * 256
         return self.ga.last()[off:off + 4 * self.P].view(self.torch.float32).cpu().numpy()
 
     def backward(self, gC, gO):

@@ -180,6 +180,74 @@ def test_precomp_and_override_color():
         assert cosine(x, ref) >= G_COS, k
 
 
+def _stress_scene(kind, seed):
+    """Scenes built to break a culling rule: needle-thin, huge, grazing-angle, tiny and near-camera surfels."""
+    import synthetic
+    rng = np.random.default_rng(seed)
+    sc = synthetic.make_scene(1500, 208, 136, seed=seed, px_radius=5.0, z_near=0.6, z_far=9.0)
+    P = sc["means3D"].shape[0]
+    if kind == "needles":        # 100:1 anisotropy, every orientation
+        sc["scales"] = sc["scales"] * np.where(rng.random((P, 1)) < 0.5, [[12.0, 0.12]], [[0.1, 10.0]]).astype(np.float32)
+    elif kind == "huge":         # footprints of hundreds of pixels, some crossing the camera plane
+        sc["scales"] = sc["scales"] * rng.choice([1.0, 8.0, 40.0], size=(P, 1)).astype(np.float32)
+    elif kind == "tiny":         # sub-pixel surfels: the low-pass disc carries the whole footprint
+        sc["scales"] = sc["scales"] * rng.choice([0.02, 0.2, 1.0], size=(P, 1)).astype(np.float32)
+    elif kind == "grazing":      # discs seen almost edge-on (normal ~ perpendicular to the view ray)
+        d = sc["means3D"] - sc["campos"][None]
+        d /= np.linalg.norm(d, axis=1, keepdims=True)
+        t1 = np.cross(d, rng.normal(size=(P, 3))); t1 /= np.linalg.norm(t1, axis=1, keepdims=True)
+        n = t1 + 0.03 * rng.normal(size=(P, 1)) * d                     # normal almost perpendicular to the ray
+        n /= np.linalg.norm(n, axis=1, keepdims=True)
+        a = np.cross(n, d); a /= np.linalg.norm(a, axis=1, keepdims=True)
+        b = np.cross(n, a)
+        R = np.stack([a, b, n], 2)                                      # columns = disc axes, normal
+        R[np.linalg.det(R) < 0, :, 0] *= -1
+        w = np.sqrt(np.maximum(0, 1 + R[:, 0, 0] + R[:, 1, 1] + R[:, 2, 2])) / 2 + 1e-9
+        q = np.stack([w, (R[:, 2, 1] - R[:, 1, 2]) / (4 * w), (R[:, 0, 2] - R[:, 2, 0]) / (4 * w), (R[:, 1, 0] - R[:, 0, 1]) / (4 * w)], 1)
+        sc["rotations"] = (q / np.linalg.norm(q, axis=1, keepdims=True)).astype(np.float32)
+        sc["scales"] = (sc["scales"] * 3.0).astype(np.float32)
+    elif kind == "opaque_faint":  # opacities at both ends: 1/255-ish (empty footprints) and ~1 (widest footprints)
+        sc["opacities"] = rng.choice([0.0035, 0.0045, 0.02, 0.999], size=(P, 1)).astype(np.float32)
+    sc["bg"] = np.array([0.1, 0.3, 0.7], np.float32)
+    return sc
+
+
+@pytest.mark.parametrize("kind", ["plain", "needles", "huge", "tiny", "grazing", "opaque_faint"])
+def test_culling_is_exact(kind):
+    """Every cull (footprint-restricted tile emission, per-quad / per-sub-tile instance masks) only ever removes
+    (pixel, surfel) pairs that contribute nothing: images and gradients must be BIT-IDENTICAL with culling on and off,
+    and with culling off the instance count is exactly the reference's rect count."""
+    import surfel_native as n
+    from oracle.surfel_oracle import Oracle
+    lib = n.load()
+    o = Oracle("f64")
+    for seed in (11, 12):
+        a = scene_args(_stress_scene(kind, seed))
+        rng = np.random.default_rng(seed)
+        gC = rng.normal(size=(3, a["H"], a["W"])).astype(np.float32); gO = rng.normal(size=(7, a["H"], a["W"])).astype(np.float32)
+        res = []
+        try:
+            for cull in (1, 0):
+                assert lib.surfel_set_option(b"cull", cull) == 0
+                run = HipRun(a).forward()
+                g = run.backward(gC, gO)
+                res.append((run.R, run.color.cpu().numpy(), run.others.cpu().numpy(), run.radii.cpu().numpy(), g))
+        finally:
+            lib.surfel_set_option(b"cull", 1)
+        (R1, c1, o1, r1, g1), (R0, c0, o0, r0, g0) = res
+        assert R1 <= R0 and np.array_equal(r1, r0)
+        assert np.array_equal(c1, c0), "%s/%d: colour differs with culling" % (kind, seed)
+        assert np.array_equal(o1, o0), "%s/%d: allmap differs with culling" % (kind, seed)
+        for k in g1:
+            assert np.isfinite(g1[k]).all(), "%s/%d: dL/d%s has non-finite entries" % (kind, seed, k)
+            assert np.array_equal(g1[k], g0[k]), "%s/%d: dL/d%s differs with culling (max |d| %.3e)" % (
+                kind, seed, k, np.abs(g1[k].astype(np.float64) - g0[k]).max())
+        # culling off = the reference's binning: instance count equals the oracle's rect count when radii agree
+        Rref, _, _, radii, _ = oracle_forward(o, a, depth_key=None)
+        if np.array_equal(r0, radii):
+            assert R0 == Rref, (R0, Rref)
+
+
 def test_backward_is_bit_reproducible():
     sc = _scene("C1", seed=1)
     a = scene_args(sc)
