@@ -44,22 +44,47 @@ constexpr int BB = 64;    // instances per accumulate/flush sub-batch
 constexpr int NV = 18;    // gradient values per instance
 constexpr int NVP = 20;   // padded to 5 registers x 4 rows for the wave reduction
 
-// Wave-wide sum of 20 per-lane values in 50 instructions (vs 6 DPP adds per value = 120):
-//   10 x fold32 -> 10 regs, 5 x fold16 -> 5 regs, 5 x 4 row_ror adds.  Afterwards register j holds,
-//   in every lane of row q (= lane>>4), the total of value 4j + {0,2,1,3}[q].
-__device__ __forceinline__ void wave_reduce20(const float (&v)[NVP], float (&z)[5]) {
-    float x[10];
+// Wave-wide sum of 20 per-lane values.  Measured issue costs on gfx950 (scripts/ubench/valu_rate.hip, v_fma = 1):
+// v_add_f32_dpp 1.4, v_permlane{16,32}_swap 3.0 — so the lanes are folded INSIDE their 16-lane rows first, where
+// DPP adds can merge two registers into one by writing disjoint lane banks of one destination (bank_mask), and
+// only the 5 surviving registers cross rows through permlane swaps:
+//   fold8 x10 (20 DPP) -> fold4 x5 (10 DPP) -> quad sum x5 (10 DPP) -> fold16 x3, fold32 x2 (5 swaps + 5 adds)
+// = 40 DPP adds + 5 swaps + 5 adds (~76 issue units; folding across rows first costs 15 swaps, ~100 units).
+// Result: u0 holds in quad q (lanes 4q..4q+3) of row r the total of value 4r + {0,2,1,3}[q]; u1 holds in quad q
+// of row 0 the total of value 16 + {0,2,1,3}[q].
+//   fold8 : out = [lanes 0-7 : a(l)+a(l+8) | lanes 8-15 : b(l)+b(l-8)]
+//   fold4 : out = [bank0 : c(l)+c(l+4) | bank1 : d(l)+d(l-4) | bank2 : c | bank3 : d]
+// The s_nop covers the 2 wait states a DPP source needs after a VALU write (the compiler cannot see into the asm).
+__device__ __forceinline__ float row_fold8(float a, float b) {
+    float out;
+    asm volatile("s_nop 1\n\t"
+                 "v_add_f32_dpp %0, %1, %1 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_add_f32_dpp %0, %2, %2 row_ror:8 row_mask:0xf bank_mask:0xc"
+                 : "=&v"(out) : "v"(a), "v"(b));
+    return out;
+}
+__device__ __forceinline__ float row_fold4(float c, float d) {
+    float out;
+    asm volatile("s_nop 1\n\t"
+                 "v_add_f32_dpp %0, %1, %1 row_ror:12 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_add_f32_dpp %0, %2, %2 row_ror:4 row_mask:0xf bank_mask:0xa"
+                 : "=&v"(out) : "v"(c), "v"(d));
+    return out;
+}
+__device__ __forceinline__ void wave_reduce20(const float (&v)[NVP], float& u0, float& u1) {
+    float a[10], z[5];
 #pragma unroll
-    for (int i = 0; i < 10; i++) x[i] = fold32(v[2 * i], v[2 * i + 1]);
+    for (int i = 0; i < 10; i++) a[i] = row_fold8(v[2 * i], v[2 * i + 1]);
 #pragma unroll
-    for (int j = 0; j < 5; j++) {
-        float t = fold16(x[2 * j], x[2 * j + 1]);
-        t = row_ror_add<0x128>(t);
-        t = row_ror_add<0x124>(t);
-        t = row_ror_add<0x122>(t);
-        t = row_ror_add<0x121>(t);
-        z[j] = t;
+    for (int m = 0; m < 5; m++) {
+        float t = row_fold4(a[2 * m], a[2 * m + 1]);
+        t = row_ror_add<0xB1>(t);      // quad_perm [1,0,3,2]
+        t = row_ror_add<0x4E>(t);      // quad_perm [2,3,0,1]
+        z[m] = t;
     }
+    const float t0 = fold16(z[0], z[1]), t1 = fold16(z[2], z[3]), t2 = fold16(z[4], z[4]);
+    u0 = fold32(t0, t1);
+    u1 = fold32(t2, t2);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -111,10 +136,10 @@ __global__ void __launch_bounds__(BLOCK) blend_bwd_kernel(BlendBwdArgs a) {
     float T = T_final;
     float X = T_final * (a.bg[0] * gC0 + a.bg[1] * gC1 + a.bg[2] * gC2);     // suffix sum, seeded with the background term
     constexpr float MC1 = FAR_N / (FAR_N - NEAR_N), MC2 = (FAR_N * NEAR_N) / (FAR_N - NEAR_N);
-    // LDS slot address pattern of the reduced values: lane (row q, first lane) stores value 4j + {0,2,1,3}[q]
-    const int row = lane >> 4;
-    const int vslot = ((row & 1) << 1) | (row >> 1);
-    const bool writer = (lane & 15) == 0;
+    // after wave_reduce20 the quad leaders hold the totals: u0 -> value 4*row + {0,2,1,3}[quad], u1 (row 0) -> 16 + ...
+    const int row = lane >> 4, quad = (lane >> 2) & 3;
+    const int vslot = 4 * row + (((quad & 1) << 1) | (quad >> 1));      // value index this lane's u0 holds
+    const bool writer = (lane & 3) == 0;                                 // one lane per quad
 
     for (int hi = maxc; hi > 0; hi -= BS) {
         const int mb = min(BS, hi);
@@ -206,11 +231,11 @@ __global__ void __launch_bounds__(BLOCK) blend_bwd_kernel(BlendBwdArgs a) {
                     gv[8] = dL_dz - (pxf * nk2 + pyf * nl2);
                     gv[9] = g2 * dx; gv[10] = g2 * dy;
                 }
-                float z[5];
-                wave_reduce20(gv, z);
+                float u0, u1;
+                wave_reduce20(gv, u0, u1);
                 if (writer) {
-#pragma unroll
-                    for (int q = 0; q < 5; q++) s_acc[wave][jj][4 * q + vslot] = z[q];
+                    s_acc[wave][jj][vslot] = u0;
+                    if (row == 0) s_acc[wave][jj][16 + vslot] = u1;      // row 0: values 16, 17 and the two zero pads
                 }
                 wmask |= 1ull << jj;
             }
