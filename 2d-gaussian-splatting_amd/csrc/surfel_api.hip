@@ -100,11 +100,12 @@ struct BinState {    // per-instance state ("binningBuffer"); point_list is alwa
 };
 
 struct ImgState {    // per-pixel / per-tile state ("imgBuffer")
-    uint2* ranges; float* final_T; uint32_t* n_contrib;
+    uint2* ranges; uint32_t* total; float* final_T; uint32_t* n_contrib;
     static ImgState carve(void* base, int W, int H, size_t* total) {
         Carver c(base); ImgState im;
         const size_t tiles = (size_t)((W + TILE - 1) / TILE) * ((H + TILE - 1) / TILE);
-        im.ranges = c.take<uint2>(tiles);
+        im.ranges = c.take<uint2>(tiles + R_SLOTS / 2);       // [tiles] ranges + R_SLOTS partial instance totals (zeroed together)
+        im.total = reinterpret_cast<uint32_t*>(im.ranges + tiles);
         im.final_T = c.take<float>((size_t)3 * W * H);
         im.n_contrib = c.take<uint32_t>((size_t)2 * W * H);
         if (total) *total = c.size();
@@ -153,9 +154,15 @@ struct StageTimer {
         if (_e) return fail(SURFEL_E_HIP, kStageNames[st], (hipError_t)_e);                \
     } while (0)
 
+hipEvent_t r_event() {
+    thread_local hipEvent_t e = nullptr;
+    if (!e) { if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) e = nullptr; }
+    return e;
+}
+
 uint32_t* pinned_u32() {
     thread_local uint32_t* p = nullptr;
-    if (!p) { if (hipHostMalloc(reinterpret_cast<void**>(&p), 64, hipHostMallocDefault) != hipSuccess) p = nullptr; }
+    if (!p) { if (hipHostMalloc(reinterpret_cast<void**>(&p), sizeof(uint32_t) * R_SLOTS, hipHostMallocDefault) != hipSuccess) p = nullptr; }
     return p;
 }
 
@@ -232,7 +239,7 @@ int64_t surfel_rasterize_forward(surfel_alloc_fn geom_alloc, void* geom_user, su
     void* img_base = image_alloc(image_user, img_bytes);
     if (!img_base) return fail(SURFEL_E_ALLOC, "image buffer allocation failed");
     ImgState img = ImgState::carve(img_base, width, height, nullptr);
-    HIP_TRY(hipMemsetAsync(img.ranges, 0, sizeof(uint2) * (size_t)gx * gy, s));
+    HIP_TRY(hipMemsetAsync(img.ranges, 0, sizeof(uint2) * ((size_t)gx * gy + R_SLOTS / 2), s));
 
     StageTimer tm(debug, s);
     int64_t R = 0;
@@ -259,28 +266,31 @@ int64_t surfel_rasterize_forward(surfel_alloc_fn geom_alloc, void* geom_user, su
         pa.transMat_precomp = transMat_precomp; pa.colors_precomp = colors_precomp; pa.shs = shs;
         pa.viewmatrix = viewmatrix; pa.projmatrix = projmatrix; pa.campos = cam_pos;
         pa.rec = geom.rec; pa.depths = geom.depths; pa.depth_keys = geom.dkey_a; pa.ident = geom.ord_a; pa.radii = radii;
-        pa.tiles_touched = geom.tiles_touched; pa.clamped = geom.clamped;
+        pa.tiles_touched = geom.tiles_touched; pa.clamped = geom.clamped; pa.total_instances = img.total;
         tm.begin();
         launch_preprocess_fwd(pa, s);
         STAGE_END(tm, ST_PRE);
+        // The instance count sizes the binning buffers, so it has to reach the host (one 4-byte D2H).  It is copied
+        // right behind preprocess and waited for only after the depth sort + scan have been enqueued: the host then
+        // allocates and enqueues the rest of the forward while the device is still sorting.
+        uint32_t* hR = pinned_u32();
+        hipEvent_t evR = r_event();
+        if (!hR || !evR) return fail(SURFEL_E_HIP, "pinned buffer / event creation failed");
+        HIP_TRY(hipMemcpyAsync(hR, img.total, sizeof(uint32_t) * R_SLOTS, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipEventRecord(evR, s));
 
         tm.begin();
         // (1) surfel order by view depth (stable; culled surfels carry key 0xffffffff and sort last)
         const int which = radix_sort_pairs_u32(geom.dkey_a, geom.ord_a, geom.dkey_b, geom.ord_b, (size_t)P, 0, 32, geom.temp, s);
         const uint32_t* order = which ? geom.ord_b : geom.ord_a;
-        size_t tb = temp_bytes;
         // (2) instance offsets in depth order
         GatherTiles gt{geom.tiles_touched, order};
         auto gin = rocprim::make_transform_iterator(rocprim::make_counting_iterator<uint32_t>(0u), gt);
-        tb = temp_bytes;
+        size_t tb = temp_bytes;
         HIP_TRY(rocprim::inclusive_scan(geom.temp, tb, gin, geom.offsets, (size_t)P, rocprim::plus<uint32_t>(), s));
-        // The instance count sizes the binning buffers, so it has to reach the host (one 4-byte D2H).
-        uint32_t* hR = pinned_u32();
-        if (!hR) return fail(SURFEL_E_HIP, "hipHostMalloc failed");
-        HIP_TRY(hipMemcpyAsync(hR, geom.offsets + (P - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-        HIP_TRY(hipStreamSynchronize(s));
-        R = (int64_t)*hR;
         STAGE_END(tm, ST_SCAN);
+        HIP_TRY(hipEventSynchronize(evR));
+        for (int k = 0; k < R_SLOTS; k++) R += (int64_t)hR[k];
 
         const int end_bit = higher_msb((uint32_t)(gx * gy));
         const size_t sort_bytes = radix_sort_scratch_bytes((size_t)R);

@@ -5,21 +5,11 @@
 //                     result is bit-reproducible and never crosses XCD L2s with device-scope RMWs.
 //                     (A per-DPP-row walk like the forward's was measured slower here: its per-row partial
 //                     sums need LDS float atomics, ~45 LDS cycles each, and the kernel turns LDS-bound.)
-//   preprocess_bwd  : per-surfel sum of its instance records, then the chain rule into means,
-//                     scales, rotations, opacity and SH.
 // Semantics: oracle/surfel_oracle.c stages 4-5 (restating the absent diff-surfel-rasterization).
 #include "surfel_common.h"
 #include "surfel_kernels.h"
 
 namespace surfel {
-
-__device__ __constant__ float BSH_C0 = 0.28209479177387814f;
-__device__ __constant__ float BSH_C1 = 0.4886025119029199f;
-__device__ __constant__ float BSH_C2[5] = {1.0925484305920792f, -1.0925484305920792f, 0.31539156525252005f,
-                                           -1.0925484305920792f, 0.5462742152960396f};
-__device__ __constant__ float BSH_C3[7] = {-0.5900435899266435f, 2.890611442640554f, -0.4570457994644658f,
-                                           0.3731763325901154f, -0.4570457994644658f, 1.445305721320277f,
-                                           -0.5900435899266435f};
 
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
@@ -41,8 +31,7 @@ __device__ __forceinline__ float fold16(float x, float y) {
 
 constexpr int BS = 128;   // instances staged per outer batch (one 80-B gather per thread of waves 0-1)
 constexpr int BB = 64;    // instances per accumulate/flush sub-batch
-constexpr int NV = 18;    // gradient values per instance
-constexpr int NVP = 20;   // padded to 5 registers x 4 rows for the wave reduction
+constexpr int NVP = 20;   // 18 gradient values per instance, padded to 20 for the wave reduction
 
 // Wave-wide sum of 20 per-lane values.  Measured issue costs on gfx950 (scripts/ubench/valu_rate.hip, v_fma = 1):
 // v_add_f32_dpp 1.4, v_permlane{16,32}_swap 3.0 — so the lanes are folded INSIDE their 16-lane rows first, where
@@ -282,220 +271,8 @@ __global__ void __launch_bounds__(BLOCK) blend_bwd_kernel(BlendBwdArgs a) {
     }
 }
 
-// ---------------------------------------------------------------------------------------------
-// preprocess_bwd: one thread per surfel.
-// ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ void store3(float* p, size_t i, float x, float y, float z) { p[3 * i] = x; p[3 * i + 1] = y; p[3 * i + 2] = z; }
-
-// Every output element of every surfel is written here (zeros for culled surfels and inactive SH degrees),
-// so the caller does not have to zero-fill nine gradient tensors per step.
-__global__ void __launch_bounds__(256) preprocess_bwd_kernel(PreprocessBwdArgs a) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= a.P) return;
-    const bool precomp = a.transMat_precomp != nullptr;
-    const bool vis = a.radii[i] > 0;
-    float4* __restrict__ gshq = a.shs ? reinterpret_cast<float4*>(a.dL_dsh + (size_t)i * a.M * 3) : nullptr;
-    if (!vis) {
-        a.dL_dopacity[i] = 0.f;
-        store3(a.dL_dnormal, i, 0.f, 0.f, 0.f); store3(a.dL_dcolors, i, 0.f, 0.f, 0.f);
-        store3(a.dL_dmeans2D, i, 0.f, 0.f, 0.f); store3(a.dL_dmeans3D, i, 0.f, 0.f, 0.f);
-#pragma unroll
-        for (int q = 0; q < 9; q++) a.dL_dtransMat[9 * (size_t)i + q] = 0.f;
-        if (!precomp) {
-            reinterpret_cast<float2*>(a.dL_dscales)[i] = make_float2(0.f, 0.f);
-            reinterpret_cast<float4*>(a.dL_drots)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-        if (gshq) {
-            if (a.M == 16) {
-#pragma unroll
-                for (int v = 0; v < 12; v++) gshq[v] = make_float4(0.f, 0.f, 0.f, 0.f);
-            } else {
-                for (int v = 0; v < a.M * 3; v++) a.dL_dsh[(size_t)i * a.M * 3 + v] = 0.f;
-            }
-        }
-        return;
-    }
-    // 1. gather-sum this surfel's instance gradient records (contiguous in emission order, fixed order)
-    float g[NV];
-#pragma unroll
-    for (int q = 0; q < NV; q++) g[q] = 0.f;
-    const float4* __restrict__ rq = reinterpret_cast<const float4*>(a.rec + (size_t)i * REC_F);
-    const float4 r4 = rq[4];
-    const uint32_t beg = __float_as_uint(r4.z);          // inst_base patched by emit_instances
-    const uint32_t end = beg + a.tiles_touched[i];
-    for (uint32_t k = beg; k < end; k++) {
-        const float4* __restrict__ src = reinterpret_cast<const float4*>(a.grec + (size_t)k * GREC_F);
-        const float4 v0 = src[0], v1 = src[1], v2 = src[2], v3 = src[3], v4 = src[4];
-        g[0] += v0.x; g[1] += v0.y; g[2] += v0.z; g[3] += v0.w;
-        g[4] += v1.x; g[5] += v1.y; g[6] += v1.z; g[7] += v1.w;
-        g[8] += v2.x; g[9] += v2.y; g[10] += v2.z; g[11] += v2.w;
-        g[12] += v3.x; g[13] += v3.y; g[14] += v3.z; g[15] += v3.w;
-        g[16] += v4.x; g[17] += v4.y;
-    }
-    a.dL_dopacity[i] = g[14];
-    store3(a.dL_dnormal, i, g[11], g[12], g[13]);
-    store3(a.dL_dcolors, i, g[15], g[16], g[17]);
-
-    const float4 r0 = rq[0], r1 = rq[1], r2 = rq[2];
-    const float T[9] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w, r2.x};
-    float gT[9];
-#pragma unroll
-    for (int q = 0; q < 9; q++) gT[q] = g[q];
-    const float gx2 = g[9], gy2 = g[10];
-    if (gx2 != 0.f || gy2 != 0.f) {
-        const float t[3] = {CUTOFF * CUTOFF, CUTOFF * CUTOFF, -1.f};
-        const float d = t[0] * T[6] * T[6] + t[1] * T[7] * T[7] + t[2] * T[8] * T[8];
-        const float id = 1.f / d;
-        float f[3], dd = 0.f;
-#pragma unroll
-        for (int k = 0; k < 3; k++) {
-            f[k] = t[k] * id;
-            dd += (gx2 * T[k] * T[6 + k] + gy2 * T[3 + k] * T[6 + k]) * f[k];
-        }
-        dd *= -id;
-#pragma unroll
-        for (int k = 0; k < 3; k++) {
-            gT[k] += gx2 * f[k] * T[6 + k];
-            gT[3 + k] += gy2 * f[k] * T[6 + k];
-            gT[6 + k] += gx2 * f[k] * T[k] + gy2 * f[k] * T[3 + k] + dd * t[k] * T[6 + k] * 2.f;
-        }
-    }
-    const float px = a.means3D[3 * (size_t)i], py = a.means3D[3 * (size_t)i + 1], pz = a.means3D[3 * (size_t)i + 2];
-    float dmx = 0.f, dmy = 0.f, dmz = 0.f;
-    if (precomp) {
-        // the centre term is folded into dL/dtransMat, and the densification statistic uses the folded value
-#pragma unroll
-        for (int q = 0; q < 9; q++) a.dL_dtransMat[9 * (size_t)i + q] = gT[q];
-        store3(a.dL_dmeans2D, i, gT[2] * T[8] * 0.5f * (float)a.W, gT[5] * T[8] * 0.5f * (float)a.H, 0.f);
-    } else {
-#pragma unroll
-        for (int q = 0; q < 9; q++) a.dL_dtransMat[9 * (size_t)i + q] = g[q];
-        // densification statistic from the blend-stage dL/dT (before the centre term is folded in)
-        store3(a.dL_dmeans2D, i, g[2] * T[8] * 0.5f * (float)a.W, g[5] * T[8] * 0.5f * (float)a.H, 0.f);
-        const float* __restrict__ vm = a.viewmatrix;
-        float Pm[12];
-        world2pix(a.projmatrix, a.W, a.H, Pm);
-        const float4 q = reinterpret_cast<const float4*>(a.rotations)[i];
-        const float2 sc = reinterpret_cast<const float2*>(a.scales)[i];
-        const float s = rsqrtf(q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w);
-        const float w = q.x * s, x = q.y * s, y = q.z * s, z = q.w * s;
-        const float sx = a.scale_modifier * sc.x, sy = a.scale_modifier * sc.y;
-        const float R00 = 1.f - 2.f * (y * y + z * z), R01 = 2.f * (x * y - w * z), R02 = 2.f * (x * z + w * y);
-        const float R10 = 2.f * (x * y + w * z), R11 = 1.f - 2.f * (x * x + z * z), R12 = 2.f * (y * z - w * x);
-        const float R20 = 2.f * (x * z - w * y), R21 = 2.f * (y * z + w * x), R22 = 1.f - 2.f * (x * x + y * y);
-        // dL/dA[r][j] = sum_c gT[3c+r] * Pm[j][c]
-        float dA[3][3];
-#pragma unroll
-        for (int r = 0; r < 3; r++)
-#pragma unroll
-            for (int j = 0; j < 3; j++) dA[r][j] = gT[r] * Pm[3 * j] + gT[3 + r] * Pm[3 * j + 1] + gT[6 + r] * Pm[3 * j + 2];
-        // normal path
-        const float nx = vm[0] * R02 + vm[4] * R12 + vm[8] * R22;
-        const float ny = vm[1] * R02 + vm[5] * R12 + vm[9] * R22;
-        const float nz = vm[2] * R02 + vm[6] * R12 + vm[10] * R22;
-        const float vx = vm[0] * px + vm[4] * py + vm[8] * pz + vm[12];
-        const float vy = vm[1] * px + vm[5] * py + vm[9] * pz + vm[13];
-        const float vz = vm[2] * px + vm[6] * py + vm[10] * pz + vm[14];
-        const float flip = (-(vx * nx + vy * ny + vz * nz)) > 0.f ? 1.f : -1.f;
-        const float dtn0 = flip * (vm[0] * g[11] + vm[1] * g[12] + vm[2] * g[13]);
-        const float dtn1 = flip * (vm[4] * g[11] + vm[5] * g[12] + vm[6] * g[13]);
-        const float dtn2 = flip * (vm[8] * g[11] + vm[9] * g[12] + vm[10] * g[13]);
-        // dL/dR[r][c]
-        const float d00 = dA[0][0] * sx, d10 = dA[0][1] * sx, d20 = dA[0][2] * sx;
-        const float d01 = dA[1][0] * sy, d11 = dA[1][1] * sy, d21 = dA[1][2] * sy;
-        const float d02 = dtn0, d12 = dtn1, d22 = dtn2;
-        reinterpret_cast<float2*>(a.dL_dscales)[i] = make_float2(a.scale_modifier * (dA[0][0] * R00 + dA[0][1] * R10 + dA[0][2] * R20),
-                                                                 a.scale_modifier * (dA[1][0] * R01 + dA[1][1] * R11 + dA[1][2] * R21));
-        dmx = dA[2][0]; dmy = dA[2][1]; dmz = dA[2][2];
-        float4 gq;
-        gq.x = 2.f * (x * (d21 - d12) + y * (d02 - d20) + z * (d10 - d01));
-        gq.y = 2.f * (-2.f * x * (d11 + d22) + y * (d01 + d10) + z * (d02 + d20) + w * (d21 - d12));
-        gq.z = 2.f * (x * (d01 + d10) - 2.f * y * (d00 + d22) + z * (d12 + d21) + w * (d02 - d20));
-        gq.w = 2.f * (x * (d02 + d20) + y * (d12 + d21) - 2.f * z * (d00 + d11) + w * (d10 - d01));
-        reinterpret_cast<float4*>(a.dL_drots)[i] = gq;
-    }
-
-    if (a.shs != nullptr) {
-        const float dox = px - a.campos[0], doy = py - a.campos[1], doz = pz - a.campos[2];
-        const float sum2 = dox * dox + doy * doy + doz * doz;
-        const float il = rsqrtf(sum2);
-        const float x = dox * il, y = doy * il, z = doz * il;
-        const uint8_t cb = a.clamped[i];
-        const float gR[3] = {(cb & 1) ? 0.f : g[15], (cb & 2) ? 0.f : g[16], (cb & 4) ? 0.f : g[17]};
-        // SH basis B[k] and its direction derivatives dB[k]/d{x,y,z} for the active degree (zero above it)
-        float B[16], Bx[16], By[16], Bz[16];
-#pragma unroll
-        for (int k = 0; k < 16; k++) { B[k] = 0.f; Bx[k] = 0.f; By[k] = 0.f; Bz[k] = 0.f; }
-        B[0] = BSH_C0;
-        if (a.D > 0) {
-            B[1] = -BSH_C1 * y; By[1] = -BSH_C1;
-            B[2] = BSH_C1 * z;  Bz[2] = BSH_C1;
-            B[3] = -BSH_C1 * x; Bx[3] = -BSH_C1;
-            if (a.D > 1) {
-                const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
-                B[4] = BSH_C2[0] * xy; Bx[4] = BSH_C2[0] * y; By[4] = BSH_C2[0] * x;
-                B[5] = BSH_C2[1] * yz; By[5] = BSH_C2[1] * z; Bz[5] = BSH_C2[1] * y;
-                B[6] = BSH_C2[2] * (2.f * zz - xx - yy); Bx[6] = BSH_C2[2] * -2.f * x; By[6] = BSH_C2[2] * -2.f * y; Bz[6] = BSH_C2[2] * 4.f * z;
-                B[7] = BSH_C2[3] * xz; Bx[7] = BSH_C2[3] * z; Bz[7] = BSH_C2[3] * x;
-                B[8] = BSH_C2[4] * (xx - yy); Bx[8] = BSH_C2[4] * 2.f * x; By[8] = BSH_C2[4] * -2.f * y;
-                if (a.D > 2) {
-                    B[9] = BSH_C3[0] * y * (3.f * xx - yy); Bx[9] = BSH_C3[0] * 6.f * xy; By[9] = BSH_C3[0] * 3.f * (xx - yy);
-                    B[10] = BSH_C3[1] * xy * z; Bx[10] = BSH_C3[1] * yz; By[10] = BSH_C3[1] * xz; Bz[10] = BSH_C3[1] * xy;
-                    B[11] = BSH_C3[2] * y * (4.f * zz - xx - yy); Bx[11] = BSH_C3[2] * -2.f * xy; By[11] = BSH_C3[2] * (-3.f * yy + 4.f * zz - xx); Bz[11] = BSH_C3[2] * 8.f * yz;
-                    B[12] = BSH_C3[3] * z * (2.f * zz - 3.f * xx - 3.f * yy); Bx[12] = BSH_C3[3] * -6.f * xz; By[12] = BSH_C3[3] * -6.f * yz; Bz[12] = BSH_C3[3] * 3.f * (2.f * zz - xx - yy);
-                    B[13] = BSH_C3[4] * x * (4.f * zz - xx - yy); Bx[13] = BSH_C3[4] * (-3.f * xx + 4.f * zz - yy); By[13] = BSH_C3[4] * -2.f * xy; Bz[13] = BSH_C3[4] * 8.f * xz;
-                    B[14] = BSH_C3[5] * z * (xx - yy); Bx[14] = BSH_C3[5] * 2.f * xz; By[14] = BSH_C3[5] * -2.f * yz; Bz[14] = BSH_C3[5] * (xx - yy);
-                    B[15] = BSH_C3[6] * x * (xx - 3.f * yy); Bx[15] = BSH_C3[6] * 3.f * (xx - yy); By[15] = BSH_C3[6] * -6.f * xy;
-                }
-            }
-        }
-        float gdx = 0.f, gdy = 0.f, gdz = 0.f;
-        if (a.M == 16) {
-            // one pass over the 48 coefficients as 12 float4: read sh (for the direction gradient), write dL/dsh
-            const float4* __restrict__ shq = reinterpret_cast<const float4*>(a.shs + (size_t)i * 48);
-#pragma unroll
-            for (int v = 0; v < 12; v++) {
-                const float4 c4 = shq[v];
-                const float cv[4] = {c4.x, c4.y, c4.z, c4.w};
-                float o[4];
-#pragma unroll
-                for (int e = 0; e < 4; e++) {
-                    const int flat = 4 * v + e, k = flat / 3, c = flat % 3;
-                    o[e] = B[k] * gR[c];
-                    const float t = cv[e] * gR[c];
-                    gdx += Bx[k] * t; gdy += By[k] * t; gdz += Bz[k] * t;
-                }
-                gshq[v] = make_float4(o[0], o[1], o[2], o[3]);
-            }
-        } else {
-            const float* __restrict__ sh = a.shs + (size_t)i * a.M * 3;
-            float* __restrict__ gsh = a.dL_dsh + (size_t)i * a.M * 3;
-#pragma unroll
-            for (int k = 0; k < 16; k++) {
-                if (k < a.M) {
-#pragma unroll
-                    for (int c = 0; c < 3; c++) {
-                        gsh[3 * k + c] = B[k] * gR[c];
-                        const float t = sh[3 * k + c] * gR[c];
-                        gdx += Bx[k] * t; gdy += By[k] * t; gdz += Bz[k] * t;
-                    }
-                }
-            }
-            for (int k = 16; k < a.M; k++) { gsh[3 * k] = 0.f; gsh[3 * k + 1] = 0.f; gsh[3 * k + 2] = 0.f; }
-        }
-        const float il3 = il * il * il;
-        dmx += ((sum2 - dox * dox) * gdx - doy * dox * gdy - doz * dox * gdz) * il3;
-        dmy += (-dox * doy * gdx + (sum2 - doy * doy) * gdy - doz * doy * gdz) * il3;
-        dmz += (-dox * doz * gdx - doy * doz * gdy + (sum2 - doz * doz) * gdz) * il3;
-    }
-    store3(a.dL_dmeans3D, i, dmx, dmy, dmz);
-}
-
 void launch_blend_bwd(const BlendBwdArgs& a, hipStream_t s) {
     hipLaunchKernelGGL(blend_bwd_kernel, dim3(a.gx * a.gy), dim3(BLOCK), 0, s, a);
-}
-void launch_preprocess_bwd(const PreprocessBwdArgs& a, hipStream_t s) {
-    if (a.P > 0) hipLaunchKernelGGL(preprocess_bwd_kernel, dim3((a.P + 255) / 256), dim3(256), 0, s, a);
 }
 
 }  // namespace surfel

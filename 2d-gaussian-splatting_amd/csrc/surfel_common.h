@@ -9,6 +9,7 @@ namespace surfel {
 constexpr int TILE = 16;            // tile edge in pixels (fixed by the reference's binning semantics)
 constexpr int BLOCK = TILE * TILE;  // 256 threads = 4 waves
 constexpr int WAVE = 64;
+constexpr int R_SLOTS = 64;         // partial instance totals (summed on the host)
 
 // rasterizer constants (oracle/surfel_oracle.c holds the same list with provenance)
 constexpr float NEAR_N = 0.2f;

@@ -13,6 +13,7 @@ struct PreprocessArgs {
     const float* transMat_precomp; const float* colors_precomp; const float* shs;
     const float* viewmatrix; const float* projmatrix; const float* campos;
     float* rec; float* depths; uint32_t* depth_keys; uint32_t* ident; int* radii; uint32_t* tiles_touched; uint8_t* clamped;
+    uint32_t* total_instances;     // [R_SLOTS], zeroed by the caller; sum over slots = sum(tiles_touched)
 };
 
 struct BlendFwdArgs {
