@@ -190,6 +190,28 @@ int surfel_last_stage_ids(int* ids, int cap) {
     return n;
 }
 
+int surfel_debug_sort_pairs(surfel_alloc_fn scratch_alloc, void* scratch_user, uint32_t* keys, uint32_t* vals, int64_t n,
+                            int begin_bit, int end_bit, void* stream) {
+    if (!scratch_alloc || n < 0 || (n > 0 && (!keys || !vals)) || begin_bit < 0 || end_bit > 32 || begin_bit >= end_bit)
+        return fail(SURFEL_E_INVALID, "bad arguments");
+    if (n == 0) return 0;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const size_t sb = radix_sort_scratch_bytes((size_t)n);
+    const size_t words = align_up((size_t)n * sizeof(uint32_t));
+    char* base = static_cast<char*>(scratch_alloc(scratch_user, 2 * words + sb));
+    if (!base) return fail(SURFEL_E_ALLOC, "sort scratch allocation failed");
+    uint32_t* kb = reinterpret_cast<uint32_t*>(base);
+    uint32_t* vb = reinterpret_cast<uint32_t*>(base + words);
+    const int w = radix_sort_pairs_u32(keys, vals, kb, vb, (size_t)n, begin_bit, end_bit, base + 2 * words, s);
+    if (w < 0) return fail(SURFEL_E_LIMIT, "sort size limit");
+    if (w == 1) {
+        HIP_TRY(hipMemcpyAsync(keys, kb, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
+        HIP_TRY(hipMemcpyAsync(vals, vb, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
+    }
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
 int surfel_set_option(const char* name, int value) {
     if (name && std::strcmp(name, "cull") == 0) { g_opt_cull = value ? 1 : 0; return 0; }
     return fail(SURFEL_E_INVALID, "unknown option");
@@ -282,6 +304,7 @@ int64_t surfel_rasterize_forward(surfel_alloc_fn geom_alloc, void* geom_user, su
         tm.begin();
         // (1) surfel order by view depth (stable; culled surfels carry key 0xffffffff and sort last)
         const int which = radix_sort_pairs_u32(geom.dkey_a, geom.ord_a, geom.dkey_b, geom.ord_b, (size_t)P, 0, 32, geom.temp, s);
+        if (which < 0) return fail(SURFEL_E_LIMIT, "too many surfels for the depth sort");
         const uint32_t* order = which ? geom.ord_b : geom.ord_a;
         // (2) instance offsets in depth order
         GatherTiles gt{geom.tiles_touched, order};
@@ -310,6 +333,7 @@ int64_t surfel_rasterize_forward(surfel_alloc_fn geom_alloc, void* geom_user, su
             STAGE_END(tm, ST_EMIT);
             tm.begin();
             const int wk = radix_sort_pairs_u32(bin.keys_a, va, bin.keys_b, vb, (size_t)R, 0, end_bit, bin.sort_temp, s);
+            if (wk < 0) return fail(SURFEL_E_LIMIT, "too many tile instances for the tile sort");
             const uint32_t* sorted_keys = wk ? bin.keys_b : bin.keys_a;
             STAGE_END(tm, ST_SORT);
             tm.begin();

@@ -1,12 +1,23 @@
-// surfel_sort.hip — stable LSD radix sort of (u32 key, u32 value) pairs for the binning stages, gfx950.
+// surfel_sort.hip — stable LSD radix sort of (u32 key, u32 value) pairs for gfx950: ONE launch per 8-bit pass.
 //
-// Why not rocPRIM here: the two sorts on the hot path are small and oddly shaped — P surfels by 32 depth bits
-// and R instances by the 12-16 tile-id bits — and rocPRIM's generic dispatch costs ~0.14 ms each at the
-// BASELINE configs[1] size (300 k surfels / 0.6 M instances).  This version is 3 launches per pass (8- or 11-bit digits):
-//   histogram  : per-block digit counts  -> hist[digit][block]
-//   scan       : one workgroup per digit, exclusive scan over blocks, digit total -> total[digit]
-//   scatter    : wave64 match-by-ballot ranks (no atomics, order-preserving => stable), coalesced-run stores
-// Traffic per pass: 4 B (hist) + 8 B read + 8 B written per element; all integer, HBM-streaming work.
+// Why not rocPRIM here: the two sorts on the hot path are small and oddly shaped — P surfels by 32 depth bits and R
+// instances by the 12-17 tile-id bits — and at BASELINE configs[1] (300 k surfels / 0.6 M instances) every extra
+// launch costs more than the bytes it moves.  Structure ("onesweep"):
+//   os_hist   : digit histograms of ALL passes in one sweep over the keys (the multiset of digits of a pass does not
+//               depend on the order earlier passes leave behind); also clears the look-back state.  Callers that
+//               produce the keys themselves can fill the histogram on the fly and skip this launch.
+//   os_pass   : one launch per pass.  A workgroup takes the next 2048-item tile (ticket order = input order), ranks
+//               its items with wave64 match-by-ballot (no atomics, order-preserving => stable), publishes its digit
+//               counts, and obtains the counts of all earlier tiles by decoupled look-back over their published
+//               (aggregate | inclusive-prefix) words — one 32-bit word per (tile, digit) carrying flag and value, stored
+//               and loaded at agent scope, so there is no separate payload to order.  Predecessor tiles hold smaller
+//               tickets, i.e. they are already running, so the spin always terminates.
+// Items are then scattered with coalesced same-digit runs.  Traffic per pass: 16 B/item + 1 KB of status per tile.
+// The look-back form is used while the whole grid is (nearly) resident (n <= RS_ONESWEEP_MAX): there a pass costs
+// 16 us instead of 30 us for three launches.  Beyond that, the number of in-flight tiles exceeds what one look-back
+// round (RS_LB words, ~1 us of agent-scope latency) can absorb and the chain throttles the scatter (measured 190 us
+// per pass at 10 M items vs 125 us), so large inputs take the classic three launches per pass:
+//   rs_hist (per-tile digit counts) -> rs_scan (one workgroup per digit over the tiles) -> the same scatter.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -15,17 +26,68 @@
 namespace surfel {
 
 constexpr int RS_THREADS = 256;
-constexpr int RS_IPT = 8;                       // items per thread
-constexpr int RS_TILE = RS_THREADS * RS_IPT;    // 2048 items per workgroup
-constexpr int RS_FUSED_MAX_BLOCKS = 1024;       // up to here the scatter kernel scans the block histograms itself
+// items per thread: 8 (2048-item tiles) for large inputs — long same-digit store runs, 1 KB of status per 16 KB of
+// pairs; 2 (512-item tiles) for small ones, where the whole grid is resident and the critical path of one tile
+// (sweeps x ballot ranking at one wave per SIMD) is what a pass costs.
+// (512-item tiles were measured 2x SLOWER at 0.3-0.6 M items: 4x the tickets, status words and look-back depth.)
+constexpr int RS_IPT = 8;
+constexpr int RS_TILE = RS_THREADS * RS_IPT;
+constexpr size_t RS_ONESWEEP_MAX = (size_t)1 << 20;
+static inline bool rs_onesweep(size_t n) { return n <= RS_ONESWEEP_MAX; }
+constexpr int RS_BITS = 8;
+constexpr int RS_RADIX = 1 << RS_BITS;
+constexpr int RS_MAX_PASSES = 4;
+constexpr int RS_LB = 16;                       // look-back window (tiles per round)
+constexpr uint32_t ST_AGG = 1u << 30, ST_PREFIX = 2u << 30, ST_VALUE = (1u << 30) - 1u;
 
-// digit histogram of one 2048-item block -> hist[digit][block]
-template <int BITS>
+// scratch layout (u32 words): ghist[RS_MAX_PASSES][256] | ticket[RS_MAX_PASSES] (+pad to 64) | status[passes][nblocks][256]
+constexpr size_t RS_HEAD_WORDS = RS_MAX_PASSES * RS_RADIX + 64;
+
+static inline uint32_t rs_nblocks(size_t n) { return (uint32_t)((n + RS_TILE - 1) / RS_TILE); }
+
+size_t radix_sort_scratch_bytes(size_t n) {
+    if (!rs_onesweep(n)) return ((size_t)RS_RADIX * rs_nblocks(n) + RS_RADIX) * sizeof(uint32_t) + 256;   // hist[digit][tile] | total[digit]
+    return (RS_HEAD_WORDS + (size_t)RS_MAX_PASSES * rs_nblocks(n) * RS_RADIX) * sizeof(uint32_t) + 256;
+}
+int radix_sort_passes(size_t, int begin_bit, int end_bit) { return (end_bit - begin_bit + RS_BITS - 1) / RS_BITS; }
+size_t radix_sort_head_bytes() { return RS_HEAD_WORDS * sizeof(uint32_t); }
+
+__device__ __forceinline__ uint32_t ld_agent(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_agent(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// digit histograms of every pass -> ghist (pre-zeroed); clears the look-back status words of this sort
+__global__ void __launch_bounds__(RS_THREADS) os_hist_kernel(const uint32_t* __restrict__ keys, uint32_t n, int begin_bit, int end_bit,
+                                                             int passes, uint32_t* __restrict__ ghist, uint32_t* __restrict__ status,
+                                                             uint32_t nblocks) {
+    __shared__ uint32_t s_h[RS_MAX_PASSES][RS_RADIX];
+    for (int p = 0; p < passes; p++) s_h[p][threadIdx.x] = 0;
+    for (int p = 0; p < passes; p++) status[((size_t)p * nblocks + blockIdx.x) * RS_RADIX + threadIdx.x] = 0u;
+    __syncthreads();
+    const uint32_t base = blockIdx.x * (RS_THREADS * RS_IPT);
+#pragma unroll
+    for (int it = 0; it < RS_IPT; it++) {
+        const uint32_t e = base + it * RS_THREADS + threadIdx.x;
+        if (e < n) {
+            const uint32_t k = keys[e];
+            for (int p = 0; p < passes; p++) {
+                const int bit = begin_bit + p * RS_BITS;
+                const int nb = min(RS_BITS, end_bit - bit);
+                atomicAdd(&s_h[p][(k >> bit) & ((1u << nb) - 1u)], 1u);
+            }
+        }
+    }
+    __syncthreads();
+    for (int p = 0; p < passes; p++) {
+        const uint32_t c = s_h[p][threadIdx.x];
+        if (c) atomicAdd(&ghist[p * RS_RADIX + threadIdx.x], c);
+    }
+}
+
+// ---- large-n path: per-tile digit counts -> hist[digit][tile], then one workgroup per digit scans its row
 __global__ void __launch_bounds__(RS_THREADS) rs_hist_kernel(const uint32_t* __restrict__ keys, uint32_t n, int shift, uint32_t mask,
                                                              uint32_t* __restrict__ hist, uint32_t nblocks) {
-    constexpr int RADIX = 1 << BITS;
-    __shared__ uint32_t s_h[RADIX];
-    for (int d = threadIdx.x; d < RADIX; d += RS_THREADS) s_h[d] = 0;
+    __shared__ uint32_t s_h[RS_RADIX];
+    s_h[threadIdx.x] = 0;
     __syncthreads();
     const uint32_t base = blockIdx.x * RS_TILE;
 #pragma unroll
@@ -34,10 +96,8 @@ __global__ void __launch_bounds__(RS_THREADS) rs_hist_kernel(const uint32_t* __r
         if (e < n) atomicAdd(&s_h[(keys[e] >> shift) & mask], 1u);
     }
     __syncthreads();
-    for (int d = threadIdx.x; d < RADIX; d += RS_THREADS) hist[(size_t)d * nblocks + blockIdx.x] = s_h[d];
+    hist[(size_t)threadIdx.x * nblocks + blockIdx.x] = s_h[threadIdx.x];
 }
-
-// one workgroup per digit: in-place exclusive scan of hist[digit][0..nblocks), total[digit] = sum  (large-n path)
 __global__ void __launch_bounds__(RS_THREADS) rs_scan_kernel(uint32_t* __restrict__ hist, uint32_t nblocks, uint32_t* __restrict__ total) {
     __shared__ uint32_t s_w[4];
     __shared__ uint32_t s_carry;
@@ -64,78 +124,101 @@ __global__ void __launch_bounds__(RS_THREADS) rs_scan_kernel(uint32_t* __restric
     if (threadIdx.x == 0) total[blockIdx.x] = s_carry;
 }
 
-// Stable scatter of one block.  FUSED: the block derives its global digit offsets straight from the raw block
-// histograms (sum of the blocks before it + full-row totals) — no separate scan launch; used for small n.
-template <int BITS, bool FUSED>
-__global__ void __launch_bounds__(RS_THREADS) rs_scatter_kernel(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ vals,
-                                                                uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out, uint32_t n,
-                                                                int shift, uint32_t mask, const uint32_t* __restrict__ hist,
-                                                                const uint32_t* __restrict__ total, uint32_t nblocks) {
-    constexpr int RADIX = 1 << BITS;
-    constexpr int DPT = RADIX / RS_THREADS;       // digits owned per thread in the offset phases (contiguous)
-    __shared__ uint32_t s_cnt[4][RADIX];          // per-wave digit counts -> then per-wave output offsets
-    __shared__ uint32_t s_base[RADIX];
+// one pass: tile ticket -> local ranks -> look-back -> scatter
+// LOOKBACK: ghist = digit totals, status/ticket = look-back state.  !LOOKBACK: ghist = total[digit] from rs_scan,
+// status = hist[digit][tile] already exclusive-scanned over the tiles, tile = blockIdx.x.
+template <bool LOOKBACK>
+__global__ void __launch_bounds__(RS_THREADS) os_pass_kernel(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ vals,
+                                                             uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out, uint32_t n,
+                                                             int shift, uint32_t mask, const uint32_t* __restrict__ ghist,
+                                                             uint32_t* __restrict__ status, uint32_t* __restrict__ ticket, uint32_t nblocks) {
+    __shared__ uint32_t s_cnt[4][RS_RADIX];      // per-wave digit counts -> then per-wave output offsets
     __shared__ uint32_t s_w[4];
+    __shared__ uint32_t s_tile;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    // global base of every digit = exclusive scan of the digit totals + this block's offset inside the digit
-    {
-        uint32_t tot[DPT], mine[DPT], run = 0;
+    const uint32_t d_t = threadIdx.x;            // the digit this thread owns in the offset phases
+    if (LOOKBACK && threadIdx.x == 0) s_tile = atomicAdd(ticket, 1u);
 #pragma unroll
-        for (int q = 0; q < DPT; q++) {
-            const uint32_t d = threadIdx.x * DPT + q;
-            if (FUSED) {
-                const uint32_t* row = hist + (size_t)d * nblocks;
-                uint32_t before = 0, all = 0;
-                for (uint32_t b = 0; b < nblocks; b++) { const uint32_t c = row[b]; all += c; before += (b < blockIdx.x) ? c : 0u; }
-                tot[q] = all; mine[q] = before;
-            } else {
-                tot[q] = total[d]; mine[q] = hist[(size_t)d * nblocks + blockIdx.x];
-            }
-            run += tot[q];
-#pragma unroll
-            for (int w = 0; w < 4; w++) s_cnt[w][d] = 0;
-        }
-        uint32_t x = run;                          // inclusive scan of per-thread totals across the block
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) { const uint32_t y = __shfl_up(x, o); if (lane >= o) x += y; }
-        if (lane == 63) s_w[wave] = x;
-        __syncthreads();
-        uint32_t off = x - run;
-        for (int w = 0; w < wave; w++) off += s_w[w];
-#pragma unroll
-        for (int q = 0; q < DPT; q++) { s_base[threadIdx.x * DPT + q] = off + mine[q]; off += tot[q]; }
-    }
-    // phase A: wave w owns items [w*512, w*512+512) of the tile, 8 sweeps of 64 consecutive items
-    const uint32_t wbase = blockIdx.x * RS_TILE + wave * (64 * RS_IPT);
+    for (int w = 0; w < 4; w++) s_cnt[w][d_t] = 0;
+    __syncthreads();
+    const uint32_t tile = LOOKBACK ? s_tile : blockIdx.x;
+    // phase A: wave w owns a contiguous quarter of the tile, RS_IPT sweeps of 64 consecutive items
+    const uint32_t wbase = tile * (RS_THREADS * RS_IPT) + wave * (64 * RS_IPT);
     uint32_t k[RS_IPT], v[RS_IPT], rank[RS_IPT];
-    const unsigned long long lt = (1ull << lane) - 1ull;
 #pragma unroll
     for (int it = 0; it < RS_IPT; it++) {
         const uint32_t e = wbase + it * 64 + lane;
         const bool valid = e < n;
         k[it] = valid ? keys[e] : 0xffffffffu;
         v[it] = valid ? vals[e] : 0u;
+    }
+#pragma unroll
+    for (int it = 0; it < RS_IPT; it++) {
+        const uint32_t e = wbase + it * 64 + lane;
+        const bool valid = e < n;
         const uint32_t d = (k[it] >> shift) & mask;
         unsigned long long mm = __ballot(valid);
 #pragma unroll
-        for (int b = 0; b < BITS; b++) {
+        for (int b = 0; b < RS_BITS; b++) {
             const bool bit = (d >> b) & 1u;
             const unsigned long long bal = __ballot(bit);
             mm &= bit ? bal : ~bal;
         }
-        const uint32_t prev = s_cnt[wave][d];                 // running count of this digit in this wave (broadcast read)
-        const uint32_t before = (uint32_t)__popcll(mm & lt);
-        rank[it] = prev + before;
-        if (valid && before == 0) s_cnt[wave][d] = prev + (uint32_t)__popcll(mm);   // group leader bumps the counter
+        if (!valid) mm = 0ull;                   // invalid lanes matched each other's padding digit: they own nothing
+        const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(mm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mm, 0u));
+        const uint32_t prev = valid ? s_cnt[wave][d] : 0u;   // same-wave LDS ops are program-ordered
+        rank[it] = prev + below;
+        if (valid && below == 0) s_cnt[wave][d] = prev + (uint32_t)__popcll(mm);
     }
     __syncthreads();
-    // phase B: per-wave output offsets for every digit
+    // tile count of this thread's digit; publish it, look back for the sum over earlier tiles
+    const uint32_t c0 = s_cnt[0][d_t], c1 = s_cnt[1][d_t], c2 = s_cnt[2][d_t], c3 = s_cnt[3][d_t];
+    const uint32_t cnt = c0 + c1 + c2 + c3;
+    uint32_t* my = status + (size_t)tile * RS_RADIX + d_t;
+    uint32_t excl = 0;
+    if (!LOOKBACK) {
+        excl = status[(size_t)d_t * nblocks + tile];
+    } else if (tile == 0) {
+        st_agent(my, cnt | ST_PREFIX);
+    } else {
+        st_agent(my, cnt | ST_AGG);
+        // Look back RS_LB tiles per round with independent loads.  When the whole grid is resident (small n) every tile
+        // publishes its aggregate at the same moment and a one-word-per-step walk would resolve in ~sqrt(2*tiles) dependent
+        // agent-scope loads (~0.7 us each); batching the window cuts the number of dependent rounds by sqrt(RS_LB).
+        int p = (int)tile - 1;                   // nearest tile not yet accounted for
+        bool done = false;
+        while (!done) {
+            uint32_t w[RS_LB];
 #pragma unroll
-    for (int q = 0; q < DPT; q++) {
-        const uint32_t d = threadIdx.x * DPT + q;
-        uint32_t off = s_base[d];
+            for (int i = 0; i < RS_LB; i++) w[i] = (p - i >= 0) ? ld_agent(status + (size_t)(p - i) * RS_RADIX + d_t) : ST_PREFIX;
+            int used = 0;
 #pragma unroll
-        for (int w = 0; w < 4; w++) { const uint32_t c = s_cnt[w][d]; s_cnt[w][d] = off; off += c; }
+            for (int i = 0; i < RS_LB; i++) {
+                if (!done && used == i) {
+                    if ((w[i] >> 30) != 0u) {
+                        excl += w[i] & ST_VALUE;
+                        used = i + 1;
+                        if (w[i] & ST_PREFIX) done = true;
+                    }
+                }
+            }
+            p -= used;                           // a not-yet-published word stops the round; the next round re-reads from it
+            if (!done && used == 0) __builtin_amdgcn_s_sleep(1);
+        }
+        st_agent(my, (excl + cnt) | ST_PREFIX);
+    }
+    // global base of every digit = exclusive scan of the digit totals + everything earlier tiles hold of this digit
+    {
+        const uint32_t tot = ghist[d_t];
+        uint32_t x = tot;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const uint32_t y = __shfl_up(x, o); if (lane >= o) x += y; }
+        if (lane == 63) s_w[wave] = x;
+        __syncthreads();
+        uint32_t off = x - tot + excl;
+        for (int w = 0; w < wave; w++) off += s_w[w];
+        // per-wave output offsets of this digit
+        s_cnt[0][d_t] = off; s_cnt[1][d_t] = off + c0; s_cnt[2][d_t] = off + c0 + c1; s_cnt[3][d_t] = off + c0 + c1 + c2;
     }
     __syncthreads();
     // phase C: scatter
@@ -144,60 +227,56 @@ __global__ void __launch_bounds__(RS_THREADS) rs_scatter_kernel(const uint32_t* 
         const uint32_t e = wbase + it * 64 + lane;
         if (e < n) {
             const uint32_t d = (k[it] >> shift) & mask;
-            const uint32_t pos = s_cnt[wave][d] + rank[it];
-            keys_out[pos] = k[it];
-            vals_out[pos] = v[it];
+            const uint32_t dst = s_cnt[wave][d] + rank[it];
+            keys_out[dst] = k[it];
+            vals_out[dst] = v[it];
         }
     }
 }
 
-// Digit width: small inputs are launch-bound (every launch costs ~4.5 us of dispatch floor), so they take 11-bit digits
-// = fewer passes; large inputs take 8-bit digits (smaller per-block histograms, longer same-digit store runs).
-// (A scatter that scans the block histograms itself — the FUSED template path — was measured NOT to pay: its
-// O(radix x nblocks) prologue per block costs more than the 4.8 us scan launch it saves.)
-static bool rs_small(size_t n) { return (n + RS_TILE - 1) / RS_TILE <= RS_FUSED_MAX_BLOCKS; }
-static int rs_bits(size_t n) { return rs_small(n) ? 11 : 8; }
-
-size_t radix_sort_scratch_bytes(size_t n) {
-    const size_t nblocks = (n + RS_TILE - 1) / RS_TILE;
-    const size_t radix = (size_t)1 << rs_bits(n);
-    return (radix * nblocks + radix) * sizeof(uint32_t) + 256;
-}
-
-int radix_sort_passes(size_t n, int begin_bit, int end_bit) {
-    const int bits = rs_bits(n);
-    return (end_bit - begin_bit + bits - 1) / bits;
-}
+// clears ghist/ticket head + (via os_hist) the status words; `prepared` callers did both themselves
+void radix_sort_prepare_async(void* scratch, hipStream_t s) { (void)hipMemsetAsync(scratch, 0, RS_HEAD_WORDS * sizeof(uint32_t), s); }
 
 // Sorts on key bits [begin_bit, end_bit).  Buffers ping-pong a -> b -> a ...; returns 0 if the result is in (keys_a, vals_a),
-// 1 if in (keys_b, vals_b).
+// 1 if in (keys_b, vals_b); -1 if n is too large for the 30-bit look-back counters.
 int radix_sort_pairs_u32(uint32_t* keys_a, uint32_t* vals_a, uint32_t* keys_b, uint32_t* vals_b, size_t n, int begin_bit, int end_bit,
                          void* scratch, hipStream_t s) {
     if (n == 0) return 0;
-    const uint32_t nblocks = (uint32_t)((n + RS_TILE - 1) / RS_TILE);
-    const bool small = rs_small(n);
-    const int bits = rs_bits(n);
+    if (n >= ST_VALUE) return -1;
+    const uint32_t nblocks = rs_nblocks(n);
     const int passes = radix_sort_passes(n, begin_bit, end_bit);
-    const int per = (end_bit - begin_bit + passes - 1) / passes;          // spread the bits evenly over the passes
-    uint32_t* hist = static_cast<uint32_t*>(scratch);
-    uint32_t* total = hist + ((size_t)1 << bits) * nblocks;
+    if (passes > RS_MAX_PASSES) return -1;
     int cur = 0;
-    for (int bit = begin_bit; bit < end_bit; bit += per) {
-        const int nb = end_bit - bit < per ? end_bit - bit : per;
+    if (!rs_onesweep(n)) {
+        uint32_t* hist = static_cast<uint32_t*>(scratch);
+        uint32_t* total = hist + (size_t)RS_RADIX * nblocks;
+        for (int p = 0; p < passes; p++) {
+            const int bit = begin_bit + p * RS_BITS;
+            const int nb = end_bit - bit < RS_BITS ? end_bit - bit : RS_BITS;
+            const uint32_t mask = (1u << nb) - 1u;
+            const uint32_t* kin = cur ? keys_b : keys_a; const uint32_t* vin = cur ? vals_b : vals_a;
+            uint32_t* kout = cur ? keys_a : keys_b; uint32_t* vout = cur ? vals_a : vals_b;
+            hipLaunchKernelGGL(rs_hist_kernel, dim3(nblocks), dim3(RS_THREADS), 0, s, kin, (uint32_t)n, bit, mask, hist, nblocks);
+            hipLaunchKernelGGL(rs_scan_kernel, dim3(RS_RADIX), dim3(RS_THREADS), 0, s, hist, nblocks, total);
+            hipLaunchKernelGGL(os_pass_kernel<false>, dim3(nblocks), dim3(RS_THREADS), 0, s, kin, vin, kout, vout, (uint32_t)n, bit, mask, total, hist,
+                               (uint32_t*)nullptr, nblocks);
+            cur ^= 1;
+        }
+        return cur;
+    }
+    uint32_t* ghist = static_cast<uint32_t*>(scratch);
+    uint32_t* ticket = ghist + RS_MAX_PASSES * RS_RADIX;
+    uint32_t* status = ghist + RS_HEAD_WORDS;
+    radix_sort_prepare_async(scratch, s);
+    hipLaunchKernelGGL(os_hist_kernel, dim3(nblocks), dim3(RS_THREADS), 0, s, keys_a, (uint32_t)n, begin_bit, end_bit, passes, ghist, status, nblocks);
+    for (int p = 0; p < passes; p++) {
+        const int bit = begin_bit + p * RS_BITS;
+        const int nb = end_bit - bit < RS_BITS ? end_bit - bit : RS_BITS;
         const uint32_t mask = (1u << nb) - 1u;
         const uint32_t* kin = cur ? keys_b : keys_a; const uint32_t* vin = cur ? vals_b : vals_a;
         uint32_t* kout = cur ? keys_a : keys_b; uint32_t* vout = cur ? vals_a : vals_b;
-        if (small) {
-            hipLaunchKernelGGL(rs_hist_kernel<11>, dim3(nblocks), dim3(RS_THREADS), 0, s, kin, (uint32_t)n, bit, mask, hist, nblocks);
-            hipLaunchKernelGGL(rs_scan_kernel, dim3(2048), dim3(RS_THREADS), 0, s, hist, nblocks, total);
-            hipLaunchKernelGGL((rs_scatter_kernel<11, false>), dim3(nblocks), dim3(RS_THREADS), 0, s, kin, vin, kout, vout, (uint32_t)n, bit, mask,
-                               hist, total, nblocks);
-        } else {
-            hipLaunchKernelGGL(rs_hist_kernel<8>, dim3(nblocks), dim3(RS_THREADS), 0, s, kin, (uint32_t)n, bit, mask, hist, nblocks);
-            hipLaunchKernelGGL(rs_scan_kernel, dim3(256), dim3(RS_THREADS), 0, s, hist, nblocks, total);
-            hipLaunchKernelGGL((rs_scatter_kernel<8, false>), dim3(nblocks), dim3(RS_THREADS), 0, s, kin, vin, kout, vout, (uint32_t)n, bit, mask,
-                               hist, total, nblocks);
-        }
+        hipLaunchKernelGGL(os_pass_kernel<true>, dim3(nblocks), dim3(RS_THREADS), 0, s, kin, vin, kout, vout, (uint32_t)n, bit, mask,
+                           ghist + p * RS_RADIX, status + (size_t)p * nblocks * RS_RADIX, ticket + p, nblocks);
         cur ^= 1;
     }
     return cur;

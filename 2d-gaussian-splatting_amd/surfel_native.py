@@ -18,7 +18,7 @@ ALLOC_FN = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_size_t)
 
 EXPORTS = ["surfel_abi_version", "surfel_last_error", "surfel_rasterize_forward", "surfel_rasterize_backward",
            "surfel_mark_visible", "surfel_knn_dist2", "surfel_last_stage_ms", "surfel_last_stage_ids", "surfel_stage_name",
-           "surfel_collect_stage_ms", "surfel_set_option"]
+           "surfel_collect_stage_ms", "surfel_set_option", "surfel_debug_sort_pairs"]
 
 _lib = None
 _lock = threading.Lock()
@@ -57,6 +57,8 @@ def load():
         lib.surfel_collect_stage_ms.argtypes = [C.POINTER(C.c_float), C.POINTER(C.c_int), i]
         lib.surfel_stage_name.restype = C.c_char_p
         lib.surfel_stage_name.argtypes = [i]
+        lib.surfel_debug_sort_pairs.restype = i
+        lib.surfel_debug_sort_pairs.argtypes = [ALLOC_FN, vp, vp, vp, i64, i, i, vp]
         lib.surfel_set_option.restype = i
         lib.surfel_set_option.argtypes = [C.c_char_p, i]
         if lib.surfel_abi_version() != 1:

@@ -119,6 +119,11 @@ int surfel_last_stage_ids(int* ids, int cap);
 int surfel_collect_stage_ms(float* sum_ms, int* count, int cap);
 const char* surfel_stage_name(int stage);
 
+/* Test entry: the library's stable LSD radix sort of (u32 key, u32 value) pairs on key bits [begin_bit, end_bit),
+ * in place (device pointers, n < 2^30).  scratch_alloc is called once.  Returns 0 or a SURFEL_E_* code. */
+int surfel_debug_sort_pairs(surfel_alloc_fn scratch_alloc, void* scratch_user, uint32_t* keys, uint32_t* vals, int64_t n,
+                            int begin_bit, int end_bit, void* stream);
+
 /* Process-wide tuning / test switches; returns 0, or SURFEL_E_INVALID for an unknown name.
  *   "cull" (default 1): 0 disables every exact-preserving cull (tile emission restricted to the surfel's
  *          alpha>=1/255 footprint, per-quad / per-sub-tile instance masks) so the blend kernels visit every

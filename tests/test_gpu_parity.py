@@ -248,6 +248,35 @@ def test_culling_is_exact(kind):
             assert R0 == Rref, (R0, Rref)
 
 
+@pytest.mark.parametrize("n,bits", [(1, (0, 32)), (63, (0, 32)), (2047, (0, 12)), (2048, (0, 32)), (2049, (3, 17)), (300_000, (0, 32)),
+                                    (611_573, (0, 12)), (3_000_001, (0, 32)), (5_000_000, (0, 15))])
+def test_radix_sort_is_stable_and_exact(n, bits):
+    """The one-launch-per-pass radix sort (decoupled look-back) against numpy's stable argsort, incl. heavy duplicates."""
+    import torch
+    import surfel_native as nat
+    lib = nat.load()
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(n)
+    lo, hi = bits
+    for trial in range(3):
+        if trial == 0:
+            keys = rng.integers(0, 2 ** 32, n, dtype=np.uint64).astype(np.uint32)
+        elif trial == 1:   # few distinct keys: long same-digit runs, every tie must keep input order
+            keys = rng.choice(rng.integers(0, 2 ** 32, 7, dtype=np.uint64).astype(np.uint32), n)
+        else:              # float depth bits, like the hot path
+            keys = rng.uniform(0.2, 60.0, n).astype(np.float32).view(np.uint32)
+        vals = np.arange(n, dtype=np.uint32)
+        k = torch.from_numpy(keys.view(np.int32)).to(dev); v = torch.from_numpy(vals.view(np.int32)).to(dev)
+        alloc = nat.TorchAllocator(dev)
+        rc = lib.surfel_debug_sort_pairs(alloc.cb, None, nat.ptr(k), nat.ptr(v), n, lo, hi, nat.current_stream_ptr(dev))
+        assert rc == 0, nat.last_error()
+        torch.cuda.synchronize()
+        field = (keys >> np.uint32(lo)) & np.uint32((1 << (hi - lo)) - 1 if hi - lo < 32 else 0xffffffff)
+        order = np.argsort(field, kind="stable")
+        assert np.array_equal(v.cpu().numpy().view(np.uint32), vals[order]), "trial %d: order differs" % trial
+        assert np.array_equal(k.cpu().numpy().view(np.uint32), keys[order])
+
+
 def test_backward_is_bit_reproducible():
     sc = _scene("C1", seed=1)
     a = scene_args(sc)
