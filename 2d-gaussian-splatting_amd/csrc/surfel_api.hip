@@ -1,5 +1,5 @@
 // surfel_api.hip — C ABI (include/surfel_hip.h) of libsurfel_hip.so: stage orchestration, scratch
-// carving, rocPRIM scan / radix sort.  Host code only; kernels live in surfel_forward.hip,
+// carving.  Host code only; kernels live in surfel_forward.hip,
 // surfel_backward.hip and knn.hip.
 #include <cstdio>
 #include <cstring>
@@ -8,9 +8,6 @@
 #include <vector>
 
 #include <hip/hip_runtime.h>
-#include <rocprim/device/device_scan.hpp>
-#include <rocprim/iterator/counting_iterator.hpp>
-#include <rocprim/iterator/transform_iterator.hpp>
 
 #include "../../include/surfel_hip.h"
 #include "surfel_common.h"
@@ -61,7 +58,7 @@ struct GeomState {   // per-surfel state ("geomBuffer")
     float* rec; float* depths; uint32_t* tiles_touched; uint8_t* clamped;
     uint32_t *dkey_a, *dkey_b, *ord_a, *ord_b;   // depth-bit keys / surfel order (double buffers of the P-sized sort)
     uint32_t* offsets;                            // inclusive scan of tiles_touched in depth order
-    char* temp; size_t temp_bytes;                // rocPRIM scratch (max of scan / P-sized sort)
+    char* temp; size_t temp_bytes;                // scratch of the P-sized sort, then of the scan
     static GeomState carve(void* base, int P, size_t temp_bytes, size_t* total) {
         Carver c(base); GeomState g;
         g.rec = c.take<float>((size_t)P * REC_F);
@@ -76,12 +73,6 @@ struct GeomState {   // per-surfel state ("geomBuffer")
         if (total) *total = c.size();
         return g;
     }
-};
-
-// tiles_touched gathered through the depth order, as a rocPRIM input iterator for the scan
-struct GatherTiles {
-    const uint32_t* tiles; const uint32_t* order;
-    __host__ __device__ uint32_t operator()(uint32_t k) const { return tiles[order[k]]; }
 };
 
 struct BinState {    // per-instance state ("binningBuffer"); point_list is always at a fixed offset
@@ -268,13 +259,9 @@ int64_t surfel_rasterize_forward(surfel_alloc_fn geom_alloc, void* geom_user, su
     GeomState geom{};
     BinState bin{};
     if (P > 0) {
-        // scratch sizes (host-side queries only)
-        size_t scan_bytes = 0;
-        GatherTiles gq{nullptr, nullptr};
-        auto gin0 = rocprim::make_transform_iterator(rocprim::make_counting_iterator<uint32_t>(0u), gq);
-        HIP_TRY(rocprim::inclusive_scan(nullptr, scan_bytes, gin0, (uint32_t*)nullptr, (size_t)P, rocprim::plus<uint32_t>(), s));
-        const size_t psort_bytes = radix_sort_scratch_bytes((size_t)P);
-        const size_t temp_bytes = scan_bytes > psort_bytes ? scan_bytes : psort_bytes;
+        // scratch sizes (host-side queries only): [depth-sort scratch | scan state]
+        const size_t psort_bytes = align_up(radix_sort_scratch_bytes((size_t)P));
+        const size_t temp_bytes = psort_bytes + scan_scratch_words((size_t)P) * sizeof(uint32_t);
         size_t geom_bytes = 0;
         GeomState::carve(nullptr, P, temp_bytes, &geom_bytes);
         void* geom_base = geom_alloc(geom_user, geom_bytes);
@@ -289,6 +276,9 @@ int64_t surfel_rasterize_forward(surfel_alloc_fn geom_alloc, void* geom_user, su
         pa.viewmatrix = viewmatrix; pa.projmatrix = projmatrix; pa.campos = cam_pos;
         pa.rec = geom.rec; pa.depths = geom.depths; pa.depth_keys = geom.dkey_a; pa.ident = geom.ord_a; pa.radii = radii;
         pa.tiles_touched = geom.tiles_touched; pa.clamped = geom.clamped; pa.total_instances = img.total;
+        uint32_t* scan_state = reinterpret_cast<uint32_t*>(geom.temp + psort_bytes);
+        pa.zero_a = reinterpret_cast<uint32_t*>(geom.temp); pa.zero_a_words = (uint32_t)radix_sort_head_words((size_t)P);
+        pa.zero_b = scan_state; pa.zero_b_words = (uint32_t)scan_scratch_words((size_t)P);
         tm.begin();
         launch_preprocess_fwd(pa, s);
         STAGE_END(tm, ST_PRE);
@@ -303,14 +293,11 @@ int64_t surfel_rasterize_forward(surfel_alloc_fn geom_alloc, void* geom_user, su
 
         tm.begin();
         // (1) surfel order by view depth (stable; culled surfels carry key 0xffffffff and sort last)
-        const int which = radix_sort_pairs_u32(geom.dkey_a, geom.ord_a, geom.dkey_b, geom.ord_b, (size_t)P, 0, 32, geom.temp, s);
+        const int which = radix_sort_pairs_u32(geom.dkey_a, geom.ord_a, geom.dkey_b, geom.ord_b, (size_t)P, 0, 32, geom.temp, s, true);
         if (which < 0) return fail(SURFEL_E_LIMIT, "too many surfels for the depth sort");
         const uint32_t* order = which ? geom.ord_b : geom.ord_a;
-        // (2) instance offsets in depth order
-        GatherTiles gt{geom.tiles_touched, order};
-        auto gin = rocprim::make_transform_iterator(rocprim::make_counting_iterator<uint32_t>(0u), gt);
-        size_t tb = temp_bytes;
-        HIP_TRY(rocprim::inclusive_scan(geom.temp, tb, gin, geom.offsets, (size_t)P, rocprim::plus<uint32_t>(), s));
+        // (2) instance offsets in depth order: inclusive scan of tiles_touched[order[k]]
+        launch_scan_gather(geom.tiles_touched, order, geom.offsets, (size_t)P, scan_state, s);
         STAGE_END(tm, ST_SCAN);
         HIP_TRY(hipEventSynchronize(evR));
         for (int k = 0; k < R_SLOTS; k++) R += (int64_t)hR[k];
@@ -329,10 +316,11 @@ int64_t surfel_rasterize_forward(surfel_alloc_fn geom_alloc, void* geom_user, su
             uint32_t* va = odd ? bin.vals_alt : bin.point_list;
             uint32_t* vb = odd ? bin.point_list : bin.vals_alt;
             tm.begin();
-            launch_emit_instances(P, geom.rec, order, geom.offsets, bin.keys_a, va, gx, s);
+            launch_emit_instances(P, geom.rec, order, geom.offsets, bin.keys_a, va, gx, reinterpret_cast<uint32_t*>(bin.sort_temp),
+                                  (uint32_t)radix_sort_head_words((size_t)R), s);
             STAGE_END(tm, ST_EMIT);
             tm.begin();
-            const int wk = radix_sort_pairs_u32(bin.keys_a, va, bin.keys_b, vb, (size_t)R, 0, end_bit, bin.sort_temp, s);
+            const int wk = radix_sort_pairs_u32(bin.keys_a, va, bin.keys_b, vb, (size_t)R, 0, end_bit, bin.sort_temp, s, true);
             if (wk < 0) return fail(SURFEL_E_LIMIT, "too many tile instances for the tile sort");
             const uint32_t* sorted_keys = wk ? bin.keys_b : bin.keys_a;
             STAGE_END(tm, ST_SORT);

@@ -14,6 +14,8 @@ struct PreprocessArgs {
     const float* viewmatrix; const float* projmatrix; const float* campos;
     float* rec; float* depths; uint32_t* depth_keys; uint32_t* ident; int* radii; uint32_t* tiles_touched; uint8_t* clamped;
     uint32_t* total_instances;     // [R_SLOTS], zeroed by the caller; sum over slots = sum(tiles_touched)
+    uint32_t* zero_a; uint32_t zero_a_words;   // scratch words this kernel clears for the launches that follow
+    uint32_t* zero_b; uint32_t zero_b_words;   // (sort head, scan state) — saves two memset launches
 };
 
 struct BlendFwdArgs {
@@ -43,7 +45,7 @@ struct PreprocessBwdArgs {
 
 void launch_preprocess_fwd(const PreprocessArgs& a, hipStream_t s);
 void launch_emit_instances(int P, float* rec, const uint32_t* order, const uint32_t* offsets_sorted, uint32_t* keys,
-                           uint32_t* vals, int gx, hipStream_t s);
+                           uint32_t* vals, int gx, uint32_t* zero_ptr, uint32_t zero_words, hipStream_t s);
 void launch_tile_ranges(int64_t R, const uint32_t* keys, uint2* ranges, hipStream_t s);
 void launch_blend_fwd(const BlendFwdArgs& a, hipStream_t s);
 void launch_mark_visible(int P, const float* means3D, const float* vm, uint8_t* present, hipStream_t s);
@@ -54,6 +56,9 @@ size_t knn_scratch_bytes(int P);
 size_t radix_sort_scratch_bytes(size_t n);
 int radix_sort_passes(size_t n, int begin_bit, int end_bit);
 int radix_sort_pairs_u32(uint32_t* keys_a, uint32_t* vals_a, uint32_t* keys_b, uint32_t* vals_b, size_t n, int begin_bit, int end_bit,
-                         void* scratch, hipStream_t s);
+                         void* scratch, hipStream_t s, bool head_zeroed = false);
+size_t radix_sort_head_words(size_t n);       // words at the start of the sort scratch that must be zero (head_zeroed callers)
+size_t scan_scratch_words(size_t n);          // zeroed scratch of launch_scan_gather
+void launch_scan_gather(const uint32_t* vals, const uint32_t* order, uint32_t* out, size_t n, void* zeroed_scratch, hipStream_t s);
 
 }  // namespace surfel

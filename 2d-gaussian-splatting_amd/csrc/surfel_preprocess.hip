@@ -236,6 +236,8 @@ __device__ __forceinline__ uint32_t preprocess_one(const PreprocessArgs& a, cons
 __global__ void __launch_bounds__(256) preprocess_fwd_kernel(PreprocessArgs a) {
     __shared__ uint32_t s_tot[4];
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    for (uint32_t w = (uint32_t)i; w < a.zero_a_words; w += gridDim.x * blockDim.x) a.zero_a[w] = 0u;
+    for (uint32_t w = (uint32_t)i; w < a.zero_b_words; w += gridDim.x * blockDim.x) a.zero_b[w] = 0u;
     uint32_t tiles = i < a.P ? preprocess_one(a, i) : 0u;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) tiles += __shfl_xor(tiles, o);
@@ -261,8 +263,10 @@ __global__ void __launch_bounds__(256) preprocess_fwd_kernel(PreprocessArgs a) {
 // ---------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) emit_instances_kernel(int P, float* rec, const uint32_t* __restrict__ order,
                                                              const uint32_t* __restrict__ offsets_sorted, uint32_t* __restrict__ keys,
-                                                             uint32_t* __restrict__ vals, int gx) {
+                                                             uint32_t* __restrict__ vals, int gx, uint32_t* __restrict__ zero_ptr,
+                                                             uint32_t zero_words) {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    for (uint32_t w = (uint32_t)k; w < zero_words; w += gridDim.x * blockDim.x) zero_ptr[w] = 0u;    // head of the tile sort that follows
     if (k >= P) return;
     const uint32_t off = (k == 0) ? 0u : offsets_sorted[k - 1];
     const int n = (int)(offsets_sorted[k] - off);
@@ -527,8 +531,9 @@ void launch_preprocess_fwd(const PreprocessArgs& a, hipStream_t s) {
     if (a.P > 0) hipLaunchKernelGGL(preprocess_fwd_kernel, dim3((a.P + 255) / 256), dim3(256), 0, s, a);
 }
 void launch_emit_instances(int P, float* rec, const uint32_t* order, const uint32_t* offsets_sorted, uint32_t* keys, uint32_t* vals,
-                           int gx, hipStream_t s) {
-    if (P > 0) hipLaunchKernelGGL(emit_instances_kernel, dim3((P + 255) / 256), dim3(256), 0, s, P, rec, order, offsets_sorted, keys, vals, gx);
+                           int gx, uint32_t* zero_ptr, uint32_t zero_words, hipStream_t s) {
+    if (P > 0) hipLaunchKernelGGL(emit_instances_kernel, dim3((P + 255) / 256), dim3(256), 0, s, P, rec, order, offsets_sorted, keys, vals, gx,
+                                  zero_ptr, zero_words);
 }
 void launch_tile_ranges(int64_t R, const uint32_t* keys, uint2* ranges, hipStream_t s) {
     if (R > 0) hipLaunchKernelGGL(tile_ranges_kernel, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, s, R, keys, ranges);

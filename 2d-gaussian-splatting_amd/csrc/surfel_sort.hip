@@ -234,13 +234,87 @@ __global__ void __launch_bounds__(RS_THREADS) os_pass_kernel(const uint32_t* __r
     }
 }
 
-// clears ghist/ticket head + (via os_hist) the status words; `prepared` callers did both themselves
-void radix_sort_prepare_async(void* scratch, hipStream_t s) { (void)hipMemsetAsync(scratch, 0, RS_HEAD_WORDS * sizeof(uint32_t), s); }
+// The look-back head (ghist + tickets) has to be zero when a sort starts.  Callers whose previous kernel can clear
+// radix_sort_head_words(n) words at the start of the scratch pass head_zeroed = true and save the memset launch.
+size_t radix_sort_head_words(size_t n) { return rs_onesweep(n) ? RS_HEAD_WORDS : 0; }
+
+// ---- inclusive scan of tiles[order[k]] (single launch, decoupled look-back; status word = flag | 30-bit value) -----------
+constexpr int SC_IPT = 8, SC_TILE = RS_THREADS * SC_IPT;
+size_t scan_scratch_words(size_t n) { return 64 + (n + SC_TILE - 1) / SC_TILE; }     // ticket (+pad) | status[tiles]; must be zero
+
+__global__ void __launch_bounds__(RS_THREADS) scan_gather_kernel(const uint32_t* __restrict__ vals, const uint32_t* __restrict__ order,
+                                                                 uint32_t* __restrict__ out, uint32_t n, uint32_t* __restrict__ scratch) {
+    __shared__ uint32_t s_w[4];
+    __shared__ uint32_t s_tile, s_excl;
+    uint32_t* ticket = scratch;
+    uint32_t* status = scratch + 64;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) s_tile = atomicAdd(ticket, 1u);
+    __syncthreads();
+    const uint32_t tile = s_tile;
+    const uint32_t base = tile * SC_TILE + threadIdx.x * SC_IPT;
+    uint32_t v[SC_IPT], sum = 0;
+#pragma unroll
+    for (int i = 0; i < SC_IPT; i++) {
+        const uint32_t e = base + i;
+        v[i] = e < n ? vals[order[e]] : 0u;
+        sum += v[i];
+    }
+    uint32_t x = sum;                              // inclusive scan of the per-thread sums over the workgroup
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const uint32_t y = __shfl_up(x, o); if (lane >= o) x += y; }
+    if (lane == 63) s_w[wave] = x;
+    __syncthreads();
+    uint32_t woff = 0;
+    for (int w = 0; w < wave; w++) woff += s_w[w];
+    const uint32_t agg = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+    if (wave == 0) {
+        // wave 0 publishes the tile aggregate and looks back 64 tiles per round
+        uint32_t excl = 0;
+        if (tile == 0) {
+            if (lane == 0) st_agent(status, agg | ST_PREFIX);
+        } else {
+            if (lane == 0) st_agent(status + tile, agg | ST_AGG);
+            int p = (int)tile - 1;
+            for (;;) {
+                const int idx = p - lane;
+                const uint32_t sw = idx >= 0 ? ld_agent(status + idx) : ST_PREFIX;
+                const unsigned long long ready = __ballot((sw >> 30) != 0u);
+                const unsigned long long pref = __ballot((sw & ST_PREFIX) != 0u);
+                const int nready = ready == ~0ull ? 64 : __builtin_ctzll(~ready);       // leading run of published words
+                const int firstp = pref ? __builtin_ctzll(pref) : 64;
+                const int take = min(nready, firstp + 1);                                // up to and including the first prefix
+                uint32_t c = lane < take ? (sw & ST_VALUE) : 0u;
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
+                excl += c;
+                if (firstp < nready) break;
+                p -= take;
+                if (take == 0) __builtin_amdgcn_s_sleep(1);
+            }
+            if (lane == 0) st_agent(status + tile, (excl + agg) | ST_PREFIX);
+        }
+        if (lane == 0) s_excl = excl;
+    }
+    __syncthreads();
+    uint32_t run = s_excl + woff + x - sum;        // exclusive prefix of this thread's first item
+#pragma unroll
+    for (int i = 0; i < SC_IPT; i++) {
+        run += v[i];
+        if (base + i < n) out[base + i] = run;
+    }
+}
+
+void launch_scan_gather(const uint32_t* vals, const uint32_t* order, uint32_t* out, size_t n, void* zeroed_scratch, hipStream_t s) {
+    if (n == 0) return;
+    hipLaunchKernelGGL(scan_gather_kernel, dim3((unsigned)((n + SC_TILE - 1) / SC_TILE)), dim3(RS_THREADS), 0, s, vals, order, out, (uint32_t)n,
+                       static_cast<uint32_t*>(zeroed_scratch));
+}
 
 // Sorts on key bits [begin_bit, end_bit).  Buffers ping-pong a -> b -> a ...; returns 0 if the result is in (keys_a, vals_a),
 // 1 if in (keys_b, vals_b); -1 if n is too large for the 30-bit look-back counters.
 int radix_sort_pairs_u32(uint32_t* keys_a, uint32_t* vals_a, uint32_t* keys_b, uint32_t* vals_b, size_t n, int begin_bit, int end_bit,
-                         void* scratch, hipStream_t s) {
+                         void* scratch, hipStream_t s, bool head_zeroed) {
     if (n == 0) return 0;
     if (n >= ST_VALUE) return -1;
     const uint32_t nblocks = rs_nblocks(n);
@@ -267,7 +341,7 @@ int radix_sort_pairs_u32(uint32_t* keys_a, uint32_t* vals_a, uint32_t* keys_b, u
     uint32_t* ghist = static_cast<uint32_t*>(scratch);
     uint32_t* ticket = ghist + RS_MAX_PASSES * RS_RADIX;
     uint32_t* status = ghist + RS_HEAD_WORDS;
-    radix_sort_prepare_async(scratch, s);
+    if (!head_zeroed) (void)hipMemsetAsync(scratch, 0, RS_HEAD_WORDS * sizeof(uint32_t), s);
     hipLaunchKernelGGL(os_hist_kernel, dim3(nblocks), dim3(RS_THREADS), 0, s, keys_a, (uint32_t)n, begin_bit, end_bit, passes, ghist, status, nblocks);
     for (int p = 0; p < passes; p++) {
         const int bit = begin_bit + p * RS_BITS;
