@@ -17,6 +17,17 @@ _n.load()  # fail loudly at import time if the HIP extension is missing
 
 last_num_rendered = 0   # instance count R of the most recent forward (introspection for bench / tests)
 
+_grad_arena = None
+
+
+def set_grad_arena(arena):
+    """Optional (multi-GPU): a dict of preallocated fp32 tensors — any of means3D [P,3], sh [P,M,3], opacities [P,1],
+    scales [P,2], rotations [P,4] — that the backward writes its gradients into and returns, instead of fresh tensors.
+    surfel_dist.GradBucket.arena() hands out views of ONE flat buffer, so the gradient all-reduce needs no packing pass.
+    The kernels write every element, so the tensors need no zeroing.  None restores the default."""
+    global _grad_arena
+    _grad_arena = arena
+
 
 class GaussianRasterizationSettings(NamedTuple):
     image_height: int
@@ -99,11 +110,21 @@ class _RasterizeGaussians(torch.autograd.Function):
         P, M, H, W = ctx.dims
         dev = means3D.device
         z = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)   # the kernels write every element
-        g_means2D, g_normal, g_opac, g_colors = z(P, 3), z(P, 3), z(P, 1), z(P, 3)
-        g_means3D, g_trans = z(P, 3), z(P, 9)
-        g_sh = z(P, M, 3) if has_sh else None
-        g_scales = z(P, 2) if has_sr else None
-        g_rots = z(P, 4) if has_sr else None
+        arena = _grad_arena or {}
+
+        def out(name, *shape):
+            t = arena.get(name)
+            if t is None:
+                return z(*shape)
+            if tuple(t.shape) != shape or t.dtype != torch.float32 or t.device != dev or not t.is_contiguous():
+                raise RuntimeError("grad arena tensor %r does not match %s fp32 contiguous on %s" % (name, shape, dev))
+            return t
+        g_means2D, g_normal, g_colors = z(P, 3), z(P, 3), z(P, 3)
+        g_opac = out("opacities", P, 1)
+        g_means3D, g_trans = out("means3D", P, 3), z(P, 9)
+        g_sh = out("sh", P, M, 3) if has_sh else None
+        g_scales = out("scales", P, 2) if has_sr else None
+        g_rots = out("rotations", P, 4) if has_sr else None
         gc = grad_out_color.contiguous().float() if grad_out_color is not None else torch.zeros((3, H, W), device=dev)
         gd = grad_depth.contiguous().float() if grad_depth is not None else torch.zeros((7, H, W), device=dev)
         sa = _n.TorchAllocator(dev)

@@ -26,7 +26,9 @@ from typing import Dict, List, Optional, Sequence
 import torch
 import torch.distributed as dist
 
-BUCKET_LAYOUT = (("xyz", 3), ("f_dc", 3), ("f_rest", 45), ("opacity", 1), ("scaling", 2), ("rotation", 4))
+# One flat fp32 buffer, planar by gradient tensor (the rasterizer's own outputs, so they can be written in place):
+# xyz 3 | sh 48 (= f_dc 3 + f_rest 45 per surfel, the reference's two SH parameter groups) | opacity 1 | scaling 2 | rotation 4
+BUCKET_LAYOUT = (("xyz", 3), ("sh", 48), ("opacity", 1), ("scaling", 2), ("rotation", 4))
 BUCKET_FLOATS = sum(n for _, n in BUCKET_LAYOUT)      # 58 floats = 232 B per surfel
 
 
@@ -42,15 +44,35 @@ def view_indices(n_views: int, world: int, rank: int, iteration: int, seed: int 
 
 
 class GradBucket:
-    """Flat [P, 58] fp32 gradient bucket: pack -> ONE all-reduce(SUM) -> unpack."""
+    """Flat fp32 gradient bucket of 58 floats / surfel: fill -> ONE all-reduce(SUM) -> read.
+
+    Zero-copy use: `diff_surfel_rasterization.set_grad_arena(bucket.arena())` makes the rasterizer's backward write its
+    per-surfel gradients straight into the bucket's sections, so a step is backward -> all_reduce with no packing pass.
+    `pack()` (copies) serves gradients that live elsewhere, e.g. parameter .grad tensors behind activation functions."""
 
     def __init__(self, P: int, device, group=None):
         self.P, self.group = P, group
-        self.buf = torch.empty((P, BUCKET_FLOATS), dtype=torch.float32, device=device)
+        self.buf = torch.empty((P * BUCKET_FLOATS,), dtype=torch.float32, device=device)
+        self.views, off = {}, 0
+        for name, n in BUCKET_LAYOUT:
+            self.views[name] = self.buf[off:off + P * n].view(P, n)
+            off += P * n
+
+    def arena(self) -> Dict[str, torch.Tensor]:
+        """Output tensors for the rasterizer's backward, aliasing the bucket (see set_grad_arena)."""
+        v = self.views
+        return dict(means3D=v["xyz"], sh=v["sh"].view(self.P, 16, 3), opacities=v["opacity"], scales=v["scaling"],
+                    rotations=v["rotation"])
 
     def pack(self, grads: Dict[str, torch.Tensor]):
-        views = [grads[name].reshape(self.P, n) for name, n in BUCKET_LAYOUT]
-        torch.cat(views, dim=1, out=self.buf)
+        """grads: xyz, opacity, scaling, rotation and either sh [P,16,3] or f_dc [P,1,3] + f_rest [P,15,3]."""
+        P = self.P
+        for name, n in BUCKET_LAYOUT:
+            if name == "sh" and "sh" not in grads:
+                dst = self.views["sh"].view(P, 16, 3)
+                dst[:, :1].copy_(grads["f_dc"].reshape(P, 1, 3)); dst[:, 1:].copy_(grads["f_rest"].reshape(P, 15, 3))
+            else:
+                self.views[name].copy_(grads[name].reshape(P, n))
         return self.buf
 
     def all_reduce(self, average: bool = True, async_op: bool = False):
@@ -60,10 +82,11 @@ class GradBucket:
         return work
 
     def unpack(self, like: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
-        out, c = {}, 0
-        for name, n in BUCKET_LAYOUT:
-            out[name] = self.buf[:, c:c + n].reshape(like[name].shape)
-            c += n
+        out = {}
+        sh = self.views["sh"].view(self.P, 16, 3)
+        for name in like:
+            src = sh[:, :1] if name == "f_dc" else sh[:, 1:] if name == "f_rest" else sh if name == "sh" else self.views[name]
+            out[name] = src.reshape(like[name].shape)
         return out
 
 

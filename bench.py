@@ -78,6 +78,9 @@ def main():
     gC = torch.randn((3, H, W), generator=g).to(dev); gO = torch.randn((7, H, W), generator=g).to(dev)
     import surfel_dist
     bucket = surfel_dist.GradBucket(P, dev) if world > 1 else None
+    if bucket is not None:      # the backward writes its gradients straight into the all-reduce bucket
+        import diff_surfel_rasterization as _dsr
+        _dsr.set_grad_arena(bucket.arena())
     state = {}
 
     def step():
@@ -86,10 +89,7 @@ def main():
                                     scales=scales, rotations=rots, cov3D_precomp=None)
         torch.autograd.backward([color, allmap], [gC, gO])
         if world > 1:
-            sg = shs.grad
-            bucket.pack(dict(xyz=means3D.grad, f_dc=sg[:, :1], f_rest=sg[:, 1:], opacity=opac.grad, scaling=scales.grad,
-                             rotation=rots.grad))
-            bucket.all_reduce(average=True)
+            bucket.all_reduce(average=True)      # ONE collective per step over the flat 232 B/surfel bucket
         state["radii"] = radii
         for p_ in params:
             p_.grad = None
