@@ -59,3 +59,23 @@ def test_product_never_imports_oracle():
             if f.endswith((".py", ".hip", ".h")):
                 txt = open(os.path.join(root, f)).read()
                 assert "import oracle" not in txt and "from oracle" not in txt and "liboracle" not in txt, f
+
+
+def test_allocator_frees_by_refcount():
+    """The allocator callback must not sit in a reference cycle: its buffers have to die with the last reference,
+    not at the next cyclic-GC pass (at 10 M surfels a cycle grew the device footprint by ~13 GB per step)."""
+    import ctypes as C
+    import gc
+    import weakref
+    import torch
+    import surfel_native as n
+    gc.disable()
+    try:
+        a = n.TorchAllocator("cpu")
+        p = a.cb(None, 4096)
+        assert p and a.last().numel() == 4096
+        w_alloc, w_buf = weakref.ref(a), weakref.ref(a.last())
+        del a
+        assert w_alloc() is None and w_buf() is None, "TorchAllocator is kept alive by a reference cycle"
+    finally:
+        gc.enable()
