@@ -12,6 +12,7 @@
 #include "../../include/surfel_hip.h"
 #include "surfel_common.h"
 #include "surfel_kernels.h"
+#include "train_kernels.h"
 
 using namespace surfel;
 
@@ -164,6 +165,10 @@ int higher_msb(uint32_t n) {   // number of bits needed to represent values < n
 }
 
 }  // namespace
+
+namespace surfel {
+int api_fail(int code, const char* what, hipError_t e) { return fail(code, what, e); }
+}  // namespace surfel
 
 extern "C" {
 

@@ -1,0 +1,29 @@
+// train_kernels.h — launchers of the training-iteration kernels (train_loss.hip, train_post.hip, train_optim.hip),
+// called from the C ABI in train_api.hip (include/surfel_train.h).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+namespace surfel {
+
+int ssim_blocks(int H, int W);
+void launch_ssim_fwd(int planes, int H, int W, const float* img, const float* gt, float* dmaps, float* partials, hipStream_t s);
+void launch_ssim_bwd(int planes, int H, int W, const float* img, const float* gt, const float* dmaps, float c_l1, float c_ssim,
+                     const float* g_l1_dev, const float* g_ssim_dev, float* grad_img, hipStream_t s);
+void launch_reduce_partials(const float* partials, int groups, int n, int stride, float scale, float* out, hipStream_t s);
+
+int post_blocks(int H, int W);
+void launch_post_fwd(int H, int W, const float* allmap, const float* cam, float ratio, float* maps, float* partials, hipStream_t s);
+void launch_post_bwd(int H, int W, const float* allmap, const float* cam, float ratio, const float* gmaps, float c_normal, float c_dist,
+                     const float* gscale_dev, float* gall, hipStream_t s);
+
+void launch_activate(int P, const float* theta, float* act, hipStream_t s);
+void launch_adam(int P, float* theta, const float* grad, float* m, float* v, float* act, const float* lr, float beta1, float beta2, float eps,
+                 float bc1, float bc2_sqrt, float grad_scale, hipStream_t s);
+void launch_densify_stats(int P, const float* g2d, const int* radii, float* accum, float* denom, float* maxr, hipStream_t s);
+
+// error plumbing shared with surfel_api.hip (thread-local message behind surfel_last_error())
+int api_fail(int code, const char* what, hipError_t e = hipSuccess);
+
+}  // namespace surfel

@@ -1,0 +1,153 @@
+// train_optim.hip — the surfel parameter store's kernels on gfx950: activations, fused Adam (+ activation backward
+// + next iteration's activations) and the densification statistics.  Pure HBM streaming (28 B per parameter float).
+//
+// Store layout (raw parameters, gradients, Adam moments, all-reduce bucket all share it), P surfels:
+//   xyz 3P | sh 48P | opacity P | scaling 2P | rotation 4P      = 58 floats / surfel
+// Reference semantics restated: scene/gaussian_model.py:95-115 (exp / normalize / sigmoid), :153-162 (six Adam
+// groups, eps 1e-15), torch.optim.Adam's update rule, train.py:126-128 + gaussian_model.py:405-407 (statistics).
+#include <hip/hip_runtime.h>
+
+#include "train_kernels.h"
+
+namespace surfel {
+
+namespace {
+
+struct AdamK {
+    float lr[6];          // xyz, f_dc, f_rest, opacity, scaling, rotation
+    float beta1, beta2, eps;
+    float bc1, bc2_sqrt;  // 1 - beta1^t, sqrt(1 - beta2^t)
+    float grad_scale;
+};
+
+// torch.optim.Adam (single-tensor form): m = b1 m + (1-b1) g ; v = b2 v + (1-b2) g^2 ;
+// p -= (lr / bc1) * m / (sqrt(v) / sqrt(bc2) + eps)
+__device__ __forceinline__ float adam_update(float p, float g, float& m, float& v, float lr, const AdamK& k) {
+    m = k.beta1 * m + (1.f - k.beta1) * g;
+    v = k.beta2 * v + (1.f - k.beta2) * g * g;
+    const float denom = sqrtf(v) / k.bc2_sqrt + k.eps;
+    return p - (lr / k.bc1) * (m / denom);
+}
+
+__device__ __forceinline__ float sigmoidf(float x) { return 1.f / (1.f + expf(-x)); }
+
+// elementwise sections: xyz (3P) then sh (48P), contiguous at the start of the store
+__global__ __launch_bounds__(256) void adam_elem_kernel(size_t n_xyz, size_t n_all, float* __restrict__ theta, const float* __restrict__ grad,
+                                                        float* __restrict__ m, float* __restrict__ v, AdamK k) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_all; i += stride) {
+        float lr;
+        if (i < n_xyz) lr = k.lr[0];
+        else lr = ((i - n_xyz) % 48) < 3 ? k.lr[1] : k.lr[2];
+        float mi = m[i], vi = v[i];
+        theta[i] = adam_update(theta[i], grad[i] * k.grad_scale, mi, vi, lr, k);
+        m[i] = mi; v[i] = vi;
+    }
+}
+
+// per-surfel sections behind activation functions; also refreshes the activated values
+__global__ __launch_bounds__(256) void adam_act_kernel(int P, float* __restrict__ theta, const float* __restrict__ grad, float* __restrict__ m,
+                                                       float* __restrict__ v, float* __restrict__ act, AdamK k) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P) return;
+    const size_t o_op = (size_t)51 * P, o_sc = (size_t)52 * P, o_rot = (size_t)54 * P;
+    {   // opacity = sigmoid(x)
+        const size_t o = o_op + i;
+        const float x = theta[o], s = sigmoidf(x);
+        const float g = grad[o] * k.grad_scale * s * (1.f - s);
+        float mi = m[o], vi = v[o];
+        const float xn = adam_update(x, g, mi, vi, k.lr[3], k);
+        theta[o] = xn; m[o] = mi; v[o] = vi;
+        act[i] = sigmoidf(xn);
+    }
+#pragma unroll
+    for (int j = 0; j < 2; j++) {   // scaling = exp(x)
+        const size_t o = o_sc + 2 * (size_t)i + j;
+        const float x = theta[o], s = expf(x);
+        const float g = grad[o] * k.grad_scale * s;
+        float mi = m[o], vi = v[o];
+        const float xn = adam_update(x, g, mi, vi, k.lr[4], k);
+        theta[o] = xn; m[o] = mi; v[o] = vi;
+        act[(size_t)P + 2 * (size_t)i + j] = expf(xn);
+    }
+    {   // rotation = q / max(|q|, 1e-12)
+        const size_t o = o_rot + 4 * (size_t)i;
+        float q[4], g[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) { q[j] = theta[o + j]; g[j] = grad[o + j] * k.grad_scale; }
+        const float len = sqrtf(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+        const float inv = 1.f / fmaxf(len, 1e-12f);
+        float gq[4];
+        if (len >= 1e-12f) {
+            const float ug = (q[0] * g[0] + q[1] * g[1] + q[2] * g[2] + q[3] * g[3]) * inv;
+#pragma unroll
+            for (int j = 0; j < 4; j++) gq[j] = (g[j] - q[j] * inv * ug) * inv;
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; j++) gq[j] = g[j] * inv;
+        }
+        float qn[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            float mi = m[o + j], vi = v[o + j];
+            qn[j] = adam_update(q[j], gq[j], mi, vi, k.lr[5], k);
+            theta[o + j] = qn[j]; m[o + j] = mi; v[o + j] = vi;
+        }
+        const float ln = sqrtf(qn[0] * qn[0] + qn[1] * qn[1] + qn[2] * qn[2] + qn[3] * qn[3]);
+        const float in = 1.f / fmaxf(ln, 1e-12f);
+#pragma unroll
+        for (int j = 0; j < 4; j++) act[(size_t)3 * P + 4 * (size_t)i + j] = qn[j] * in;
+    }
+}
+
+__global__ __launch_bounds__(256) void activate_kernel(int P, const float* __restrict__ theta, float* __restrict__ act) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P) return;
+    const size_t o_op = (size_t)51 * P, o_sc = (size_t)52 * P, o_rot = (size_t)54 * P;
+    act[i] = sigmoidf(theta[o_op + i]);
+    act[(size_t)P + 2 * (size_t)i] = expf(theta[o_sc + 2 * (size_t)i]);
+    act[(size_t)P + 2 * (size_t)i + 1] = expf(theta[o_sc + 2 * (size_t)i + 1]);
+    float q[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) q[j] = theta[o_rot + 4 * (size_t)i + j];
+    const float len = sqrtf(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+    const float inv = 1.f / fmaxf(len, 1e-12f);
+#pragma unroll
+    for (int j = 0; j < 4; j++) act[(size_t)3 * P + 4 * (size_t)i + j] = q[j] * inv;
+}
+
+__global__ __launch_bounds__(256) void densify_stats_kernel(int P, const float* __restrict__ g2d, const int* __restrict__ radii,
+                                                            float* __restrict__ accum, float* __restrict__ denom, float* __restrict__ maxr) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P) return;
+    const int r = radii[i];
+    if (r <= 0) return;
+    const float gx = g2d[3 * (size_t)i], gy = g2d[3 * (size_t)i + 1], gz = g2d[3 * (size_t)i + 2];
+    accum[i] += sqrtf(gx * gx + gy * gy + gz * gz);
+    denom[i] += 1.f;
+    maxr[i] = fmaxf(maxr[i], (float)r);
+}
+
+}  // namespace
+
+void launch_activate(int P, const float* theta, float* act, hipStream_t s) {
+    hipLaunchKernelGGL(activate_kernel, dim3((P + 255) / 256), dim3(256), 0, s, P, theta, act);
+}
+
+void launch_adam(int P, float* theta, const float* grad, float* m, float* v, float* act, const float* lr, float beta1, float beta2, float eps,
+                 float bc1, float bc2_sqrt, float grad_scale, hipStream_t s) {
+    AdamK k;
+    for (int i = 0; i < 6; i++) k.lr[i] = lr[i];
+    k.beta1 = beta1; k.beta2 = beta2; k.eps = eps; k.bc1 = bc1; k.bc2_sqrt = bc2_sqrt; k.grad_scale = grad_scale;
+    const size_t n_xyz = (size_t)3 * P, n_all = (size_t)51 * P;
+    size_t blocks = (n_all + 256 * 4 - 1) / (256 * 4);
+    if (blocks > 65536) blocks = 65536;
+    hipLaunchKernelGGL(adam_elem_kernel, dim3((unsigned)blocks), dim3(256), 0, s, n_xyz, n_all, theta, grad, m, v, k);
+    hipLaunchKernelGGL(adam_act_kernel, dim3((P + 255) / 256), dim3(256), 0, s, P, theta, grad, m, v, act, k);
+}
+
+void launch_densify_stats(int P, const float* g2d, const int* radii, float* accum, float* denom, float* maxr, hipStream_t s) {
+    hipLaunchKernelGGL(densify_stats_kernel, dim3((P + 255) / 256), dim3(256), 0, s, P, g2d, radii, accum, denom, maxr);
+}
+
+}  // namespace surfel

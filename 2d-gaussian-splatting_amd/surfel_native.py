@@ -18,7 +18,10 @@ ALLOC_FN = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_size_t)
 
 EXPORTS = ["surfel_abi_version", "surfel_last_error", "surfel_rasterize_forward", "surfel_rasterize_backward",
            "surfel_mark_visible", "surfel_knn_dist2", "surfel_last_stage_ms", "surfel_last_stage_ids", "surfel_stage_name",
-           "surfel_collect_stage_ms", "surfel_set_option", "surfel_debug_sort_pairs"]
+           "surfel_collect_stage_ms", "surfel_set_option", "surfel_debug_sort_pairs",
+           # include/surfel_train.h
+           "surfel_l1_ssim_forward", "surfel_l1_ssim_backward", "surfel_render_post_forward", "surfel_render_post_backward",
+           "surfel_reduce_partials", "surfel_activate", "surfel_adam_step", "surfel_densify_stats"]
 
 _lib = None
 _lock = threading.Lock()
@@ -61,6 +64,19 @@ def load():
         lib.surfel_debug_sort_pairs.argtypes = [ALLOC_FN, vp, vp, vp, i64, i, i, vp]
         lib.surfel_set_option.restype = i
         lib.surfel_set_option.argtypes = [C.c_char_p, i]
+        # ---- include/surfel_train.h
+        fp = C.POINTER(C.c_float)
+        for name, args in (("surfel_l1_ssim_forward", [i, i, i, vp, vp, vp, vp, vp]),
+                           ("surfel_l1_ssim_backward", [i, i, i, vp, vp, vp, f, f, vp, vp, vp, vp]),
+                           ("surfel_render_post_forward", [i, i, vp, vp, f, vp, vp, vp]),
+                           ("surfel_render_post_backward", [i, i, vp, vp, f, vp, f, f, vp, vp, vp]),
+                           ("surfel_reduce_partials", [vp, i, i, i, f, vp, vp]),
+                           ("surfel_activate", [i, vp, vp, vp]),
+                           ("surfel_adam_step", [i, vp, vp, vp, vp, vp, fp, f, f, f, i, f, vp]),
+                           ("surfel_densify_stats", [i, vp, vp, vp, vp, vp, vp])):
+            fn = getattr(lib, name)
+            fn.restype = i
+            fn.argtypes = args
         if lib.surfel_abi_version() != 1:
             raise ImportError("libsurfel_hip.so ABI version mismatch")
         _lib = lib

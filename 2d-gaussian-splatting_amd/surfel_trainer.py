@@ -1,0 +1,213 @@
+"""Training driver on MI355X: the loop of /root/reference/train.py:31-144 on the fused kernels, with the
+view-parallel multi-GPU step of surfel_dist.py.
+
+Per iteration (1 view per GPU):  rasterize -> photometric loss (1 fwd + 1 bwd kernel) -> regularisers straight from allmap
+(1 fwd + 1 bwd kernel) -> rasterizer backward writing into the flat gradient store -> densification statistics (1 kernel)
+-> [one all-reduce of the store over RCCL] -> fused Adam + activations (2 kernels).  The reference spends ~150 small PyTorch
+kernels on the same work around its rasterizer.
+
+Semantics kept from the reference: learning-rate schedule, SH degree every 1000 iterations, lambda_dist after 3000 and
+lambda_normal after 7000 iterations, densify/prune/opacity-reset schedule, no optimiser update on the iterations that
+re-create the parameters (densification), Adam(eps=1e-15).  Multi-GPU: G views per step with averaged gradients; the
+densification statistics are accumulated locally and all-reduced only when a densification is due.
+"""
+import math
+import random
+import time
+from types import SimpleNamespace
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+import surfel_dist
+from surfel_losses import photometric_loss
+from surfel_model import GaussianModel
+from surfel_render import Camera, rasterize, regularizers, render
+
+
+def optimization_params(**over):
+    """Defaults of arguments/__init__.py:75-95 (OptimizationParams)."""
+    d = dict(iterations=30_000, position_lr_init=0.00016, position_lr_final=0.0000016, position_lr_delay_mult=0.01,
+             position_lr_max_steps=30_000, feature_lr=0.0025, opacity_lr=0.05, scaling_lr=0.005, rotation_lr=0.001,
+             percent_dense=0.01, lambda_dssim=0.2, lambda_dist=0.0, lambda_normal=0.05, opacity_cull=0.05,
+             densification_interval=100, opacity_reset_interval=3000, densify_from_iter=500, densify_until_iter=15_000,
+             densify_grad_threshold=0.0002, dist_from_iter=3000, normal_from_iter=7000)
+    d.update(over)
+    return SimpleNamespace(**d)
+
+
+def pipeline_params(**over):
+    """Defaults of arguments/__init__.py:66-72 (PipelineParams)."""
+    d = dict(convert_SHs_python=False, compute_cov3D_python=False, depth_ratio=0.0, debug=False)
+    d.update(over)
+    return SimpleNamespace(**d)
+
+
+def psnr(img1, img2):
+    """utils/image_utils.py:19-21."""
+    mse = ((img1 - img2) ** 2).reshape(img1.shape[0], -1).mean(1, keepdim=True)
+    return 20 * torch.log10(1.0 / torch.sqrt(mse))
+
+
+# ------------------------------------------------------------------------------------------------ synthetic captures
+def look_at(eye, target=(0.0, 0.0, 0.0), up=(0.0, -1.0, 0.0)):
+    """(R, T) in the reference's Camera convention: R = C2W rotation (columns = camera x right, y down, z forward), T = W2C translation."""
+    eye = np.asarray(eye, np.float64); target = np.asarray(target, np.float64)
+    fwd = target - eye; fwd /= np.linalg.norm(fwd)
+    right = np.cross(fwd, np.asarray(up, np.float64)); right /= np.linalg.norm(right)
+    down = np.cross(fwd, right)
+    R = np.stack([right, down, fwd], axis=1)
+    return R, -R.T @ eye
+
+
+def orbit_cameras(n_views, W, H, radius=4.0, fov_deg=50.0, device="cuda", seed=0):
+    """Cameras on a sphere of `radius` looking at the origin (NeRF-synthetic style), images filled in later."""
+    rng = np.random.default_rng(seed)
+    fovx = math.radians(fov_deg)
+    fovy = 2 * math.atan(math.tan(fovx / 2) * H / W)
+    cams = []
+    for i in range(n_views):
+        az = 2 * math.pi * (i + 0.5 * rng.uniform()) / n_views
+        el = math.radians(rng.uniform(-25, 35))
+        eye = radius * np.array([math.cos(el) * math.cos(az), -math.sin(el), math.cos(el) * math.sin(az)])
+        R, T = look_at(eye)
+        cams.append(Camera(colmap_id=i, R=R, T=T, FoVx=fovx, FoVy=fovy, image=torch.zeros(3, H, W), image_name="syn_%03d" % i, uid=i,
+                           data_device=device))
+    return cams
+
+
+def cameras_extent(cams):
+    """Scene radius as scene/dataset_readers.py:40-64 (getNerfppNorm) computes it: 1.1 x max distance of a camera from the mean."""
+    c = torch.stack([cam.camera_center for cam in cams]).double().cpu().numpy()
+    return float(np.linalg.norm(c - c.mean(0, keepdims=True), axis=1).max() * 1.1)
+
+
+def synthetic_object(P, device, seed=0, extent=1.2, px_scale=0.03):
+    """A ground-truth surfel set: a thick random shell of oriented discs around the origin (raw, pre-activation parameters)."""
+    g = torch.Generator().manual_seed(seed)
+    d = torch.randn((P, 3), generator=g); d = d / d.norm(dim=1, keepdim=True)
+    r = extent * (0.6 + 0.4 * torch.rand((P, 1), generator=g))
+    xyz = d * r
+    # discs roughly tangent to the shell: rotate z-axis onto the radial direction
+    z = torch.tensor([0.0, 0.0, 1.0]).expand(P, 3)
+    axis = torch.cross(z, d, dim=1); s = axis.norm(dim=1, keepdim=True).clamp_min(1e-8); axis = axis / s
+    ang = torch.atan2(s.squeeze(1), (z * d).sum(1))
+    quat = torch.cat([torch.cos(ang / 2)[:, None], axis * torch.sin(ang / 2)[:, None]], dim=1)
+    scaling = torch.log(px_scale * torch.exp(0.4 * torch.randn((P, 2), generator=g)))
+    opacity = torch.logit(torch.rand((P, 1), generator=g) * 0.5 + 0.45)
+    f_dc = torch.randn((P, 1, 3), generator=g) * 0.8
+    f_rest = torch.randn((P, 15, 3), generator=g) * 0.05
+    m = GaussianModel(3, device=device)
+    m.set_parameters(xyz, f_dc, f_rest, opacity, scaling, quat)
+    m.active_sh_degree = 3
+    return m
+
+
+def capture_views(gt_model, cams, background, pipe=None):
+    """Fill the cameras' original_image with renders of the ground-truth surfels (the synthetic stand-in for a dataset)."""
+    pipe = pipe or pipeline_params()
+    with torch.no_grad():
+        for cam in cams:
+            img = render(cam, gt_model, pipe, background)["render"]
+            cam.original_image = img.clamp(0.0, 1.0).contiguous()
+    return cams
+
+
+# ------------------------------------------------------------------------------------------------ the loop
+class Trainer:
+    def __init__(self, model, cams, opt=None, pipe=None, white_background=False, extent=None, seed=0):
+        self.model, self.cams = model, cams
+        self.opt = opt or optimization_params()
+        self.pipe = pipe or pipeline_params()
+        self.white_background = white_background
+        self.background = torch.tensor([1.0, 1.0, 1.0] if white_background else [0.0, 0.0, 0.0], dtype=torch.float32, device=model.device)
+        self.extent = extent if extent is not None else cameras_extent(cams)
+        self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+        self.rank = dist.get_rank() if self.world > 1 else 0
+        self.seed = seed
+        self._rng = random.Random(seed)
+        self._stack = []
+        self.iteration = 0
+        self.last = {}
+        if model.grad is None:
+            model.training_setup(self.opt)
+
+    def _next_camera(self):
+        if self.world > 1:
+            return self.cams[surfel_dist.view_indices(len(self.cams), self.world, self.rank, self.iteration - 1, self.seed)]
+        if not self._stack:                       # train.py:64-67: pop a random view from a refilled stack
+            self._stack = list(range(len(self.cams)))
+        return self.cams[self._stack.pop(self._rng.randint(0, len(self._stack) - 1))]
+
+    def _reduce_stats(self):
+        m = self.model
+        packed = torch.cat([m.xyz_gradient_accum, m.denom], dim=1).contiguous()
+        dist.all_reduce(packed, op=dist.ReduceOp.SUM)
+        m.xyz_gradient_accum, m.denom = packed[:, :1].contiguous(), packed[:, 1:2].contiguous()
+        dist.all_reduce(m.max_radii2D, op=dist.ReduceOp.MAX)
+
+    def step(self):
+        """One training iteration (train.py:54-138).  Returns nothing; `self.last` holds device scalars for logging."""
+        self.iteration += 1
+        it, opt, m = self.iteration, self.opt, self.model
+        m.update_learning_rate(it)
+        if it % 1000 == 0:
+            m.oneupSHdegree()
+        cam = self._next_camera()
+        m.bind()
+        image, radii, allmap, means2D = rasterize(cam, m, self.pipe, self.background)
+        loss, pm = photometric_loss(image, cam.original_image, opt.lambda_dssim)
+        lam_n = opt.lambda_normal if it > opt.normal_from_iter else 0.0
+        lam_d = opt.lambda_dist if it > opt.dist_from_iter else 0.0
+        rm = None
+        if lam_n > 0.0 or lam_d > 0.0:
+            reg, rm = regularizers(allmap, cam, self.pipe.depth_ratio, lam_n, lam_d)
+            loss = loss + reg
+        loss.backward()
+        self.last = dict(loss=loss.detach(), photometric=pm, regularizers=rm, points=m.P)
+        with torch.no_grad():
+            rebuilt = False
+            if it < opt.densify_until_iter:
+                m.add_densification_stats(means2D.grad, radii=radii)
+                if it > opt.densify_from_iter and it % opt.densification_interval == 0:
+                    if self.world > 1:
+                        self._reduce_stats()
+                    size_threshold = 20 if it > opt.opacity_reset_interval else None
+                    m.densify_and_prune(opt.densify_grad_threshold, opt.opacity_cull, self.extent, size_threshold)
+                    rebuilt = True
+                if it % opt.opacity_reset_interval == 0 or (self.white_background and it == opt.densify_from_iter):
+                    m.reset_opacity()
+                    if not rebuilt:      # the reference re-creates only the opacity parameter: its update is skipped this iteration
+                        m._gv["opacity"].zero_()
+            if it < opt.iterations and not rebuilt:     # re-created parameters carry no gradient in the reference: no update
+                if self.world > 1:
+                    dist.all_reduce(m.grad, op=dist.ReduceOp.SUM)       # ONE collective over the 232 B/surfel store
+                m.optimizer_step(grad_scale=1.0 / self.world)
+
+    def evaluate(self, cams=None):
+        """Mean PSNR / L1 over views (training_report, train.py:201-232)."""
+        cams = cams or self.cams
+        with torch.no_grad():
+            ps, l1 = [], []
+            for cam in cams:
+                img = torch.clamp(render(cam, self.model, self.pipe, self.background)["render"], 0.0, 1.0)
+                gt = torch.clamp(cam.original_image, 0.0, 1.0)
+                ps.append(psnr(img, gt).mean()); l1.append((img - gt).abs().mean())
+            return float(torch.stack(ps).mean()), float(torch.stack(l1).mean())
+
+
+def training(model, cams, opt=None, pipe=None, iterations=None, white_background=False, log_every=0, seed=0):
+    """Run the loop; returns the Trainer (model trained in place).  log_every > 0 prints loss / points / it/s."""
+    opt = opt or optimization_params()
+    if iterations is not None:
+        opt.iterations = iterations
+    tr = Trainer(model, cams, opt, pipe, white_background, seed=seed)
+    t0 = time.perf_counter()
+    for _ in range(opt.iterations):
+        tr.step()
+        if log_every and tr.iteration % log_every == 0 and tr.rank == 0:
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            print("[it %d] loss %.5f points %d  %.1f it/s" % (tr.iteration, float(tr.last["loss"]), model.P, tr.iteration / dt), flush=True)
+    return tr

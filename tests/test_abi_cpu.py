@@ -9,9 +9,12 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _declared_symbols():
-    src = open(os.path.join(REPO, "include", "surfel_hip.h")).read()
-    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
-    return sorted(set(re.findall(r"\b(surfel_[a-z0-9_]+)\s*\(", src)) - {"surfel_alloc_fn"})
+    syms = set()
+    for hdr in ("surfel_hip.h", "surfel_train.h"):
+        src = open(os.path.join(REPO, "include", hdr)).read()
+        src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+        syms |= set(re.findall(r"\b(surfel_[a-z0-9_]+)\s*\(", src))
+    return sorted(syms - {"surfel_alloc_fn"})
 
 
 def test_library_exports_every_declared_symbol():
@@ -79,3 +82,42 @@ def test_allocator_frees_by_refcount():
         assert w_alloc() is None and w_buf() is None, "TorchAllocator is kept alive by a reference cycle"
     finally:
         gc.enable()
+
+
+def test_train_header_symbols_are_exported():
+    """every function include/surfel_train.h declares is exported by the library"""
+    import re
+    import surfel_native as n
+    lib = n.load()
+    hdr = open(os.path.join(REPO, "include", "surfel_train.h")).read()
+    names = set(re.findall(r"\bint\s+(surfel_\w+)\s*\(", hdr))
+    assert len(names) == 8
+    for name in names:
+        assert hasattr(lib, name), name
+        assert name in n.EXPORTS
+
+
+def test_ply_roundtrip_and_reference_layout(tmp_path):
+    """point_cloud.ply as scene/gaussian_model.py:176-207 lays it out: 61 float properties, binary little endian."""
+    import numpy as np
+    import surfel_io
+    names = ["x", "y", "z", "nx", "ny", "nz"] + ["f_dc_%d" % i for i in range(3)] + ["f_rest_%d" % i for i in range(45)] + \
+        ["opacity", "scale_0", "scale_1"] + ["rot_%d" % i for i in range(4)]
+    assert len(names) == 61
+    rng = np.random.default_rng(0)
+    cols = rng.normal(size=(37, 61)).astype(np.float32)
+    p = str(tmp_path / "pc.ply")
+    surfel_io.write_ply(p, names, cols)
+    raw = open(p, "rb").read()
+    head = raw[:raw.index(b"end_header\n") + 11].decode()
+    assert head.startswith("ply\nformat binary_little_endian 1.0\nelement vertex 37\nproperty float x\n")
+    assert len(raw) == len(head) + 37 * 61 * 4
+    back = surfel_io.read_ply(p)
+    assert list(back) == names
+    for i, n_ in enumerate(names):
+        assert np.array_equal(back[n_], cols[:, i])
+    # ascii variant (what MeshLab / CloudCompare may re-save)
+    with open(p, "w") as f:
+        f.write("ply\nformat ascii 1.0\ncomment x\nelement vertex 2\nproperty float x\nproperty double y\nend_header\n1 2\n3 4\n")
+    b2 = surfel_io.read_ply(p)
+    assert b2["x"].tolist() == [1.0, 3.0] and b2["y"].tolist() == [2.0, 4.0]
