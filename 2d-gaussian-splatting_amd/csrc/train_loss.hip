@@ -171,6 +171,34 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __res
     if (tid == 0) out[g * stride + k] = red[0] * scale;
 }
 
+// All loss scalars of an iteration in one workgroup, fixed summation order (train.py:72-88):
+// out = [Ll1, ssim, normal_err, dist, photometric, total],  photometric = (1-l)*Ll1 + l*(1-ssim),
+// total = photometric + lambda_normal*normal_err + lambda_dist*dist.   pb may be NULL (no regularisers this iteration).
+__global__ __launch_bounds__(256) void loss_finalize_kernel(const float* __restrict__ pa, int na, float scale_a, const float* __restrict__ pb,
+                                                            int nb, float scale_b, float lambda_dssim, float lambda_normal,
+                                                            float lambda_dist, float* __restrict__ out) {
+    __shared__ float red[4][256];
+    const int tid = threadIdx.x;
+    float a0 = 0.f, a1 = 0.f, b0 = 0.f, b1 = 0.f;
+    for (int i = tid; i < na; i += 256) { a0 += pa[2 * (size_t)i]; a1 += pa[2 * (size_t)i + 1]; }
+    if (pb) for (int i = tid; i < nb; i += 256) { b0 += pb[2 * (size_t)i]; b1 += pb[2 * (size_t)i + 1]; }
+    red[0][tid] = a0; red[1][tid] = a1; red[2][tid] = b0; red[3][tid] = b1;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (tid < s) {
+#pragma unroll
+            for (int k = 0; k < 4; k++) red[k][tid] += red[k][tid + s];
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        const float l1 = red[0][0] * scale_a, ss = red[1][0] * scale_a, ne = red[2][0] * scale_b, di = red[3][0] * scale_b;
+        const float ph = (1.f - lambda_dssim) * l1 + lambda_dssim * (1.f - ss);
+        out[0] = l1; out[1] = ss; out[2] = ne; out[3] = di; out[4] = ph;
+        out[5] = ph + lambda_normal * ne + lambda_dist * di;
+    }
+}
+
 }  // namespace
 
 int ssim_blocks(int H, int W) { return ((W + ST - 1) / ST) * ((H + ST - 1) / ST); }
@@ -189,6 +217,12 @@ void launch_ssim_bwd(int planes, int H, int W, const float* img, const float* gt
 
 void launch_reduce_partials(const float* partials, int groups, int n, int stride, float scale, float* out, hipStream_t s) {
     hipLaunchKernelGGL(reduce_partials_kernel, dim3(groups, stride), dim3(256), 0, s, partials, n, stride, scale, out);
+}
+
+void launch_loss_finalize(const float* pa, int na, float scale_a, const float* pb, int nb, float scale_b, float lambda_dssim,
+                          float lambda_normal, float lambda_dist, float* out, hipStream_t s) {
+    hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, s, pa, na, scale_a, pb, nb, scale_b, lambda_dssim, lambda_normal,
+                       lambda_dist, out);
 }
 
 }  // namespace surfel

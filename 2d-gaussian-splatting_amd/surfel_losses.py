@@ -129,3 +129,73 @@ def photometric_loss(image, gt_image, lambda_dssim=0.2):
     """loss = (1 - lambda_dssim) * l1_loss + lambda_dssim * (1 - ssim)   (train.py:72-74), fused.
     Returns (loss, means) with means = [Ll1, ssim] (detached, device) for logging."""
     return _PhotometricLoss.apply(image, gt_image, lambda_dssim)
+
+
+class _TrainLoss(torch.autograd.Function):
+    """The whole loss of a training iteration (train.py:72-88) as one autograd node:
+    (1-l)*L1 + l*(1-SSIM) + lambda_normal*mean(1 - rend_normal.surf_normal) + lambda_dist*mean(rend_dist)
+    forward = SSIM kernel [+ post-processing kernel] + one finalize launch; backward = one kernel per input.
+    Returns (total, scalars) with scalars = [Ll1, ssim, normal_err, dist, photometric, total] (detached)."""
+
+    @staticmethod
+    def forward(ctx, image, allmap, gt, cam, depth_ratio, lambda_dssim, lambda_normal, lambda_dist):
+        planes, H, W = _planes(image, gt)
+        x = image.detach().contiguous().float(); y = gt.detach().contiguous().float()
+        dev = x.device
+        lib = _n.load()
+        reg = (lambda_normal != 0.0 or lambda_dist != 0.0) and allmap is not None
+        nblk = ((W + 31) // 32) * ((H + 31) // 32)
+        dmaps = torch.empty((3, planes, H, W), dtype=torch.float32, device=dev)
+        partials = torch.empty((planes * nblk, 2), dtype=torch.float32, device=dev)
+        out = torch.empty((6,), dtype=torch.float32, device=dev)
+        s = _n.current_stream_ptr(dev)
+        am = pb = None
+        npost = 0
+        with torch.cuda.device(dev):
+            _check(lib.surfel_l1_ssim_forward(planes, H, W, _n.ptr(x), _n.ptr(y), _n.ptr(dmaps), _n.ptr(partials), s), "surfel_l1_ssim_forward")
+            if reg:
+                am = allmap.detach().contiguous().float()
+                npost = ((W + 15) // 16) * ((H + 15) // 16)
+                maps = torch.empty((9, H, W), dtype=torch.float32, device=dev)
+                pb = torch.empty((npost, 2), dtype=torch.float32, device=dev)
+                _check(lib.surfel_render_post_forward(H, W, _n.ptr(am), _n.ptr(cam), float(depth_ratio), _n.ptr(maps), _n.ptr(pb), s),
+                       "surfel_render_post_forward")
+            _check(lib.surfel_loss_finalize(_n.ptr(partials), planes * nblk, planes * H * W, _n.ptr(pb), npost, H * W, float(lambda_dssim),
+                                            float(lambda_normal) if reg else 0.0, float(lambda_dist) if reg else 0.0, _n.ptr(out), s),
+                   "surfel_loss_finalize")
+        ctx.k = (planes, H, W, float(depth_ratio), float(lambda_dssim), float(lambda_normal), float(lambda_dist), reg)
+        ctx.shapes = (tuple(image.shape), None if allmap is None else tuple(allmap.shape))
+        ctx.save_for_backward(x, y, dmaps, am, cam)
+        ctx.mark_non_differentiable(out)
+        return out[5].clone(), out
+
+    @staticmethod
+    def backward(ctx, g_total, g_out):
+        planes, H, W, ratio, lam, ln, ld, reg = ctx.k
+        x, y, dmaps, am, cam = ctx.saved_tensors
+        dev = x.device
+        lib = _n.load()
+        N = float(planes * H * W)
+        g = g_total.contiguous().float().reshape(1)
+        grad_img = torch.empty_like(x)
+        grad_am = None
+        s = _n.current_stream_ptr(dev)
+        with torch.cuda.device(dev):
+            _check(lib.surfel_l1_ssim_backward(planes, H, W, _n.ptr(x), _n.ptr(y), _n.ptr(dmaps), (1.0 - lam) / N, -lam / N, _n.ptr(g), _n.ptr(g),
+                                               _n.ptr(grad_img), s), "surfel_l1_ssim_backward")
+            if reg:
+                grad_am = torch.empty_like(am)
+                _check(lib.surfel_render_post_backward(H, W, _n.ptr(am), _n.ptr(cam), ratio, None, ln / (H * W), ld / (H * W), _n.ptr(g),
+                                                       _n.ptr(grad_am), s), "surfel_render_post_backward")
+        return grad_img.view(ctx.shapes[0]), grad_am, None, None, None, None, None, None
+
+
+def train_loss(image, allmap, gt_image, cam_consts, depth_ratio, lambda_dssim, lambda_normal, lambda_dist):
+    """Total loss of train.py:72-88 from the rasterizer's two outputs; cam_consts = the camera's 24-float block
+    (surfel_render.post_consts) or None when both regulariser weights are 0."""
+    if cam_consts is None:
+        if lambda_normal != 0.0 or lambda_dist != 0.0:
+            raise ValueError("regularisers need the camera constants")
+        cam_consts = torch.empty(0, device=image.device)
+        allmap = None
+    return _TrainLoss.apply(image, allmap, gt_image, cam_consts, depth_ratio, lambda_dssim, lambda_normal, lambda_dist)

@@ -21,9 +21,9 @@ import torch
 import torch.distributed as dist
 
 import surfel_dist
-from surfel_losses import photometric_loss
+from surfel_losses import train_loss
 from surfel_model import GaussianModel
-from surfel_render import Camera, rasterize, regularizers, render
+from surfel_render import Camera, rasterize, render
 
 
 def optimization_params(**over):
@@ -157,15 +157,13 @@ class Trainer:
         cam = self._next_camera()
         m.bind()
         image, radii, allmap, means2D = rasterize(cam, m, self.pipe, self.background)
-        loss, pm = photometric_loss(image, cam.original_image, opt.lambda_dssim)
         lam_n = opt.lambda_normal if it > opt.normal_from_iter else 0.0
         lam_d = opt.lambda_dist if it > opt.dist_from_iter else 0.0
-        rm = None
-        if lam_n > 0.0 or lam_d > 0.0:
-            reg, rm = regularizers(allmap, cam, self.pipe.depth_ratio, lam_n, lam_d)
-            loss = loss + reg
+        reg = lam_n > 0.0 or lam_d > 0.0
+        loss, scalars = train_loss(image, allmap if reg else None, cam.original_image, cam.post_consts() if reg else None,
+                                   self.pipe.depth_ratio, opt.lambda_dssim, lam_n, lam_d)
         loss.backward()
-        self.last = dict(loss=loss.detach(), photometric=pm, regularizers=rm, points=m.P)
+        self.last = dict(loss=scalars[5], scalars=scalars, points=m.P)     # [Ll1, ssim, normal_err, dist, photometric, total] on the device
         with torch.no_grad():
             rebuilt = False
             if it < opt.densify_until_iter:

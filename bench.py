@@ -46,6 +46,7 @@ def main():
     ap.add_argument("--workload", default="C2", help="synthetic config name (synthetic.CONFIGS); C2 = BASELINE configs[1] shape")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-1080p", action="store_true")
+    ap.add_argument("--no-train-iter", action="store_true")
     args = ap.parse_args()
 
     import numpy as np
@@ -166,6 +167,14 @@ def main():
     if rank == 0 and world == 1 and not args.no_1080p:
         from helpers_bench import fwd_1080p
         out["fwd_1080p"] = fwd_1080p(dev)
+
+    # ---- full training iteration (losses, regularisers, Adam around the rasterizer), N=1 leg only
+    if rank == 0 and world == 1 and not args.no_train_iter:
+        from helpers_bench import train_iter
+        import diff_surfel_rasterization as _d
+        _d.set_grad_arena(None)
+        out["train_iter"] = train_iter(dev, args.workload if args.workload in ("C1", "C2", "C3", "C4") else "C2")
+        _d.set_grad_arena(None)
 
     # ---- CPU baseline: the oracle's fp32 OpenMP port, same workload shape, rank 0 / N=1 only
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -64,3 +64,57 @@ def cpu_baseline(workload="C2"):
             "sample": "%s-synthetic (%d surfels, %dx%d): %d fwd+bwd passes of the fp32 OpenMP oracle port, %.1f s of wall time; "
                       "per pass fwd %.3f s, bwd %.3f s" % (sample, P, W, H, passes, tf + tb, tf / passes, tb / passes),
             "fwd_bwd_Msplats_per_s": round(P * passes / (tf + tb) / 1e6, 4)}
+
+
+def train_iter(dev, workload="C2", iters=60, warmup=15, n_views=8):
+    """Full training iterations/s of the loop of /root/reference/train.py:54-138 on the fused kernels (surfel_trainer.py):
+    rasterize fwd -> L1+SSIM -> normal/distortion regularisers -> rasterize bwd -> densification statistics -> Adam, one
+    view per iteration, every loss term on (the DTU configuration: lambda_dist 1000, lambda_normal 0.05, depth_ratio 1).
+    Scene: the bench workload's surfels seen from n_views nearby cameras; targets = renders of the unperturbed surfels;
+    the trained model starts from perturbed parameters.  Densification is off inside the timed window (it runs every 100
+    iterations in the reference and is host-side torch indexing there as here)."""
+    import math
+    import torch
+    import synthetic
+    import surfel_model
+    import surfel_trainer as TR
+    from surfel_render import Camera
+    P, W, H, zf = synthetic.CONFIGS[workload]
+    cams, sc0 = [], None
+    for k in range(n_views):
+        sc = synthetic.make_scene(P, W, H, seed=0, z_far=zf, view_index=k)
+        sc0 = sc0 or sc
+        w2c = sc["viewmatrix"].T.astype(np.float64)
+        cams.append(Camera(colmap_id=k, R=w2c[:3, :3].T, T=w2c[:3, 3], FoVx=2 * math.atan(sc["tanfovx"]), FoVy=2 * math.atan(sc["tanfovy"]),
+                           image=torch.zeros(3, H, W), image_name="bench_%d" % k, uid=k, data_device=dev))
+    t = lambda x: torch.as_tensor(np.ascontiguousarray(x))
+    raw = dict(xyz=t(sc0["means3D"]), f_dc=t(sc0["shs"][:, :1]), f_rest=t(sc0["shs"][:, 1:]), opacity=torch.logit(t(sc0["opacities"]).clamp(1e-4, 1 - 1e-4)),
+               scaling=torch.log(t(sc0["scales"])), rotation=t(sc0["rotations"]))
+    gt = surfel_model.GaussianModel(3, device=dev)
+    gt.set_parameters(**raw); gt.active_sh_degree = 3
+    bg = torch.zeros(3, device=dev)
+    TR.capture_views(gt, cams, bg)
+    g = torch.Generator().manual_seed(7)
+    model = surfel_model.GaussianModel(3, device=dev)
+    model.set_parameters(raw["xyz"] + 0.01 * torch.randn(raw["xyz"].shape, generator=g), raw["f_dc"] * 0.5, raw["f_rest"] * 0.0,
+                         raw["opacity"] - 0.5, raw["scaling"] + 0.1 * torch.randn(raw["scaling"].shape, generator=g), raw["rotation"])
+    model.active_sh_degree = 3
+    model.spatial_lr_scale = TR.cameras_extent(cams) if n_views > 1 else 1.0
+    opt = TR.optimization_params(iterations=10 ** 9, densify_from_iter=10 ** 9, dist_from_iter=0, normal_from_iter=0, lambda_dist=1000.0,
+                                 lambda_normal=0.05, opacity_reset_interval=10 ** 9)
+    tr = TR.Trainer(model, cams, opt, TR.pipeline_params(depth_ratio=1.0))
+    del gt
+    l0 = None
+    for i in range(warmup):
+        tr.step()
+        if i == 0:
+            l0 = float(tr.last["loss"])
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        tr.step()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    return {"workload": "%s-synthetic surfels (%d), %dx%d, %d views, full iteration: fwd + L1/SSIM + normal/dist regularisers + bwd + stats + Adam"
+                        % (workload, P, W, H, n_views), "iters_per_s": round(iters / dt, 2), "ms_per_iter": round(dt / iters * 1e3, 4),
+            "loss_first": round(l0, 5), "loss_last": round(float(tr.last["loss"]), 5), "iters": iters, "warmup": warmup}

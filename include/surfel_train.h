@@ -11,6 +11,7 @@
  *                             utils/point_utils.py:9-37 (depths_to_points / depth_to_normal) and, in fused mode,
  *                             the regularisers of train.py:80-85
  *   surfel_reduce_partials    the `.mean()` reductions of the above, in a fixed (bit-reproducible) order
+ *   surfel_loss_finalize      the scalar arithmetic of train.py:72-88 (loss, regularisers, total) in the same launch
  *   surfel_adam_step          scene/gaussian_model.py:95-115 (activations, backward folded in) +
  *                             torch.optim.Adam(eps=1e-15) over the six groups of :153-162, train.py:136-138
  *   surfel_activate           scene/gaussian_model.py:95-115 forward only (after (re)building the store)
@@ -79,6 +80,15 @@ int surfel_render_post_backward(int H, int W, const float* allmap, const float* 
 
 /* out[g*stride + k] = scale * sum_i partials[(g*n + i)*stride + k], fixed summation order. groups*stride <= 65535. */
 int surfel_reduce_partials(const float* partials, int groups, int n, int stride, float scale, float* out, void* stream);
+
+/*
+ * All loss scalars of one training iteration (train.py:72-88) from the two partial-sum arrays, one launch, fixed order:
+ *   out6 = [Ll1, ssim, mean normal error, mean distortion, photometric, total]
+ *   photometric = (1-lambda_dssim)*Ll1 + lambda_dssim*(1-ssim);  total = photometric + lambda_normal*[2] + lambda_dist*[3]
+ * ssim_partials [n_ssim,2] over n_pixels_planes = planes*H*W elements; post_partials [n_post,2] over n_pixels = H*W, or NULL.
+ */
+int surfel_loss_finalize(const float* ssim_partials, int n_ssim, int n_pixels_planes, const float* post_partials, int n_post,
+                         int n_pixels, float lambda_dssim, float lambda_normal, float lambda_dist, float* out6, void* stream);
 
 /*
  * The surfel parameter store: ONE flat fp32 buffer of 58 floats per surfel, planar by section

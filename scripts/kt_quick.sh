@@ -2,7 +2,7 @@
 # quick kernel-trace stats on the GPU box: bash scripts/kt_quick.sh <tag> [bench args...]
 TAG=${1:-q}; shift; ROOT=$(pwd); OUT=$ROOT/gpurun_out/kt_$TAG; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o kt -- python $ROOT/bench.py --no-cpu-baseline --no-1080p "$@" > $OUT/bench.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o kt -- python $ROOT/bench.py --no-cpu-baseline --no-1080p --no-train-iter "$@" > $OUT/bench.log 2>&1
 cd $ROOT
 find $OUT -name '*.db' -delete; find $OUT -name '*kernel_trace.csv' -delete
 python - <<PY

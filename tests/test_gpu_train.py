@@ -375,3 +375,37 @@ def test_training_converges_and_densifies():
     assert math.isfinite(p1) and p1 > p0 + 3.0, (p0, p1)
     assert model.P != P0                      # densification / pruning happened
     assert torch.isfinite(model.theta).all() and model.step_count < opt.iterations
+
+
+@pytest.mark.parametrize("ratio", [0, 1])
+def test_single_node_train_loss_matches_reference_sum(gt, ratio):
+    """train.py:72-88 as one autograd node: value and both gradients equal the reference's separately computed pieces."""
+    import torch
+    import surfel_losses as L
+    import surfel_render as R
+    view = _View(gt)
+    W, H = int(gt["post_W"]), int(gt["post_H"])
+    rng = np.random.default_rng(3)
+    tgt = rng.uniform(0, 1, size=(3, H, W)).astype(np.float32)
+    img = np.clip(tgt + 0.1 * rng.normal(size=tgt.shape), 0, 1).astype(np.float32)
+    from oracle import train_oracle as O
+    o = O.photometric(img, tgt, 0.2)
+    ln, ld = float(gt["post_lambda_normal"]), float(gt["post_lambda_dist"])
+    x = T(img).requires_grad_(True); am = T(gt["post_allmap"]).requires_grad_(True)
+    cam = T(R.post_consts(gt["post_world_view_transform"], gt["post_full_proj_transform"], W, H))
+    total, sc = L.train_loss(x, am, T(tgt), cam, float(ratio), 0.2, ln, ld)
+    sc = sc.cpu().numpy()
+    ne, di = float(gt["post_r%d_normal_err_mean" % ratio]), float(gt["post_r%d_dist_mean" % ratio])
+    assert abs(sc[0] - o["l1"]) < 2e-6 and abs(sc[1] - o["ssim"]) < 2e-5 and abs(sc[2] - ne) < 1e-4 and abs(sc[3] - di) < 1e-7
+    assert abs(sc[4] - o["loss"]) < 2e-5 and abs(float(total.detach()) - (o["loss"] + ln * ne + ld * di)) < 3e-5 and sc[5] == float(total.detach())
+    (2.0 * total).backward()
+    grad_ok(x.grad.cpu().numpy() / 2.0, o["g_loss"])
+    g, gref = am.grad.cpu().numpy() / 2.0, gt["post_r%d_g_reg" % ratio]
+    ok = np.isfinite(gref)
+    assert close_frac(g[ok], gref[ok], 2e-3 * np.abs(gref[ok]).mean(), 2e-2) > 0.99 and cosine(g[ok], gref[ok]) > 0.9999
+    # no regularisers: allmap is not touched
+    x2 = T(img).requires_grad_(True)
+    t2, sc2 = L.train_loss(x2, None, T(tgt), None, 0.0, 0.2, 0.0, 0.0)
+    assert abs(float(t2.detach()) - o["loss"]) < 2e-5 and float(sc2[2]) == 0.0
+    t2.backward()
+    grad_ok(x2.grad.cpu().numpy(), o["g_loss"])
