@@ -193,7 +193,7 @@ def rasterize(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, overri
         tanfovx=math.tan(viewpoint_camera.FoVx * 0.5), tanfovy=math.tan(viewpoint_camera.FoVy * 0.5), bg=bg_color,
         scale_modifier=scaling_modifier, viewmatrix=viewpoint_camera.world_view_transform,
         projmatrix=viewpoint_camera.full_proj_transform, sh_degree=pc.active_sh_degree, campos=viewpoint_camera.camera_center,
-        prefiltered=False, debug=bool(getattr(pipe, "debug", False)))
+        prefiltered=False, debug=int(getattr(pipe, "debug", 0)))
     rasterizer = GaussianRasterizer(raster_settings=raster_settings)
     scales = rotations = cov3D_precomp = None
     if getattr(pipe, "compute_cov3D_python", False):

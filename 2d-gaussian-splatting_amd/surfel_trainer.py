@@ -163,7 +163,7 @@ class Trainer:
         loss, scalars = train_loss(image, allmap if reg else None, cam.original_image, cam.post_consts() if reg else None,
                                    self.pipe.depth_ratio, opt.lambda_dssim, lam_n, lam_d)
         loss.backward()
-        self.last = dict(loss=scalars[5], scalars=scalars, points=m.P)     # [Ll1, ssim, normal_err, dist, photometric, total] on the device
+        self.last = dict(loss=scalars[5], scalars=scalars, points=m.P, radii=radii)     # [Ll1, ssim, normal_err, dist, photometric, total] on the device
         with torch.no_grad():
             rebuilt = False
             if it < opt.densify_until_iter:

@@ -1,13 +1,15 @@
 #!/usr/bin/env python
-"""bench.py — throughput of the surfel-rasterizer hot path on MI355X (contract: see task statement).
+"""bench.py — training-iteration throughput of the surfel hot path on MI355X (contract: see task statement).
 
-A "step" = one forward + backward pass of the rasterizer (the reference's render() native call +
-its autograd backward, /root/reference/train.py:69,90) over one synthetic view, through the product's
-drop-in Python surface (diff_surfel_rasterization.GaussianRasterizer), inputs resident in HBM.
-N > 1: view-parallel — every rank renders a different view of the same replicated surfel set, then
-ONE RCCL all-reduce of the per-surfel gradient bucket (58 floats/surfel). Weak scaling.
+A "step" = ONE FULL TRAINING ITERATION of the reference's loop (/root/reference/train.py:54-138) on one synthetic view per
+GPU: rasterizer forward (preprocess / sort / blend) -> L1 + SSIM -> normal + distortion regularisers -> rasterizer backward
+-> densification statistics -> [N > 1: ONE RCCL all-reduce of the 232 B/surfel gradient store] -> Adam step.
+Everything runs through the product's drop-in surface (surfel_trainer.Trainer over diff_surfel_rasterization +
+include/surfel_train.h kernels); inputs (parameters, target images, cameras) are resident in HBM before the timed region.
+N > 1: view-parallel — every rank trains on a different view of the same replicated surfel set per step (weak scaling).
 
-Prints ONE JSON line on rank 0.  `value` = whole-job views/s (= train-iteration rasterizer rate at N=1).
+Prints ONE JSON line on rank 0.  `value` = whole-job training iterations (views) per second.
+Side legs at N = 1: rasterizer-only fwd+bwd, forward-only Msplats/s @1080p (BASELINE metric), CPU baseline (oracle port).
 """
 import argparse
 import json
@@ -46,15 +48,14 @@ def main():
     ap.add_argument("--workload", default="C2", help="synthetic config name (synthetic.CONFIGS); C2 = BASELINE configs[1] shape")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-1080p", action="store_true")
-    ap.add_argument("--no-train-iter", action="store_true")
+    ap.add_argument("--no-raster-only", action="store_true")
+    ap.add_argument("--no-train-iter", action="store_true", help="(kept for older scripts; the timed step IS the training iteration)")
     args = ap.parse_args()
 
-    import numpy as np
     import torch
     import torch.distributed as dist
     import synthetic
     import surfel_native
-    from diff_surfel_rasterization import GaussianRasterizationSettings, GaussianRasterizer
 
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -66,34 +67,11 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)
 
+    from helpers_bench import make_trainer
     P, W, H, zf = synthetic.CONFIGS[args.workload]
-    sc = synthetic.make_scene(P, W, H, seed=0, z_far=zf, view_index=rank)
-    t = lambda x: torch.as_tensor(np.ascontiguousarray(x)).to(dev)
-    rs = GaussianRasterizationSettings(image_height=H, image_width=W, tanfovx=sc["tanfovx"], tanfovy=sc["tanfovy"], bg=t(sc["bg"]),
-                                       scale_modifier=1.0, viewmatrix=t(sc["viewmatrix"]), projmatrix=t(sc["projmatrix"]),
-                                       sh_degree=3, campos=t(sc["campos"]), prefiltered=False, debug=3)   # 3 = HIP events around the dominant kernel only, no sync
-    rast = GaussianRasterizer(raster_settings=rs)
-    params = [t(sc[k]).requires_grad_(True) for k in ("means3D", "shs", "opacities", "scales", "rotations")]
-    means3D, shs, opac, scales, rots = params
-    g = torch.Generator(device="cpu").manual_seed(1234 + rank)
-    gC = torch.randn((3, H, W), generator=g).to(dev); gO = torch.randn((7, H, W), generator=g).to(dev)
-    import surfel_dist
-    bucket = surfel_dist.GradBucket(P, dev) if world > 1 else None
-    if bucket is not None:      # the backward writes its gradients straight into the all-reduce bucket
-        import diff_surfel_rasterization as _dsr
-        _dsr.set_grad_arena(bucket.arena())
-    state = {}
-
-    def step():
-        means2D = torch.zeros_like(means3D, requires_grad=True)
-        color, radii, allmap = rast(means3D=means3D, means2D=means2D, shs=shs, colors_precomp=None, opacities=opac,
-                                    scales=scales, rotations=rots, cov3D_precomp=None)
-        torch.autograd.backward([color, allmap], [gC, gO])
-        if world > 1:
-            bucket.all_reduce(average=True)      # ONE collective per step over the flat 232 B/surfel bucket
-        state["radii"] = radii
-        for p_ in params:
-            p_.grad = None
+    n_views = max(8, world)
+    tr = make_trainer(dev, args.workload, n_views=n_views)      # Trainer picks up the process group: all-reduce + averaged Adam step
+    tr.pipe.debug = 3       # HIP events around the dominant kernel only (blend_bwd), resolved after the timed region, no sync
 
     def fence():
         torch.cuda.synchronize()
@@ -102,30 +80,33 @@ def main():
             torch.cuda.synchronize()
 
     for _ in range(args.warmup):
-        step()
+        tr.step()
     fence()
+    loss_first = float(tr.last["loss"])
     surfel_native.collect_stage_times()     # drop warm-up events
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        step()
+        tr.step()
     fence()
     dt = time.perf_counter() - t0
     dom_stage = surfel_native.collect_stage_times()        # {"blend_bwd": (total_ms, launches)} from the timed region itself
-    # per-stage breakdown: a second, untimed pass of the same steps with every stage bracketed by events
+    loss_last = float(tr.last["loss"])
+    # per-stage breakdown of the rasterizer: a second, untimed pass with every stage bracketed by events
     # (bracketing all ~9 stages costs ~10 us each, which would perturb the timed region by ~9 % at this size)
-    rast.raster_settings = rs._replace(debug=2)
+    tr.pipe.debug = 2
     for _ in range(max(5, args.steps // 2)):
-        step()
+        tr.step()
     fence()
     stages = surfel_native.collect_stage_times()
     stages.update(dom_stage)
+    tr.pipe.debug = 0
     if world > 1:
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
     # ---- workload statistics for the roofline (P, V, R, n_pass)
-    V = int((state["radii"] > 0).sum().item())
+    V = int((tr.last["radii"] > 0).sum().item())
     import diff_surfel_rasterization
     R = int(diff_surfel_rasterization.last_num_rendered)
     tiles = ((W + 15) // 16) * ((H + 15) // 16)
@@ -134,7 +115,7 @@ def main():
     out = None
     if rank == 0:
         ms_per_step = dt / args.steps * 1e3
-        views_per_s = world * args.steps / dt
+        iters_per_s = world * args.steps / dt
         per_kernel = {k: v[0] / v[1] for k, v in stages.items()}
         dom = max(per_kernel, key=per_kernel.get) if per_kernel else None
         roof = None
@@ -154,29 +135,36 @@ def main():
                     "all_kernels_ms": {k: round(v, 4) for k, v in per_kernel.items()},
                     "all_kernels_GBps": {k: round(algorithmic_bytes(k, P, V, R, W, H, n_pass) / (v * 1e-3) / 1e9, 1)
                                          for k, v in per_kernel.items() if v > 0}}
-        out = {"metric": "train iters/sec (rasterizer fwd+bwd per view) + fwd Msplats/s @1080p", "value": round(views_per_s, 3),
-               "unit": "view-iters/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        out = {"metric": "train iters/sec (full iteration: rasterizer fwd+bwd, L1+SSIM, normal+dist regularisers, Adam) + fwd Msplats/s @1080p",
+               "value": round(iters_per_s, 3), "unit": "train-iters/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                "dtype": "f32", "data": "synthetic",
-               "config": {"workload": "%s-synthetic: %d random surfels, %dx%d, sh_degree 3, rasterizer fwd+bwd, 1 view/GPU/step"
-                                      % (args.workload, P, W, H), "P": P, "visible": V, "instances_R": R, "n_pass": n_pass,
-                          "tiles": tiles, "parallelism": "view-parallel dp%d, 1 all-reduce of 232 B/surfel" % world},
-               "fwd_bwd_Msplats_per_s": round(world * P * args.steps / dt / 1e6, 2), "roofline": roof}
+               "config": {"workload": "%s-synthetic: %d random surfels, %dx%d, sh_degree 3, %d target views rendered from the unperturbed "
+                                      "surfels, 1 view/GPU/iteration, lambda_dssim 0.2, lambda_normal 0.05, lambda_dist 1000, depth_ratio 1, "
+                                      "Adam on 58 floats/surfel" % (args.workload, P, W, H, n_views),
+                          "P": P, "visible": V, "instances_R": R, "n_pass": n_pass, "tiles": tiles,
+                          "parallelism": "view-parallel dp%d, 1 all-reduce of 232 B/surfel per iteration" % world},
+               "loss_first": round(loss_first, 5), "loss_last": round(loss_last, 5),
+               "train_Msplats_per_s": round(world * P * args.steps / dt / 1e6, 2), "roofline": roof}
+
+    if world > 1:
+        dist.barrier()
+    del tr
+    import diff_surfel_rasterization as _d
+    _d.set_grad_arena(None)
+    torch.cuda.empty_cache()
+
+    # ---- rasterizer alone (the north-star hot path without loss / optimiser), N=1 leg only
+    if rank == 0 and world == 1 and not args.no_raster_only:
+        from helpers_bench import raster_fwd_bwd
+        out["raster_fwd_bwd"] = raster_fwd_bwd(dev, args.workload)
 
     # ---- forward-only Msplats/s @1080p (BASELINE metric, N=1 leg only)
     if rank == 0 and world == 1 and not args.no_1080p:
         from helpers_bench import fwd_1080p
         out["fwd_1080p"] = fwd_1080p(dev)
 
-    # ---- full training iteration (losses, regularisers, Adam around the rasterizer), N=1 leg only
-    if rank == 0 and world == 1 and not args.no_train_iter:
-        from helpers_bench import train_iter
-        import diff_surfel_rasterization as _d
-        _d.set_grad_arena(None)
-        out["train_iter"] = train_iter(dev, args.workload if args.workload in ("C1", "C2", "C3", "C4") else "C2")
-        _d.set_grad_arena(None)
-
-    # ---- CPU baseline: the oracle's fp32 OpenMP port, same workload shape, rank 0 / N=1 only
+    # ---- CPU baseline: the oracle's fp32 OpenMP port of the rasterizer, same workload shape, rank 0 / N=1 only
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from helpers_bench import cpu_baseline
         out["cpu_baseline"] = cpu_baseline(args.workload)

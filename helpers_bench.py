@@ -61,18 +61,17 @@ def cpu_baseline(workload="C2"):
         tf += t1 - t0; tb += t2 - t1; passes += 1
     cores = int(os.environ.get("OMP_NUM_THREADS", os.cpu_count() or 1))
     return {"value": round(passes / (tf + tb), 4), "unit": "view-iters/s", "cores": cores, "kind": "port",
-            "sample": "%s-synthetic (%d surfels, %dx%d): %d fwd+bwd passes of the fp32 OpenMP oracle port, %.1f s of wall time; "
+            "sample": "%s-synthetic (%d surfels, %dx%d): %d rasterizer fwd+bwd passes of the fp32 OpenMP oracle port (the dominant part of "
+                      "an iteration; loss and Adam are NOT included, which favours the CPU figure), %.1f s of wall time; "
                       "per pass fwd %.3f s, bwd %.3f s" % (sample, P, W, H, passes, tf + tb, tf / passes, tb / passes),
             "fwd_bwd_Msplats_per_s": round(P * passes / (tf + tb) / 1e6, 4)}
 
 
-def train_iter(dev, workload="C2", iters=60, warmup=15, n_views=8):
-    """Full training iterations/s of the loop of /root/reference/train.py:54-138 on the fused kernels (surfel_trainer.py):
-    rasterize fwd -> L1+SSIM -> normal/distortion regularisers -> rasterize bwd -> densification statistics -> Adam, one
-    view per iteration, every loss term on (the DTU configuration: lambda_dist 1000, lambda_normal 0.05, depth_ratio 1).
-    Scene: the bench workload's surfels seen from n_views nearby cameras; targets = renders of the unperturbed surfels;
-    the trained model starts from perturbed parameters.  Densification is off inside the timed window (it runs every 100
-    iterations in the reference and is host-side torch indexing there as here)."""
+def make_trainer(dev, workload="C2", n_views=8, regularizers=True):
+    """The bench's training job: the workload's synthetic surfels (synthetic.make_scene) seen from n_views nearby
+    cameras; targets = renders of the unperturbed surfels; the trained model starts from perturbed parameters.  Every loss term
+    is on (the DTU configuration: lambda_dist 1000, lambda_normal 0.05, depth_ratio 1) unless regularizers=False.  Densification
+    is off (it runs every 100 iterations in the reference and is host-side torch indexing there as here)."""
     import math
     import torch
     import synthetic
@@ -94,16 +93,25 @@ def train_iter(dev, workload="C2", iters=60, warmup=15, n_views=8):
     gt.set_parameters(**raw); gt.active_sh_degree = 3
     bg = torch.zeros(3, device=dev)
     TR.capture_views(gt, cams, bg)
+    del gt
     g = torch.Generator().manual_seed(7)
     model = surfel_model.GaussianModel(3, device=dev)
     model.set_parameters(raw["xyz"] + 0.01 * torch.randn(raw["xyz"].shape, generator=g), raw["f_dc"] * 0.5, raw["f_rest"] * 0.0,
                          raw["opacity"] - 0.5, raw["scaling"] + 0.1 * torch.randn(raw["scaling"].shape, generator=g), raw["rotation"])
     model.active_sh_degree = 3
     model.spatial_lr_scale = TR.cameras_extent(cams) if n_views > 1 else 1.0
-    opt = TR.optimization_params(iterations=10 ** 9, densify_from_iter=10 ** 9, dist_from_iter=0, normal_from_iter=0, lambda_dist=1000.0,
-                                 lambda_normal=0.05, opacity_reset_interval=10 ** 9)
-    tr = TR.Trainer(model, cams, opt, TR.pipeline_params(depth_ratio=1.0))
-    del gt
+    far = 10 ** 9
+    opt = TR.optimization_params(iterations=far, densify_from_iter=far, opacity_reset_interval=far, dist_from_iter=0 if regularizers else far,
+                                 normal_from_iter=0 if regularizers else far, lambda_dist=1000.0, lambda_normal=0.05)
+    return TR.Trainer(model, cams, opt, TR.pipeline_params(depth_ratio=1.0))
+
+
+def train_iter(dev, workload="C2", iters=60, warmup=15, n_views=8):
+    """Full training iterations/s (one view per iteration) of make_trainer's job, timed on its own."""
+    import torch
+    import synthetic
+    P, W, H, zf = synthetic.CONFIGS[workload]
+    tr = make_trainer(dev, workload, n_views)
     l0 = None
     for i in range(warmup):
         tr.step()
@@ -118,3 +126,40 @@ def train_iter(dev, workload="C2", iters=60, warmup=15, n_views=8):
     return {"workload": "%s-synthetic surfels (%d), %dx%d, %d views, full iteration: fwd + L1/SSIM + normal/dist regularisers + bwd + stats + Adam"
                         % (workload, P, W, H, n_views), "iters_per_s": round(iters / dt, 2), "ms_per_iter": round(dt / iters * 1e3, 4),
             "loss_first": round(l0, 5), "loss_last": round(float(tr.last["loss"]), 5), "iters": iters, "warmup": warmup}
+
+
+def raster_fwd_bwd(dev, workload="C2", iters=40, warmup=10):
+    """The rasterizer alone (forward + backward with random upstream gradients, no loss / optimiser): ms per view."""
+    import torch
+    import synthetic
+    from diff_surfel_rasterization import GaussianRasterizationSettings, GaussianRasterizer
+    import diff_surfel_rasterization as dsr
+    dsr.set_grad_arena(None)
+    P, W, H, zf = synthetic.CONFIGS[workload]
+    sc = synthetic.make_scene(P, W, H, seed=0, z_far=zf)
+    t = lambda x: torch.as_tensor(np.ascontiguousarray(x)).to(dev)
+    rs = GaussianRasterizationSettings(image_height=H, image_width=W, tanfovx=sc["tanfovx"], tanfovy=sc["tanfovy"], bg=t(sc["bg"]),
+                                       scale_modifier=1.0, viewmatrix=t(sc["viewmatrix"]), projmatrix=t(sc["projmatrix"]),
+                                       sh_degree=3, campos=t(sc["campos"]), prefiltered=False, debug=False)
+    rast = GaussianRasterizer(raster_settings=rs)
+    params = [t(sc[k]).requires_grad_(True) for k in ("means3D", "shs", "opacities", "scales", "rotations")]
+    g = torch.Generator(device="cpu").manual_seed(1234)
+    gC = torch.randn((3, H, W), generator=g).to(dev); gO = torch.randn((7, H, W), generator=g).to(dev)
+
+    def step():
+        m2 = torch.zeros_like(params[0], requires_grad=True)
+        color, radii, allmap = rast(means3D=params[0], means2D=m2, shs=params[1], colors_precomp=None, opacities=params[2], scales=params[3],
+                                    rotations=params[4], cov3D_precomp=None)
+        torch.autograd.backward([color, allmap], [gC, gO])
+        for p_ in params:
+            p_.grad = None
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        step()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    return {"workload": "%s-synthetic, rasterizer forward+backward only, N(0,1) upstream gradients" % workload,
+            "ms_per_view": round(dt / iters * 1e3, 4), "views_per_s": round(iters / dt, 2), "Msplats_per_s": round(P * iters / dt / 1e6, 2)}

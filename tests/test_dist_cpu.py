@@ -114,3 +114,53 @@ def test_tile_band_sharding_matches_full_render():
         acc = part if acc is None else [x + y for x, y in zip(acc, part)]
     for got, ref in zip(acc, [g_full.dL_dmeans3D, g_full.dL_dscales, g_full.dL_drots, g_full.dL_dopacity, g_full.dL_dsh]):
         assert np.abs(got - ref).max() <= 2e-3 * np.abs(ref).max()
+
+
+def _trainer_stats_worker(rank, world, port, q):
+    """The trainer's N>1 collectives on the flat store, with gloo on CPU tensors (the kernels themselves need a GPU)."""
+    import os
+    import types
+    import torch
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import surfel_trainer as TR
+        P = 11
+        model = types.SimpleNamespace(
+            xyz_gradient_accum=torch.arange(P, dtype=torch.float32).reshape(P, 1) * (rank + 1),
+            denom=torch.full((P, 1), float(rank + 1)),
+            max_radii2D=torch.arange(P, dtype=torch.float32) * (1 if rank == 0 else -1) + rank,
+            grad=torch.arange(P * 58, dtype=torch.float32) * (rank + 1))
+        tr = TR.Trainer.__new__(TR.Trainer)
+        tr.model, tr.world, tr.rank = model, world, rank
+        tr._reduce_stats()
+        dist.all_reduce(model.grad, op=dist.ReduceOp.SUM)        # the per-iteration collective of Trainer.step
+        # every rank draws a different view of the same permutation
+        views = [TR.surfel_dist.view_indices(9, world, rank, it, seed=3) for it in range(6)]
+        q.put((rank, model.xyz_gradient_accum.reshape(-1).tolist(), model.denom.reshape(-1).tolist(), model.max_radii2D.tolist(),
+               float(model.grad.sum()), views))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_trainer_collectives_world2():
+    import torch
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_trainer_stats_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    P = 11
+    for rank, acc, den, mr, gsum, views in res:
+        assert acc == [3.0 * i for i in range(P)]                  # (1 + 2) * i
+        assert den == [3.0] * P
+        assert mr == [max(float(i), float(-i + 1)) for i in range(P)]
+        assert gsum == 3.0 * sum(range(P * 58))
+    assert all(a != b for a, b in zip(res[0][5], res[1][5]))       # distinct views per step across ranks
