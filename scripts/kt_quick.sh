@@ -9,6 +9,6 @@ python - <<PY
 import csv, glob
 f = glob.glob("$OUT/**/*kernel_stats.csv", recursive=True)[0]
 for r in csv.DictReader(open(f)):
-    n = r["Name"].split("(")[0].replace("surfel::","").replace("void ","")[:50]
+    n = r["Name"].replace("(anonymous namespace)::","").split("(")[0].replace("surfel::","").replace("void ","")[:50]
     print("%-52s calls %5s  avg %9.1f us  tot %5.1f%%" % (n, r["Calls"], float(r["AverageNs"])/1e3, float(r["Percentage"])))
 PY

@@ -26,7 +26,7 @@ STAGE_OF = {"preprocess_fwd_kernel": "preprocess_fwd", "emit_instances_kernel": 
 
 
 def short(name):
-    n = name.split("(")[0].replace("surfel::", "").replace("void ", "")
+    n = name.replace("(anonymous namespace)::", "").split("(")[0].replace("surfel::", "").replace("void ", "")
     n = re.sub(r"<.*", "", n)
     return n[:80]
 
@@ -71,13 +71,14 @@ def main():
     for sub in ("fetch", "write", "sq"):
         for k, cs in pmc_means(os.path.join(src, sub)).items():
             merged[k].update(cs)
-    merged = {k: v for k, v in merged.items() if k in STAGE_OF or k.startswith("rs_") or "knn" in k}
+    ours = ("rs_", "os_", "scan_", "ssim_", "post_", "adam_", "loss_", "densify_", "activate_", "reduce_")
+    merged = {k: v for k, v in merged.items() if k in STAGE_OF or k.startswith(ours) or "knn" in k}
     traffic = {}
     for k, cs in merged.items():
         if "FETCH_SIZE" in cs and "WRITE_SIZE" in cs:
             cs["HBM_bytes_per_launch"] = int(2 * cs["FETCH_SIZE"] * 1024 + cs["WRITE_SIZE"] * 1024)
-            if k in STAGE_OF:
-                traffic[STAGE_OF[k]] = cs["HBM_bytes_per_launch"]
+            if k in STAGE_OF or k.startswith(("ssim_", "post_", "adam_")):
+                traffic[STAGE_OF.get(k, k.replace("_kernel", ""))] = cs["HBM_bytes_per_launch"]
     json.dump(merged, open(os.path.join(dst, "%s_%s_pmc.json" % (tag, wl)), "w"), indent=1, sort_keys=True)
     tf = os.path.join(dst, "pmc_traffic.json")
     allt = json.load(open(tf)) if os.path.exists(tf) else {}

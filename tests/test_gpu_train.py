@@ -409,3 +409,28 @@ def test_single_node_train_loss_matches_reference_sum(gt, ratio):
     assert abs(float(t2.detach()) - o["loss"]) < 2e-5 and float(sc2[2]) == 0.0
     t2.backward()
     grad_ok(x2.grad.cpu().numpy(), o["g_loss"])
+
+
+def test_render_python_covariance_and_override_color_paths():
+    """render()'s compute_cov3D_python branch (gaussian_renderer/__init__.py:59-75 with scene/gaussian_model.py:27-33) and
+    override_color produce the same image as the native scale/rotation + SH path."""
+    import torch
+    import surfel_render as R
+    import surfel_trainer as TR
+    m = TR.synthetic_object(2000, dev(), seed=4, px_scale=0.06)
+    cam = TR.orbit_cameras(1, 88, 72, device=dev())[0]
+    bg = torch.tensor([0.1, 0.2, 0.3], device=dev())
+    torch.set_grad_enabled(False)
+    a = R.render(cam, m, TR.pipeline_params(), bg)
+    b = R.render(cam, m, TR.pipeline_params(compute_cov3D_python=True), bg)
+    assert close_frac(b["render"].cpu().numpy(), a["render"].cpu().numpy(), 2e-4, 1e-3) > 0.995
+    assert close_frac(b["rend_alpha"].cpu().numpy(), a["rend_alpha"].cpu().numpy(), 2e-4, 1e-3) > 0.995
+    assert float((a["radii"] > 0).float().mean()) > 0.3
+    col = torch.rand((m.P, 3), device=dev())
+    c = R.render(cam, m, TR.pipeline_params(), bg, override_color=col)
+    assert c["render"].shape == a["render"].shape and not torch.allclose(c["render"], a["render"])
+    assert torch.equal(c["radii"], a["radii"]) and torch.allclose(c["rend_alpha"], a["rend_alpha"], atol=1e-6)
+    # scaling_modifier shrinks footprints (viewer path, gaussian_renderer/__init__.py:19,42)
+    d = R.render(cam, m, TR.pipeline_params(), bg, scaling_modifier=0.5)
+    torch.set_grad_enabled(True)
+    assert float(d["rend_alpha"].sum()) < float(a["rend_alpha"].sum())
