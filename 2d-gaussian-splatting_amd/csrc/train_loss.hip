@@ -13,7 +13,6 @@ namespace {
 constexpr int ST = 32;             // output tile edge
 constexpr int SR = 5;              // window radius
 constexpr int SHALO = ST + 2 * SR; // 42
-constexpr int SPITCH = SHALO + 1;  // LDS row pitch (odd: the two half-waves of a ds_read_b32 land on distinct banks)
 constexpr float SSIM_C1 = 0.01f * 0.01f;
 constexpr float SSIM_C2 = 0.03f * 0.03f;
 
@@ -28,10 +27,17 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
+// LDS layout (42 KB -> 3 workgroups / CU): the staged 42x42 tile as float2 (x,y) with pitch XP, the horizontal moments as
+// float4 (E[x], E[y], E[x^2], E[y^2]) with pitch HZP + float (E[xy]).  Each thread slides an 11-tap window over 14 consecutive
+// elements held in registers (4 outputs per 14 LDS reads instead of 44), horizontally then vertically.
+constexpr int XP = 46;            // float2 pitch of the staged tile (even: 16-B aligned b128 reads at even columns)
+constexpr int HZP = ST + 1;       // float4 pitch of the horizontal-pass result
+
 __global__ __launch_bounds__(256) void ssim_fwd_kernel(int H, int W, const float* __restrict__ img, const float* __restrict__ gt,
                                                        float* __restrict__ dmaps, size_t map_stride, float* __restrict__ partials) {
-    __shared__ float sx[SHALO * SPITCH], sy[SHALO * SPITCH];
-    __shared__ float hz[5][SHALO * ST];
+    __shared__ float2 sxy[SHALO * XP];
+    __shared__ float4 hz4[SHALO * HZP];
+    __shared__ float hz1[SHALO * ST];
     __shared__ float red[8];
     const int tid = threadIdx.x;
     const int plane = blockIdx.z;
@@ -43,52 +49,74 @@ __global__ __launch_bounds__(256) void ssim_fwd_kernel(int H, int W, const float
         const int r = i / SHALO, c = i - r * SHALO;
         const int gy = y0 + r - SR, gx = x0 + c - SR;
         const bool in = gy >= 0 && gy < H && gx >= 0 && gx < W;
-        sx[r * SPITCH + c] = in ? X[(size_t)gy * W + gx] : 0.f;
-        sy[r * SPITCH + c] = in ? Y[(size_t)gy * W + gx] : 0.f;
+        sxy[r * XP + c] = in ? make_float2(X[(size_t)gy * W + gx], Y[(size_t)gy * W + gx]) : make_float2(0.f, 0.f);
     }
     __syncthreads();
-    // horizontal pass: 42 rows x 32 columns, five moments
-    for (int i = tid; i < SHALO * ST; i += 256) {
-        const int r = i >> 5, c = i & 31;
-        float a = 0.f, b = 0.f, aa = 0.f, bb = 0.f, ab = 0.f;
+    // horizontal pass: item = (row r of 42, group of 4 output columns)
+    for (int it = tid; it < SHALO * (ST / 4); it += 256) {
+        const int r = it >> 3, c0 = (it & 7) << 2;
+        float xv[14], yv[14];
+        const float4* src = reinterpret_cast<const float4*>(&sxy[r * XP + c0]);
 #pragma unroll
-        for (int k = 0; k < 11; k++) {
-            const float xv = sx[r * SPITCH + c + k], yv = sy[r * SPITCH + c + k], w = kG[k];
-            const float wx = w * xv, wy = w * yv;
-            a += wx; b += wy; aa += wx * xv; bb += wy * yv; ab += wx * yv;
+        for (int k = 0; k < 7; k++) { const float4 t = src[k]; xv[2 * k] = t.x; yv[2 * k] = t.y; xv[2 * k + 1] = t.z; yv[2 * k + 1] = t.w; }
+        float a[4] = {0.f, 0.f, 0.f, 0.f}, b[4] = {0.f, 0.f, 0.f, 0.f}, aa[4] = {0.f, 0.f, 0.f, 0.f}, bb[4] = {0.f, 0.f, 0.f, 0.f},
+              ab[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int e = 0; e < 14; e++) {
+            const float x = xv[e], y = yv[e], xx = x * x, yy = y * y, xy = x * y;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int k = e - j;
+                if (k >= 0 && k < 11) {
+                    const float w = kG[k];
+                    a[j] += w * x; b[j] += w * y; aa[j] += w * xx; bb[j] += w * yy; ab[j] += w * xy;
+                }
+            }
         }
-        hz[0][i] = a; hz[1][i] = b; hz[2][i] = aa; hz[3][i] = bb; hz[4][i] = ab;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            hz4[r * HZP + c0 + j] = make_float4(a[j], b[j], aa[j], bb[j]);
+            hz1[r * ST + c0 + j] = ab[j];
+        }
     }
     __syncthreads();
-    // vertical pass: thread -> column tid&31, rows (tid>>5) + 8*j
-    const int c = tid & 31, r0 = tid >> 5;
+    // vertical pass: thread -> column c, output rows 4g .. 4g+3
+    const int c = tid & 31, g = tid >> 5;
+    float mu1[4] = {0.f, 0.f, 0.f, 0.f}, mu2[4] = {0.f, 0.f, 0.f, 0.f}, e11[4] = {0.f, 0.f, 0.f, 0.f}, e22[4] = {0.f, 0.f, 0.f, 0.f},
+          e12[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int e = 0; e < 14; e++) {
+        const float4 h = hz4[(4 * g + e) * HZP + c];
+        const float h1 = hz1[(4 * g + e) * ST + c];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int k = e - j;
+            if (k >= 0 && k < 11) {
+                const float w = kG[k];
+                mu1[j] += w * h.x; mu2[j] += w * h.y; e11[j] += w * h.z; e22[j] += w * h.w; e12[j] += w * h1;
+            }
+        }
+    }
     float l1 = 0.f, ss = 0.f;
 #pragma unroll
     for (int j = 0; j < 4; j++) {
-        const int r = r0 + 8 * j;
-        float mu1 = 0.f, mu2 = 0.f, e11 = 0.f, e22 = 0.f, e12 = 0.f;
-#pragma unroll
-        for (int k = 0; k < 11; k++) {
-            const float w = kG[k];
-            const int o = (r + k) * ST + c;
-            mu1 += w * hz[0][o]; mu2 += w * hz[1][o]; e11 += w * hz[2][o]; e22 += w * hz[3][o]; e12 += w * hz[4][o];
-        }
+        const int r = 4 * g + j;
         const int gy = y0 + r, gx = x0 + c;
         if (gy < H && gx < W) {
-            const float mu1_sq = mu1 * mu1, mu2_sq = mu2 * mu2, mu12 = mu1 * mu2;
-            const float s1 = e11 - mu1_sq, s2 = e22 - mu2_sq, s12 = e12 - mu12;
+            const float mu1_sq = mu1[j] * mu1[j], mu2_sq = mu2[j] * mu2[j], mu12 = mu1[j] * mu2[j];
+            const float s1 = e11[j] - mu1_sq, s2 = e22[j] - mu2_sq, s12 = e12[j] - mu12;
             const float A = 2.f * mu12 + SSIM_C1, B = 2.f * s12 + SSIM_C2;
             const float C = mu1_sq + mu2_sq + SSIM_C1, D = s1 + s2 + SSIM_C2;
             const float iCD = 1.f / (C * D);
             const float S = A * B * iCD;
-            const float xv = sx[(r + SR) * SPITCH + c + SR], yv = sy[(r + SR) * SPITCH + c + SR];
-            l1 += fabsf(xv - yv);
+            const float2 v = sxy[(r + SR) * XP + c + SR];
+            l1 += fabsf(v.x - v.y);
             ss += S;
             if (dmaps) {
                 const size_t o = poff + (size_t)gy * W + gx;
-                dmaps[o] = 2.f * mu2 * (B - A) * iCD + 2.f * mu1 * S * (1.f / D - 1.f / C);   // dS/dmu1 (mu1, E[x^2], E[xy] independent)
-                dmaps[map_stride + o] = -S / D;                                             // dS/dE[x^2]
-                dmaps[2 * map_stride + o] = 2.f * A * iCD;                                  // dS/dE[xy]
+                dmaps[o] = 2.f * mu2[j] * (B - A) * iCD + 2.f * mu1[j] * S * (1.f / D - 1.f / C);   // dS/dmu1 (mu1, E[x^2], E[xy] independent)
+                dmaps[map_stride + o] = -S / D;                                                   // dS/dE[x^2]
+                dmaps[2 * map_stride + o] = 2.f * A * iCD;                                        // dS/dE[xy]
             }
         }
     }
@@ -106,8 +134,9 @@ __global__ __launch_bounds__(256) void ssim_bwd_kernel(int H, int W, const float
                                                        const float* __restrict__ dmaps, size_t map_stride, float c_l1, float c_ssim,
                                                        const float* __restrict__ g_l1_dev, const float* __restrict__ g_ssim_dev,
                                                        float* __restrict__ grad_img) {
-    __shared__ float sm[3][SHALO * SPITCH];
-    __shared__ float hz[3][SHALO * ST];
+    __shared__ float2 s12[SHALO * XP];      // (M1, M2)
+    __shared__ float s3[SHALO * XP];        // M3
+    __shared__ float4 hz[SHALO * HZP];      // horizontal pass of (M1, M2, M3, -)
     const int tid = threadIdx.x;
     const int plane = blockIdx.z;
     const int x0 = blockIdx.x * ST, y0 = blockIdx.y * ST;
@@ -117,40 +146,53 @@ __global__ __launch_bounds__(256) void ssim_bwd_kernel(int H, int W, const float
         const int gy = y0 + r - SR, gx = x0 + c - SR;
         const bool in = gy >= 0 && gy < H && gx >= 0 && gx < W;
         const size_t o = poff + (size_t)gy * W + gx;
-#pragma unroll
-        for (int m = 0; m < 3; m++) sm[m][r * SPITCH + c] = in ? dmaps[m * map_stride + o] : 0.f;
+        s12[r * XP + c] = in ? make_float2(dmaps[o], dmaps[map_stride + o]) : make_float2(0.f, 0.f);
+        s3[r * XP + c] = in ? dmaps[2 * map_stride + o] : 0.f;
     }
     __syncthreads();
-    for (int i = tid; i < SHALO * ST; i += 256) {
-        const int r = i >> 5, c = i & 31;
-        float a = 0.f, b = 0.f, d = 0.f;
+    for (int it = tid; it < SHALO * (ST / 4); it += 256) {
+        const int r = it >> 3, c0 = (it & 7) << 2;
+        float m1[14], m2[14], m3[14];
+        const float4* src = reinterpret_cast<const float4*>(&s12[r * XP + c0]);
 #pragma unroll
-        for (int k = 0; k < 11; k++) {
-            const float w = kG[k];
-            a += w * sm[0][r * SPITCH + c + k]; b += w * sm[1][r * SPITCH + c + k]; d += w * sm[2][r * SPITCH + c + k];
+        for (int k = 0; k < 7; k++) { const float4 t = src[k]; m1[2 * k] = t.x; m2[2 * k] = t.y; m1[2 * k + 1] = t.z; m2[2 * k + 1] = t.w; }
+        const float2* src3 = reinterpret_cast<const float2*>(&s3[r * XP + c0]);
+#pragma unroll
+        for (int k = 0; k < 7; k++) { const float2 t = src3[k]; m3[2 * k] = t.x; m3[2 * k + 1] = t.y; }
+        float a[4] = {0.f, 0.f, 0.f, 0.f}, b[4] = {0.f, 0.f, 0.f, 0.f}, d[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int e = 0; e < 14; e++) {
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int k = e - j;
+                if (k >= 0 && k < 11) { const float w = kG[k]; a[j] += w * m1[e]; b[j] += w * m2[e]; d[j] += w * m3[e]; }
+            }
         }
-        hz[0][i] = a; hz[1][i] = b; hz[2][i] = d;
+#pragma unroll
+        for (int j = 0; j < 4; j++) hz[r * HZP + c0 + j] = make_float4(a[j], b[j], d[j], 0.f);
     }
     __syncthreads();
     const float k_l1 = c_l1 * (g_l1_dev ? g_l1_dev[0] : 1.f), k_ss = c_ssim * (g_ssim_dev ? g_ssim_dev[0] : 1.f);
-    const int c = tid & 31, r0 = tid >> 5;
+    const int c = tid & 31, g = tid >> 5;
+    float a[4] = {0.f, 0.f, 0.f, 0.f}, b[4] = {0.f, 0.f, 0.f, 0.f}, d[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int e = 0; e < 14; e++) {
+        const float4 h = hz[(4 * g + e) * HZP + c];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int k = e - j;
+            if (k >= 0 && k < 11) { const float w = kG[k]; a[j] += w * h.x; b[j] += w * h.y; d[j] += w * h.z; }
+        }
+    }
 #pragma unroll
     for (int j = 0; j < 4; j++) {
-        const int r = r0 + 8 * j;
-        const int gy = y0 + r, gx = x0 + c;
+        const int gy = y0 + 4 * g + j, gx = x0 + c;
         if (gy >= H || gx >= W) continue;
-        float a = 0.f, b = 0.f, d = 0.f;
-#pragma unroll
-        for (int k = 0; k < 11; k++) {
-            const float w = kG[k];
-            const int o = (r + k) * ST + c;
-            a += w * hz[0][o]; b += w * hz[1][o]; d += w * hz[2][o];
-        }
         const size_t o = poff + (size_t)gy * W + gx;
         const float xv = img[o], yv = gt[o];
         const float df = xv - yv;
         const float sgn = df > 0.f ? 1.f : (df < 0.f ? -1.f : 0.f);
-        grad_img[o] = k_l1 * sgn + k_ss * (a + 2.f * xv * b + yv * d);
+        grad_img[o] = k_l1 * sgn + k_ss * (a[j] + 2.f * xv * b[j] + yv * d[j]);
     }
 }
 

@@ -61,11 +61,17 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (no CPU fallback for the rasterizer)")
+    backend = os.environ.get("SURFEL_DIST_BACKEND", "nccl")     # "gloo": rehearsal of the N>1 path with all ranks on one GPU
+    if backend != "nccl":
+        local = local % torch.cuda.device_count()
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     from helpers_bench import make_trainer
     P, W, H, zf = synthetic.CONFIGS[args.workload]
@@ -129,9 +135,22 @@ def main():
                     traffic = json.load(open(tf)).get(args.workload, {}).get(dom)
                 except Exception:
                     traffic = None
+            # second yardstick for the VALU-bound blend kernels: issued VALU wave-instructions per launch (SQ_INSTS_VALU from the
+            # committed PMC pass) against the chip's fp32 vector issue peak: 157.3 TFLOP/s / 128 flop per wave-FMA (MI355X_MICROARCH.md)
+            valu = None
+            try:
+                import glob
+                pm = sorted(glob.glob(os.path.join(REPO, "profiles", "r*_%s_pmc.json" % args.workload)))[-1]
+                n_inst = json.load(open(pm)).get(dom + "_kernel", {}).get("SQ_INSTS_VALU")
+                if n_inst:
+                    rate = n_inst / (per_kernel[dom] * 1e-3) / 1e9
+                    valu = {"wave_insts_per_launch": int(n_inst), "achieved_Ginst_per_s": round(rate, 1), "peak_Ginst_per_s": 1228.9,
+                            "frac": round(rate / 1228.9, 4), "source": os.path.basename(pm)}
+            except Exception:
+                valu = None
             roof = {"bound": "hbm", "kernel": dom, "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic, "algorithmic_bytes": int(B),
-                    "kernel_ms": round(per_kernel[dom], 4),
+                    "kernel_ms": round(per_kernel[dom], 4), "valu_issue": valu,
                     "all_kernels_ms": {k: round(v, 4) for k, v in per_kernel.items()},
                     "all_kernels_GBps": {k: round(algorithmic_bytes(k, P, V, R, W, H, n_pass) / (v * 1e-3) / 1e9, 1)
                                          for k, v in per_kernel.items() if v > 0}}

@@ -1,7 +1,8 @@
 #!/bin/bash
 # Run ON THE GPU BOX from the repo root (via gpurun):  bash scripts/profile_gpu.sh <tag> [workload]
 # Produces under gpurun_out/prof_<tag>/ :
-#   kt/      rocprofv3 --kernel-trace --stats of the default `python bench.py` command
+#   kt/      rocprofv3 --kernel-trace --stats of `python bench.py` (timed training step only: side legs off, so the per-kernel
+#            averages are those of the timed region)
 #   fetch/   --pmc FETCH_SIZE   (own pass: FETCH_SIZE takes 3 of the 4 TCC slots)
 #   write/   --pmc WRITE_SIZE   (own pass)
 #   sq/      --pmc SQ_* issue/wait counters
@@ -13,7 +14,7 @@ ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -o kt -- python $ROOT/bench.py --workload $WL > $OUT/bench_kt.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -o kt -- python $ROOT/bench.py --workload $WL --no-raster-only --no-1080p --no-cpu-baseline > $OUT/bench_kt.log 2>&1
 SHORT="--workload $WL --steps 8 --warmup 2 --no-cpu-baseline --no-1080p --no-train-iter"
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -o p -- python $ROOT/bench.py $SHORT > $OUT/bench_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/write -o p -- python $ROOT/bench.py $SHORT > $OUT/bench_write.log 2>&1
