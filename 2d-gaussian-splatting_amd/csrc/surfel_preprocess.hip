@@ -457,6 +457,7 @@ __global__ void __launch_bounds__(256) preprocess_bwd_kernel(PreprocessBwdArgs a
         const float x = dox * il, y = doy * il, z = doz * il;
         const uint8_t cb = a.clamped[i];
         const float gR[3] = {(cb & 1) ? 0.f : g[15], (cb & 2) ? 0.f : g[16], (cb & 4) ? 0.f : g[17]};
+        store3(a.dL_dcolors, i, gR[0], gR[1], gR[2]);      // SH mode: gradient w.r.t. the pre-clamp SH colour (include/surfel_hip.h)
         // SH basis B[k] and its direction derivatives dB[k]/d{x,y,z} for the active degree (zero above it)
         float B[16], Bx[16], By[16], Bz[16];
 #pragma unroll

@@ -83,6 +83,14 @@ int surfel_adam_step(int P, float* theta, const float* grad, float* m, float* v,
     return launched("adam kernels");
 }
 
+int surfel_sh_grad_gather(int P, int D, int N, const float* means3D, const float* campos_all, const float* gcol_all, float* dL_dsh, void* stream) {
+    if (P < 0 || D < 0 || D > 3 || N < 1 || (P > 0 && (!means3D || !campos_all || !gcol_all || !dL_dsh)))
+        return api_fail(SURFEL_E_INVALID, "sh_grad_gather: bad arguments");
+    if (P == 0) return 0;
+    launch_sh_grad_gather(P, D, N, means3D, campos_all, gcol_all, dL_dsh, static_cast<hipStream_t>(stream));
+    return launched("sh_grad_gather_kernel");
+}
+
 int surfel_densify_stats(int P, const float* dL_dmeans2D, const int* radii, float* grad_accum, float* denom, float* max_radii, void* stream) {
     if (P < 0 || (P > 0 && (!dL_dmeans2D || !radii || !grad_accum || !denom || !max_radii)))
         return api_fail(SURFEL_E_INVALID, "densify_stats: bad arguments");

@@ -2,7 +2,9 @@
 // + next iteration's activations) and the densification statistics.  Pure HBM streaming (28 B per parameter float).
 //
 // Store layout (raw parameters, gradients, Adam moments, all-reduce bucket all share it), P surfels:
-//   xyz 3P | sh 48P | opacity P | scaling 2P | rotation 4P      = 58 floats / surfel
+//   xyz 3P | opacity P | scaling 2P | rotation 4P | sh 48P      = 58 floats / surfel
+// (the 10 geometry floats first: under view-parallel training only they are all-reduced; the SH block is rebuilt from an
+// all-gather of 3 floats / surfel / rank, see sh_grad_gather_kernel)
 // Reference semantics restated: scene/gaussian_model.py:95-115 (exp / normalize / sigmoid), :153-162 (six Adam
 // groups, eps 1e-15), torch.optim.Adam's update rule, train.py:126-128 + gaussian_model.py:405-407 (statistics).
 #include <hip/hip_runtime.h>
@@ -31,14 +33,15 @@ __device__ __forceinline__ float adam_update(float p, float g, float& m, float& 
 
 __device__ __forceinline__ float sigmoidf(float x) { return 1.f / (1.f + expf(-x)); }
 
-// elementwise sections: xyz (3P) then sh (48P), contiguous at the start of the store
-__global__ __launch_bounds__(256) void adam_elem_kernel(size_t n_xyz, size_t n_all, float* __restrict__ theta, const float* __restrict__ grad,
-                                                        float* __restrict__ m, float* __restrict__ v, AdamK k) {
+// elementwise sections: xyz (3P floats at offset 0) and sh (48P floats at offset 10P); j runs over the 51P of them
+__global__ __launch_bounds__(256) void adam_elem_kernel(size_t n_xyz, size_t n_all, size_t sh_shift, float* __restrict__ theta,
+                                                        const float* __restrict__ grad, float* __restrict__ m, float* __restrict__ v, AdamK k) {
     const size_t stride = (size_t)gridDim.x * blockDim.x;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_all; i += stride) {
+    for (size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x; j < n_all; j += stride) {
         float lr;
-        if (i < n_xyz) lr = k.lr[0];
-        else lr = ((i - n_xyz) % 48) < 3 ? k.lr[1] : k.lr[2];
+        size_t i = j;
+        if (j < n_xyz) lr = k.lr[0];
+        else { lr = ((j - n_xyz) % 48) < 3 ? k.lr[1] : k.lr[2]; i = j + sh_shift; }
         float mi = m[i], vi = v[i];
         theta[i] = adam_update(theta[i], grad[i] * k.grad_scale, mi, vi, lr, k);
         m[i] = mi; v[i] = vi;
@@ -50,7 +53,7 @@ __global__ __launch_bounds__(256) void adam_act_kernel(int P, float* __restrict_
                                                        float* __restrict__ v, float* __restrict__ act, AdamK k) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= P) return;
-    const size_t o_op = (size_t)51 * P, o_sc = (size_t)52 * P, o_rot = (size_t)54 * P;
+    const size_t o_op = (size_t)3 * P, o_sc = (size_t)4 * P, o_rot = (size_t)6 * P;
     {   // opacity = sigmoid(x)
         const size_t o = o_op + i;
         const float x = theta[o], s = sigmoidf(x);
@@ -103,7 +106,7 @@ __global__ __launch_bounds__(256) void adam_act_kernel(int P, float* __restrict_
 __global__ __launch_bounds__(256) void activate_kernel(int P, const float* __restrict__ theta, float* __restrict__ act) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= P) return;
-    const size_t o_op = (size_t)51 * P, o_sc = (size_t)52 * P, o_rot = (size_t)54 * P;
+    const size_t o_op = (size_t)3 * P, o_sc = (size_t)4 * P, o_rot = (size_t)6 * P;
     act[i] = sigmoidf(theta[o_op + i]);
     act[(size_t)P + 2 * (size_t)i] = expf(theta[o_sc + 2 * (size_t)i]);
     act[(size_t)P + 2 * (size_t)i + 1] = expf(theta[o_sc + 2 * (size_t)i + 1]);
@@ -128,7 +131,67 @@ __global__ __launch_bounds__(256) void densify_stats_kernel(int P, const float* 
     maxr[i] = fmaxf(maxr[i], (float)r);
 }
 
+// View-parallel training: dL/dSH of the summed loss is  sum_r basis(dir(mean, campos_r)) (x) g_r  with g_r = rank r's
+// clamp-masked dL/dcolour (3 floats / surfel).  Exchanging g_r (all-gather, 12 B/surfel/rank) and rebuilding the 48 SH
+// gradients here replaces an all-reduce of 192 B/surfel; ranks are summed in rank order, so every replica gets the same bits.
+// Basis exactly as preprocess_bwd (the reference's eval_sh, utils/sh_utils.py:57-112), zero above the active degree D.
+__device__ __constant__ float GSH_C0 = 0.28209479177387814f;
+__device__ __constant__ float GSH_C1 = 0.4886025119029199f;
+__device__ __constant__ float GSH_C2[5] = {1.0925484305920792f, -1.0925484305920792f, 0.31539156525252005f, -1.0925484305920792f,
+                                           0.5462742152960396f};
+__device__ __constant__ float GSH_C3[7] = {-0.5900435899266435f, 2.890611442640554f, -0.4570457994644658f, 0.3731763325901154f,
+                                           -0.4570457994644658f, 1.445305721320277f, -0.5900435899266435f};
+
+__global__ __launch_bounds__(256) void sh_grad_gather_kernel(int P, int D, int N, const float* __restrict__ means3D,
+                                                             const float* __restrict__ campos_all, const float* __restrict__ gcol_all,
+                                                             float* __restrict__ dL_dsh) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P) return;
+    const float px = means3D[3 * (size_t)i], py = means3D[3 * (size_t)i + 1], pz = means3D[3 * (size_t)i + 2];
+    float acc[48];
+#pragma unroll
+    for (int q = 0; q < 48; q++) acc[q] = 0.f;
+    for (int r = 0; r < N; r++) {
+        const float* __restrict__ g = gcol_all + ((size_t)r * P + i) * 3;
+        const float gR[3] = {g[0], g[1], g[2]};
+        if (gR[0] == 0.f && gR[1] == 0.f && gR[2] == 0.f) continue;      // culled on rank r (or fully clamped): contributes zeros
+        const float dox = px - campos_all[3 * r], doy = py - campos_all[3 * r + 1], doz = pz - campos_all[3 * r + 2];
+        const float il = rsqrtf(dox * dox + doy * doy + doz * doz);
+        const float x = dox * il, y = doy * il, z = doz * il;
+        float B[16];
+#pragma unroll
+        for (int k = 0; k < 16; k++) B[k] = 0.f;
+        B[0] = GSH_C0;
+        if (D > 0) {
+            B[1] = -GSH_C1 * y; B[2] = GSH_C1 * z; B[3] = -GSH_C1 * x;
+            if (D > 1) {
+                const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+                B[4] = GSH_C2[0] * xy; B[5] = GSH_C2[1] * yz; B[6] = GSH_C2[2] * (2.f * zz - xx - yy); B[7] = GSH_C2[3] * xz;
+                B[8] = GSH_C2[4] * (xx - yy);
+                if (D > 2) {
+                    B[9] = GSH_C3[0] * y * (3.f * xx - yy); B[10] = GSH_C3[1] * xy * z; B[11] = GSH_C3[2] * y * (4.f * zz - xx - yy);
+                    B[12] = GSH_C3[3] * z * (2.f * zz - 3.f * xx - 3.f * yy); B[13] = GSH_C3[4] * x * (4.f * zz - xx - yy);
+                    B[14] = GSH_C3[5] * z * (xx - yy); B[15] = GSH_C3[6] * x * (xx - 3.f * yy);
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+#pragma unroll
+            for (int c = 0; c < 3; c++) acc[3 * k + c] += B[k] * gR[c];
+        }
+    }
+    float4* __restrict__ out = reinterpret_cast<float4*>(dL_dsh + (size_t)i * 48);
+#pragma unroll
+    for (int q = 0; q < 12; q++) out[q] = make_float4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
+}
+
 }  // namespace
+
+void launch_sh_grad_gather(int P, int D, int N, const float* means3D, const float* campos_all, const float* gcol_all, float* dL_dsh,
+                           hipStream_t s) {
+    hipLaunchKernelGGL(sh_grad_gather_kernel, dim3((P + 255) / 256), dim3(256), 0, s, P, D, N, means3D, campos_all, gcol_all, dL_dsh);
+}
 
 void launch_activate(int P, const float* theta, float* act, hipStream_t s) {
     hipLaunchKernelGGL(activate_kernel, dim3((P + 255) / 256), dim3(256), 0, s, P, theta, act);
@@ -142,7 +205,7 @@ void launch_adam(int P, float* theta, const float* grad, float* m, float* v, flo
     const size_t n_xyz = (size_t)3 * P, n_all = (size_t)51 * P;
     size_t blocks = (n_all + 256 * 4 - 1) / (256 * 4);
     if (blocks > 65536) blocks = 65536;
-    hipLaunchKernelGGL(adam_elem_kernel, dim3((unsigned)blocks), dim3(256), 0, s, n_xyz, n_all, theta, grad, m, v, k);
+    hipLaunchKernelGGL(adam_elem_kernel, dim3((unsigned)blocks), dim3(256), 0, s, n_xyz, n_all, (size_t)7 * P, theta, grad, m, v, k);
     hipLaunchKernelGGL(adam_act_kernel, dim3((P + 255) / 256), dim3(256), 0, s, P, theta, grad, m, v, act, k);
 }
 

@@ -22,7 +22,8 @@ _grad_arena = None
 
 def set_grad_arena(arena):
     """Optional (multi-GPU): a dict of preallocated fp32 tensors — any of means3D [P,3], sh [P,M,3], opacities [P,1],
-    scales [P,2], rotations [P,4] — that the backward writes its gradients into and returns, instead of fresh tensors.
+    scales [P,2], rotations [P,4], colors [P,3] (dL/dcolour; in SH mode the clamp-masked dL/d(SH colour) that
+    surfel_sh_grad_gather exchanges) — that the backward writes its gradients into and returns, instead of fresh tensors.
     surfel_dist.GradBucket.arena() hands out views of ONE flat buffer, so the gradient all-reduce needs no packing pass.
     The kernels write every element, so the tensors need no zeroing.  None restores the default."""
     global _grad_arena
@@ -119,7 +120,7 @@ class _RasterizeGaussians(torch.autograd.Function):
             if tuple(t.shape) != shape or t.dtype != torch.float32 or t.device != dev or not t.is_contiguous():
                 raise RuntimeError("grad arena tensor %r does not match %s fp32 contiguous on %s" % (name, shape, dev))
             return t
-        g_means2D, g_normal, g_colors = z(P, 3), z(P, 3), z(P, 3)
+        g_means2D, g_normal, g_colors = z(P, 3), z(P, 3), out("colors", P, 3)
         g_opac = out("opacities", P, 1)
         g_means3D, g_trans = out("means3D", P, 3), z(P, 9)
         g_sh = out("sh", P, M, 3) if has_sh else None

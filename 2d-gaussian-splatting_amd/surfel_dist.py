@@ -27,8 +27,9 @@ import torch
 import torch.distributed as dist
 
 # One flat fp32 buffer, planar by gradient tensor (the rasterizer's own outputs, so they can be written in place):
-# xyz 3 | sh 48 (= f_dc 3 + f_rest 45 per surfel, the reference's two SH parameter groups) | opacity 1 | scaling 2 | rotation 4
-BUCKET_LAYOUT = (("xyz", 3), ("sh", 48), ("opacity", 1), ("scaling", 2), ("rotation", 4))
+# xyz 3 | opacity 1 | scaling 2 | rotation 4 | sh 48 (= f_dc 3 + f_rest 45 per surfel, the reference's two SH parameter groups)
+# — the same layout as the surfel parameter store (include/surfel_train.h).
+BUCKET_LAYOUT = (("xyz", 3), ("opacity", 1), ("scaling", 2), ("rotation", 4), ("sh", 48))
 BUCKET_FLOATS = sum(n for _, n in BUCKET_LAYOUT)      # 58 floats = 232 B per surfel
 
 

@@ -2,7 +2,7 @@
 :124-146, training_setup :148-166, update_learning_rate :168-174, save/load_ply :193-255, reset_opacity :209-212,
 densify_and_prune :389-403, add_densification_stats :405-407, capture/restore :58-92) but laid out for the GPU:
 
-  * ONE flat fp32 store of 58 floats/surfel, planar by section  xyz 3P | sh 48P | opacity P | scaling 2P | rotation 4P
+  * ONE flat fp32 store of 58 floats/surfel, planar by section  xyz 3P | opacity P | scaling 2P | rotation 4P | sh 48P
     (include/surfel_train.h).  Raw parameters, gradients, Adam moments and the multi-GPU all-reduce bucket share this
     layout, so an optimiser step is ONE fused HIP launch pair (surfel_adam_step: activation backward + Adam + next
     iteration's activations) instead of 6 parameter groups x ~10 kernels, and the gradient all-reduce is ONE collective on
@@ -25,7 +25,8 @@ import torch
 import surfel_native as _n
 from simple_knn._C import distCUDA2
 
-SECTIONS = (("xyz", 3), ("sh", 48), ("opacity", 1), ("scaling", 2), ("rotation", 4))
+SECTIONS = (("xyz", 3), ("opacity", 1), ("scaling", 2), ("rotation", 4), ("sh", 48))
+GEOM_FLOATS = 10     # xyz + opacity + scaling + rotation: the contiguous prefix that view-parallel training all-reduces
 FLOATS = 58
 SH_C0 = 0.28209479177387814          # utils/sh_utils.py:26
 GROUPS = ("xyz", "f_dc", "f_rest", "opacity", "scaling", "rotation")   # Adam groups, scene/gaussian_model.py:153-160
@@ -76,6 +77,20 @@ def _views(buf, P):
     return out
 
 
+def exchange_collectives(grad, gcol, P, group=None):
+    """The two data-path collectives of a view-parallel step: all-reduce(SUM) of the geometry prefix of the flat gradient
+    store (in place) and all-gather of the per-rank colour gradients -> [world, P, 3]."""
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    dist.all_reduce(grad[:GEOM_FLOATS * P], op=dist.ReduceOp.SUM, group=group)
+    gall = torch.empty((world, P, 3), dtype=torch.float32, device=gcol.device)
+    try:
+        dist.all_gather_into_tensor(gall, gcol.contiguous(), group=group)
+    except (RuntimeError, NotImplementedError):          # backends without the flat form
+        dist.all_gather([gall[r] for r in range(world)], gcol.contiguous(), group=group)
+    return gall
+
+
 class GaussianModel:
     def __init__(self, sh_degree: int, device="cuda"):
         self.active_sh_degree = 0
@@ -111,6 +126,7 @@ class GaussianModel:
         self.grad = torch.zeros(P * FLOATS, dtype=torch.float32, device=dev)
         self.m = torch.zeros(P * FLOATS, dtype=torch.float32, device=dev)
         self.v = torch.zeros(P * FLOATS, dtype=torch.float32, device=dev)
+        self.gcol = torch.zeros((P, 3), dtype=torch.float32, device=dev)     # clamp-masked dL/dcolour of this rank's view
         self._gv = _views(self.grad, P)
 
     def _set(self, xyz, f_dc, f_rest, opacity, scaling, rotation):
@@ -219,7 +235,7 @@ class GaussianModel:
         import diff_surfel_rasterization as dsr
         gv = self._gv
         dsr.set_grad_arena(dict(means3D=gv["xyz"], sh=gv["sh"].view(self.P, 16, 3), opacities=gv["opacity"], scales=gv["scaling"],
-                                rotations=gv["rotation"]))
+                                rotations=gv["rotation"], colors=self.gcol))
 
     def update_learning_rate(self, iteration):
         lr = expon_lr(iteration, **self._lr_args)
@@ -236,6 +252,24 @@ class GaussianModel:
                                             _n.current_stream_ptr(self.device))
         if rc < 0:
             raise RuntimeError("surfel_adam_step failed: %s" % _n.last_error())
+
+    def exchange_gradients(self, campos_all, group=None):
+        """View-parallel step: make self.grad the SUM over ranks of the per-view gradients with
+          * ONE all-reduce of the contiguous geometry prefix (xyz, opacity, scaling, rotation: 40 B/surfel) and
+          * ONE all-gather of the clamp-masked dL/dcolour (12 B/surfel/rank) from which every rank rebuilds the 48 SH gradients
+            (surfel_sh_grad_gather) — exact, summed in rank order, so replicas stay bit-identical —
+        instead of all-reducing all 232 B/surfel.  campos_all [world,3]: camera centres of the ranks' views of this step."""
+        gall = exchange_collectives(self.grad, self.gcol, self.P, group)
+        self.sh_grad_from_colours(campos_all, gall)
+
+    def sh_grad_from_colours(self, campos_all, gcol_all):
+        """grad.sh = sum_r basis(dir(xyz, campos_all[r])) (x) gcol_all[r]  for the active SH degree (one HIP launch)."""
+        c = campos_all.contiguous().float(); g = gcol_all.contiguous().float()
+        with torch.cuda.device(self.device):
+            rc = _n.load().surfel_sh_grad_gather(self.P, int(self.active_sh_degree), int(g.shape[0]), _n.ptr(self._pv["xyz"]), _n.ptr(c),
+                                                 _n.ptr(g), _n.ptr(self._gv["sh"]), _n.current_stream_ptr(self.device))
+        if rc < 0:
+            raise RuntimeError("surfel_sh_grad_gather failed: %s" % _n.last_error())
 
     # ------------------------------------------------------------------ densification (scene/gaussian_model.py:257-407)
     def add_densification_stats(self, viewspace_point_tensor, update_filter=None, radii=None):
@@ -283,6 +317,7 @@ class GaussianModel:
         if m is not None:
             self.m, self.v = m, v
             self.grad = torch.zeros(Pn * FLOATS, dtype=torch.float32, device=self.device)
+            self.gcol = torch.zeros((Pn, 3), dtype=torch.float32, device=self.device)
             self._gv = _views(self.grad, Pn)
             self.bind()
         self._activate_host_or_device()

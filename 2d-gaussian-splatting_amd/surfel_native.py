@@ -21,7 +21,7 @@ EXPORTS = ["surfel_abi_version", "surfel_last_error", "surfel_rasterize_forward"
            "surfel_collect_stage_ms", "surfel_set_option", "surfel_debug_sort_pairs",
            # include/surfel_train.h
            "surfel_l1_ssim_forward", "surfel_l1_ssim_backward", "surfel_render_post_forward", "surfel_render_post_backward",
-           "surfel_reduce_partials", "surfel_loss_finalize", "surfel_activate", "surfel_adam_step", "surfel_densify_stats"]
+           "surfel_reduce_partials", "surfel_loss_finalize", "surfel_activate", "surfel_adam_step", "surfel_sh_grad_gather", "surfel_densify_stats"]
 
 _lib = None
 _lock = threading.Lock()
@@ -74,6 +74,7 @@ def load():
                            ("surfel_loss_finalize", [vp, i, i, vp, i, i, f, f, f, vp, vp]),
                            ("surfel_activate", [i, vp, vp, vp]),
                            ("surfel_adam_step", [i, vp, vp, vp, vp, vp, fp, f, f, f, i, f, vp]),
+                           ("surfel_sh_grad_gather", [i, i, i, vp, vp, vp, vp, vp]),
                            ("surfel_densify_stats", [i, vp, vp, vp, vp, vp, vp])):
             fn = getattr(lib, name)
             fn.restype = i

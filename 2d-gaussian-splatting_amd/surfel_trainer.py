@@ -3,7 +3,8 @@ view-parallel multi-GPU step of surfel_dist.py.
 
 Per iteration (1 view per GPU):  rasterize -> photometric loss (1 fwd + 1 bwd kernel) -> regularisers straight from allmap
 (1 fwd + 1 bwd kernel) -> rasterizer backward writing into the flat gradient store -> densification statistics (1 kernel)
--> [one all-reduce of the store over RCCL] -> fused Adam + activations (2 kernels).  The reference spends ~150 small PyTorch
+-> [RCCL: one all-reduce of the 40 B/surfel geometry gradients + one all-gather of 12 B/surfel/rank colour gradients, from which
+the 192 B/surfel SH gradients are rebuilt locally] -> fused Adam + activations (2 kernels).  The reference spends ~150 small PyTorch
 kernels on the same work around its rasterizer.
 
 Semantics kept from the reference: learning-rate schedule, SH degree every 1000 iterations, lambda_dist after 3000 and
@@ -133,9 +134,13 @@ class Trainer:
         if model.grad is None:
             model.training_setup(self.opt)
 
+    def _step_views(self):
+        """Camera indices of ALL ranks for the current iteration (every rank computes the same schedule)."""
+        return [surfel_dist.view_indices(len(self.cams), self.world, r, self.iteration - 1, self.seed) for r in range(self.world)]
+
     def _next_camera(self):
         if self.world > 1:
-            return self.cams[surfel_dist.view_indices(len(self.cams), self.world, self.rank, self.iteration - 1, self.seed)]
+            return self.cams[self._step_views()[self.rank]]
         if not self._stack:                       # train.py:64-67: pop a random view from a refilled stack
             self._stack = list(range(len(self.cams)))
         return self.cams[self._stack.pop(self._rng.randint(0, len(self._stack) - 1))]
@@ -180,7 +185,10 @@ class Trainer:
                         m._gv["opacity"].zero_()
             if it < opt.iterations and not rebuilt:     # re-created parameters carry no gradient in the reference: no update
                 if self.world > 1:
-                    dist.all_reduce(m.grad, op=dist.ReduceOp.SUM)       # ONE collective over the 232 B/surfel store
+                    # all-reduce of the 40 B/surfel geometry prefix + all-gather of 12 B/surfel/rank colour gradients; the 192 B/surfel
+                    # SH gradients are rebuilt locally from them (exact, rank-ordered sum) instead of being all-reduced
+                    campos_all = torch.stack([self.cams[v].camera_center for v in self._step_views()])
+                    m.exchange_gradients(campos_all)
                 m.optimizer_step(grad_scale=1.0 / self.world)
 
     def evaluate(self, cams=None):

@@ -3,7 +3,8 @@
 
 A "step" = ONE FULL TRAINING ITERATION of the reference's loop (/root/reference/train.py:54-138) on one synthetic view per
 GPU: rasterizer forward (preprocess / sort / blend) -> L1 + SSIM -> normal + distortion regularisers -> rasterizer backward
--> densification statistics -> [N > 1: ONE RCCL all-reduce of the 232 B/surfel gradient store] -> Adam step.
+-> densification statistics -> [N > 1: RCCL all-reduce of the 40 B/surfel geometry gradients + all-gather of the 12 B/surfel/rank
+colour gradients, SH gradients rebuilt locally] -> Adam step.
 Everything runs through the product's drop-in surface (surfel_trainer.Trainer over diff_surfel_rasterization +
 include/surfel_train.h kernels); inputs (parameters, target images, cameras) are resident in HBM before the timed region.
 N > 1: view-parallel — every rank trains on a different view of the same replicated surfel set per step (weak scaling).
@@ -162,7 +163,8 @@ def main():
                                       "surfels, 1 view/GPU/iteration, lambda_dssim 0.2, lambda_normal 0.05, lambda_dist 1000, depth_ratio 1, "
                                       "Adam on 58 floats/surfel" % (args.workload, P, W, H, n_views),
                           "P": P, "visible": V, "instances_R": R, "n_pass": n_pass, "tiles": tiles,
-                          "parallelism": "view-parallel dp%d, 1 all-reduce of 232 B/surfel per iteration" % world},
+                          "parallelism": "view-parallel dp%d; per iteration 1 all-reduce of 40 B/surfel (geometry gradients) + 1 all-gather of "
+                                         "12 B/surfel/rank (colour gradients -> SH gradients rebuilt locally)" % world},
                "loss_first": round(loss_first, 5), "loss_last": round(loss_last, 5),
                "train_Msplats_per_s": round(world * P * args.steps / dt / 1e6, 2), "roofline": roof}
 

@@ -92,8 +92,9 @@ int surfel_loss_finalize(const float* ssim_partials, int n_ssim, int n_pixels_pl
 
 /*
  * The surfel parameter store: ONE flat fp32 buffer of 58 floats per surfel, planar by section
- *   xyz 3P | sh 48P ([P,16,3]: coefficient 0 = f_dc, 1..15 = f_rest) | opacity P | scaling 2P | rotation 4P
- * (raw, pre-activation values; the six Adam groups of scene/gaussian_model.py:153-160).  Gradients, Adam moments
+ *   xyz 3P | opacity P | scaling 2P | rotation 4P | sh 48P ([P,16,3]: coefficient 0 = f_dc, 1..15 = f_rest)
+ * (raw, pre-activation values; the six Adam groups of scene/gaussian_model.py:153-160; the 10 geometry floats come
+ * first so that view-parallel training all-reduces one contiguous 40 B/surfel prefix).  Gradients, Adam moments
  * and the all-reduce bucket use the same layout.  `act` [7P] = sigmoid(opacity) P | exp(scaling) 2P |
  * normalize(rotation) 4P — what the rasterizer consumes.
  */
@@ -109,6 +110,16 @@ int surfel_activate(int P, const float* theta, float* act, void* stream);
  */
 int surfel_adam_step(int P, float* theta, const float* grad, float* m, float* v, float* act, const float* lr,
                      float beta1, float beta2, float eps, int t, float grad_scale, void* stream);
+
+/*
+ * View-parallel training (new; the reference is single-GPU): the SH gradient of the summed loss rebuilt from every
+ * rank's clamp-masked dL/dcolour instead of all-reducing 192 B/surfel:
+ *   dL_dsh[P,16,3] = sum_{r<N} basis(normalize(means3D - campos_all[r])) (x) gcol_all[r, :, :]      (rank order, D = active degree)
+ * gcol_all [N,P,3] = all-gather of surfel_rasterize_backward's dL_dcolors (in SH mode: masked by the forward's clamp);
+ * campos_all [N,3] = the camera centres of the N views of this step.  Basis as utils/sh_utils.py:57-112.
+ */
+int surfel_sh_grad_gather(int P, int D, int N, const float* means3D, const float* campos_all, const float* gcol_all,
+                          float* dL_dsh, void* stream);
 
 /*
  * Densification statistics of one rendered view: for surfels with radii > 0:

@@ -122,7 +122,7 @@ def render_post_np(allmap, wvt, fpt, W, H, depth_ratio, wmaps=None, lambda_norma
 
 
 # ------------------------------------------------------------------------------------------------ parameter store
-SECTIONS = (("xyz", 3), ("sh", 48), ("opacity", 1), ("scaling", 2), ("rotation", 4))
+SECTIONS = (("xyz", 3), ("opacity", 1), ("scaling", 2), ("rotation", 4), ("sh", 48))
 
 
 def activate(opacity, scaling, rotation):

@@ -135,7 +135,13 @@ def _trainer_stats_worker(rank, world, port, q):
         tr = TR.Trainer.__new__(TR.Trainer)
         tr.model, tr.world, tr.rank = model, world, rank
         tr._reduce_stats()
-        dist.all_reduce(model.grad, op=dist.ReduceOp.SUM)        # the per-iteration collective of Trainer.step
+        import surfel_model as SM
+        gcol = torch.full((P, 3), float(rank + 1))
+        gall = SM.exchange_collectives(model.grad, gcol, P)        # the per-iteration collectives of Trainer.step
+        assert gall.shape == (world, P, 3) and all(float(gall[r].min()) == float(gall[r].max()) == r + 1 for r in range(world))
+        # geometry prefix summed, SH block left to be rebuilt from the gathered colour gradients
+        assert torch.equal(model.grad[10 * P:], torch.arange(P * 58, dtype=torch.float32)[10 * P:] * (rank + 1))
+        model.grad[10 * P:] = torch.arange(P * 58, dtype=torch.float32)[10 * P:] * 3
         # every rank draws a different view of the same permutation
         views = [TR.surfel_dist.view_indices(9, world, rank, it, seed=3) for it in range(6)]
         q.put((rank, model.xyz_gradient_accum.reshape(-1).tolist(), model.denom.reshape(-1).tolist(), model.max_radii2D.tolist(),
