@@ -368,7 +368,6 @@ int surfel_rasterize_backward(surfel_alloc_fn scratch_alloc, void* scratch_user,
     if (!scratch_alloc || !geom_buffer || !binning_buffer || !image_buffer) return fail(SURFEL_E_INVALID, "buffer / allocator is NULL");
     if (!dL_dout_color || !dL_dout_others || !dL_dmeans2D || !dL_dnormal || !dL_dopacity || !dL_dcolors || !dL_dmeans3D || !dL_dtransMat)
         return fail(SURFEL_E_INVALID, "gradient pointer is NULL");
-    if (shs && !dL_dsh) return fail(SURFEL_E_INVALID, "dL_dsh is NULL");
     if (!transMat_precomp && (!dL_dscales || !dL_drots || !scales || !rotations)) return fail(SURFEL_E_INVALID, "scale/rotation pointers are NULL");
     const int gx = (width + TILE - 1) / TILE, gy = (height + TILE - 1) / TILE;
 

@@ -329,7 +329,7 @@ __global__ void __launch_bounds__(256) preprocess_bwd_kernel(PreprocessBwdArgs a
     if (i >= a.P) return;
     const bool precomp = a.transMat_precomp != nullptr;
     const bool vis = a.radii[i] > 0;
-    float4* __restrict__ gshq = a.shs ? reinterpret_cast<float4*>(a.dL_dsh + (size_t)i * a.M * 3) : nullptr;
+    float4* __restrict__ gshq = (a.shs && a.dL_dsh) ? reinterpret_cast<float4*>(a.dL_dsh + (size_t)i * a.M * 3) : nullptr;
     if (!vis) {
         a.dL_dopacity[i] = 0.f;
         store3(a.dL_dnormal, i, 0.f, 0.f, 0.f); store3(a.dL_dcolors, i, 0.f, 0.f, 0.f);
@@ -501,23 +501,23 @@ __global__ void __launch_bounds__(256) preprocess_bwd_kernel(PreprocessBwdArgs a
                     const float t = cv[e] * gR[c];
                     gdx += Bx[k] * t; gdy += By[k] * t; gdz += Bz[k] * t;
                 }
-                gshq[v] = make_float4(o[0], o[1], o[2], o[3]);
+                if (gshq) gshq[v] = make_float4(o[0], o[1], o[2], o[3]);
             }
         } else {
             const float* __restrict__ sh = a.shs + (size_t)i * a.M * 3;
-            float* __restrict__ gsh = a.dL_dsh + (size_t)i * a.M * 3;
+            float* __restrict__ gsh = a.dL_dsh ? a.dL_dsh + (size_t)i * a.M * 3 : nullptr;
 #pragma unroll
             for (int k = 0; k < 16; k++) {
                 if (k < a.M) {
 #pragma unroll
                     for (int c = 0; c < 3; c++) {
-                        gsh[3 * k + c] = B[k] * gR[c];
+                        if (gsh) gsh[3 * k + c] = B[k] * gR[c];
                         const float t = sh[3 * k + c] * gR[c];
                         gdx += Bx[k] * t; gdy += By[k] * t; gdz += Bz[k] * t;
                     }
                 }
             }
-            for (int k = 16; k < a.M; k++) { gsh[3 * k] = 0.f; gsh[3 * k + 1] = 0.f; gsh[3 * k + 2] = 0.f; }
+            if (gsh) for (int k = 16; k < a.M; k++) { gsh[3 * k] = 0.f; gsh[3 * k + 1] = 0.f; gsh[3 * k + 2] = 0.f; }
         }
         const float il3 = il * il * il;
         dmx += ((sum2 - dox * dox) * gdx - doy * dox * gdy - doz * dox * gdz) * il3;

@@ -142,13 +142,9 @@ __device__ __constant__ float GSH_C2[5] = {1.0925484305920792f, -1.0925484305920
 __device__ __constant__ float GSH_C3[7] = {-0.5900435899266435f, 2.890611442640554f, -0.4570457994644658f, 0.3731763325901154f,
                                            -0.4570457994644658f, 1.445305721320277f, -0.5900435899266435f};
 
-__global__ __launch_bounds__(256) void sh_grad_gather_kernel(int P, int D, int N, const float* __restrict__ means3D,
-                                                             const float* __restrict__ campos_all, const float* __restrict__ gcol_all,
-                                                             float* __restrict__ dL_dsh) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= P) return;
-    const float px = means3D[3 * (size_t)i], py = means3D[3 * (size_t)i + 1], pz = means3D[3 * (size_t)i + 2];
-    float acc[48];
+// acc[48] += sum over ranks of basis_r (x) g_r for surfel i (rank order)
+__device__ __forceinline__ void sh_grad_rebuild(int i, int P, int D, int N, float px, float py, float pz, const float* __restrict__ campos_all,
+                                                const float* __restrict__ gcol_all, float (&acc)[48]) {
 #pragma unroll
     for (int q = 0; q < 48; q++) acc[q] = 0.f;
     for (int r = 0; r < N; r++) {
@@ -181,9 +177,48 @@ __global__ __launch_bounds__(256) void sh_grad_gather_kernel(int P, int D, int N
             for (int c = 0; c < 3; c++) acc[3 * k + c] += B[k] * gR[c];
         }
     }
+}
+
+__global__ __launch_bounds__(256) void sh_grad_gather_kernel(int P, int D, int N, const float* __restrict__ means3D,
+                                                             const float* __restrict__ campos_all, const float* __restrict__ gcol_all,
+                                                             float* __restrict__ dL_dsh) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P) return;
+    float acc[48];
+    sh_grad_rebuild(i, P, D, N, means3D[3 * (size_t)i], means3D[3 * (size_t)i + 1], means3D[3 * (size_t)i + 2], campos_all, gcol_all, acc);
     float4* __restrict__ out = reinterpret_cast<float4*>(dL_dsh + (size_t)i * 48);
 #pragma unroll
     for (int q = 0; q < 12; q++) out[q] = make_float4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
+}
+
+// Adam on the SH block with the gradients rebuilt in registers from the colour gradients: the 192 B/surfel SH gradient never
+// exists in HBM (the rasterizer's backward skips writing it, this kernel skips reading it).  Must run BEFORE the xyz update
+// (the view directions use the positions the forward saw).
+__global__ __launch_bounds__(256) void adam_sh_kernel(int P, int D, int N, float* __restrict__ theta, float* __restrict__ m, float* __restrict__ v,
+                                                      const float* __restrict__ campos_all, const float* __restrict__ gcol_all, AdamK k) {
+    // one workgroup = 64 surfels: wave 0 rebuilds their 48 SH gradients into LDS, then all 256 threads run Adam over the
+    // 64 x 48 contiguous floats of theta / m / v (coalesced)
+    __shared__ float s_g[64 * 49];
+    const int tid = threadIdx.x;
+    const int i0 = blockIdx.x * 64;
+    if (tid < 64) {
+        const int i = i0 + tid;
+        if (i < P) {
+            float acc[48];
+            sh_grad_rebuild(i, P, D, N, theta[3 * (size_t)i], theta[3 * (size_t)i + 1], theta[3 * (size_t)i + 2], campos_all, gcol_all, acc);
+#pragma unroll
+            for (int q = 0; q < 48; q++) s_g[tid * 49 + q] = acc[q] * k.grad_scale;
+        }
+    }
+    __syncthreads();
+    const int n = min(64, P - i0) * 48;
+    const size_t o = (size_t)10 * P + (size_t)48 * i0;
+    for (int e = tid; e < n; e += 256) {
+        const int sfl = e / 48, flat = e - sfl * 48;
+        float mi = m[o + e], vi = v[o + e];
+        theta[o + e] = adam_update(theta[o + e], s_g[sfl * 49 + flat], mi, vi, flat < 3 ? k.lr[1] : k.lr[2], k);
+        m[o + e] = mi; v[o + e] = vi;
+    }
 }
 
 }  // namespace
@@ -198,11 +233,16 @@ void launch_activate(int P, const float* theta, float* act, hipStream_t s) {
 }
 
 void launch_adam(int P, float* theta, const float* grad, float* m, float* v, float* act, const float* lr, float beta1, float beta2, float eps,
-                 float bc1, float bc2_sqrt, float grad_scale, hipStream_t s) {
+                 float bc1, float bc2_sqrt, float grad_scale, int D, int N, const float* campos_all, const float* gcol_all, hipStream_t s) {
     AdamK k;
     for (int i = 0; i < 6; i++) k.lr[i] = lr[i];
     k.beta1 = beta1; k.beta2 = beta2; k.eps = eps; k.bc1 = bc1; k.bc2_sqrt = bc2_sqrt; k.grad_scale = grad_scale;
-    const size_t n_xyz = (size_t)3 * P, n_all = (size_t)51 * P;
+    const size_t n_xyz = (size_t)3 * P;
+    size_t n_all = (size_t)51 * P;
+    if (gcol_all) {      // SH gradients rebuilt from the colour gradients inside the SH Adam kernel (before xyz moves)
+        hipLaunchKernelGGL(adam_sh_kernel, dim3((P + 63) / 64), dim3(256), 0, s, P, D, N, theta, m, v, campos_all, gcol_all, k);
+        n_all = n_xyz;
+    }
     size_t blocks = (n_all + 256 * 4 - 1) / (256 * 4);
     if (blocks > 65536) blocks = 65536;
     hipLaunchKernelGGL(adam_elem_kernel, dim3((unsigned)blocks), dim3(256), 0, s, n_xyz, n_all, (size_t)7 * P, theta, grad, m, v, k);

@@ -25,7 +25,8 @@ def set_grad_arena(arena):
     scales [P,2], rotations [P,4], colors [P,3] (dL/dcolour; in SH mode the clamp-masked dL/d(SH colour) that
     surfel_sh_grad_gather exchanges) — that the backward writes its gradients into and returns, instead of fresh tensors.
     surfel_dist.GradBucket.arena() hands out views of ONE flat buffer, so the gradient all-reduce needs no packing pass.
-    The kernels write every element, so the tensors need no zeroing.  None restores the default."""
+    The kernels write every element, so the tensors need no zeroing.  An explicit `sh=None` entry makes the backward skip the
+    SH-coefficient gradients altogether (their autograd gradient is then None).  None restores the default."""
     global _grad_arena
     _grad_arena = arena
 
@@ -123,7 +124,8 @@ class _RasterizeGaussians(torch.autograd.Function):
         g_means2D, g_normal, g_colors = z(P, 3), z(P, 3), out("colors", P, 3)
         g_opac = out("opacities", P, 1)
         g_means3D, g_trans = out("means3D", P, 3), z(P, 9)
-        g_sh = out("sh", P, M, 3) if has_sh else None
+        skip_sh = has_sh and "sh" in arena and arena["sh"] is None     # caller rebuilds dL/dSH from dL/dcolour (include/surfel_train.h)
+        g_sh = out("sh", P, M, 3) if (has_sh and not skip_sh) else None
         g_scales = out("scales", P, 2) if has_sr else None
         g_rots = out("rotations", P, 4) if has_sr else None
         gc = grad_out_color.contiguous().float() if grad_out_color is not None else torch.zeros((3, H, W), device=dev)

@@ -230,26 +230,34 @@ class GaussianModel:
         self._alloc_training()
         self.bind()
 
-    def bind(self):
-        """Point the rasterizer's backward at this model's gradient store (zero-copy)."""
+    def bind(self, sh_grad=True):
+        """Point the rasterizer's backward at this model's gradient store (zero-copy).  sh_grad=False: the backward skips the
+        192 B/surfel SH gradients; optimizer_step(colour_grads=...) rebuilds them in registers from the colour gradients."""
         import diff_surfel_rasterization as dsr
         gv = self._gv
-        dsr.set_grad_arena(dict(means3D=gv["xyz"], sh=gv["sh"].view(self.P, 16, 3), opacities=gv["opacity"], scales=gv["scaling"],
-                                rotations=gv["rotation"], colors=self.gcol))
+        dsr.set_grad_arena(dict(means3D=gv["xyz"], sh=gv["sh"].view(self.P, 16, 3) if sh_grad else None, opacities=gv["opacity"],
+                                scales=gv["scaling"], rotations=gv["rotation"], colors=self.gcol))
 
     def update_learning_rate(self, iteration):
         lr = expon_lr(iteration, **self._lr_args)
         self.lr[0] = lr
         return lr
 
-    def optimizer_step(self, grad_scale=1.0):
-        """optimizer.step() + zero_grad (train.py:136-138) as one fused launch pair; refreshes the activations."""
+    def optimizer_step(self, grad_scale=1.0, colour_grads=None):
+        """optimizer.step() + zero_grad (train.py:136-138) as fused launches; refreshes the activations.
+        colour_grads = (campos_all [N,3], gcol_all [N,P,3]): the SH block's gradients are rebuilt from the views' colour
+        gradients inside the kernel (N = 1: this rank's view; N > 1: after exchange_collectives) instead of read from self.grad."""
         self.step_count += 1
         lr = (C.c_float * 6)(*self.lr)
+        cam = gc = None
+        N = 0
+        if colour_grads is not None:
+            cam, gc = colour_grads[0].contiguous().float(), colour_grads[1].contiguous().float()
+            N = int(gc.shape[0])
         with torch.cuda.device(self.device):
             rc = _n.load().surfel_adam_step(self.P, _n.ptr(self.theta), _n.ptr(self.grad), _n.ptr(self.m), _n.ptr(self.v), _n.ptr(self.act),
                                             lr, self.betas[0], self.betas[1], self.eps, self.step_count, float(grad_scale),
-                                            _n.current_stream_ptr(self.device))
+                                            int(self.active_sh_degree), N, _n.ptr(cam), _n.ptr(gc), _n.current_stream_ptr(self.device))
         if rc < 0:
             raise RuntimeError("surfel_adam_step failed: %s" % _n.last_error())
 

@@ -13,6 +13,7 @@ re-create the parameters (densification), Adam(eps=1e-15).  Multi-GPU: G views p
 densification statistics are accumulated locally and all-reduced only when a densification is due.
 """
 import math
+import os
 import random
 import time
 from types import SimpleNamespace
@@ -23,7 +24,7 @@ import torch.distributed as dist
 
 import surfel_dist
 from surfel_losses import train_loss
-from surfel_model import GaussianModel
+from surfel_model import GaussianModel, exchange_collectives
 from surfel_render import Camera, rasterize, render
 
 
@@ -131,6 +132,9 @@ class Trainer:
         self._stack = []
         self.iteration = 0
         self.last = {}
+        # fused SH path (default): the rasterizer's backward skips the 192 B/surfel SH gradients, the optimiser kernel rebuilds them
+        # from the 12 B/surfel colour gradients.  Always on under view-parallel training (that is how the gradients are exchanged).
+        self.fused_sh = self.world > 1 or os.environ.get("SURFEL_SH_FUSED", "1") != "0"
         if model.grad is None:
             model.training_setup(self.opt)
 
@@ -160,7 +164,7 @@ class Trainer:
         if it % 1000 == 0:
             m.oneupSHdegree()
         cam = self._next_camera()
-        m.bind()
+        m.bind(sh_grad=not self.fused_sh)      # fused: the SH gradients are rebuilt inside the optimiser kernel from the colour gradients
         image, radii, allmap, means2D = rasterize(cam, m, self.pipe, self.background)
         lam_n = opt.lambda_normal if it > opt.normal_from_iter else 0.0
         lam_d = opt.lambda_dist if it > opt.dist_from_iter else 0.0
@@ -186,10 +190,12 @@ class Trainer:
             if it < opt.iterations and not rebuilt:     # re-created parameters carry no gradient in the reference: no update
                 if self.world > 1:
                     # all-reduce of the 40 B/surfel geometry prefix + all-gather of 12 B/surfel/rank colour gradients; the 192 B/surfel
-                    # SH gradients are rebuilt locally from them (exact, rank-ordered sum) instead of being all-reduced
+                    # SH gradients are rebuilt from them (exact, rank-ordered sum) instead of being all-reduced
                     campos_all = torch.stack([self.cams[v].camera_center for v in self._step_views()])
-                    m.exchange_gradients(campos_all)
-                m.optimizer_step(grad_scale=1.0 / self.world)
+                    gcol_all = exchange_collectives(m.grad, m.gcol, m.P)
+                elif self.fused_sh:
+                    campos_all, gcol_all = cam.camera_center[None], m.gcol[None]
+                m.optimizer_step(grad_scale=1.0 / self.world, colour_grads=(campos_all, gcol_all) if self.fused_sh else None)
 
     def evaluate(self, cams=None):
         """Mean PSNR / L1 over views (training_report, train.py:201-232)."""

@@ -107,9 +107,13 @@ int surfel_activate(int P, const float* theta, float* act, void* stream);
  * all-reduce).  Adam exactly as torch.optim.Adam(betas, eps, no weight decay, no amsgrad) at step `t` (1-based),
  * per-group learning rates lr[6] = xyz, f_dc, f_rest, opacity, scaling, rotation (host array).
  * Writes theta, m, v in place and the new activated values to act.
+ * SH block: with gcol_all == NULL its gradients are read from grad like the rest.  With gcol_all [N,P,3] (+ campos_all [N,3],
+ * active degree D) they are rebuilt in registers as in surfel_sh_grad_gather — the 192 B/surfel SH gradient is then never
+ * written (surfel_rasterize_backward accepts dL_dsh == NULL) nor read; N = 1 for single-GPU training.
  */
 int surfel_adam_step(int P, float* theta, const float* grad, float* m, float* v, float* act, const float* lr,
-                     float beta1, float beta2, float eps, int t, float grad_scale, void* stream);
+                     float beta1, float beta2, float eps, int t, float grad_scale,
+                     int D, int N, const float* campos_all, const float* gcol_all, void* stream);
 
 /*
  * View-parallel training (new; the reference is single-GPU): the SH gradient of the summed loss rebuilt from every
