@@ -95,8 +95,10 @@ __device__ __forceinline__ uint32_t preprocess_one(const PreprocessArgs& a, cons
             float dx = px - a.campos[0], dy = py - a.campos[1], dz = pz - a.campos[2];
             const float il = rsqrtf(dx * dx + dy * dy + dz * dz);
             dx *= il; dy *= il; dz *= il;
-            // basis values for the active degree
+            // basis values for the active degree (zero above it)
             float B[16];
+#pragma unroll
+            for (int k = 1; k < 16; k++) B[k] = 0.f;
             B[0] = SH_C0;
             int nb = 1;
             if (a.D > 0) {
@@ -113,21 +115,34 @@ __device__ __forceinline__ uint32_t preprocess_one(const PreprocessArgs& a, cons
                     }
                 }
             }
-            // coefficients are [M][3] floats = 12 float4 for M = 16; walk them as float4 (16-B loads),
-            // statically indexed (a runtime-indexed B[] would live in scratch), skipping the float4s
-            // that hold only inactive coefficients (wave-uniform branch)
+            // coefficients are [M][3] floats = 12 float4 for M = 16.  ALL loads of the surfel are issued back to back before any
+            // use (one round trip, and each 128-B line is consumed while it is still in L2): with the loads interleaved with the
+            // FMAs the compiler serialised 12 dependent round trips and the kernel fetched 2.6x its algorithmic bytes.
+            // Only the float4s holding active coefficients are read (wave-uniform degree): 1 / 3 / 7 / 12.
             if (a.M == 16) {
+                float4 c4[12];
+#pragma unroll
+                for (int v = 0; v < 12; v++) c4[v] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (a.D > 2) {
+#pragma unroll
+                    for (int v = 0; v < 12; v++) c4[v] = shq[v];
+                } else if (a.D == 2) {
+#pragma unroll
+                    for (int v = 0; v < 7; v++) c4[v] = shq[v];
+                } else if (a.D == 1) {
+#pragma unroll
+                    for (int v = 0; v < 3; v++) c4[v] = shq[v];
+                } else {
+                    c4[0] = shq[0];
+                }
                 float acc[3] = {0.f, 0.f, 0.f};
 #pragma unroll
                 for (int v = 0; v < 12; v++) {
-                    if (4 * v < 3 * nb) {
-                        const float4 c4 = shq[v];
-                        const float cv[4] = {c4.x, c4.y, c4.z, c4.w};
+                    const float cv[4] = {c4[v].x, c4[v].y, c4[v].z, c4[v].w};
 #pragma unroll
-                        for (int e = 0; e < 4; e++) {
-                            const int flat = 4 * v + e;          // = 3*coef + channel
-                            if (flat / 3 < 16) acc[flat % 3] += (flat / 3 < nb ? B[flat / 3] : 0.f) * cv[e];
-                        }
+                    for (int e = 0; e < 4; e++) {
+                        const int flat = 4 * v + e;          // = 3*coef + channel; B is zero above the active degree
+                        acc[flat % 3] += B[flat / 3] * cv[e];
                     }
                 }
                 r = acc[0]; g = acc[1]; b = acc[2];
@@ -355,7 +370,8 @@ __global__ void __launch_bounds__(256) preprocess_bwd_kernel(PreprocessBwdArgs a
 #pragma unroll
     for (int q = 0; q < NV; q++) g[q] = 0.f;
     const float4* __restrict__ rq = reinterpret_cast<const float4*>(a.rec + (size_t)i * REC_F);
-    const float4 r4 = rq[4];
+    // the whole record is read up front (one round trip; its one or two 128-B lines are consumed while still in L2)
+    const float4 r4 = rq[4], r0 = rq[0], r1 = rq[1], r2 = rq[2];
     const uint32_t beg = __float_as_uint(r4.z);          // inst_base patched by emit_instances
     const uint32_t end = beg + a.tiles_touched[i];
     for (uint32_t k = beg; k < end; k++) {
@@ -371,7 +387,6 @@ __global__ void __launch_bounds__(256) preprocess_bwd_kernel(PreprocessBwdArgs a
     store3(a.dL_dnormal, i, g[11], g[12], g[13]);
     store3(a.dL_dcolors, i, g[15], g[16], g[17]);
 
-    const float4 r0 = rq[0], r1 = rq[1], r2 = rq[2];
     const float T[9] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w, r2.x};
     float gT[9];
 #pragma unroll
