@@ -21,7 +21,6 @@ extern "C" {
 
 int surfel_l1_ssim_forward(int planes, int H, int W, const float* img, const float* gt, float* dmaps, float* partials, void* stream) {
     if (planes <= 0 || H <= 0 || W <= 0 || !img || !gt || !partials) return api_fail(SURFEL_E_INVALID, "l1_ssim_forward: bad arguments");
-    if (planes > 65535) return api_fail(SURFEL_E_LIMIT, "l1_ssim_forward: more than 65535 planes");
     launch_ssim_fwd(planes, H, W, img, gt, dmaps, partials, static_cast<hipStream_t>(stream));
     const int rc = launched("ssim_fwd_kernel");
     return rc < 0 ? rc : ssim_blocks(H, W);
@@ -30,7 +29,6 @@ int surfel_l1_ssim_forward(int planes, int H, int W, const float* img, const flo
 int surfel_l1_ssim_backward(int planes, int H, int W, const float* img, const float* gt, const float* dmaps, float c_l1, float c_ssim,
                             const float* g_l1_dev, const float* g_ssim_dev, float* grad_img, void* stream) {
     if (planes <= 0 || H <= 0 || W <= 0 || !img || !gt || !dmaps || !grad_img) return api_fail(SURFEL_E_INVALID, "l1_ssim_backward: bad arguments");
-    if (planes > 65535) return api_fail(SURFEL_E_LIMIT, "l1_ssim_backward: more than 65535 planes");
     launch_ssim_bwd(planes, H, W, img, gt, dmaps, c_l1, c_ssim, g_l1_dev, g_ssim_dev, grad_img, static_cast<hipStream_t>(stream));
     return launched("ssim_bwd_kernel");
 }

@@ -4,6 +4,7 @@
 // kernels per direction.  One workgroup = 4 waves = a 32x32 output tile staged with a 5-pixel halo (42x42).
 #include <hip/hip_runtime.h>
 
+#include "surfel_common.h"
 #include "train_kernels.h"
 
 namespace surfel {
@@ -40,8 +41,12 @@ __global__ __launch_bounds__(256) void ssim_fwd_kernel(int H, int W, const float
     __shared__ float hz1[SHALO * ST];
     __shared__ float red[8];
     const int tid = threadIdx.x;
-    const int plane = blockIdx.z;
-    const int x0 = blockIdx.x * ST, y0 = blockIdx.y * ST;
+    // workgroup b runs on XCD b % 8: every XCD gets a contiguous run of (plane, tile) so that neighbouring tiles' halos hit in
+    // one L2 instead of being fetched from HBM once per XCD
+    const int gxt = (W + ST - 1) / ST, ntile = gxt * ((H + ST - 1) / ST);
+    const int lin = xcd_tile(blockIdx.x, gridDim.x);
+    const int plane = lin / ntile, tile = lin - plane * ntile;
+    const int x0 = (tile % gxt) * ST, y0 = (tile / gxt) * ST;
     const size_t poff = (size_t)plane * H * W;
     const float* X = img + poff;
     const float* Y = gt + poff;
@@ -124,7 +129,7 @@ __global__ __launch_bounds__(256) void ssim_fwd_kernel(int H, int W, const float
     if ((tid & 63) == 0) { red[2 * (tid >> 6)] = l1; red[2 * (tid >> 6) + 1] = ss; }
     __syncthreads();
     if (tid == 0) {
-        const size_t blk = ((size_t)plane * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+        const size_t blk = (size_t)lin;
         partials[2 * blk] = (red[0] + red[2]) + (red[4] + red[6]);
         partials[2 * blk + 1] = (red[1] + red[3]) + (red[5] + red[7]);
     }
@@ -138,8 +143,12 @@ __global__ __launch_bounds__(256) void ssim_bwd_kernel(int H, int W, const float
     __shared__ float s3[SHALO * XP];        // M3
     __shared__ float4 hz[SHALO * HZP];      // horizontal pass of (M1, M2, M3, -)
     const int tid = threadIdx.x;
-    const int plane = blockIdx.z;
-    const int x0 = blockIdx.x * ST, y0 = blockIdx.y * ST;
+    // workgroup b runs on XCD b % 8: every XCD gets a contiguous run of (plane, tile) so that neighbouring tiles' halos hit in
+    // one L2 instead of being fetched from HBM once per XCD
+    const int gxt = (W + ST - 1) / ST, ntile = gxt * ((H + ST - 1) / ST);
+    const int lin = xcd_tile(blockIdx.x, gridDim.x);
+    const int plane = lin / ntile, tile = lin - plane * ntile;
+    const int x0 = (tile % gxt) * ST, y0 = (tile / gxt) * ST;
     const size_t poff = (size_t)plane * H * W;
     for (int i = tid; i < SHALO * SHALO; i += 256) {
         const int r = i / SHALO, c = i - r * SHALO;
@@ -246,13 +255,13 @@ __global__ __launch_bounds__(256) void loss_finalize_kernel(const float* __restr
 int ssim_blocks(int H, int W) { return ((W + ST - 1) / ST) * ((H + ST - 1) / ST); }
 
 void launch_ssim_fwd(int planes, int H, int W, const float* img, const float* gt, float* dmaps, float* partials, hipStream_t s) {
-    dim3 grid((W + ST - 1) / ST, (H + ST - 1) / ST, planes);
+    dim3 grid(ssim_blocks(H, W) * planes);
     hipLaunchKernelGGL(ssim_fwd_kernel, grid, dim3(256), 0, s, H, W, img, gt, dmaps, (size_t)planes * H * W, partials);
 }
 
 void launch_ssim_bwd(int planes, int H, int W, const float* img, const float* gt, const float* dmaps, float c_l1, float c_ssim,
                      const float* g_l1_dev, const float* g_ssim_dev, float* grad_img, hipStream_t s) {
-    dim3 grid((W + ST - 1) / ST, (H + ST - 1) / ST, planes);
+    dim3 grid(ssim_blocks(H, W) * planes);
     hipLaunchKernelGGL(ssim_bwd_kernel, grid, dim3(256), 0, s, H, W, img, gt, dmaps, (size_t)planes * H * W, c_l1, c_ssim, g_l1_dev,
                        g_ssim_dev, grad_img);
 }

@@ -8,6 +8,7 @@
 
 #include <cfloat>
 
+#include "surfel_common.h"
 #include "train_kernels.h"
 
 namespace surfel {
@@ -69,7 +70,11 @@ __global__ __launch_bounds__(256) void post_fwd_kernel(int H, int W, const float
     __shared__ float red[8];
     const Cam c = load_cam(cam);
     const int tid = threadIdx.x;
-    const int x0 = blockIdx.x * PT, y0 = blockIdx.y * PT;
+    // workgroup b runs on XCD b % 8: give every XCD a contiguous band of tiles so that the halos neighbouring tiles share are
+    // served by one L2 instead of being fetched from HBM once per XCD (measured 2.4x the algorithmic bytes without this)
+    const int gxt = (W + PT - 1) / PT;
+    const int tile = xcd_tile(blockIdx.x, gridDim.x);
+    const int x0 = (tile % gxt) * PT, y0 = (tile / gxt) * PT;
     const size_t HW = (size_t)H * W;
     for (int i = tid; i < HB * HB; i += 256) {
         const int r = i / HB, cc = i - r * HB;
@@ -108,10 +113,7 @@ __global__ __launch_bounds__(256) void post_fwd_kernel(int H, int W, const float
             for (int j = 0; j < 3; j++) sn[j] = v[j] * inv * alpha;
         }
         const float dist = allmap[6 * HW + o];
-        const int q = (ly + 1) * HB + lx + 1;
-        // own surf_depth: recover from the staged point would lose bits; recompute
-        const float sd = surf_depth_at(allmap, HW, o, ratio);
-        (void)q;
+        const float sd = surf_depth_at(allmap, HW, o, ratio);      // recomputed: recovering it from the staged point would lose bits
         maps[o] = alpha;
         maps[HW + o] = rn[0]; maps[2 * HW + o] = rn[1]; maps[3 * HW + o] = rn[2];
         maps[4 * HW + o] = dist;
@@ -125,7 +127,7 @@ __global__ __launch_bounds__(256) void post_fwd_kernel(int H, int W, const float
         if ((tid & 63) == 0) { red[2 * (tid >> 6)] = e_n; red[2 * (tid >> 6) + 1] = e_d; }
         __syncthreads();
         if (tid == 0) {
-            const size_t blk = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
+            const size_t blk = (size_t)tile;
             partials[2 * blk] = (red[0] + red[2]) + (red[4] + red[6]);
             partials[2 * blk + 1] = (red[1] + red[3]) + (red[5] + red[7]);
         }
@@ -142,7 +144,9 @@ __global__ __launch_bounds__(256) void post_bwd_kernel(int H, int W, const float
     __shared__ float sn_s[3][HD * HD];   // the pixel's surf_normal (unit normal * alpha) for the fused regulariser
     const Cam c = load_cam(cam);
     const int tid = threadIdx.x;
-    const int x0 = blockIdx.x * PT, y0 = blockIdx.y * PT;
+    const int gxt = (W + PT - 1) / PT;
+    const int tile = xcd_tile(blockIdx.x, gridDim.x);      // XCD-contiguous tile bands (see post_fwd_kernel)
+    const int x0 = (tile % gxt) * PT, y0 = (tile / gxt) * PT;
     const size_t HW = (size_t)H * W;
     const float gs = gscale_dev ? gscale_dev[0] : 1.f;
     const float cn = c_normal * gs, cd = c_dist * gs;
@@ -249,13 +253,13 @@ __global__ __launch_bounds__(256) void post_bwd_kernel(int H, int W, const float
 int post_blocks(int H, int W) { return ((W + PT - 1) / PT) * ((H + PT - 1) / PT); }
 
 void launch_post_fwd(int H, int W, const float* allmap, const float* cam, float ratio, float* maps, float* partials, hipStream_t s) {
-    dim3 grid((W + PT - 1) / PT, (H + PT - 1) / PT);
+    dim3 grid(post_blocks(H, W));
     hipLaunchKernelGGL(post_fwd_kernel, grid, dim3(256), 0, s, H, W, allmap, cam, ratio, maps, partials);
 }
 
 void launch_post_bwd(int H, int W, const float* allmap, const float* cam, float ratio, const float* gmaps, float c_normal, float c_dist,
                      const float* gscale_dev, float* gall, hipStream_t s) {
-    dim3 grid((W + PT - 1) / PT, (H + PT - 1) / PT);
+    dim3 grid(post_blocks(H, W));
     hipLaunchKernelGGL(post_bwd_kernel, grid, dim3(256), 0, s, H, W, allmap, cam, ratio, gmaps, c_normal, c_dist, gscale_dev, gall);
 }
 
