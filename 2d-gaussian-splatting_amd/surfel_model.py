@@ -357,7 +357,7 @@ class GaussianModel:
         sel = (torch.norm(grads, dim=-1) >= grad_threshold) & (self._av["scaling"].max(dim=1).values <= self.percent_dense * scene_extent)
         self.densification_postfix(self._rows(sel))
 
-    def densify_and_split(self, grads, grad_threshold, scene_extent, N=2):
+    def densify_and_split(self, grads, grad_threshold, scene_extent, N=2, generator=None):
         """Replace large surfels with a large gradient by N samples inside them (scene/gaussian_model.py:348-371)."""
         n_init = self.P
         padded = torch.zeros((n_init,), device=self.device)
@@ -365,7 +365,7 @@ class GaussianModel:
         sel = (padded >= grad_threshold) & (self._av["scaling"].max(dim=1).values > self.percent_dense * scene_extent)
         stds = self._av["scaling"][sel].repeat(N, 1)
         stds = torch.cat([stds, torch.zeros_like(stds[:, :1])], dim=-1)
-        samples = torch.normal(mean=torch.zeros_like(stds), std=stds)
+        samples = torch.normal(mean=torch.zeros_like(stds), std=stds, generator=generator)
         rots = quat_to_rotmat(self._pv["rotation"][sel]).repeat(N, 1, 1)
         new = self._rows(sel, N)
         new["xyz"] = torch.bmm(rots, samples.unsqueeze(-1)).squeeze(-1) + self._pv["xyz"][sel].repeat(N, 1)
@@ -374,11 +374,13 @@ class GaussianModel:
         prune = torch.cat((sel, torch.zeros(N * int(sel.sum()), device=self.device, dtype=torch.bool)))
         self.prune_points(prune)
 
-    def densify_and_prune(self, max_grad, min_opacity, extent, max_screen_size):
+    def densify_and_prune(self, max_grad, min_opacity, extent, max_screen_size, generator=None):
+        """generator: RNG of the split samples (None = global RNG like the reference; view-parallel training passes an identically
+        seeded generator on every rank so that the replicas stay identical)."""
         grads = self.xyz_gradient_accum / self.denom
         grads[grads.isnan()] = 0.0
         self.densify_and_clone(grads, max_grad, extent)
-        self.densify_and_split(grads, max_grad, extent)
+        self.densify_and_split(grads, max_grad, extent, generator=generator)
         prune = (self._av["opacity"] < min_opacity).squeeze()
         if max_screen_size:
             prune = prune | (self.max_radii2D > max_screen_size) | (self._av["scaling"].max(dim=1).values > 0.1 * extent)

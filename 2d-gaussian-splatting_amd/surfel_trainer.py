@@ -181,7 +181,10 @@ class Trainer:
                     if self.world > 1:
                         self._reduce_stats()
                     size_threshold = 20 if it > opt.opacity_reset_interval else None
-                    m.densify_and_prune(opt.densify_grad_threshold, opt.opacity_cull, self.extent, size_threshold)
+                    gen = None
+                    if self.world > 1:       # identical split samples on every rank
+                        gen = torch.Generator(device=m.device); gen.manual_seed(self.seed * 1_000_003 + it)
+                    m.densify_and_prune(opt.densify_grad_threshold, opt.opacity_cull, self.extent, size_threshold, generator=gen)
                     rebuilt = True
                 if it % opt.opacity_reset_interval == 0 or (self.white_background and it == opt.densify_from_iter):
                     m.reset_opacity()
