@@ -20,13 +20,15 @@ namespace {
 
 thread_local std::string g_err;
 int g_opt_cull = 1;        // surfel_set_option("cull", .)
+int g_opt_tile_sort = 1;   // surfel_set_option("tile_depth_sort", .): 0 never, 1 auto (by last frame's R / tiles), 2 always
+thread_local int64_t g_last_R = -1; thread_local int g_last_W = 0, g_last_H = 0;   // auto heuristic (speed only; results identical)
 thread_local float g_stage_ms[16];
 thread_local int g_stage_n = 0;
 thread_local int g_stage_id[16];
 
 const char* kStageNames[] = {"preprocess_fwd", "depth_sort_scan", "emit_instances", "tile_sort", "tile_ranges", "blend_fwd",
-                             "zero_grec", "blend_bwd", "preprocess_bwd", "knn"};
-enum Stage { ST_PRE = 0, ST_SCAN, ST_EMIT, ST_SORT, ST_RANGES, ST_BLEND, ST_ZERO, ST_BBWD, ST_PBWD, ST_KNN };
+                             "zero_grec", "blend_bwd", "preprocess_bwd", "knn", "tile_depth_sort"};
+enum Stage { ST_PRE = 0, ST_SCAN, ST_EMIT, ST_SORT, ST_RANGES, ST_BLEND, ST_ZERO, ST_BBWD, ST_PBWD, ST_KNN, ST_TSORT };
 
 int fail(int code, const char* what, hipError_t e = hipSuccess) {
     g_err = what;
@@ -174,7 +176,7 @@ extern "C" {
 
 int surfel_abi_version(void) { return SURFEL_ABI_VERSION; }
 const char* surfel_last_error(void) { return g_err.c_str(); }
-const char* surfel_stage_name(int stage) { return (stage >= 0 && stage < 10) ? kStageNames[stage] : "?"; }
+const char* surfel_stage_name(int stage) { return (stage >= 0 && stage < 11) ? kStageNames[stage] : "?"; }
 int surfel_last_stage_ms(float* ms, int cap) {
     int n = g_stage_n < cap ? g_stage_n : cap;
     for (int i = 0; i < n; i++) ms[i] = g_stage_ms[i];
@@ -210,6 +212,7 @@ int surfel_debug_sort_pairs(surfel_alloc_fn scratch_alloc, void* scratch_user, u
 
 int surfel_set_option(const char* name, int value) {
     if (name && std::strcmp(name, "cull") == 0) { g_opt_cull = value ? 1 : 0; return 0; }
+    if (name && std::strcmp(name, "tile_depth_sort") == 0) { g_opt_tile_sort = value < 0 ? 0 : (value > 2 ? 2 : value); return 0; }
     return fail(SURFEL_E_INVALID, "unknown option");
 }
 
@@ -224,7 +227,7 @@ int surfel_collect_stage_ms(float* sum_ms, int* count, int cap) {
         (void)hipEventDestroy(p.e0); (void)hipEventDestroy(p.e1);
     }
     g_pending.clear();
-    return 10;
+    return 11;
 }
 
 int64_t surfel_rasterize_forward(surfel_alloc_fn geom_alloc, void* geom_user, surfel_alloc_fn binning_alloc, void* binning_user,
@@ -296,16 +299,34 @@ int64_t surfel_rasterize_forward(surfel_alloc_fn geom_alloc, void* geom_user, su
         HIP_TRY(hipMemcpyAsync(hR, img.total, sizeof(uint32_t) * R_SLOTS, hipMemcpyDeviceToHost, s));
         HIP_TRY(hipEventRecord(evR, s));
 
+        // Binning path.  Per-tile depth sort (small / medium frames): emit in surfel-index order, order every tile's run by depth
+        // afterwards in LDS — no P-sized radix sort.  Depth-presorted emission (large frames): the original two-level scheme.
+        // Both give the same per-tile order (depth bits, then surfel index); the choice is a speed heuristic on the previous
+        // frame's instances per tile (unknown on the first call: decided once R has arrived).
+        const int64_t ntiles_all = (int64_t)gx * gy;
+        constexpr int64_t kTileSortMaxAvg = 1024;
+        int per_tile = g_opt_tile_sort == 2 ? 1 : (g_opt_tile_sort == 0 ? 0 : -1);
+        if (per_tile < 0 && g_last_R >= 0 && g_last_W == width && g_last_H == height) per_tile = g_last_R <= kTileSortMaxAvg * ntiles_all ? 1 : 0;
+        if (per_tile < 0) {         // first frame of this size: wait for R now (loses the host/device overlap once)
+            HIP_TRY(hipEventSynchronize(evR));
+            int64_t r0 = 0;
+            for (int k = 0; k < R_SLOTS; k++) r0 += (int64_t)hR[k];
+            per_tile = r0 <= kTileSortMaxAvg * ntiles_all ? 1 : 0;
+        }
         tm.begin();
-        // (1) surfel order by view depth (stable; culled surfels carry key 0xffffffff and sort last)
-        const int which = radix_sort_pairs_u32(geom.dkey_a, geom.ord_a, geom.dkey_b, geom.ord_b, (size_t)P, 0, 32, geom.temp, s, true);
-        if (which < 0) return fail(SURFEL_E_LIMIT, "too many surfels for the depth sort");
-        const uint32_t* order = which ? geom.ord_b : geom.ord_a;
-        // (2) instance offsets in depth order: inclusive scan of tiles_touched[order[k]]
+        const uint32_t* order = geom.ord_a;      // identity (written by preprocess)
+        if (!per_tile) {
+            // (1) surfel order by view depth (stable; culled surfels carry key 0xffffffff and sort last)
+            const int which = radix_sort_pairs_u32(geom.dkey_a, geom.ord_a, geom.dkey_b, geom.ord_b, (size_t)P, 0, 32, geom.temp, s, true);
+            if (which < 0) return fail(SURFEL_E_LIMIT, "too many surfels for the depth sort");
+            order = which ? geom.ord_b : geom.ord_a;
+        }
+        // (2) instance offsets in emission order: inclusive scan of tiles_touched[order[k]]
         launch_scan_gather(geom.tiles_touched, order, geom.offsets, (size_t)P, scan_state, s);
         STAGE_END(tm, ST_SCAN);
         HIP_TRY(hipEventSynchronize(evR));
         for (int k = 0; k < R_SLOTS; k++) R += (int64_t)hR[k];
+        g_last_R = R; g_last_W = width; g_last_H = height;
 
         const int end_bit = higher_msb((uint32_t)(gx * gy));
         const size_t sort_bytes = radix_sort_scratch_bytes((size_t)R);
@@ -332,6 +353,12 @@ int64_t surfel_rasterize_forward(surfel_alloc_fn geom_alloc, void* geom_user, su
             tm.begin();
             launch_tile_ranges(R, sorted_keys, img.ranges, s);
             STAGE_END(tm, ST_RANGES);
+            if (per_tile) {
+                // (4) every tile orders its run by (depth bits, surfel index); the ping-pong buffers of the tile sort are free now
+                tm.begin();
+                launch_tile_depth_sort(gx * gy, img.ranges, bin.point_list, geom.dkey_a, bin.vals_alt, bin.keys_a, bin.keys_b, s);
+                STAGE_END(tm, ST_TSORT);
+            }
         }
     } else {
         (void)geom_alloc(geom_user, 256);

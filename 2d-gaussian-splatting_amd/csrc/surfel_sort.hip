@@ -311,6 +311,74 @@ void launch_scan_gather(const uint32_t* vals, const uint32_t* order, uint32_t* o
                        static_cast<uint32_t*>(zeroed_scratch));
 }
 
+// ---- per-tile depth sort ---------------------------------------------------------------------------------------------
+// Small / medium frames (the BASELINE configs[1] regime): instead of depth-sorting all P surfels before emission (4 radix
+// passes, ~16 us each because they are look-back-latency-bound, not byte-bound), instances are emitted in surfel-index order,
+// grouped by the stable tile sort, and every tile then orders ITS OWN run by (float depth bits, surfel index) — the same total
+// order the depth-presorted path produces — with a bitonic network in LDS: one launch, all tiles in parallel.
+// Tiles with more than TS_CAP instances take a (slow, rare) chunked rank sort through global scratch.
+constexpr int TS_CAP = 4096;
+
+__global__ void __launch_bounds__(RS_THREADS) tile_depth_sort_kernel(const uint2* __restrict__ ranges, uint32_t* __restrict__ point_list,
+                                                                    const uint32_t* __restrict__ depth_keys, uint32_t* __restrict__ tmp_ids,
+                                                                    uint32_t* __restrict__ tmp_keys, uint32_t* __restrict__ tmp_rank) {
+    __shared__ unsigned long long s[TS_CAP];       // 32 KB: (depth bits << 32) | surfel index
+    const uint2 rg = ranges[blockIdx.x];
+    const uint32_t n = rg.y - rg.x;
+    if (n < 2u) return;
+    uint32_t* __restrict__ pl = point_list + rg.x;
+    const uint32_t tid = threadIdx.x;
+    if (n <= (uint32_t)TS_CAP) {
+        uint32_t N2 = 2;
+        while (N2 < n) N2 <<= 1;
+        for (uint32_t i = tid; i < N2; i += RS_THREADS) {
+            unsigned long long v = ~0ull;
+            if (i < n) { const uint32_t id = pl[i]; v = ((unsigned long long)depth_keys[id] << 32) | id; }
+            s[i] = v;
+        }
+        __syncthreads();
+        for (uint32_t k = 2; k <= N2; k <<= 1) {
+            for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+                for (uint32_t t = tid; t < (N2 >> 1); t += RS_THREADS) {
+                    const uint32_t i = 2u * t - (t & (j - 1u));      // bit j of i is clear
+                    const uint32_t q = i + j;
+                    const bool up = (i & k) == 0u;
+                    const unsigned long long a = s[i], b = s[q];
+                    if ((a > b) == up) { s[i] = b; s[q] = a; }
+                }
+                __syncthreads();
+            }
+        }
+        for (uint32_t i = tid; i < n; i += RS_THREADS) pl[i] = (uint32_t)s[i];
+        return;
+    }
+    // fallback: rank of element i = number of elements with a smaller (depth, index) key; chunks of TS_CAP keys through LDS
+    uint32_t* __restrict__ ids = tmp_ids + rg.x;
+    uint32_t* __restrict__ keys = tmp_keys + rg.x;
+    uint32_t* __restrict__ rank = tmp_rank + rg.x;
+    for (uint32_t i = tid; i < n; i += RS_THREADS) { const uint32_t id = pl[i]; ids[i] = id; keys[i] = depth_keys[id]; rank[i] = 0u; }
+    __syncthreads();
+    for (uint32_t c0 = 0; c0 < n; c0 += (uint32_t)TS_CAP) {
+        const uint32_t m = min((uint32_t)TS_CAP, n - c0);
+        for (uint32_t i = tid; i < m; i += RS_THREADS) s[i] = ((unsigned long long)keys[c0 + i] << 32) | ids[c0 + i];
+        __syncthreads();
+        for (uint32_t i = tid; i < n; i += RS_THREADS) {
+            const unsigned long long mine = ((unsigned long long)keys[i] << 32) | ids[i];
+            uint32_t r = 0;
+            for (uint32_t j = 0; j < m; j++) r += s[j] < mine ? 1u : 0u;
+            rank[i] += r;
+        }
+        __syncthreads();
+    }
+    for (uint32_t i = tid; i < n; i += RS_THREADS) pl[rank[i]] = ids[i];
+}
+
+void launch_tile_depth_sort(int ntiles, const uint2* ranges, uint32_t* point_list, const uint32_t* depth_keys, uint32_t* tmp_ids,
+                            uint32_t* tmp_keys, uint32_t* tmp_rank, hipStream_t st) {
+    if (ntiles > 0) hipLaunchKernelGGL(tile_depth_sort_kernel, dim3(ntiles), dim3(RS_THREADS), 0, st, ranges, point_list, depth_keys, tmp_ids,
+                                       tmp_keys, tmp_rank);
+}
+
 // Sorts on key bits [begin_bit, end_bit).  Buffers ping-pong a -> b -> a ...; returns 0 if the result is in (keys_a, vals_a),
 // 1 if in (keys_b, vals_b); -1 if n is too large for the 30-bit look-back counters.
 int radix_sort_pairs_u32(uint32_t* keys_a, uint32_t* vals_a, uint32_t* keys_b, uint32_t* vals_b, size_t n, int begin_bit, int end_bit,

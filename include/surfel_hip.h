@@ -117,7 +117,7 @@ int surfel_last_stage_ms(float* ms, int cap);
 int surfel_last_stage_ids(int* ids, int cap);
 /* debug == 2 ("profile"): stages are bracketed with HIP events on `stream` WITHOUT synchronising;
  * this resolves every pending pair, adds the durations into sum_ms[stage] / count[stage]
- * (arrays of `cap` >= 10 entries, indexed by stage id) and returns the number of stage ids. */
+ * (arrays of `cap` >= 11 entries, indexed by stage id) and returns the number of stage ids. */
 int surfel_collect_stage_ms(float* sum_ms, int* count, int cap);
 const char* surfel_stage_name(int stage);
 
@@ -130,7 +130,11 @@ int surfel_debug_sort_pairs(surfel_alloc_fn scratch_alloc, void* scratch_user, u
  *   "cull" (default 1): 0 disables every exact-preserving cull (tile emission restricted to the surfel's
  *          alpha>=1/255 footprint, per-quad / per-sub-tile instance masks) so the blend kernels visit every
  *          (pixel, surfel) pair of the reference's tile rectangles.  Results are bit-identical either way —
- *          that is what tests/test_gpu_parity.py::test_culling_is_exact checks. */
+ *          that is what tests/test_gpu_parity.py::test_culling_is_exact checks.
+ *   "tile_depth_sort" (default 1 = auto): binning path — 2: always order every tile's instance run by depth in LDS after an
+ *          index-order emission (no P-sized depth sort; fastest for small / medium frames), 0: always depth-presort the surfels
+ *          (large frames), 1: choose by the previous frame's instances per tile.  Results are bit-identical
+ *          (tests/test_gpu_parity.py::test_binning_paths_are_identical). */
 int surfel_set_option(const char* name, int value);
 
 #ifdef __cplusplus

@@ -26,7 +26,7 @@ T = st.transMat; xy = st.xy; opa = st.normal_opacity[:, 3]
 vis = np.nonzero(radii > 0)[0]
 rng = np.random.default_rng(0)
 sel = rng.choice(vis, size=min(ns, vis.size), replace=False)
-tot_pix = tot_bbox8 = tot_exact8 = tot_ref16 = tot_bbox16 = tot_exact16 = 0
+tot_pix = tot_bbox8 = tot_exact8 = tot_ref16 = tot_bbox16 = tot_exact16 = tot_exact4 = 0
 hist = []
 for i in sel:
     Tu, Tv, Tw = T[i, 0:3], T[i, 3:6], T[i, 6:9]
@@ -57,6 +57,7 @@ for i in sel:
     ne8 = len(set(zip((xx + x0) // 8, (yy + y0) // 8)))
     nb16 = (bx1 // 16 - bx0 // 16 + 1) * (by1 // 16 - by0 // 16 + 1)
     ne16 = len(set(zip((xx + x0) // 16, (yy + y0) // 16)))
+    tot_exact4 += len(set(zip((xx + x0) // 4, (yy + y0) // 4)))
     tot_pix += n; tot_bbox8 += nb8; tot_exact8 += ne8; tot_bbox16 += nb16; tot_exact16 += ne16
     hist.append(n)
 m = len(sel)
@@ -65,4 +66,5 @@ print("  footprint pixels / surfel          : %.1f (median %.0f)" % (tot_pix / m
 print("  reference 16x16 rect tiles / surfel: %.2f" % (tot_ref16 / m))
 print("  16x16 tiles, tight bbox / exact    : %.2f / %.2f" % (tot_bbox16 / m, tot_exact16 / m))
 print("  8x8 tiles,  tight bbox / exact     : %.2f / %.2f" % (tot_bbox8 / m, tot_exact8 / m))
+print("  4x4 sub-tiles, exact               : %.2f  (= %.2f wave passes of 4 rows; vs %.2f 8x8 visits)" % (tot_exact4 / m, tot_exact4 / m / 4.0, tot_exact8 / m))
 print("  lane utilisation per 8x8 visit     : bbox %.3f, exact %.3f" % (tot_pix / (64.0 * tot_bbox8), tot_pix / (64.0 * tot_exact8)))

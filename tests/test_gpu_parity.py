@@ -251,6 +251,45 @@ def test_culling_is_exact(kind):
             assert R0 == Rref, (R0, Rref)
 
 
+@pytest.mark.parametrize("kind", ["plain", "huge", "ties", "crowded"])
+def test_binning_paths_are_identical(kind):
+    """The two binning paths — depth-presorted emission vs index-order emission + per-tile depth sort in LDS — must give
+    BIT-IDENTICAL images and gradients (same per-tile order: depth bits, then surfel index).  'ties' holds many exactly equal
+    depths; 'crowded' piles > 4096 instances onto single tiles to take the rank-sort fallback."""
+    import surfel_native as n
+    import synthetic
+    lib = n.load()
+    if kind in ("plain", "huge"):
+        sc = _stress_scene(kind, 21)
+    elif kind == "ties":
+        sc = synthetic.make_scene(3000, 160, 120, seed=5, px_radius=6.0, z_near=2.0, z_far=6.0, tilt=False)
+        # identity rotation camera: view depth = world z + const; quantise z so that hundreds of surfels share a depth bit pattern
+        sc["means3D"][:, 2] = np.round(sc["means3D"][:, 2] * 2.0) / 2.0
+    else:
+        sc = synthetic.make_scene(9000, 96, 64, seed=6, px_radius=30.0, z_near=2.0, z_far=8.0)
+        sc["opacities"] = np.full_like(sc["opacities"], 0.02)         # faint: nothing saturates, every instance is blended
+    a = scene_args(sc)
+    rng = np.random.default_rng(3)
+    gC = rng.normal(size=(3, a["H"], a["W"])).astype(np.float32); gO = rng.normal(size=(7, a["H"], a["W"])).astype(np.float32)
+    res = []
+    try:
+        for mode in (0, 2):
+            assert lib.surfel_set_option(b"tile_depth_sort", mode) == 0
+            run = HipRun(a).forward()
+            g = run.backward(gC, gO)
+            res.append((run.R, run.color.cpu().numpy(), run.others.cpu().numpy(), run.radii.cpu().numpy(), g))
+    finally:
+        lib.surfel_set_option(b"tile_depth_sort", 1)
+    (R0, c0, o0, r0, g0), (R2, c2, o2, r2, g2) = res
+    assert R0 == R2 and R0 > 0 and np.array_equal(r0, r2)
+    if kind == "crowded":
+        tiles = ((a["W"] + 15) // 16) * ((a["H"] + 15) // 16)
+        assert R0 > 4096 * tiles * 0.5, "scene not crowded enough to reach the fallback (%d instances on %d tiles)" % (R0, tiles)
+    assert np.array_equal(c0, c2) and np.array_equal(o0, o2), "%s: images differ between the binning paths" % kind
+    for k in g0:
+        assert np.array_equal(g0[k], g2[k]), "%s: dL/d%s differs between the binning paths" % (kind, k)
+
+
 @pytest.mark.parametrize("n,bits", [(1, (0, 32)), (63, (0, 32)), (2047, (0, 12)), (2048, (0, 32)), (2049, (3, 17)), (300_000, (0, 32)),
                                     (611_573, (0, 12)), (3_000_001, (0, 32)), (5_000_000, (0, 15))])
 def test_radix_sort_is_stable_and_exact(n, bits):
