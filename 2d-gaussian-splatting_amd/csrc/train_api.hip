@@ -56,11 +56,11 @@ int surfel_reduce_partials(const float* partials, int groups, int n, int stride,
 }
 
 int surfel_loss_finalize(const float* ssim_partials, int n_ssim, int n_pixels_planes, const float* post_partials, int n_post, int n_pixels,
-                         float lambda_dssim, float lambda_normal, float lambda_dist, float* out6, void* stream) {
+                         float lambda_dssim, float lambda_normal, float lambda_dist, float* out6, float* total_out, void* stream) {
     if (!ssim_partials || n_ssim <= 0 || n_pixels_planes <= 0 || !out6 || (post_partials && (n_post <= 0 || n_pixels <= 0)))
         return api_fail(SURFEL_E_INVALID, "loss_finalize: bad arguments");
     launch_loss_finalize(ssim_partials, n_ssim, 1.f / (float)n_pixels_planes, post_partials, n_post, post_partials ? 1.f / (float)n_pixels : 0.f,
-                         lambda_dssim, lambda_normal, lambda_dist, out6, static_cast<hipStream_t>(stream));
+                         lambda_dssim, lambda_normal, lambda_dist, out6, total_out, static_cast<hipStream_t>(stream));
     return launched("loss_finalize_kernel");
 }
 

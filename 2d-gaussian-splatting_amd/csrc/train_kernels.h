@@ -13,7 +13,7 @@ void launch_ssim_bwd(int planes, int H, int W, const float* img, const float* gt
                      const float* g_l1_dev, const float* g_ssim_dev, float* grad_img, hipStream_t s);
 void launch_reduce_partials(const float* partials, int groups, int n, int stride, float scale, float* out, hipStream_t s);
 void launch_loss_finalize(const float* pa, int na, float scale_a, const float* pb, int nb, float scale_b, float lambda_dssim,
-                          float lambda_normal, float lambda_dist, float* out, hipStream_t s);
+                          float lambda_normal, float lambda_dist, float* out, float* total_out, hipStream_t s);
 
 int post_blocks(int H, int W);
 void launch_post_fwd(int H, int W, const float* allmap, const float* cam, float ratio, float* maps, float* partials, hipStream_t s);

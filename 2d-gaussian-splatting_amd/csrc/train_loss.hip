@@ -227,7 +227,7 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __res
 // total = photometric + lambda_normal*normal_err + lambda_dist*dist.   pb may be NULL (no regularisers this iteration).
 __global__ __launch_bounds__(256) void loss_finalize_kernel(const float* __restrict__ pa, int na, float scale_a, const float* __restrict__ pb,
                                                             int nb, float scale_b, float lambda_dssim, float lambda_normal,
-                                                            float lambda_dist, float* __restrict__ out) {
+                                                            float lambda_dist, float* __restrict__ out, float* __restrict__ total_out) {
     __shared__ float red[4][256];
     const int tid = threadIdx.x;
     float a0 = 0.f, a1 = 0.f, b0 = 0.f, b1 = 0.f;
@@ -246,7 +246,9 @@ __global__ __launch_bounds__(256) void loss_finalize_kernel(const float* __restr
         const float l1 = red[0][0] * scale_a, ss = red[1][0] * scale_a, ne = red[2][0] * scale_b, di = red[3][0] * scale_b;
         const float ph = (1.f - lambda_dssim) * l1 + lambda_dssim * (1.f - ss);
         out[0] = l1; out[1] = ss; out[2] = ne; out[3] = di; out[4] = ph;
-        out[5] = ph + lambda_normal * ne + lambda_dist * di;
+        const float tot = ph + lambda_normal * ne + lambda_dist * di;
+        out[5] = tot;
+        if (total_out) total_out[0] = tot;
     }
 }
 
@@ -271,9 +273,9 @@ void launch_reduce_partials(const float* partials, int groups, int n, int stride
 }
 
 void launch_loss_finalize(const float* pa, int na, float scale_a, const float* pb, int nb, float scale_b, float lambda_dssim,
-                          float lambda_normal, float lambda_dist, float* out, hipStream_t s) {
+                          float lambda_normal, float lambda_dist, float* out, float* total_out, hipStream_t s) {
     hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, s, pa, na, scale_a, pb, nb, scale_b, lambda_dssim, lambda_normal,
-                       lambda_dist, out);
+                       lambda_dist, out, total_out);
 }
 
 }  // namespace surfel

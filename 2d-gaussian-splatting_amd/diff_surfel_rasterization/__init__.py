@@ -100,6 +100,7 @@ class _RasterizeGaussians(torch.autograd.Function):
                                 (colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geomBuffer,
                                  binningBuffer, imgBuffer, bg, viewmatrix, projmatrix, campos)))
         ctx.mark_non_differentiable(radii)
+        ctx.set_materialize_grads(False)      # unused outputs arrive as None in backward instead of zero-filled tensors
         return out_color, radii, out_others
 
     @staticmethod

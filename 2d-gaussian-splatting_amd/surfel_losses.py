@@ -148,6 +148,7 @@ class _TrainLoss(torch.autograd.Function):
         dmaps = torch.empty((3, planes, H, W), dtype=torch.float32, device=dev)
         partials = torch.empty((planes * nblk, 2), dtype=torch.float32, device=dev)
         out = torch.empty((6,), dtype=torch.float32, device=dev)
+        total = torch.empty((), dtype=torch.float32, device=dev)
         s = _n.current_stream_ptr(dev)
         am = pb = None
         npost = 0
@@ -161,18 +162,21 @@ class _TrainLoss(torch.autograd.Function):
                 _check(lib.surfel_render_post_forward(H, W, _n.ptr(am), _n.ptr(cam), float(depth_ratio), _n.ptr(maps), _n.ptr(pb), s),
                        "surfel_render_post_forward")
             _check(lib.surfel_loss_finalize(_n.ptr(partials), planes * nblk, planes * H * W, _n.ptr(pb), npost, H * W, float(lambda_dssim),
-                                            float(lambda_normal) if reg else 0.0, float(lambda_dist) if reg else 0.0, _n.ptr(out), s),
+                                            float(lambda_normal) if reg else 0.0, float(lambda_dist) if reg else 0.0, _n.ptr(out), _n.ptr(total), s),
                    "surfel_loss_finalize")
+        ctx.set_materialize_grads(False)
         ctx.k = (planes, H, W, float(depth_ratio), float(lambda_dssim), float(lambda_normal), float(lambda_dist), reg)
         ctx.shapes = (tuple(image.shape), None if allmap is None else tuple(allmap.shape))
         ctx.save_for_backward(x, y, dmaps, am, cam)
         ctx.mark_non_differentiable(out)
-        return out[5].clone(), out
+        return total, out
 
     @staticmethod
     def backward(ctx, g_total, g_out):
         planes, H, W, ratio, lam, ln, ld, reg = ctx.k
         x, y, dmaps, am, cam = ctx.saved_tensors
+        if g_total is None:
+            return None, None, None, None, None, None, None, None
         dev = x.device
         lib = _n.load()
         N = float(planes * H * W)

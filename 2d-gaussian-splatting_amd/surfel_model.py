@@ -62,6 +62,7 @@ class _ParamGate(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, anchor, t):
+        ctx.set_materialize_grads(False)      # a skipped gradient (None) must not be turned into a zero-filled tensor
         return t.view_as(t)
 
     @staticmethod

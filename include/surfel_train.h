@@ -86,9 +86,11 @@ int surfel_reduce_partials(const float* partials, int groups, int n, int stride,
  *   out6 = [Ll1, ssim, mean normal error, mean distortion, photometric, total]
  *   photometric = (1-lambda_dssim)*Ll1 + lambda_dssim*(1-ssim);  total = photometric + lambda_normal*[2] + lambda_dist*[3]
  * ssim_partials [n_ssim,2] over n_pixels_planes = planes*H*W elements; post_partials [n_post,2] over n_pixels = H*W, or NULL.
+ * total_out (nullable): a second, separately owned copy of out6[5] (the differentiable output of an autograd node).
  */
 int surfel_loss_finalize(const float* ssim_partials, int n_ssim, int n_pixels_planes, const float* post_partials, int n_post,
-                         int n_pixels, float lambda_dssim, float lambda_normal, float lambda_dist, float* out6, void* stream);
+                         int n_pixels, float lambda_dssim, float lambda_normal, float lambda_dist, float* out6, float* total_out,
+                         void* stream);
 
 /*
  * The surfel parameter store: ONE flat fp32 buffer of 58 floats per surfel, planar by section
