@@ -356,7 +356,7 @@ int64_t surfel_rasterize_forward(surfel_alloc_fn geom_alloc, void* geom_user, su
             if (per_tile) {
                 // (4) every tile orders its run by (depth bits, surfel index); the ping-pong buffers of the tile sort are free now
                 tm.begin();
-                launch_tile_depth_sort(gx * gy, img.ranges, bin.point_list, geom.dkey_a, bin.vals_alt, bin.keys_a, bin.keys_b, s);
+                launch_tile_depth_sort(gx * gy, R, img.ranges, bin.point_list, geom.dkey_a, bin.vals_alt, bin.keys_a, bin.keys_b, s);
                 STAGE_END(tm, ST_TSORT);
             }
         }

@@ -59,7 +59,7 @@ int radix_sort_pairs_u32(uint32_t* keys_a, uint32_t* vals_a, uint32_t* keys_b, u
                          void* scratch, hipStream_t s, bool head_zeroed = false);
 size_t radix_sort_head_words(size_t n);       // words at the start of the sort scratch that must be zero (head_zeroed callers)
 size_t scan_scratch_words(size_t n);          // zeroed scratch of launch_scan_gather
-void launch_tile_depth_sort(int ntiles, const uint2* ranges, uint32_t* point_list, const uint32_t* depth_keys, uint32_t* tmp_ids,
+void launch_tile_depth_sort(int ntiles, int64_t R, const uint2* ranges, uint32_t* point_list, const uint32_t* depth_keys, uint32_t* tmp_ids,
                             uint32_t* tmp_keys, uint32_t* tmp_rank, hipStream_t s);
 void launch_scan_gather(const uint32_t* vals, const uint32_t* order, uint32_t* out, size_t n, void* zeroed_scratch, hipStream_t s);
 

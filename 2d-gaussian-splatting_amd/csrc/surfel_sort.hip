@@ -317,8 +317,66 @@ void launch_scan_gather(const uint32_t* vals, const uint32_t* order, uint32_t* o
 // grouped by the stable tile sort, and every tile then orders ITS OWN run by (float depth bits, surfel index) — the same total
 // order the depth-presorted path produces — with a bitonic network in LDS: one launch, all tiles in parallel.
 // Tiles with more than TS_CAP instances take a (slow, rare) chunked rank sort through global scratch.
-constexpr int TS_CAP = 4096;
 
+// Bitonic network over 256*E keys held E per thread in registers (element index = e*256 + tid): partners 256 or more apart are
+// another register of the same thread, partners closer than a wave come by lane shuffle, only distances 64 / 128 go through
+// LDS.  Fully unrolled so that every register index is a compile-time constant.
+template <int E>
+__device__ __forceinline__ void tile_sort_regs(uint32_t n, uint32_t* __restrict__ pl, const uint32_t* __restrict__ depth_keys,
+                                               unsigned long long* __restrict__ s, uint32_t tid) {
+    unsigned long long v[E];
+#pragma unroll
+    for (int e = 0; e < E; e++) {
+        const uint32_t idx = (uint32_t)e * RS_THREADS + tid;
+        v[e] = ~0ull;
+        if (idx < n) { const uint32_t id = pl[idx]; v[e] = ((unsigned long long)depth_keys[id] << 32) | id; }
+    }
+#pragma unroll
+    for (uint32_t k = 2; k <= (uint32_t)RS_THREADS * E; k <<= 1) {
+#pragma unroll
+        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+            if (j >= (uint32_t)RS_THREADS) {
+#pragma unroll
+                for (int e = 0; e < E; e++) {
+                    const int e2 = e | (int)(j / RS_THREADS);
+                    if ((e & (int)(j / RS_THREADS)) == 0 && e2 < E) {
+                        const bool up = ((((uint32_t)e * RS_THREADS + tid) & k) == 0u);
+                        const unsigned long long a = v[e], b = v[e2];
+                        if ((a > b) == up) { v[e] = b; v[e2] = a; }
+                    }
+                }
+            } else {
+                unsigned long long pv[E];
+                if (j >= 64u) {
+#pragma unroll
+                    for (int e = 0; e < E; e++) s[e * RS_THREADS + tid] = v[e];
+                    __syncthreads();
+#pragma unroll
+                    for (int e = 0; e < E; e++) pv[e] = s[e * RS_THREADS + (tid ^ j)];
+                    __syncthreads();
+                } else {
+#pragma unroll
+                    for (int e = 0; e < E; e++) pv[e] = __shfl_xor(v[e], (int)j, 64);
+                }
+#pragma unroll
+                for (int e = 0; e < E; e++) {
+                    const uint32_t idx = (uint32_t)e * RS_THREADS + tid;
+                    const bool take_min = ((idx & j) == 0u) == ((idx & k) == 0u);
+                    v[e] = ((pv[e] < v[e]) == take_min) ? pv[e] : v[e];
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < E; e++) {
+        const uint32_t idx = (uint32_t)e * RS_THREADS + tid;
+        if (idx < n) pl[idx] = (uint32_t)v[e];
+    }
+}
+
+// TS_CAP = largest run sorted by the LDS network (8 B of LDS per key: 2048 -> 16 KB -> 10 workgroups / CU for frames whose tiles
+// are small; 4096 -> 32 KB otherwise).
+template <int TS_CAP>
 __global__ void __launch_bounds__(RS_THREADS) tile_depth_sort_kernel(const uint2* __restrict__ ranges, uint32_t* __restrict__ point_list,
                                                                     const uint32_t* __restrict__ depth_keys, uint32_t* __restrict__ tmp_ids,
                                                                     uint32_t* __restrict__ tmp_keys, uint32_t* __restrict__ tmp_rank) {
@@ -328,6 +386,10 @@ __global__ void __launch_bounds__(RS_THREADS) tile_depth_sort_kernel(const uint2
     if (n < 2u) return;
     uint32_t* __restrict__ pl = point_list + rg.x;
     const uint32_t tid = threadIdx.x;
+    // up to 1024 instances: E elements per thread, the network runs in registers (see tile_sort_regs)
+    if (n <= (uint32_t)RS_THREADS) { tile_sort_regs<1>(n, pl, depth_keys, s, tid); return; }
+    if (n <= 2u * RS_THREADS) { tile_sort_regs<2>(n, pl, depth_keys, s, tid); return; }
+    if (n <= 4u * RS_THREADS) { tile_sort_regs<4>(n, pl, depth_keys, s, tid); return; }
     if (n <= (uint32_t)TS_CAP) {
         uint32_t N2 = 2;
         while (N2 < n) N2 <<= 1;
@@ -373,10 +435,15 @@ __global__ void __launch_bounds__(RS_THREADS) tile_depth_sort_kernel(const uint2
     for (uint32_t i = tid; i < n; i += RS_THREADS) pl[rank[i]] = ids[i];
 }
 
-void launch_tile_depth_sort(int ntiles, const uint2* ranges, uint32_t* point_list, const uint32_t* depth_keys, uint32_t* tmp_ids,
+void launch_tile_depth_sort(int ntiles, int64_t R, const uint2* ranges, uint32_t* point_list, const uint32_t* depth_keys, uint32_t* tmp_ids,
                             uint32_t* tmp_keys, uint32_t* tmp_rank, hipStream_t st) {
-    if (ntiles > 0) hipLaunchKernelGGL(tile_depth_sort_kernel, dim3(ntiles), dim3(RS_THREADS), 0, st, ranges, point_list, depth_keys, tmp_ids,
-                                       tmp_keys, tmp_rank);
+    if (ntiles <= 0) return;
+    if (R <= (int64_t)256 * ntiles)
+        hipLaunchKernelGGL(tile_depth_sort_kernel<2048>, dim3(ntiles), dim3(RS_THREADS), 0, st, ranges, point_list, depth_keys, tmp_ids, tmp_keys,
+                           tmp_rank);
+    else
+        hipLaunchKernelGGL(tile_depth_sort_kernel<4096>, dim3(ntiles), dim3(RS_THREADS), 0, st, ranges, point_list, depth_keys, tmp_ids, tmp_keys,
+                           tmp_rank);
 }
 
 // Sorts on key bits [begin_bit, end_bit).  Buffers ping-pong a -> b -> a ...; returns 0 if the result is in (keys_a, vals_a),
