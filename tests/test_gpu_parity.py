@@ -273,21 +273,23 @@ def test_binning_paths_are_identical(kind):
     gC = rng.normal(size=(3, a["H"], a["W"])).astype(np.float32); gO = rng.normal(size=(7, a["H"], a["W"])).astype(np.float32)
     res = []
     try:
-        for mode in (0, 2):
+        for mode in (0, 2, 1, 1):          # presorted | per-tile depth sort | auto (twice: first-frame and steady-state decisions)
             assert lib.surfel_set_option(b"tile_depth_sort", mode) == 0
             run = HipRun(a).forward()
             g = run.backward(gC, gO)
             res.append((run.R, run.color.cpu().numpy(), run.others.cpu().numpy(), run.radii.cpu().numpy(), g))
     finally:
         lib.surfel_set_option(b"tile_depth_sort", 1)
-    (R0, c0, o0, r0, g0), (R2, c2, o2, r2, g2) = res
-    assert R0 == R2 and R0 > 0 and np.array_equal(r0, r2)
+    R0, c0, o0, r0, g0 = res[0]
+    assert R0 > 0
     if kind == "crowded":
         tiles = ((a["W"] + 15) // 16) * ((a["H"] + 15) // 16)
         assert R0 > 4096 * tiles * 0.5, "scene not crowded enough to reach the fallback (%d instances on %d tiles)" % (R0, tiles)
-    assert np.array_equal(c0, c2) and np.array_equal(o0, o2), "%s: images differ between the binning paths" % kind
-    for k in g0:
-        assert np.array_equal(g0[k], g2[k]), "%s: dL/d%s differs between the binning paths" % (kind, k)
+    for m, (R2, c2, o2, r2, g2) in enumerate(res[1:]):
+        assert R0 == R2 and np.array_equal(r0, r2)
+        assert np.array_equal(c0, c2) and np.array_equal(o0, o2), "%s: images differ between the binning paths (%d)" % (kind, m)
+        for k in g0:
+            assert np.array_equal(g0[k], g2[k]), "%s: dL/d%s differs between the binning paths (%d)" % (kind, k, m)
 
 
 @pytest.mark.parametrize("n,bits", [(1, (0, 32)), (63, (0, 32)), (2047, (0, 12)), (2048, (0, 32)), (2049, (3, 17)), (300_000, (0, 32)),
