@@ -374,14 +374,27 @@ __global__ void __launch_bounds__(256) preprocess_bwd_kernel(PreprocessBwdArgs a
     const float4 r4 = rq[4], r0 = rq[0], r1 = rq[1], r2 = rq[2];
     const uint32_t beg = __float_as_uint(r4.z);          // inst_base patched by emit_instances
     const uint32_t end = beg + a.tiles_touched[i];
-    for (uint32_t k = beg; k < end; k++) {
-        const float4* __restrict__ src = reinterpret_cast<const float4*>(a.grec + (size_t)k * GREC_F);
-        const float4 v0 = src[0], v1 = src[1], v2 = src[2], v3 = src[3], v4 = src[4];
+    // two records (10 independent 16-B loads) in flight per step; the additions keep the emission order, so the sums are
+    // bit-identical to the one-record walk (large frames hold ~10 records per surfel and were latency-bound here)
+    auto add_rec = [&](const float4& v0, const float4& v1, const float4& v2, const float4& v3, const float4& v4) {
         g[0] += v0.x; g[1] += v0.y; g[2] += v0.z; g[3] += v0.w;
         g[4] += v1.x; g[5] += v1.y; g[6] += v1.z; g[7] += v1.w;
         g[8] += v2.x; g[9] += v2.y; g[10] += v2.z; g[11] += v2.w;
         g[12] += v3.x; g[13] += v3.y; g[14] += v3.z; g[15] += v3.w;
         g[16] += v4.x; g[17] += v4.y;
+    };
+    uint32_t k = beg;
+    for (; k + 1 < end; k += 2) {
+        const float4* __restrict__ src = reinterpret_cast<const float4*>(a.grec + (size_t)k * GREC_F);
+        const float4 v0 = src[0], v1 = src[1], v2 = src[2], v3 = src[3], v4 = src[4];
+        const float4 w0 = src[5], w1 = src[6], w2 = src[7], w3 = src[8], w4 = src[9];
+        add_rec(v0, v1, v2, v3, v4);
+        add_rec(w0, w1, w2, w3, w4);
+    }
+    if (k < end) {
+        const float4* __restrict__ src = reinterpret_cast<const float4*>(a.grec + (size_t)k * GREC_F);
+        const float4 v0 = src[0], v1 = src[1], v2 = src[2], v3 = src[3], v4 = src[4];
+        add_rec(v0, v1, v2, v3, v4);
     }
     a.dL_dopacity[i] = g[14];
     store3(a.dL_dnormal, i, g[11], g[12], g[13]);
