@@ -44,6 +44,15 @@ def view_indices(n_views: int, world: int, rank: int, iteration: int, seed: int 
     return int(perm[(k * world + rank) % n_views])
 
 
+def epoch_schedule(n_views: int, world: int, epoch: int, seed: int = 0) -> List[List[int]]:
+    """The whole epoch of view_indices at once: schedule[k][rank] = view of `rank` at step k of `epoch` (identical values;
+    callers cache it so that a training step costs no RNG work on the host)."""
+    per_epoch = max(1, n_views // world)
+    g = torch.Generator().manual_seed(seed * 1_000_003 + epoch)
+    perm = torch.randperm(n_views, generator=g).tolist()
+    return [[perm[(k * world + r) % n_views] for r in range(world)] for k in range(per_epoch)]
+
+
 class GradBucket:
     """Flat fp32 gradient bucket of 58 floats / surfel: fill -> ONE all-reduce(SUM) -> read.
 

@@ -132,6 +132,7 @@ class Trainer:
         self._stack = []
         self.iteration = 0
         self.last = {}
+        self._epoch, self._epoch_views, self._epoch_campos, self._centers = -1, None, None, None
         # fused SH path (default): the rasterizer's backward skips the 192 B/surfel SH gradients, the optimiser kernel rebuilds them
         # from the 12 B/surfel colour gradients.  Always on under view-parallel training (that is how the gradients are exchanged).
         self.fused_sh = self.world > 1 or os.environ.get("SURFEL_SH_FUSED", "1") != "0"
@@ -139,12 +140,23 @@ class Trainer:
             model.training_setup(self.opt)
 
     def _step_views(self):
-        """Camera indices of ALL ranks for the current iteration (every rank computes the same schedule)."""
-        return [surfel_dist.view_indices(len(self.cams), self.world, r, self.iteration - 1, self.seed) for r in range(self.world)]
+        """(camera indices of ALL ranks for the current iteration, their camera centres [world,3] on the device).  Every rank
+        computes the same schedule (surfel_dist.view_indices); it is built once per epoch, so a step costs no host RNG work
+        and no device gather."""
+        per_epoch = max(1, len(self.cams) // self.world)
+        epoch, k = divmod(self.iteration - 1, per_epoch)
+        if self._epoch != epoch:
+            self._epoch = epoch
+            self._epoch_views = surfel_dist.epoch_schedule(len(self.cams), self.world, epoch, self.seed)
+            if self._centers is None:
+                self._centers = torch.stack([c.camera_center for c in self.cams]).contiguous()
+            idx = torch.tensor(self._epoch_views, dtype=torch.long, device=self._centers.device)
+            self._epoch_campos = self._centers[idx.reshape(-1)].reshape(per_epoch, self.world, 3).contiguous()
+        return self._epoch_views[k], self._epoch_campos[k]
 
     def _next_camera(self):
         if self.world > 1:
-            return self.cams[self._step_views()[self.rank]]
+            return self.cams[self._step_views()[0][self.rank]]
         if not self._stack:                       # train.py:64-67: pop a random view from a refilled stack
             self._stack = list(range(len(self.cams)))
         return self.cams[self._stack.pop(self._rng.randint(0, len(self._stack) - 1))]
@@ -194,7 +206,7 @@ class Trainer:
                 if self.world > 1:
                     # all-reduce of the 40 B/surfel geometry prefix + all-gather of 12 B/surfel/rank colour gradients; the 192 B/surfel
                     # SH gradients are rebuilt from them (exact, rank-ordered sum) instead of being all-reduced
-                    campos_all = torch.stack([self.cams[v].camera_center for v in self._step_views()])
+                    campos_all = self._step_views()[1]
                     gcol_all = exchange_collectives(m.grad, m.gcol, m.P)
                 elif self.fused_sh:
                     campos_all, gcol_all = cam.camera_center[None], m.gcol[None]

@@ -144,6 +144,12 @@ def _trainer_stats_worker(rank, world, port, q):
         model.grad[10 * P:] = torch.arange(P * 58, dtype=torch.float32)[10 * P:] * 3
         # every rank draws a different view of the same permutation
         views = [TR.surfel_dist.view_indices(9, world, rank, it, seed=3) for it in range(6)]
+        # the cached per-epoch schedule the trainer uses is the same function
+        per_epoch = max(1, 9 // world)
+        for it in range(10):
+            ep, k = divmod(it, per_epoch)
+            sched = TR.surfel_dist.epoch_schedule(9, world, ep, seed=3)
+            assert sched[k] == [TR.surfel_dist.view_indices(9, world, r, it, seed=3) for r in range(world)]
         q.put((rank, model.xyz_gradient_accum.reshape(-1).tolist(), model.denom.reshape(-1).tolist(), model.max_radii2D.tolist(),
                float(model.grad.sum()), views))
     finally:
