@@ -191,6 +191,8 @@ def main():
         surrogate.backward()
         gm.optimizer.step()
         gm.optimizer.zero_grad(set_to_none=True)
+        if it == 2:        # the reference's own checkpoint tuple (train.py:142-144) after two iterations
+            torch.save((gm.capture(), it), os.path.join(os.path.dirname(os.path.abspath(__file__)), "ref_chkpnt2.pth"))
         out.update({"adam_g%d_xyz" % it: g_xyz.numpy(), "adam_g%d_features" % it: g_feat.numpy(), "adam_g%d_opacity" % it: g_op.numpy(),
                     "adam_g%d_scaling" % it: g_sc.numpy(), "adam_g%d_rotation" % it: g_rot.numpy(),
                     "adam_theta%d_xyz" % it: gm._xyz.detach().numpy().copy(), "adam_theta%d_f_dc" % it: gm._features_dc.detach().numpy().copy(),

@@ -519,3 +519,31 @@ def test_fused_sh_adam_equals_explicit_sh_gradients():
     b.grad.copy_(tot); b._gv["sh"].fill_(float("nan"))
     b.optimizer_step(grad_scale=0.5, colour_grads=(torch.stack([c.camera_center for c in cams]), torch.stack(gc)))
     assert torch.allclose(a.theta, b.theta, rtol=1e-5, atol=1e-7), float((a.theta - b.theta).abs().max())
+
+
+def test_resume_from_reference_checkpoint(gt):
+    """A chkpnt*.pth written by the REFERENCE (torch.save((gaussians.capture(), iteration)), train.py:142-144; generated by
+    tests/golden/make_golden_train.py after two of its iterations) restores into the flat store — parameters, Adam moments, step
+    count, learning rates — and the third iteration then lands exactly where the reference's third iteration landed."""
+    import torch
+    import surfel_model as M
+    import surfel_trainer as TR
+    (args, it) = torch.load(os.path.join(REPO, "tests", "golden", "ref_chkpnt2.pth"), weights_only=False, map_location="cpu")
+    assert it == 2
+    m = M.GaussianModel(3, device=dev())
+    m.restore(args, TR.optimization_params())
+    assert m.step_count == 2 and m.P == int(gt["adam_P"]) and abs(m.spatial_lr_scale - float(gt["adam_spatial_lr_scale"])) < 1e-12
+    for name, mine in (("xyz", m._xyz), ("f_dc", m._features_dc), ("f_rest", m._features_rest), ("opacity", m._opacity),
+                       ("scaling", m._scaling), ("rotation", m._rotation)):
+        assert np.array_equal(mine.cpu().numpy(), gt["adam_theta2_%s" % name]), name
+    assert float(m.m.abs().sum()) > 0 and float(m.v.abs().sum()) > 0
+    m.update_learning_rate(3)
+    assert np.allclose(np.array(m.lr, np.float64), gt["adam_lrs"][2], rtol=1e-6)
+    gv = m._gv
+    gv["xyz"].copy_(T(gt["adam_g3_xyz"])); gv["sh"].copy_(T(gt["adam_g3_features"]).reshape(m.P, 48))
+    gv["opacity"].copy_(T(gt["adam_g3_opacity"])); gv["scaling"].copy_(T(gt["adam_g3_scaling"])); gv["rotation"].copy_(T(gt["adam_g3_rotation"]))
+    m.optimizer_step()
+    for name, mine in (("xyz", m._xyz), ("f_dc", m._features_dc), ("f_rest", m._features_rest), ("opacity", m._opacity),
+                       ("scaling", m._scaling), ("rotation", m._rotation)):
+        ref = gt["adam_theta3_%s" % name]
+        assert close_frac(mine.cpu().numpy(), ref, 2e-6, 2e-6) == 1.0, (name, np.abs(mine.cpu().numpy() - ref).max())
