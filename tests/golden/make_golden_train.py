@@ -216,6 +216,40 @@ def main():
         out.update({"dens_g2d_%d" % view: g2d.numpy(), "dens_radii_%d" % view: radii.numpy()})
     out.update(dens_accum=gm.xyz_gradient_accum.numpy(), dens_denom=gm.denom.numpy(), dens_max_radii=gm.max_radii2D.numpy())
 
+    # ------------------------------------------------------------------ densify_and_prune (scene/gaussian_model.py:348-403)
+    P = 300
+    dm = GaussianModel(3)
+    dm.spatial_lr_scale = 1.0
+    dm._xyz = torch.nn.Parameter(torch.tensor(rng.normal(size=(P, 3)).astype(np.float32)))
+    dm._features_dc = torch.nn.Parameter(torch.tensor(rng.normal(size=(P, 1, 3)).astype(np.float32)))
+    dm._features_rest = torch.nn.Parameter(torch.tensor(0.1 * rng.normal(size=(P, 15, 3)).astype(np.float32)))
+    dm._scaling = torch.nn.Parameter(torch.tensor(rng.normal(-3.0, 0.8, size=(P, 2)).astype(np.float32)))
+    dm._rotation = torch.nn.Parameter(torch.tensor(rng.normal(size=(P, 4)).astype(np.float32)))
+    dm._opacity = torch.nn.Parameter(torch.tensor(rng.normal(-1.0, 2.0, size=(P, 1)).astype(np.float32)))
+    dm.max_radii2D = torch.tensor(rng.integers(0, 40, size=P).astype(np.float32))
+    dm.training_setup(opt)
+    # give the optimiser a state to carry through the re-indexing
+    (dm.get_xyz.sum() + dm.get_features.sum() + dm.get_opacity.sum() + dm.get_scaling.sum() + dm.get_rotation.sum()).backward()
+    dm.update_learning_rate(1); dm.optimizer.step(); dm.optimizer.zero_grad(set_to_none=True)
+    dm.xyz_gradient_accum = torch.tensor(np.abs(rng.normal(0, 4e-4, size=(P, 1))).astype(np.float32))
+    dm.denom = torch.tensor(rng.integers(0, 3, size=(P, 1)).astype(np.float32))          # zeros -> NaN grads -> 0
+    extent, max_grad, min_opacity, max_screen = 4.0, 0.0002, 0.05, 20
+    out.update(dens2_in_accum=dm.xyz_gradient_accum.numpy().copy(), dens2_in_denom=dm.denom.numpy().copy(),
+               dens2_in_max_radii=dm.max_radii2D.numpy().copy())
+    before = {k: getattr(dm, "_" + k).detach().numpy().copy() for k in ("xyz", "features_dc", "features_rest", "scaling", "rotation", "opacity")}
+    before_m = dm.optimizer.state[dm.optimizer.param_groups[0]["params"][0]]["exp_avg"].numpy().copy()
+    torch.manual_seed(0)
+    dm.densify_and_prune(max_grad, min_opacity, extent, max_screen)
+    out.update(dens2_extent=extent, dens2_max_grad=max_grad, dens2_min_opacity=min_opacity, dens2_max_screen=max_screen,
+               dens2_P_after=dm.get_xyz.shape[0], dens2_percent_dense=opt.percent_dense)
+    for k, v in before.items():
+        out["dens2_before_" + k] = v
+    out["dens2_before_m_xyz"] = before_m
+    for k in ("xyz", "features_dc", "features_rest", "scaling", "rotation", "opacity"):
+        out["dens2_after_" + k] = getattr(dm, "_" + k).detach().numpy().copy()
+    out["dens2_after_m_xyz"] = dm.optimizer.state[dm.optimizer.param_groups[0]["params"][0]]["exp_avg"].numpy().copy()
+    out["dens2_after_accum_sum"] = float(dm.xyz_gradient_accum.sum()); out["dens2_after_maxr_sum"] = float(dm.max_radii2D.sum())
+
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "ref_train.npz")
     np.savez_compressed(path, **out)
     print("wrote", path, os.path.getsize(path), "bytes,", len(out), "arrays")

@@ -547,3 +547,40 @@ def test_resume_from_reference_checkpoint(gt):
                        ("scaling", m._scaling), ("rotation", m._rotation)):
         ref = gt["adam_theta3_%s" % name]
         assert close_frac(mine.cpu().numpy(), ref, 2e-6, 2e-6) == 1.0, (name, np.abs(mine.cpu().numpy() - ref).max())
+
+
+def test_densify_and_prune_matches_reference_model(gt):
+    """scene/gaussian_model.py:348-403 executed by the REFERENCE's GaussianModel on CPU (golden) vs the flat-store implementation:
+    same surviving / cloned / split rows in the same order, same copied attributes, same shrunken scales, Adam moments carried
+    for surviving rows and zero for new ones, statistics reset.  Only the split samples' positions are random (different RNG
+    streams on CPU and GPU): they are checked to lie in their parent's disc plane within a few sigma."""
+    import torch
+    import surfel_model as M
+    import surfel_trainer as TR
+    b = {k: gt["dens2_before_" + k] for k in ("xyz", "features_dc", "features_rest", "scaling", "rotation", "opacity")}
+    m = M.GaussianModel(3, device=dev())
+    m.set_parameters(b["xyz"], b["features_dc"], b["features_rest"], b["opacity"], b["scaling"], b["rotation"])
+    m.spatial_lr_scale = 1.0
+    opt = TR.optimization_params()
+    assert opt.percent_dense == float(gt["dens2_percent_dense"])
+    m.training_setup(opt)
+    M._views(m.m, m.P)["xyz"].copy_(T(gt["dens2_before_m_xyz"]))
+    m.xyz_gradient_accum = T(gt["dens2_in_accum"]); m.denom = T(gt["dens2_in_denom"]); m.max_radii2D = T(gt["dens2_in_max_radii"])
+    torch.manual_seed(0)
+    m.densify_and_prune(float(gt["dens2_max_grad"]), float(gt["dens2_min_opacity"]), float(gt["dens2_extent"]), int(gt["dens2_max_screen"]))
+    assert m.P == int(gt["dens2_P_after"])
+    a = {k: gt["dens2_after_" + k] for k in ("xyz", "features_dc", "features_rest", "scaling", "rotation", "opacity")}
+    assert np.array_equal(m._features_dc.cpu().numpy(), a["features_dc"]) and np.array_equal(m._features_rest.cpu().numpy(), a["features_rest"])
+    assert np.array_equal(m._rotation.cpu().numpy(), a["rotation"]) and np.array_equal(m._opacity.cpu().numpy(), a["opacity"])
+    assert close_frac(m._scaling.cpu().numpy(), a["scaling"], 2e-6, 2e-6) == 1.0
+    xyz = m._xyz.cpu().numpy(); mom = M._views(m.m, m.P)["xyz"].cpu().numpy()
+    ref_m = gt["dens2_after_m_xyz"]
+    fixed = np.all(xyz == a["xyz"], axis=1)                                     # rows whose position is not a random sample
+    n_rand = int((~fixed).sum())
+    assert 0 < n_rand < m.P and n_rand % 2 == 0
+    assert np.array_equal(mom[fixed], ref_m[fixed]) and float(np.abs(mom[~fixed]).sum()) == 0 and float(np.abs(ref_m[~fixed]).sum()) == 0
+    # the random rows are exactly the reference's split samples: their scales are the parents' divided by 1.6, and both
+    # implementations put them within a few sigma of the same parent position
+    sig = np.exp(a["scaling"][~fixed]).max(axis=1) * 1.6
+    assert (np.linalg.norm(xyz[~fixed] - a["xyz"][~fixed], axis=1) < 12.0 * sig + 1e-6).all()
+    assert float(m.xyz_gradient_accum.abs().sum()) == 0 and float(m.denom.sum()) == 0 and float(m.max_radii2D.sum()) == 0
