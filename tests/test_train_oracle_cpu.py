@@ -90,3 +90,20 @@ def test_densify_stats_match_reference(gt):
     assert close(acc, gt["dens_accum"].reshape(-1), 1e-6, 1e-6).all()
     assert np.array_equal(den, gt["dens_denom"].reshape(-1))
     assert np.array_equal(mr, gt["dens_max_radii"].reshape(-1))
+
+
+def test_camera_matches_reference_camera():
+    """surfel_render.Camera(R, T, FoVx, FoVy) builds the matrices the reference's Camera builds (scene/cameras.py:50-59,
+    utils/graphics_utils.py:38-71): checked against the matrices captured from the reference's own Camera in ref_intree.npz."""
+    import math
+    import torch
+    import surfel_render as R
+    g = np.load(os.path.join(REPO, "tests", "golden", "ref_intree.npz"))
+    w2c = g["viewmatrix"].T.astype(np.float64)
+    H, W = int(g["image_height"]), int(g["image_width"])
+    cam = R.Camera(colmap_id=0, R=w2c[:3, :3].T, T=w2c[:3, 3], FoVx=2 * math.atan(float(g["tanfovx"])), FoVy=2 * math.atan(float(g["tanfovy"])),
+                   image=torch.zeros(3, H, W), data_device="cpu")
+    assert np.allclose(cam.world_view_transform.numpy(), g["viewmatrix"], rtol=1e-6, atol=1e-7)
+    assert np.allclose(cam.full_proj_transform.numpy(), g["projmatrix"], rtol=1e-5, atol=1e-6)
+    assert np.allclose(cam.camera_center.numpy(), g["campos"], rtol=1e-5, atol=1e-6)
+    assert cam.image_width == W and cam.image_height == H and cam.znear == 0.01 and cam.zfar == 100.0
