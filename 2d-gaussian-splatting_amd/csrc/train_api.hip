@@ -72,13 +72,14 @@ int surfel_activate(int P, const float* theta, float* act, void* stream) {
 }
 
 int surfel_adam_step(int P, float* theta, const float* grad, float* m, float* v, float* act, const float* lr, float beta1, float beta2,
-                     float eps, int t, float grad_scale, int D, int N, const float* campos_all, const float* gcol_all, void* stream) {
+                     float eps, int t, float grad_scale, int D, int N, const float* campos_all, const float* gcol_all, int parts, void* stream) {
     if (P < 0 || t < 1 || !lr || (P > 0 && (!theta || !grad || !m || !v || !act))) return api_fail(SURFEL_E_INVALID, "adam_step: bad arguments");
     if (gcol_all && (!campos_all || N < 1 || D < 0 || D > 3)) return api_fail(SURFEL_E_INVALID, "adam_step: bad colour-gradient arguments");
+    if (parts < 1 || parts > 3) return api_fail(SURFEL_E_INVALID, "adam_step: parts must be 1 (SH block), 2 (geometry sections) or 3 (both)");
     if (P == 0) return 0;
     const float bc1 = (float)(1.0 - std::pow((double)beta1, (double)t));
     const float bc2s = (float)std::sqrt(1.0 - std::pow((double)beta2, (double)t));
-    launch_adam(P, theta, grad, m, v, act, lr, beta1, beta2, eps, bc1, bc2s, grad_scale, D, N, campos_all, gcol_all, static_cast<hipStream_t>(stream));
+    launch_adam(P, theta, grad, m, v, act, lr, beta1, beta2, eps, bc1, bc2s, grad_scale, D, N, campos_all, gcol_all, parts, static_cast<hipStream_t>(stream));
     return launched("adam kernels");
 }
 

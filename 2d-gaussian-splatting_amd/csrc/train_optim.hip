@@ -233,16 +233,26 @@ void launch_activate(int P, const float* theta, float* act, hipStream_t s) {
 }
 
 void launch_adam(int P, float* theta, const float* grad, float* m, float* v, float* act, const float* lr, float beta1, float beta2, float eps,
-                 float bc1, float bc2_sqrt, float grad_scale, int D, int N, const float* campos_all, const float* gcol_all, hipStream_t s) {
+                 float bc1, float bc2_sqrt, float grad_scale, int D, int N, const float* campos_all, const float* gcol_all, int parts,
+                 hipStream_t s) {
     AdamK k;
     for (int i = 0; i < 6; i++) k.lr[i] = lr[i];
     k.beta1 = beta1; k.beta2 = beta2; k.eps = eps; k.bc1 = bc1; k.bc2_sqrt = bc2_sqrt; k.grad_scale = grad_scale;
     const size_t n_xyz = (size_t)3 * P;
     size_t n_all = (size_t)51 * P;
     if (gcol_all) {      // SH gradients rebuilt from the colour gradients inside the SH Adam kernel (before xyz moves)
-        hipLaunchKernelGGL(adam_sh_kernel, dim3((P + 63) / 64), dim3(256), 0, s, P, D, N, theta, m, v, campos_all, gcol_all, k);
+        if (parts & 1) hipLaunchKernelGGL(adam_sh_kernel, dim3((P + 63) / 64), dim3(256), 0, s, P, D, N, theta, m, v, campos_all, gcol_all, k);
         n_all = n_xyz;
+    } else if (!(parts & 1)) {
+        n_all = n_xyz;       // SH block handled by another call
+    } else if (!(parts & 2)) {
+        // SH block only, gradients read from grad: run the elementwise kernel over the SH range alone
+        size_t nsh = (size_t)48 * P, blocks_sh = (nsh + 256 * 4 - 1) / (256 * 4);
+        if (blocks_sh > 65536) blocks_sh = 65536;
+        hipLaunchKernelGGL(adam_elem_kernel, dim3((unsigned)blocks_sh), dim3(256), 0, s, (size_t)0, nsh, (size_t)10 * P, theta, grad, m, v, k);
+        return;
     }
+    if (!(parts & 2)) return;
     size_t blocks = (n_all + 256 * 4 - 1) / (256 * 4);
     if (blocks > 65536) blocks = 65536;
     hipLaunchKernelGGL(adam_elem_kernel, dim3((unsigned)blocks), dim3(256), 0, s, n_xyz, n_all, (size_t)7 * P, theta, grad, m, v, k);

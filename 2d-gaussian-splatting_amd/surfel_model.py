@@ -78,18 +78,20 @@ def _views(buf, P):
     return out
 
 
-def exchange_collectives(grad, gcol, P, group=None):
-    """The two data-path collectives of a view-parallel step: all-reduce(SUM) of the geometry prefix of the flat gradient
-    store (in place) and all-gather of the per-rank colour gradients -> [world, P, 3]."""
+def exchange_collectives(grad, gcol, P, group=None, async_op=False):
+    """The two data-path collectives of a view-parallel step: all-gather of the per-rank colour gradients -> [world, P, 3] and
+    all-reduce(SUM) of the geometry prefix of the flat gradient store (in place).  The gather is issued first: with
+    async_op=True the caller gets (gall, gather_work, reduce_work) and can update the SH block as soon as the gather has landed
+    while the all-reduce is still in flight."""
     import torch.distributed as dist
     world = dist.get_world_size(group)
-    dist.all_reduce(grad[:GEOM_FLOATS * P], op=dist.ReduceOp.SUM, group=group)
     gall = torch.empty((world, P, 3), dtype=torch.float32, device=gcol.device)
     try:
-        dist.all_gather_into_tensor(gall, gcol.contiguous(), group=group)
+        wg = dist.all_gather_into_tensor(gall, gcol.contiguous(), group=group, async_op=async_op)
     except (RuntimeError, NotImplementedError):          # backends without the flat form
-        dist.all_gather([gall[r] for r in range(world)], gcol.contiguous(), group=group)
-    return gall
+        wg = dist.all_gather([gall[r] for r in range(world)], gcol.contiguous(), group=group, async_op=async_op)
+    wr = dist.all_reduce(grad[:GEOM_FLOATS * P], op=dist.ReduceOp.SUM, group=group, async_op=async_op)
+    return (gall, wg, wr) if async_op else gall
 
 
 class GaussianModel:
@@ -244,11 +246,12 @@ class GaussianModel:
         self.lr[0] = lr
         return lr
 
-    def optimizer_step(self, grad_scale=1.0, colour_grads=None):
+    def optimizer_step(self, grad_scale=1.0, colour_grads=None, parts=3):
         """optimizer.step() + zero_grad (train.py:136-138) as fused launches; refreshes the activations.
         colour_grads = (campos_all [N,3], gcol_all [N,P,3]): the SH block's gradients are rebuilt from the views' colour
         gradients inside the kernel (N = 1: this rank's view; N > 1: after exchange_collectives) instead of read from self.grad."""
-        self.step_count += 1
+        if parts & 1:               # parts: 1 = SH block, 2 = geometry sections; a 1-then-2 pair is one step
+            self.step_count += 1
         lr = (C.c_float * 6)(*self.lr)
         cam = gc = None
         N = 0
@@ -258,7 +261,7 @@ class GaussianModel:
         with torch.cuda.device(self.device):
             rc = _n.load().surfel_adam_step(self.P, _n.ptr(self.theta), _n.ptr(self.grad), _n.ptr(self.m), _n.ptr(self.v), _n.ptr(self.act),
                                             lr, self.betas[0], self.betas[1], self.eps, self.step_count, float(grad_scale),
-                                            int(self.active_sh_degree), N, _n.ptr(cam), _n.ptr(gc), _n.current_stream_ptr(self.device))
+                                            int(self.active_sh_degree), N, _n.ptr(cam), _n.ptr(gc), int(parts), _n.current_stream_ptr(self.device))
         if rc < 0:
             raise RuntimeError("surfel_adam_step failed: %s" % _n.last_error())
 

@@ -73,7 +73,7 @@ def load():
                            ("surfel_reduce_partials", [vp, i, i, i, f, vp, vp]),
                            ("surfel_loss_finalize", [vp, i, i, vp, i, i, f, f, f, vp, vp, vp]),
                            ("surfel_activate", [i, vp, vp, vp]),
-                           ("surfel_adam_step", [i, vp, vp, vp, vp, vp, fp, f, f, f, i, f, i, i, vp, vp, vp]),
+                           ("surfel_adam_step", [i, vp, vp, vp, vp, vp, fp, f, f, f, i, f, i, i, vp, vp, i, vp]),
                            ("surfel_sh_grad_gather", [i, i, i, vp, vp, vp, vp, vp]),
                            ("surfel_densify_stats", [i, vp, vp, vp, vp, vp, vp])):
             fn = getattr(lib, name)

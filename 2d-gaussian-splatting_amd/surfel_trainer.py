@@ -207,10 +207,15 @@ class Trainer:
                     # all-reduce of the 40 B/surfel geometry prefix + all-gather of 12 B/surfel/rank colour gradients; the 192 B/surfel
                     # SH gradients are rebuilt from them (exact, rank-ordered sum) instead of being all-reduced
                     campos_all = self._step_views()[1]
-                    gcol_all = exchange_collectives(m.grad, m.gcol, m.P)
-                elif self.fused_sh:
-                    campos_all, gcol_all = cam.camera_center[None], m.gcol[None]
-                m.optimizer_step(grad_scale=1.0 / self.world, colour_grads=(campos_all, gcol_all) if self.fused_sh else None)
+                    gcol_all, w_gather, w_reduce = exchange_collectives(m.grad, m.gcol, m.P, async_op=True)
+                    w_gather.wait()          # stream-level wait: the SH block updates while the geometry all-reduce is in flight
+                    m.optimizer_step(grad_scale=1.0 / self.world, colour_grads=(campos_all, gcol_all), parts=1)
+                    w_reduce.wait()
+                    m.optimizer_step(grad_scale=1.0 / self.world, colour_grads=(campos_all, gcol_all), parts=2)
+                else:
+                    if self.fused_sh:
+                        campos_all, gcol_all = cam.camera_center[None], m.gcol[None]
+                    m.optimizer_step(grad_scale=1.0 / self.world, colour_grads=(campos_all, gcol_all) if self.fused_sh else None)
 
     def evaluate(self, cams=None):
         """Mean PSNR / L1 over views (training_report, train.py:201-232)."""

@@ -112,10 +112,13 @@ int surfel_activate(int P, const float* theta, float* act, void* stream);
  * SH block: with gcol_all == NULL its gradients are read from grad like the rest.  With gcol_all [N,P,3] (+ campos_all [N,3],
  * active degree D) they are rebuilt in registers as in surfel_sh_grad_gather — the 192 B/surfel SH gradient is then never
  * written (surfel_rasterize_backward accepts dL_dsh == NULL) nor read; N = 1 for single-GPU training.
+ * parts: 3 = the whole step; 1 = SH block only, 2 = geometry sections (xyz, opacity, scaling, rotation + activations) only —
+ * two calls with the same t make one step (1 before 2: the SH rebuild reads the positions of the forward), which lets a
+ * view-parallel trainer update the SH block as soon as the colour all-gather has landed, while the geometry all-reduce is in flight.
  */
 int surfel_adam_step(int P, float* theta, const float* grad, float* m, float* v, float* act, const float* lr,
                      float beta1, float beta2, float eps, int t, float grad_scale,
-                     int D, int N, const float* campos_all, const float* gcol_all, void* stream);
+                     int D, int N, const float* campos_all, const float* gcol_all, int parts, void* stream);
 
 /*
  * View-parallel training (new; the reference is single-GPU): the SH gradient of the summed loss rebuilt from every

@@ -584,3 +584,31 @@ def test_densify_and_prune_matches_reference_model(gt):
     sig = np.exp(a["scaling"][~fixed]).max(axis=1) * 1.6
     assert (np.linalg.norm(xyz[~fixed] - a["xyz"][~fixed], axis=1) < 12.0 * sig + 1e-6).all()
     assert float(m.xyz_gradient_accum.abs().sum()) == 0 and float(m.denom.sum()) == 0 and float(m.max_radii2D.sum()) == 0
+
+
+def test_adam_in_two_parts_equals_one_call():
+    """surfel_adam_step(parts=1) then (parts=2) — what the view-parallel trainer issues around its two collectives — is the same
+    step as one call (parts=3), with explicit SH gradients and with SH gradients rebuilt from colour gradients."""
+    import torch
+    import surfel_trainer as TR
+    d = dev()
+    cam = TR.orbit_cameras(1, 64, 48, device=d)[0]
+
+    def make():
+        m = TR.synthetic_object(1500, d, seed=9, px_scale=0.06)
+        m.spatial_lr_scale = 1.0
+        m.training_setup(TR.optimization_params())
+        g = torch.Generator().manual_seed(2)
+        m.grad.copy_(torch.randn(m.grad.shape, generator=g).to(d) * 1e-3)
+        m.gcol.copy_(torch.randn(m.gcol.shape, generator=g).to(d) * 1e-3)
+        return m
+    for fused in (False, True):
+        a, b = make(), make()
+        cg = (cam.camera_center[None], a.gcol[None]) if fused else None
+        for it in (1, 2):
+            a.update_learning_rate(it); b.update_learning_rate(it)
+            a.optimizer_step(grad_scale=0.5, colour_grads=cg)
+            b.optimizer_step(grad_scale=0.5, colour_grads=(cam.camera_center[None], b.gcol[None]) if fused else None, parts=1)
+            b.optimizer_step(grad_scale=0.5, colour_grads=(cam.camera_center[None], b.gcol[None]) if fused else None, parts=2)
+            assert a.step_count == b.step_count == it
+            assert torch.equal(a.theta, b.theta) and torch.equal(a.m, b.m) and torch.equal(a.v, b.v) and torch.equal(a.act, b.act)
