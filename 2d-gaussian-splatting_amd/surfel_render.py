@@ -184,10 +184,11 @@ def regularizers(allmap, viewpoint_camera, depth_ratio, lambda_normal, lambda_di
 
 
 # ------------------------------------------------------------------------------------------------ render()
-def rasterize(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, override_color=None):
-    """The rasterizer call of render() (gaussian_renderer/__init__.py:27-106): returns (image, radii, allmap, means2D)."""
+def rasterize(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, override_color=None, zero_means2D=True):
+    """The rasterizer call of render() (gaussian_renderer/__init__.py:27-106): returns (image, radii, allmap, means2D).
+    means2D is only the sink of the densification statistic (its values are never read); zero_means2D=False skips the fill."""
     means3D = pc.get_xyz
-    screenspace_points = torch.zeros_like(means3D, requires_grad=True)
+    screenspace_points = torch.zeros_like(means3D, requires_grad=True) if zero_means2D else torch.empty_like(means3D).requires_grad_(True)
     raster_settings = GaussianRasterizationSettings(
         image_height=int(viewpoint_camera.image_height), image_width=int(viewpoint_camera.image_width),
         tanfovx=math.tan(viewpoint_camera.FoVx * 0.5), tanfovy=math.tan(viewpoint_camera.FoVy * 0.5), bg=bg_color,

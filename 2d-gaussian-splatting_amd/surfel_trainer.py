@@ -133,6 +133,7 @@ class Trainer:
         self.iteration = 0
         self.last = {}
         self._epoch, self._epoch_views, self._epoch_campos, self._centers = -1, None, None, None
+        self._one = torch.ones((), dtype=torch.float32, device=model.device)
         # fused SH path (default): the rasterizer's backward skips the 192 B/surfel SH gradients, the optimiser kernel rebuilds them
         # from the 12 B/surfel colour gradients.  Always on under view-parallel training (that is how the gradients are exchanged).
         self.fused_sh = self.world > 1 or os.environ.get("SURFEL_SH_FUSED", "1") != "0"
@@ -177,13 +178,13 @@ class Trainer:
             m.oneupSHdegree()
         cam = self._next_camera()
         m.bind(sh_grad=not self.fused_sh)      # fused: the SH gradients are rebuilt inside the optimiser kernel from the colour gradients
-        image, radii, allmap, means2D = rasterize(cam, m, self.pipe, self.background)
+        image, radii, allmap, means2D = rasterize(cam, m, self.pipe, self.background, zero_means2D=False)
         lam_n = opt.lambda_normal if it > opt.normal_from_iter else 0.0
         lam_d = opt.lambda_dist if it > opt.dist_from_iter else 0.0
         reg = lam_n > 0.0 or lam_d > 0.0
         loss, scalars = train_loss(image, allmap if reg else None, cam.original_image, cam.post_consts() if reg else None,
                                    self.pipe.depth_ratio, opt.lambda_dssim, lam_n, lam_d)
-        loss.backward()
+        torch.autograd.backward(loss, grad_tensors=self._one)        # cached seed gradient: no ones_like fill per iteration
         self.last = dict(loss=scalars[5], scalars=scalars, points=m.P, radii=radii)     # [Ll1, ssim, normal_err, dist, photometric, total] on the device
         with torch.no_grad():
             rebuilt = False
