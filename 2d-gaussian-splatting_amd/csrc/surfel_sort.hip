@@ -386,34 +386,12 @@ __global__ void __launch_bounds__(RS_THREADS) tile_depth_sort_kernel(const uint2
     if (n < 2u) return;
     uint32_t* __restrict__ pl = point_list + rg.x;
     const uint32_t tid = threadIdx.x;
-    // up to 1024 instances: E elements per thread, the network runs in registers (see tile_sort_regs)
+    // up to TS_CAP instances: E elements per thread, the network runs in registers (see tile_sort_regs)
     if (n <= (uint32_t)RS_THREADS) { tile_sort_regs<1>(n, pl, depth_keys, s, tid); return; }
     if (n <= 2u * RS_THREADS) { tile_sort_regs<2>(n, pl, depth_keys, s, tid); return; }
     if (n <= 4u * RS_THREADS) { tile_sort_regs<4>(n, pl, depth_keys, s, tid); return; }
-    if (n <= (uint32_t)TS_CAP) {
-        uint32_t N2 = 2;
-        while (N2 < n) N2 <<= 1;
-        for (uint32_t i = tid; i < N2; i += RS_THREADS) {
-            unsigned long long v = ~0ull;
-            if (i < n) { const uint32_t id = pl[i]; v = ((unsigned long long)depth_keys[id] << 32) | id; }
-            s[i] = v;
-        }
-        __syncthreads();
-        for (uint32_t k = 2; k <= N2; k <<= 1) {
-            for (uint32_t j = k >> 1; j > 0; j >>= 1) {
-                for (uint32_t t = tid; t < (N2 >> 1); t += RS_THREADS) {
-                    const uint32_t i = 2u * t - (t & (j - 1u));      // bit j of i is clear
-                    const uint32_t q = i + j;
-                    const bool up = (i & k) == 0u;
-                    const unsigned long long a = s[i], b = s[q];
-                    if ((a > b) == up) { s[i] = b; s[q] = a; }
-                }
-                __syncthreads();
-            }
-        }
-        for (uint32_t i = tid; i < n; i += RS_THREADS) pl[i] = (uint32_t)s[i];
-        return;
-    }
+    if (n <= 8u * RS_THREADS) { tile_sort_regs<8>(n, pl, depth_keys, s, tid); return; }
+    if (TS_CAP >= 16 * RS_THREADS && n <= 16u * RS_THREADS) { tile_sort_regs<(TS_CAP >= 16 * RS_THREADS ? 16 : 8)>(n, pl, depth_keys, s, tid); return; }
     // fallback: rank of element i = number of elements with a smaller (depth, index) key; chunks of TS_CAP keys through LDS
     uint32_t* __restrict__ ids = tmp_ids + rg.x;
     uint32_t* __restrict__ keys = tmp_keys + rg.x;

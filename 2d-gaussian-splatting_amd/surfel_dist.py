@@ -20,7 +20,6 @@ identical all-reduced bucket + identical Adam step keeps the replicas bit-identi
 xGMI note: 8 GPUs are fully connected (7 links x ~153 GB/s per GPU); one large bucket lets RCCL pick a
 direct reduce-scatter + all-gather over all links — do not split it into per-tensor collectives.
 """
-import math
 from typing import Dict, List, Optional, Sequence
 
 import torch
