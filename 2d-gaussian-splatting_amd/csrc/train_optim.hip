@@ -54,6 +54,13 @@ __global__ __launch_bounds__(256) void adam_act_kernel(int P, float* __restrict_
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= P) return;
     const size_t o_op = (size_t)3 * P, o_sc = (size_t)4 * P, o_rot = (size_t)6 * P;
+#pragma unroll
+    for (int j = 0; j < 3; j++) {   // xyz (no activation): here rather than in a launch of its own
+        const size_t o = 3 * (size_t)i + j;
+        float mi = m[o], vi = v[o];
+        theta[o] = adam_update(theta[o], grad[o] * k.grad_scale, mi, vi, k.lr[0], k);
+        m[o] = mi; v[o] = vi;
+    }
     {   // opacity = sigmoid(x)
         const size_t o = o_op + i;
         const float x = theta[o], s = sigmoidf(x);
@@ -238,25 +245,18 @@ void launch_adam(int P, float* theta, const float* grad, float* m, float* v, flo
     AdamK k;
     for (int i = 0; i < 6; i++) k.lr[i] = lr[i];
     k.beta1 = beta1; k.beta2 = beta2; k.eps = eps; k.bc1 = bc1; k.bc2_sqrt = bc2_sqrt; k.grad_scale = grad_scale;
-    const size_t n_xyz = (size_t)3 * P;
-    size_t n_all = (size_t)51 * P;
-    if (gcol_all) {      // SH gradients rebuilt from the colour gradients inside the SH Adam kernel (before xyz moves)
-        if (parts & 1) hipLaunchKernelGGL(adam_sh_kernel, dim3((P + 63) / 64), dim3(256), 0, s, P, D, N, theta, m, v, campos_all, gcol_all, k);
-        n_all = n_xyz;
-    } else if (!(parts & 1)) {
-        n_all = n_xyz;       // SH block handled by another call
-    } else if (!(parts & 2)) {
-        // SH block only, gradients read from grad: run the elementwise kernel over the SH range alone
-        size_t nsh = (size_t)48 * P, blocks_sh = (nsh + 256 * 4 - 1) / (256 * 4);
-        if (blocks_sh > 65536) blocks_sh = 65536;
-        hipLaunchKernelGGL(adam_elem_kernel, dim3((unsigned)blocks_sh), dim3(256), 0, s, (size_t)0, nsh, (size_t)10 * P, theta, grad, m, v, k);
-        return;
+    // SH block (parts & 1): rebuilt from the colour gradients inside adam_sh_kernel (before xyz moves), or read from grad by the
+    // elementwise kernel.  Geometry sections (parts & 2): xyz + the activated sections, one per-surfel kernel.
+    if (parts & 1) {
+        if (gcol_all) {
+            hipLaunchKernelGGL(adam_sh_kernel, dim3((P + 63) / 64), dim3(256), 0, s, P, D, N, theta, m, v, campos_all, gcol_all, k);
+        } else {
+            size_t nsh = (size_t)48 * P, blocks_sh = (nsh + 256 * 4 - 1) / (256 * 4);
+            if (blocks_sh > 65536) blocks_sh = 65536;
+            hipLaunchKernelGGL(adam_elem_kernel, dim3((unsigned)blocks_sh), dim3(256), 0, s, (size_t)0, nsh, (size_t)10 * P, theta, grad, m, v, k);
+        }
     }
-    if (!(parts & 2)) return;
-    size_t blocks = (n_all + 256 * 4 - 1) / (256 * 4);
-    if (blocks > 65536) blocks = 65536;
-    hipLaunchKernelGGL(adam_elem_kernel, dim3((unsigned)blocks), dim3(256), 0, s, n_xyz, n_all, (size_t)7 * P, theta, grad, m, v, k);
-    hipLaunchKernelGGL(adam_act_kernel, dim3((P + 255) / 256), dim3(256), 0, s, P, theta, grad, m, v, act, k);
+    if (parts & 2) hipLaunchKernelGGL(adam_act_kernel, dim3((P + 255) / 256), dim3(256), 0, s, P, theta, grad, m, v, act, k);
 }
 
 void launch_densify_stats(int P, const float* g2d, const int* radii, float* accum, float* denom, float* maxr, hipStream_t s) {
