@@ -134,6 +134,9 @@ class Trainer:
         self.last = {}
         self._epoch, self._epoch_views, self._epoch_campos, self._centers = -1, None, None, None
         self._one = torch.ones((), dtype=torch.float32, device=model.device)
+        # RCCL: asynchronous collectives with stream-level waits (SH-block Adam overlaps the geometry all-reduce); other backends
+        # (gloo rehearsals stage through the host and block) take the plain synchronous form
+        self._async_exchange = self.world > 1 and dist.get_backend() == "nccl"
         # fused SH path (default): the rasterizer's backward skips the 192 B/surfel SH gradients, the optimiser kernel rebuilds them
         # from the 12 B/surfel colour gradients.  Always on under view-parallel training (that is how the gradients are exchanged).
         self.fused_sh = self.world > 1 or os.environ.get("SURFEL_SH_FUSED", "1") != "0"
@@ -208,11 +211,15 @@ class Trainer:
                     # all-reduce of the 40 B/surfel geometry prefix + all-gather of 12 B/surfel/rank colour gradients; the 192 B/surfel
                     # SH gradients are rebuilt from them (exact, rank-ordered sum) instead of being all-reduced
                     campos_all = self._step_views()[1]
-                    gcol_all, w_gather, w_reduce = exchange_collectives(m.grad, m.gcol, m.P, async_op=True)
-                    w_gather.wait()          # stream-level wait: the SH block updates while the geometry all-reduce is in flight
-                    m.optimizer_step(grad_scale=1.0 / self.world, colour_grads=(campos_all, gcol_all), parts=1)
-                    w_reduce.wait()
-                    m.optimizer_step(grad_scale=1.0 / self.world, colour_grads=(campos_all, gcol_all), parts=2)
+                    if self._async_exchange:
+                        gcol_all, w_gather, w_reduce = exchange_collectives(m.grad, m.gcol, m.P, async_op=True)
+                        w_gather.wait()          # stream-level wait: the SH block updates while the geometry all-reduce is in flight
+                        m.optimizer_step(grad_scale=1.0 / self.world, colour_grads=(campos_all, gcol_all), parts=1)
+                        w_reduce.wait()
+                        m.optimizer_step(grad_scale=1.0 / self.world, colour_grads=(campos_all, gcol_all), parts=2)
+                    else:
+                        gcol_all = exchange_collectives(m.grad, m.gcol, m.P)
+                        m.optimizer_step(grad_scale=1.0 / self.world, colour_grads=(campos_all, gcol_all))
                 else:
                     if self.fused_sh:
                         campos_all, gcol_all = cam.camera_center[None], m.gcol[None]
