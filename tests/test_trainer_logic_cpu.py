@@ -1,0 +1,103 @@
+"""CPU: the control flow of surfel_trainer.Trainer.step against the reference's loop (train.py:54-138) with the kernels mocked
+out — learning-rate / SH-degree schedule, lambda schedules, densification schedule, "no optimiser update on iterations that
+re-create the parameters", opacity reset, view sampling without replacement."""
+import types
+
+import pytest
+import torch
+
+
+class FakeModel:
+    def __init__(self):
+        self.device = torch.device("cpu")
+        self.P = 5
+        self.grad = torch.zeros(5 * 58)
+        self._gv = {"opacity": torch.ones(5, 1)}
+        self.gcol = torch.zeros(5, 3)
+        self.active_sh_degree = 0
+        self.log = []
+
+    def update_learning_rate(self, it): self.log.append(("lr", it))
+    def oneupSHdegree(self): self.active_sh_degree += 1; self.log.append(("sh",))
+    def bind(self, sh_grad=True): self.log.append(("bind", sh_grad))
+    def add_densification_stats(self, g, radii=None): self.log.append(("stats",))
+    def densify_and_prune(self, *a, **k): self.log.append(("densify", a, k.get("generator")))
+    def reset_opacity(self): self.log.append(("reset",))
+    def optimizer_step(self, grad_scale=1.0, colour_grads=None, parts=3): self.log.append(("adam", grad_scale, colour_grads is not None, parts))
+    def training_setup(self, opt): pass
+
+
+@pytest.fixture()
+def trainer(monkeypatch):
+    import surfel_trainer as TR
+    calls = []
+
+    def fake_rasterize(cam, m, pipe, bg, zero_means2D=True):
+        calls.append(("raster", cam.uid))
+        m2 = torch.zeros(m.P, 3, requires_grad=True)
+        img = torch.zeros(3, 4, 4, requires_grad=True)
+        return img, torch.ones(m.P, dtype=torch.int32), torch.zeros(7, 4, 4, requires_grad=True), m2
+
+    def fake_train_loss(image, allmap, gt, cam, ratio, l_dssim, l_n, l_d):
+        calls.append(("loss", allmap is not None, cam is not None, l_n, l_d))
+        return image.sum() * 0.0, torch.zeros(6)
+
+    monkeypatch.setattr(TR, "rasterize", fake_rasterize)
+    monkeypatch.setattr(TR, "train_loss", fake_train_loss)
+    cams = [types.SimpleNamespace(uid=i, original_image=torch.zeros(3, 4, 4), camera_center=torch.zeros(3), post_consts=lambda: torch.zeros(24))
+            for i in range(4)]
+    m = FakeModel()
+    opt = TR.optimization_params(iterations=60, densify_from_iter=10, densification_interval=10, densify_until_iter=45, opacity_reset_interval=30,
+                                 dist_from_iter=5, normal_from_iter=20, lambda_dist=100.0, lambda_normal=0.05)
+    tr = TR.Trainer(m, cams, opt, TR.pipeline_params(depth_ratio=1.0), extent=3.0)
+    return tr, m, calls, opt
+
+
+def test_loop_schedules_match_reference(trainer):
+    tr, m, calls, opt = trainer
+    per_it = []
+    for _ in range(opt.iterations):
+        n0, c0 = len(m.log), len(calls)
+        tr.step()
+        per_it.append((m.log[n0:], calls[c0:]))
+    for it, (log, cl) in enumerate(per_it, start=1):
+        kinds = [e[0] for e in log]
+        assert kinds[0] == "lr" and log[0][1] == it                                    # train.py:58
+        loss = [c for c in cl if c[0] == "loss"][0]
+        assert loss[3] == (opt.lambda_normal if it > opt.normal_from_iter else 0.0)    # train.py:77-78 (7000 / 3000 in the reference)
+        assert loss[4] == (opt.lambda_dist if it > opt.dist_from_iter else 0.0)
+        assert loss[1] == (it > opt.dist_from_iter)                                    # allmap only enters when a regulariser is on
+        densified = it < opt.densify_until_iter and it > opt.densify_from_iter and it % opt.densification_interval == 0
+        assert ("stats" in kinds) == (it < opt.densify_until_iter)                     # train.py:126-128
+        assert ("densify" in kinds) == densified                                       # train.py:130-132
+        if densified:
+            a = [e for e in log if e[0] == "densify"][0][1]
+            assert a[0] == opt.densify_grad_threshold and a[1] == opt.opacity_cull and a[2] == 3.0
+            assert a[3] == (20 if it > opt.opacity_reset_interval else None)           # size_threshold, train.py:131
+        assert ("reset" in kinds) == (it < opt.densify_until_iter and it % opt.opacity_reset_interval == 0)   # train.py:134-135
+        # re-created parameters carry no gradient in the reference -> no update on densification iterations, none on the last one
+        assert ("adam" in kinds) == (it < opt.iterations and not densified)            # train.py:137-139
+    # one view per iteration, sampled without replacement per epoch (train.py:64-67)
+    views = [c[1] for _, cl in per_it for c in cl if c[0] == "raster"]
+    for e in range(0, 60, 4):
+        assert sorted(views[e:e + 4]) == [0, 1, 2, 3]
+    assert m.active_sh_degree == 0                                                      # no multiple of 1000 reached (train.py:61-62)
+
+
+def test_white_background_resets_opacity_at_densify_start(monkeypatch):
+    import surfel_trainer as TR
+    monkeypatch.setattr(TR, "rasterize", lambda cam, m, pipe, bg, zero_means2D=True: (torch.zeros(3, 4, 4, requires_grad=True),
+                                                                                      torch.ones(m.P, dtype=torch.int32), None, torch.zeros(m.P, 3, requires_grad=True)))
+    monkeypatch.setattr(TR, "train_loss", lambda image, *a: (image.sum() * 0.0, torch.zeros(6)))
+    cams = [types.SimpleNamespace(uid=0, original_image=torch.zeros(3, 4, 4), camera_center=torch.zeros(3), post_consts=lambda: None)]
+    m = FakeModel()
+    opt = TR.optimization_params(iterations=12, densify_from_iter=10, densification_interval=5, opacity_reset_interval=1000, dist_from_iter=10 ** 6,
+                                 normal_from_iter=10 ** 6)
+    tr = TR.Trainer(m, cams, opt, white_background=True, extent=1.0)
+    assert tr.background.tolist() == [1.0, 1.0, 1.0]
+    for _ in range(11):
+        tr.step()
+    resets = [i for i, e in enumerate(m.log) if e[0] == "reset"]
+    assert len(resets) == 1                                                             # at iteration == densify_from_iter (train.py:134)
+    # that iteration still takes its optimiser step, with the opacity gradient dropped (the reference re-creates only that parameter)
+    assert m.log[resets[0] + 1][0] == "adam" and float(m._gv["opacity"].abs().sum()) == 0.0
