@@ -250,6 +250,15 @@ def main():
     out["dens2_after_m_xyz"] = dm.optimizer.state[dm.optimizer.param_groups[0]["params"][0]]["exp_avg"].numpy().copy()
     out["dens2_after_accum_sum"] = float(dm.xyz_gradient_accum.sum()); out["dens2_after_maxr_sum"] = float(dm.max_radii2D.sum())
 
+    # ------------------------------------------------------------------ quaternion -> rotation, splat2world (utils/general_utils.py:78-110)
+    from utils.general_utils import build_rotation
+    q = torch.tensor(rng.normal(size=(64, 4)).astype(np.float32))
+    out.update(rot_q=q.numpy(), rot_R=build_rotation(q).numpy())
+    cm = GaussianModel(3)
+    cm._xyz = torch.tensor(rng.normal(size=(64, 3)).astype(np.float32)); cm._scaling = torch.tensor(rng.normal(-2, 0.5, size=(64, 2)).astype(np.float32))
+    cm._rotation = q
+    out.update(cov_xyz=cm._xyz.numpy(), cov_scaling=cm._scaling.numpy(), cov_splat2world=cm.get_covariance(1.7).numpy())
+
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "ref_train.npz")
     np.savez_compressed(path, **out)
     print("wrote", path, os.path.getsize(path), "bytes,", len(out), "arrays")

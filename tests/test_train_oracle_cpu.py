@@ -107,3 +107,17 @@ def test_camera_matches_reference_camera():
     assert np.allclose(cam.full_proj_transform.numpy(), g["projmatrix"], rtol=1e-5, atol=1e-6)
     assert np.allclose(cam.camera_center.numpy(), g["campos"], rtol=1e-5, atol=1e-6)
     assert cam.image_width == W and cam.image_height == H and cam.znear == 0.01 and cam.zfar == 100.0
+
+
+def test_rotation_and_splat2world_match_reference(gt):
+    """surfel_model.quat_to_rotmat == utils/general_utils.build_rotation; the splat2world matrices the compute_cov3D_python path
+    feeds the rasterizer == GaussianModel.get_covariance (scene/gaussian_model.py:27-33), here evaluated with torch on CPU."""
+    import torch
+    import surfel_model as M
+    q = torch.tensor(gt["rot_q"])
+    assert np.allclose(M.quat_to_rotmat(q).numpy(), gt["rot_R"], rtol=1e-5, atol=1e-6)
+    m = M.GaussianModel.__new__(M.GaussianModel)          # no device store: only the pure-torch covariance builder is exercised
+    m.P, m.device = 64, torch.device("cpu")
+    m._pv = {"xyz": torch.tensor(gt["cov_xyz"]), "rotation": q}
+    m._av = {"scaling": torch.exp(torch.tensor(gt["cov_scaling"]))}
+    assert np.allclose(m.get_covariance(1.7).numpy(), gt["cov_splat2world"], rtol=1e-5, atol=1e-6)
