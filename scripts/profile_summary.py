@@ -71,7 +71,7 @@ def main():
     for sub in ("fetch", "write", "sq"):
         for k, cs in pmc_means(os.path.join(src, sub)).items():
             merged[k].update(cs)
-    ours = ("rs_", "os_", "scan_", "ssim_", "post_", "adam_", "loss_", "densify_", "activate_", "reduce_")
+    ours = ("rs_", "os_", "scan_", "tile_", "ssim_", "post_", "adam_", "loss_", "densify_", "activate_", "reduce_")
     merged = {k: v for k, v in merged.items() if k in STAGE_OF or k.startswith(ours) or "knn" in k}
     traffic = {}
     for k, cs in merged.items():
