@@ -34,6 +34,14 @@ __device__ __forceinline__ uint32_t preprocess_one(const PreprocessArgs& a, cons
     uint32_t dkey = 0xffffffffu;      // culled surfels sort behind every visible one
     const float* __restrict__ vm = a.viewmatrix;
     const float px = a.means3D[3 * i], py = a.means3D[3 * i + 1], pz = a.means3D[3 * i + 2];
+    // every per-surfel input is requested up front (one memory round trip instead of one per use site)
+    const float opa_in = a.opacities[i];
+    float4 q_in = make_float4(1.f, 0.f, 0.f, 0.f);
+    float2 sc_in = make_float2(1.f, 1.f);
+    if (a.transMat_precomp == nullptr) {
+        q_in = reinterpret_cast<const float4*>(a.rotations)[i];
+        sc_in = reinterpret_cast<const float2*>(a.scales)[i];
+    }
     const float vx = vm[0] * px + vm[4] * py + vm[8] * pz + vm[12];
     const float vy = vm[1] * px + vm[5] * py + vm[9] * pz + vm[13];
     const float vz = vm[2] * px + vm[6] * py + vm[10] * pz + vm[14];
@@ -42,8 +50,8 @@ __device__ __forceinline__ uint32_t preprocess_one(const PreprocessArgs& a, cons
         float T[9];
         float nx, ny, nz;
         if (a.transMat_precomp == nullptr) {
-            const float4 q = reinterpret_cast<const float4*>(a.rotations)[i];
-            const float2 sc = reinterpret_cast<const float2*>(a.scales)[i];
+            const float4 q = q_in;
+            const float2 sc = sc_in;
             const float s = rsqrtf(q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w);
             const float w = q.x * s, x = q.y * s, y = q.z * s, z = q.w * s;
             const float sx = a.scale_modifier * sc.x, sy = a.scale_modifier * sc.y;
@@ -172,7 +180,7 @@ __device__ __forceinline__ uint32_t preprocess_one(const PreprocessArgs& a, cons
         float bx0 = 1.f, bx1 = 0.f, by0 = 1.f, by1 = 0.f;       // bbox of the footprint (tile-level cull); empty
         float ecx = cx, ecy = cy, Sxx = FOOT_UNBOUNDED, Sxy = 0.f, Syy = FOOT_UNBOUNDED, r2sq = 0.f, Sdet = 1.f;
         {
-            const float opa = a.opacities[i];
+            const float opa = opa_in;
             if (opa * 255.f >= 0.999f) {
                 const float rmax = 2.f * __logf(fmaxf(opa * 255.f, 1.f)) * 1.0001f + 1e-3f;
                 const float r2 = sqrtf(0.5f * rmax) + 0.05f;
@@ -210,7 +218,7 @@ __device__ __forceinline__ uint32_t preprocess_one(const PreprocessArgs& a, cons
         float4* __restrict__ rec = reinterpret_cast<float4*>(a.rec + (size_t)i * REC_F);
         rec[0] = make_float4(T[0], T[1], T[2], T[3]);
         rec[1] = make_float4(T[4], T[5], T[6], T[7]);
-        rec[2] = make_float4(T[8], cx, cy, a.opacities[i]);
+        rec[2] = make_float4(T[8], cx, cy, opa_in);
         rec[3] = make_float4(nx, ny, nz, r);
         // Instances are emitted only for the tiles of the reference rect that the alpha>=1/255 bbox can
         // reach (a pure cull: skipped (tile, surfel) pairs contribute to no pixel, so images and gradients
