@@ -144,3 +144,36 @@ def band_settings(raster_settings, y0: int, y1: int):
     pm = raster_settings.projmatrix.clone()
     pm[:, 1] = raster_settings.projmatrix[:, 1] * (H / Hb) + raster_settings.projmatrix[:, 3] * ((H - Hb - 2.0 * y0) / Hb)
     return raster_settings._replace(image_height=Hb, projmatrix=pm, tanfovy=raster_settings.tanfovy * Hb / H)
+
+
+class _GatherBands(torch.autograd.Function):
+    """[C, Hb, W] band of this rank -> full [C, H, W] image on every rank (one all-gather of equally padded bands); the backward
+    hands the rank the rows of the gradient that belong to its band."""
+
+    @staticmethod
+    def forward(ctx, band, bounds, group):
+        world = dist.get_world_size(group); rank = dist.get_rank(group)
+        C, Hb, W = band.shape
+        hmax = max(y1 - y0 for y0, y1 in bounds)
+        send = band.detach()
+        if Hb < hmax:
+            send = torch.cat([send, send.new_zeros((C, hmax - Hb, W))], dim=1)
+        send = send.contiguous()
+        recv = send.new_empty((world, C, hmax, W))
+        try:
+            dist.all_gather_into_tensor(recv, send, group=group)
+        except (RuntimeError, NotImplementedError):
+            dist.all_gather([recv[r] for r in range(world)], send, group=group)
+        full = torch.cat([recv[r, :, :bounds[r][1] - bounds[r][0]] for r in range(world)], dim=1)
+        ctx.rows = bounds[rank]
+        return full
+
+    @staticmethod
+    def backward(ctx, g_full):
+        y0, y1 = ctx.rows
+        return g_full[:, y0:y1].contiguous(), None, None
+
+
+def gather_bands(band: torch.Tensor, bounds: Sequence[tuple], group=None) -> torch.Tensor:
+    """Assemble the full image from every rank's rows (bounds = band_bounds(H, world)); differentiable w.r.t. the own band."""
+    return _GatherBands.apply(band, list(bounds), group)

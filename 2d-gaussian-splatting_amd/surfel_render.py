@@ -184,9 +184,10 @@ def regularizers(allmap, viewpoint_camera, depth_ratio, lambda_normal, lambda_di
 
 
 # ------------------------------------------------------------------------------------------------ render()
-def rasterize(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, override_color=None, zero_means2D=True):
+def rasterize(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, override_color=None, zero_means2D=True, band=None):
     """The rasterizer call of render() (gaussian_renderer/__init__.py:27-106): returns (image, radii, allmap, means2D).
-    means2D is only the sink of the densification statistic (its values are never read); zero_means2D=False skips the fill."""
+    means2D is only the sink of the densification statistic (its values are never read); zero_means2D=False skips the fill.
+    band = (y0, y1), multiples of 16: render only those image rows (tile-band sharding, surfel_dist.band_settings)."""
     means3D = pc.get_xyz
     screenspace_points = torch.zeros_like(means3D, requires_grad=True) if zero_means2D else torch.empty_like(means3D).requires_grad_(True)
     raster_settings = GaussianRasterizationSettings(
@@ -195,6 +196,9 @@ def rasterize(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, overri
         scale_modifier=scaling_modifier, viewmatrix=viewpoint_camera.world_view_transform,
         projmatrix=viewpoint_camera.full_proj_transform, sh_degree=pc.active_sh_degree, campos=viewpoint_camera.camera_center,
         prefiltered=False, debug=int(getattr(pipe, "debug", 0)))
+    if band is not None:
+        import surfel_dist
+        raster_settings = surfel_dist.band_settings(raster_settings, int(band[0]), int(band[1]))
     rasterizer = GaussianRasterizer(raster_settings=raster_settings)
     scales = rotations = cov3D_precomp = None
     if getattr(pipe, "compute_cov3D_python", False):

@@ -118,7 +118,14 @@ def capture_views(gt_model, cams, background, pipe=None):
 
 # ------------------------------------------------------------------------------------------------ the loop
 class Trainer:
-    def __init__(self, model, cams, opt=None, pipe=None, white_background=False, extent=None, seed=0):
+    def __init__(self, model, cams, opt=None, pipe=None, white_background=False, extent=None, seed=0, sharding="views"):
+        """sharding (N > 1): "views" = every rank trains on its own view per step (default, BASELINE config 4); "bands" = all ranks
+        render row bands of the SAME view (tile-band sharding, BASELINE config 5): the bands are all-gathered into the full image,
+        the loss is evaluated on it by every rank, each rank back-propagates its own rows, and the per-surfel gradients of the bands
+        ADD UP to the single-GPU gradient (same exchange, no averaging)."""
+        if sharding not in ("views", "bands"):
+            raise ValueError("sharding must be 'views' or 'bands'")
+        self.sharding = sharding
         self.model, self.cams = model, cams
         self.opt = opt or optimization_params()
         self.pipe = pipe or pipeline_params()
@@ -159,7 +166,7 @@ class Trainer:
         return self._epoch_views[k], self._epoch_campos[k]
 
     def _next_camera(self):
-        if self.world > 1:
+        if self.world > 1 and self.sharding == "views":
             return self.cams[self._step_views()[0][self.rank]]
         if not self._stack:                       # train.py:64-67: pop a random view from a refilled stack
             self._stack = list(range(len(self.cams)))
@@ -181,7 +188,14 @@ class Trainer:
             m.oneupSHdegree()
         cam = self._next_camera()
         m.bind(sh_grad=not self.fused_sh)      # fused: the SH gradients are rebuilt inside the optimiser kernel from the colour gradients
-        image, radii, allmap, means2D = rasterize(cam, m, self.pipe, self.background, zero_means2D=False)
+        bands = self.world > 1 and self.sharding == "bands"
+        if bands:
+            bounds = surfel_dist.band_bounds(int(cam.image_height), self.world)
+            image, radii, allmap, means2D = rasterize(cam, m, self.pipe, self.background, zero_means2D=False, band=bounds[self.rank])
+            image = surfel_dist.gather_bands(image, bounds)
+            allmap = surfel_dist.gather_bands(allmap, bounds)
+        else:
+            image, radii, allmap, means2D = rasterize(cam, m, self.pipe, self.background, zero_means2D=False)
         lam_n = opt.lambda_normal if it > opt.normal_from_iter else 0.0
         lam_d = opt.lambda_dist if it > opt.dist_from_iter else 0.0
         reg = lam_n > 0.0 or lam_d > 0.0
@@ -192,9 +206,13 @@ class Trainer:
         with torch.no_grad():
             rebuilt = False
             if it < opt.densify_until_iter:
-                m.add_densification_stats(means2D.grad, radii=radii)
+                g2d = means2D.grad
+                if bands:      # one view: the statistic is the norm of the SUM over bands, visibility the union of the bands
+                    dist.all_reduce(g2d, op=dist.ReduceOp.SUM)
+                    radii = radii.clone(); dist.all_reduce(radii, op=dist.ReduceOp.MAX)
+                m.add_densification_stats(g2d, radii=radii)
                 if it > opt.densify_from_iter and it % opt.densification_interval == 0:
-                    if self.world > 1:
+                    if self.world > 1 and not bands:
                         self._reduce_stats()
                     size_threshold = 20 if it > opt.opacity_reset_interval else None
                     gen = None
@@ -210,20 +228,21 @@ class Trainer:
                 if self.world > 1:
                     # all-reduce of the 40 B/surfel geometry prefix + all-gather of 12 B/surfel/rank colour gradients; the 192 B/surfel
                     # SH gradients are rebuilt from them (exact, rank-ordered sum) instead of being all-reduced
-                    campos_all = self._step_views()[1]
+                    campos_all = cam.camera_center[None].expand(self.world, 3).contiguous() if bands else self._step_views()[1]
+                    scale = 1.0 if bands else 1.0 / self.world      # bands: partial gradients of one view add up; views: average
                     if self._async_exchange:
                         gcol_all, w_gather, w_reduce = exchange_collectives(m.grad, m.gcol, m.P, async_op=True)
                         w_gather.wait()          # stream-level wait: the SH block updates while the geometry all-reduce is in flight
-                        m.optimizer_step(grad_scale=1.0 / self.world, colour_grads=(campos_all, gcol_all), parts=1)
+                        m.optimizer_step(grad_scale=scale, colour_grads=(campos_all, gcol_all), parts=1)
                         w_reduce.wait()
-                        m.optimizer_step(grad_scale=1.0 / self.world, colour_grads=(campos_all, gcol_all), parts=2)
+                        m.optimizer_step(grad_scale=scale, colour_grads=(campos_all, gcol_all), parts=2)
                     else:
                         gcol_all = exchange_collectives(m.grad, m.gcol, m.P)
-                        m.optimizer_step(grad_scale=1.0 / self.world, colour_grads=(campos_all, gcol_all))
+                        m.optimizer_step(grad_scale=scale, colour_grads=(campos_all, gcol_all))
                 else:
                     if self.fused_sh:
                         campos_all, gcol_all = cam.camera_center[None], m.gcol[None]
-                    m.optimizer_step(grad_scale=1.0 / self.world, colour_grads=(campos_all, gcol_all) if self.fused_sh else None)
+                    m.optimizer_step(grad_scale=1.0, colour_grads=(campos_all, gcol_all) if self.fused_sh else None)
 
     def evaluate(self, cams=None):
         """Mean PSNR / L1 over views (training_report, train.py:201-232)."""

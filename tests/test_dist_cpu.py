@@ -176,3 +176,41 @@ def test_trainer_collectives_world2():
         assert mr == [max(float(i), float(-i + 1)) for i in range(P)]
         assert gsum == 3.0 * sum(range(P * 58))
     assert all(a != b for a, b in zip(res[0][5], res[1][5]))       # distinct views per step across ranks
+
+
+def _gather_bands_worker(rank, world, port, q):
+    import os
+    import torch
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import surfel_dist as sd
+        H, W = 80, 6
+        bounds = sd.band_bounds(H, world)                       # 80 rows = 5 tile rows -> two unequal bands
+        y0, y1 = bounds[rank]
+        full_ref = torch.arange(2 * H * W, dtype=torch.float32).reshape(2, H, W)
+        band = full_ref[:, y0:y1].clone().requires_grad_(True)
+        full = sd.gather_bands(band, bounds)
+        wgt = torch.linspace(-1, 1, 2 * H * W).reshape(2, H, W)
+        (full * wgt).sum().backward()
+        q.put((rank, bool(torch.equal(full, full_ref)), bool(torch.equal(band.grad, wgt[:, y0:y1])), bounds))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_gather_bands_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_gather_bands_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, ok_full, ok_grad, bounds in res:
+        assert ok_full and ok_grad
+        assert bounds[0][0] == 0 and bounds[-1][1] == 80 and bounds[0][1] == bounds[1][0] and bounds[0][1] % 16 == 0
+        assert bounds[0][1] - bounds[0][0] != bounds[1][1] - bounds[1][0]          # unequal bands: exercises the padding
