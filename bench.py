@@ -51,6 +51,9 @@ def main():
     ap.add_argument("--no-1080p", action="store_true")
     ap.add_argument("--no-raster-only", action="store_true")
     ap.add_argument("--no-train-iter", action="store_true", help="(kept for older scripts; the timed step IS the training iteration)")
+    ap.add_argument("--sharding", choices=("views", "bands"), default="views",
+                    help="N > 1: 'views' = one view per GPU per iteration (weak scaling, default); 'bands' = tile-band sharding of ONE view "
+                         "per iteration across the GPUs (strong scaling; BASELINE config 5: --workload C5)")
     args = ap.parse_args()
 
     import torch
@@ -77,7 +80,7 @@ def main():
     from helpers_bench import make_trainer
     P, W, H, zf = synthetic.CONFIGS[args.workload]
     n_views = max(8, world)
-    tr = make_trainer(dev, args.workload, n_views=n_views)      # Trainer picks up the process group: all-reduce + averaged Adam step
+    tr = make_trainer(dev, args.workload, n_views=n_views, sharding=args.sharding)      # Trainer picks up the process group
     tr.pipe.debug = 3       # HIP events around the dominant kernel only (blend_bwd), resolved after the timed region, no sync
 
     def fence():
@@ -122,7 +125,8 @@ def main():
     out = None
     if rank == 0:
         ms_per_step = dt / args.steps * 1e3
-        iters_per_s = world * args.steps / dt
+        bands = world > 1 and args.sharding == "bands"
+        iters_per_s = (1 if bands else world) * args.steps / dt
         per_kernel = {k: v[0] / v[1] for k, v in stages.items()}
         dom = max(per_kernel, key=per_kernel.get) if per_kernel else None
         roof = None
@@ -157,16 +161,17 @@ def main():
                                          for k, v in per_kernel.items() if v > 0}}
         out = {"metric": "train iters/sec (full iteration: rasterizer fwd+bwd, L1+SSIM, normal+dist regularisers, Adam) + fwd Msplats/s @1080p",
                "value": round(iters_per_s, 3), "unit": "train-iters/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-               "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+               "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "strong" if bands else "weak", "vs_baseline": None,
                "dtype": "f32", "data": "synthetic",
                "config": {"workload": "%s-synthetic: %d random surfels, %dx%d, sh_degree 3, %d target views rendered from the unperturbed "
-                                      "surfels, 1 view/GPU/iteration, lambda_dssim 0.2, lambda_normal 0.05, lambda_dist 1000, depth_ratio 1, "
-                                      "Adam on 58 floats/surfel" % (args.workload, P, W, H, n_views),
+                                      "surfels, %s, lambda_dssim 0.2, lambda_normal 0.05, lambda_dist 1000, depth_ratio 1, "
+                                      "Adam on 58 floats/surfel" % (args.workload, P, W, H, n_views, "1 view/iteration split into row bands" if bands else "1 view/GPU/iteration"),
                           "P": P, "visible": V, "instances_R": R, "n_pass": n_pass, "tiles": tiles,
-                          "parallelism": "view-parallel dp%d; per iteration 1 all-reduce of 40 B/surfel (geometry gradients) + 1 all-gather of "
-                                         "12 B/surfel/rank (colour gradients -> SH gradients rebuilt locally)" % world},
+                          "parallelism": ("tile-band sharding of one view over %d GPUs (image bands all-gathered, same gradient exchange)" % world) if bands
+                          else ("view-parallel dp%d; per iteration 1 all-reduce of 40 B/surfel (geometry gradients) + 1 all-gather of "
+                                "12 B/surfel/rank (colour gradients -> SH gradients rebuilt locally)" % world)},
                "loss_first": round(loss_first, 5), "loss_last": round(loss_last, 5),
-               "train_Msplats_per_s": round(world * P * args.steps / dt / 1e6, 2), "roofline": roof}
+               "train_Msplats_per_s": round((1 if bands else world) * P * args.steps / dt / 1e6, 2), "roofline": roof}
 
     if world > 1:
         dist.barrier()

@@ -67,7 +67,7 @@ def cpu_baseline(workload="C2"):
             "fwd_bwd_Msplats_per_s": round(P * passes / (tf + tb) / 1e6, 4)}
 
 
-def make_trainer(dev, workload="C2", n_views=8, regularizers=True):
+def make_trainer(dev, workload="C2", n_views=8, regularizers=True, sharding="views"):
     """The bench's training job: the workload's synthetic surfels (synthetic.make_scene) seen from n_views nearby
     cameras; targets = renders of the unperturbed surfels; the trained model starts from perturbed parameters.  Every loss term
     is on (the DTU configuration: lambda_dist 1000, lambda_normal 0.05, depth_ratio 1) unless regularizers=False.  Densification
@@ -103,7 +103,7 @@ def make_trainer(dev, workload="C2", n_views=8, regularizers=True):
     far = 10 ** 9
     opt = TR.optimization_params(iterations=far, densify_from_iter=far, opacity_reset_interval=far, dist_from_iter=0 if regularizers else far,
                                  normal_from_iter=0 if regularizers else far, lambda_dist=1000.0, lambda_normal=0.05)
-    return TR.Trainer(model, cams, opt, TR.pipeline_params(depth_ratio=1.0))
+    return TR.Trainer(model, cams, opt, TR.pipeline_params(depth_ratio=1.0), sharding=sharding)
 
 
 def train_iter(dev, workload="C2", iters=60, warmup=15, n_views=8):
