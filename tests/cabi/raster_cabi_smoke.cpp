@@ -1,0 +1,141 @@
+// raster_cabi_smoke.cpp — the C ABI of libsurfel_hip.so driven WITHOUT PyTorch: plain hipMalloc memory, a malloc-style allocator
+// callback, the NULL stream.  Shows that the drop-in boundary (include/surfel_hip.h, include/surfel_train.h) carries no torch
+// types; checks a few invariants of a forward + backward + loss + Adam round trip.  Built and run by tests/test_gpu_cabi.py.
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#include <hip/hip_runtime.h>
+
+#include "../../include/surfel_hip.h"
+#include "../../include/surfel_train.h"
+
+#define CHECK(x) do { if (!(x)) { std::printf("FAILED: %s (line %d): %s\n", #x, __LINE__, surfel_last_error()); return 1; } } while (0)
+
+static std::vector<void*> g_allocs;
+// allocator callback (include/surfel_hip.h surfel_alloc_fn): `user`, when given, receives the pointer (one opaque buffer each)
+static void* dev_alloc(void* user, size_t bytes) {
+    void* p = nullptr;
+    if (hipMalloc(&p, bytes ? bytes : 256) != hipSuccess) return nullptr;
+    g_allocs.push_back(p);
+    if (user) *static_cast<void**>(user) = p;
+    return p;
+}
+template <typename T> static T* upload(const std::vector<T>& h) {
+    T* d = static_cast<T*>(dev_alloc(nullptr, h.size() * sizeof(T)));
+    (void)hipMemcpy(d, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice);
+    return d;
+}
+template <typename T> static std::vector<T> download(const T* d, size_t n) {
+    std::vector<T> h(n);
+    (void)hipMemcpy(h.data(), d, n * sizeof(T), hipMemcpyDeviceToHost);
+    return h;
+}
+static float frand() { return (float)std::rand() / (float)RAND_MAX; }
+
+int main() {
+    std::srand(7);
+    const int P = 3000, W = 160, H = 96, M = 16, D = 3;
+    const float tanx = 0.5f / 1.2f, tany = tanx * H / W;
+    // camera at the origin looking down +z: world_view_transform = I; projection as utils/graphics_utils.py:51-71, stored transposed
+    const float zn = 0.01f, zf = 100.f;
+    std::vector<float> view(16, 0.f), proj(16, 0.f), campos(3, 0.f), bg = {0.1f, 0.2f, 0.3f};
+    for (int i = 0; i < 4; i++) view[5 * i] = 1.f;
+    proj[0] = 1.f / tanx; proj[5] = 1.f / tany; proj[10] = zf / (zf - zn); proj[11] = 1.f; proj[14] = -(zf * zn) / (zf - zn);   // [r][c] of P^T
+    std::vector<float> means(3 * P), scales(2 * P), rots(4 * P), opac(P), shs((size_t)P * M * 3);
+    for (int i = 0; i < P; i++) {
+        const float z = 2.f + 8.f * frand();
+        means[3 * i] = (2.f * frand() - 1.f) * 1.1f * tanx * z; means[3 * i + 1] = (2.f * frand() - 1.f) * 1.1f * tany * z; means[3 * i + 2] = z;
+        scales[2 * i] = 0.02f * z * (0.5f + frand()); scales[2 * i + 1] = 0.02f * z * (0.5f + frand());
+        float q[4], n = 0.f;
+        for (int k = 0; k < 4; k++) { q[k] = 2.f * frand() - 1.f; n += q[k] * q[k]; }
+        for (int k = 0; k < 4; k++) rots[4 * i + k] = q[k] / std::sqrt(n);
+        opac[i] = 0.2f + 0.7f * frand();
+        for (int k = 0; k < M * 3; k++) shs[(size_t)i * M * 3 + k] = (k < 3 ? 1.f : 0.1f) * (2.f * frand() - 1.f);
+    }
+    float *d_means = upload(means), *d_scales = upload(scales), *d_rots = upload(rots), *d_opac = upload(opac), *d_shs = upload(shs);
+    float *d_view = upload(view), *d_proj = upload(proj), *d_campos = upload(campos), *d_bg = upload(bg);
+    float* out_color = static_cast<float*>(dev_alloc(nullptr, sizeof(float) * 3 * W * H));
+    float* out_others = static_cast<float*>(dev_alloc(nullptr, sizeof(float) * 7 * W * H));
+    int* radii = static_cast<int*>(dev_alloc(nullptr, sizeof(int) * P));
+    CHECK(surfel_abi_version() == SURFEL_ABI_VERSION);
+
+    const size_t before = g_allocs.size();
+    void *geom = nullptr, *binning = nullptr, *image = nullptr;
+    const int64_t R = surfel_rasterize_forward(dev_alloc, &geom, dev_alloc, &binning, dev_alloc, &image, P, D, M, d_bg, W, H, d_means, d_shs, nullptr,
+                                               d_opac, d_scales, 1.f, d_rots, nullptr, d_view, d_proj, d_campos, tanx, tany, 0, out_color,
+                                               out_others, radii, 0, nullptr);
+    CHECK(R > 0);
+    CHECK(g_allocs.size() == before + 3 && geom && binning && image);     // exactly the three opaque buffers
+    CHECK(hipDeviceSynchronize() == hipSuccess);
+    const auto col = download(out_color, (size_t)3 * W * H);
+    const auto oth = download(out_others, (size_t)7 * W * H);
+    double asum = 0.0; bool finite = true;
+    for (size_t k = 0; k < col.size(); k++) finite = finite && std::isfinite(col[k]);
+    for (int k = 0; k < W * H; k++) { const float a = oth[(size_t)W * H + k]; asum += a; finite = finite && a >= 0.f && a <= 1.f; }
+    CHECK(finite);
+    CHECK(asum / (W * H) > 0.05);
+    const auto rad = download(radii, (size_t)P);
+    int vis = 0; for (int r : rad) vis += r > 0;
+    CHECK(vis > P / 2);
+
+    // loss (L1 + SSIM against a flat grey target) and its gradient through the training ABI
+    std::vector<float> target((size_t)3 * W * H, 0.5f);
+    float* d_gt = upload(target);
+    const int nblk = ((W + 31) / 32) * ((H + 31) / 32);
+    float* dmaps = static_cast<float*>(dev_alloc(nullptr, sizeof(float) * 9 * W * H));
+    float* partials = static_cast<float*>(dev_alloc(nullptr, sizeof(float) * 2 * 3 * nblk));
+    float* scal = static_cast<float*>(dev_alloc(nullptr, sizeof(float) * 8));
+    float* g_color = static_cast<float*>(dev_alloc(nullptr, sizeof(float) * 3 * W * H));
+    CHECK(surfel_l1_ssim_forward(3, H, W, out_color, d_gt, dmaps, partials, nullptr) == nblk);
+    CHECK(surfel_loss_finalize(partials, 3 * nblk, 3 * W * H, nullptr, 0, 0, 0.2f, 0.f, 0.f, scal, nullptr, nullptr) == 0);
+    CHECK(surfel_l1_ssim_backward(3, H, W, out_color, d_gt, dmaps, 0.8f / (3.f * W * H), -0.2f / (3.f * W * H), nullptr, nullptr, g_color, nullptr) == 0);
+    const auto sc = download(scal, 6);
+    CHECK(sc[0] > 0.f && sc[0] < 1.f && sc[1] > -1.f && sc[1] <= 1.f && std::fabs(sc[4] - (0.8f * sc[0] + 0.2f * (1.f - sc[1]))) < 1e-5f);
+
+    // backward into a flat 58-float/surfel gradient store, then one Adam step on a matching parameter store
+    std::vector<float> zeros7((size_t)7 * W * H, 0.f);
+    float* g_others = upload(zeros7);
+    float* grad = static_cast<float*>(dev_alloc(nullptr, sizeof(float) * 58 * P));
+    float *g2d = static_cast<float*>(dev_alloc(nullptr, sizeof(float) * 3 * P)), *gnorm = static_cast<float*>(dev_alloc(nullptr, sizeof(float) * 3 * P));
+    float *gcol = static_cast<float*>(dev_alloc(nullptr, sizeof(float) * 3 * P)), *gT = static_cast<float*>(dev_alloc(nullptr, sizeof(float) * 9 * P));
+    CHECK(surfel_rasterize_backward(dev_alloc, nullptr, P, D, M, R, d_bg, W, H, d_means, d_shs, nullptr, d_scales, 1.f, d_rots, nullptr, d_view, d_proj,
+                                    d_campos, tanx, tany, radii, geom, binning, image, g_color, g_others, g2d, gnorm, grad + 3 * P /*opacity*/,
+                                    gcol, grad /*xyz*/, gT, grad + 10 * P /*sh*/, grad + 4 * P /*scaling*/, grad + 6 * P /*rotation*/, 0, nullptr) == 0);
+    CHECK(hipDeviceSynchronize() == hipSuccess);
+    const auto g = download(grad, (size_t)58 * P);
+    double gn = 0.0; finite = true;
+    for (float v : g) { finite = finite && std::isfinite(v); gn += (double)v * v; }
+    CHECK(finite && gn > 0.0);
+    // raw parameter store: xyz | logit(opacity) | log(scaling) | rotation | sh
+    std::vector<float> theta((size_t)58 * P);
+    for (int i = 0; i < P; i++) {
+        for (int k = 0; k < 3; k++) theta[3 * i + k] = means[3 * i + k];
+        theta[3 * P + i] = std::log(opac[i] / (1.f - opac[i]));
+        theta[4 * P + 2 * i] = std::log(scales[2 * i]); theta[4 * P + 2 * i + 1] = std::log(scales[2 * i + 1]);
+        for (int k = 0; k < 4; k++) theta[6 * P + 4 * i + k] = rots[4 * i + k];
+        for (int k = 0; k < 48; k++) theta[(size_t)10 * P + (size_t)48 * i + k] = shs[(size_t)48 * i + k];
+    }
+    float* d_theta = upload(theta);
+    std::vector<float> zerosP((size_t)58 * P, 0.f);
+    float *m1 = upload(zerosP), *m2 = upload(zerosP);
+    float* act = static_cast<float*>(dev_alloc(nullptr, sizeof(float) * 7 * P));
+    CHECK(surfel_activate(P, d_theta, act, nullptr) == 0);
+    const auto a0 = download(act, (size_t)7 * P);
+    CHECK(std::fabs(a0[0] - opac[0]) < 1e-5f && std::fabs(a0[P] - scales[0]) < 1e-6f);
+    const float lr[6] = {1.6e-4f, 2.5e-3f, 1.25e-4f, 0.05f, 5e-3f, 1e-3f};
+    CHECK(surfel_adam_step(P, d_theta, grad, m1, m2, act, lr, 0.9f, 0.999f, 1e-15f, 1, 1.f, D, 0, nullptr, nullptr, 3, nullptr) == 0);
+    CHECK(hipDeviceSynchronize() == hipSuccess);
+    const auto t1 = download(d_theta, (size_t)58 * P);
+    int moved = 0;
+    for (size_t k = 0; k < t1.size(); k++) { CHECK(std::isfinite(t1[k])); moved += t1[k] != theta[k]; }
+    CHECK(moved > P);                                          // every surfel with a gradient moved by ~lr (first Adam step)
+    // argument errors come back as codes + message, never as crashes
+    CHECK(surfel_rasterize_forward(dev_alloc, nullptr, dev_alloc, nullptr, dev_alloc, nullptr, P, D, M, d_bg, W, H, d_means, d_shs, d_means /* both colour sources */,
+                                   d_opac, d_scales, 1.f, d_rots, nullptr, d_view, d_proj, d_campos, tanx, tany, 0, out_color, out_others, radii, 0, nullptr) ==
+          SURFEL_E_INVALID);
+    for (void* p : g_allocs) (void)hipFree(p);
+    std::printf("cabi smoke ok: R=%lld visible=%d L1=%.4f ssim=%.4f |grad|=%.3e moved=%d\n", (long long)R, vis, sc[0], sc[1], std::sqrt(gn), moved);
+    return 0;
+}
