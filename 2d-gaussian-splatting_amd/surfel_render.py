@@ -202,6 +202,8 @@ def rasterize(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, overri
     rasterizer = GaussianRasterizer(raster_settings=raster_settings)
     scales = rotations = cov3D_precomp = None
     if getattr(pipe, "compute_cov3D_python", False):
+        if band is not None:
+            raise ValueError("tile-band sharding needs the native homography (compute_cov3D_python builds full-image pixel matrices)")
         # the reference's python homography (gaussian_renderer/__init__.py:64-75)
         splat2world = pc.get_covariance(scaling_modifier)
         W, H = viewpoint_camera.image_width, viewpoint_camera.image_height
