@@ -41,6 +41,42 @@ def algorithmic_bytes(stage, P, V, R, W, H, n_pass):
     }.get(stage, 0)
 
 
+def _respawn(n):
+    """Re-execute this command line under torch.distributed.run with n ranks on this node; returns its exit code."""
+    import socket
+    import subprocess
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC only on this driver (RCCL / cross-process HIP memory)
+    env.setdefault("OMP_NUM_THREADS", "8")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % n, "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
+def _rehearse_spawn(args):
+    """Launch-path check that needs no GPU: rendezvous over gloo, one all-reduce, rank 0 prints what a real run would report."""
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo")
+        t = torch.ones(1)
+        dist.all_reduce(t)
+        seen = int(t.item())
+        rank = dist.get_rank()
+        dist.barrier()
+        dist.destroy_process_group()
+    else:
+        seen, rank = 1, 0
+    if rank == 0:
+        print(json.dumps({"rehearsal": True, "n_gpus": world, "ranks_in_all_reduce": seen, "requested_gpus": args.gpus}))
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -54,7 +90,19 @@ def main():
     ap.add_argument("--sharding", choices=("views", "bands"), default="views",
                     help="N > 1: 'views' = one view per GPU per iteration (weak scaling, default); 'bands' = tile-band sharding of ONE view "
                          "per iteration across the GPUs (strong scaling; BASELINE config 5: --workload C5)")
+    ap.add_argument("--rehearse-spawn", action="store_true",
+                    help="only exercise the launch path: spawn / rendezvous (gloo, no GPU needed), one all-reduce, print n_gpus and exit")
     args = ap.parse_args()
+
+    # ---- launch contract: `python bench.py --gpus N` run DIRECTLY must time N ranks.  Without a torch.distributed.run
+    # environment this process re-executes itself under it (one rank per GPU, rendezvous on 127.0.0.1) and relays the result.
+    if "WORLD_SIZE" not in os.environ:
+        if args.gpus > 1:
+            raise SystemExit(_respawn(args.gpus))
+    elif int(os.environ["WORLD_SIZE"]) != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but the launcher started WORLD_SIZE=%s ranks" % (args.gpus, os.environ["WORLD_SIZE"]))
+    if args.rehearse_spawn:
+        return _rehearse_spawn(args)
 
     import torch
     import torch.distributed as dist
@@ -68,6 +116,9 @@ def main():
     backend = os.environ.get("SURFEL_DIST_BACKEND", "nccl")     # "gloo": rehearsal of the N>1 path with all ranks on one GPU
     if backend != "nccl":
         local = local % torch.cuda.device_count()
+    elif world > torch.cuda.device_count():
+        raise SystemExit("bench.py: --gpus %d needs %d HIP devices on this node, found %d (SURFEL_DIST_BACKEND=gloo rehearses the "
+                         "N > 1 path with all ranks on the devices present)" % (world, world, torch.cuda.device_count()))
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:

@@ -238,20 +238,36 @@ int64_t oracle_preprocess(const oracle_params* prm, const float* means3D, const 
  * `depth_f32` lets the caller inject the float32 depths of the device run so both sides sort
  * on identical keys; pass NULL to use (float)depths[i].
  * ---------------------------------------------------------------------------------------- */
-typedef struct { uint64_t key; uint32_t val; uint32_t seq; } kv_t;
+typedef struct { uint32_t bits; uint32_t val; } kv_t;
 static int kv_cmp(const void* a, const void* b) {
     const kv_t* x = (const kv_t*)a; const kv_t* y = (const kv_t*)b;
-    if (x->key != y->key) return x->key < y->key ? -1 : 1;
-    return x->seq < y->seq ? -1 : (x->seq > y->seq);
+    if (x->bits != y->bits) return x->bits < y->bits ? -1 : 1;
+    return x->val < y->val ? -1 : (x->val > y->val);
 }
 
+/* The global stable sort on (tile << 32 | depth bits) with emission order (surfel-major) as the tie-break is the same
+ * order as: bucket the instances by tile, then order every tile's bucket by (depth bits, surfel index) — a surfel appears
+ * at most once per tile.  Done that way the per-tile sorts run in parallel (the C4 / C5 parity runs hold 1e7 - 1e8 instances). */
 int oracle_bin(const oracle_params* prm, const real* depths, const float* depth_f32, const int* radii, const real* xy,
                int64_t R, uint32_t* point_list, uint64_t* keys_sorted, uint32_t* ranges /* [tiles][2] */) {
     const int P = prm->P, W = prm->W, H = prm->H;
     const int gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE;
+    const int ntiles = gx * gy;
     kv_t* kv = (kv_t*)malloc(sizeof(kv_t) * (size_t)(R > 0 ? R : 1));
-    if (!kv) return -1;
-    int64_t off = 0;
+    int64_t* start = (int64_t*)calloc((size_t)ntiles + 1, sizeof(int64_t));
+    int64_t* fill = (int64_t*)malloc(sizeof(int64_t) * ((size_t)ntiles + 1));
+    if (!kv || !start || !fill) { free(kv); free(start); free(fill); return -1; }
+    int64_t total = 0;
+    for (int i = 0; i < P; i++) {
+        if (radii[i] <= 0) continue;
+        int x0, y0, x1, y1;
+        tile_rect(xy[2 * i], xy[2 * i + 1], radii[i], gx, gy, &x0, &y0, &x1, &y1);
+        for (int y = y0; y < y1; y++)
+            for (int x = x0; x < x1; x++) { start[y * gx + x + 1]++; total++; }
+    }
+    if (total != R) { free(kv); free(start); free(fill); return -3; }
+    for (int t = 0; t < ntiles; t++) start[t + 1] += start[t];
+    memcpy(fill, start, sizeof(int64_t) * ((size_t)ntiles + 1));
     for (int i = 0; i < P; i++) {
         if (radii[i] <= 0) continue;
         int x0, y0, x1, y1;
@@ -260,24 +276,23 @@ int oracle_bin(const oracle_params* prm, const real* depths, const float* depth_
         uint32_t bits; memcpy(&bits, &d, 4);
         for (int y = y0; y < y1; y++)
             for (int x = x0; x < x1; x++) {
-                if (off >= R) { free(kv); return -2; }
-                kv[off].key = ((uint64_t)(uint32_t)(y * gx + x) << 32) | bits;
-                kv[off].val = (uint32_t)i;
-                kv[off].seq = (uint32_t)off;
-                off++;
+                const int64_t k = fill[y * gx + x]++;
+                kv[k].bits = bits; kv[k].val = (uint32_t)i;
             }
     }
-    if (off != R) { free(kv); return -3; }
-    qsort(kv, (size_t)R, sizeof(kv_t), kv_cmp);
-    memset(ranges, 0, sizeof(uint32_t) * 2 * (size_t)gx * gy);
-    for (int64_t k = 0; k < R; k++) {
-        point_list[k] = kv[k].val;
-        if (keys_sorted) keys_sorted[k] = kv[k].key;
-        uint32_t tile = (uint32_t)(kv[k].key >> 32);
-        if (k == 0 || tile != (uint32_t)(kv[k - 1].key >> 32)) ranges[2 * tile] = (uint32_t)k;
-        if (k == R - 1 || tile != (uint32_t)(kv[k + 1].key >> 32)) ranges[2 * tile + 1] = (uint32_t)(k + 1);
+    memset(ranges, 0, sizeof(uint32_t) * 2 * (size_t)ntiles);
+#pragma omp parallel for schedule(dynamic, 4)
+    for (int t = 0; t < ntiles; t++) {
+        const int64_t b = start[t], e = start[t + 1];
+        if (e == b) continue;
+        qsort(kv + b, (size_t)(e - b), sizeof(kv_t), kv_cmp);
+        ranges[2 * t] = (uint32_t)b; ranges[2 * t + 1] = (uint32_t)e;
+        for (int64_t k = b; k < e; k++) {
+            point_list[k] = kv[k].val;
+            if (keys_sorted) keys_sorted[k] = ((uint64_t)(uint32_t)t << 32) | kv[k].bits;
+        }
     }
-    free(kv);
+    free(kv); free(start); free(fill);
     return 0;
 }
 
