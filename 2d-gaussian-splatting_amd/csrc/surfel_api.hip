@@ -21,6 +21,8 @@ namespace {
 thread_local std::string g_err;
 int g_opt_cull = 1;        // surfel_set_option("cull", .)
 int g_opt_tile_sort = 1;   // surfel_set_option("tile_depth_sort", .): 0 never, 1 auto (by last frame's R / tiles), 2 always
+int g_opt_bwd_variant = 0; // surfel_set_option("bwd_variant", .): 0 per-row walk, 1 per-quad walk (bit-identical)
+unsigned long long* g_blend_stats = nullptr;   // surfel_debug_set_blend_stats
 thread_local int64_t g_last_R = -1; thread_local int g_last_W = 0, g_last_H = 0;   // auto heuristic (speed only; results identical)
 thread_local float g_stage_ms[16];
 thread_local int g_stage_n = 0;
@@ -213,8 +215,11 @@ int surfel_debug_sort_pairs(surfel_alloc_fn scratch_alloc, void* scratch_user, u
 int surfel_set_option(const char* name, int value) {
     if (name && std::strcmp(name, "cull") == 0) { g_opt_cull = value ? 1 : 0; return 0; }
     if (name && std::strcmp(name, "tile_depth_sort") == 0) { g_opt_tile_sort = value < 0 ? 0 : (value > 2 ? 2 : value); return 0; }
+    if (name && std::strcmp(name, "bwd_variant") == 0) { g_opt_bwd_variant = value ? 1 : 0; return 0; }
     return fail(SURFEL_E_INVALID, "unknown option");
 }
+
+int surfel_debug_set_blend_stats(void* dev_u64x8) { g_blend_stats = static_cast<unsigned long long*>(dev_u64x8); return 0; }
 
 int surfel_collect_stage_ms(float* sum_ms, int* count, int cap) {
     for (int i = 0; i < cap; i++) { sum_ms[i] = 0.f; count[i] = 0; }
@@ -239,6 +244,10 @@ int64_t surfel_rasterize_forward(surfel_alloc_fn geom_alloc, void* geom_user, su
                                  float* out_others, int* radii, int debug, void* stream) {
     (void)tan_fovx; (void)tan_fovy; (void)prefiltered;
     g_stage_n = 0;
+    // per-call option overrides ride in the upper bits of `debug` (include/surfel_hip.h); the low byte is the debug mode
+    const int opt_cull = (debug & SURFEL_OPT_NO_CULL) ? 0 : g_opt_cull;
+    const int opt_tile_sort = ((debug >> 9) & 3) ? ((debug >> 9) & 3) - 1 : g_opt_tile_sort;
+    debug &= 0xff;
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (!geom_alloc || !binning_alloc || !image_alloc) return fail(SURFEL_E_INVALID, "allocator callback is NULL");
     if (P < 0 || width <= 0 || height <= 0) return fail(SURFEL_E_INVALID, "bad sizes");
@@ -278,7 +287,7 @@ int64_t surfel_rasterize_forward(surfel_alloc_fn geom_alloc, void* geom_user, su
 
         PreprocessArgs pa{};
         pa.P = P; pa.D = D; pa.M = M; pa.W = width; pa.H = height; pa.gx = gx; pa.gy = gy; pa.scale_modifier = scale_modifier;
-        pa.cull = g_opt_cull;
+        pa.cull = opt_cull;
         pa.means3D = means3D; pa.opacities = opacities; pa.scales = scales; pa.rotations = rotations;
         pa.transMat_precomp = transMat_precomp; pa.colors_precomp = colors_precomp; pa.shs = shs;
         pa.viewmatrix = viewmatrix; pa.projmatrix = projmatrix; pa.campos = cam_pos;
@@ -305,7 +314,7 @@ int64_t surfel_rasterize_forward(surfel_alloc_fn geom_alloc, void* geom_user, su
         // frame's instances per tile (unknown on the first call: decided once R has arrived).
         const int64_t ntiles_all = (int64_t)gx * gy;
         constexpr int64_t kTileSortMaxAvg = 640;      // bitonic work grows as n log^2 n: at ~1100 instances per tile it costs 0.25 ms vs 0.15 ms for the P-sized radix sort (C4)
-        int per_tile = g_opt_tile_sort == 2 ? 1 : (g_opt_tile_sort == 0 ? 0 : -1);
+        int per_tile = opt_tile_sort == 2 ? 1 : (opt_tile_sort == 0 ? 0 : -1);
         if (per_tile < 0 && g_last_R >= 0 && g_last_W == width && g_last_H == height) per_tile = g_last_R <= kTileSortMaxAvg * ntiles_all ? 1 : 0;
         if (per_tile < 0) {         // first frame of this size: wait for R now (loses the host/device overlap once)
             HIP_TRY(hipEventSynchronize(evR));
@@ -390,6 +399,8 @@ int surfel_rasterize_backward(surfel_alloc_fn scratch_alloc, void* scratch_user,
                               float* dL_drots, int debug, void* stream) {
     (void)tan_fovx; (void)tan_fovy; (void)colors_precomp;
     g_stage_n = 0;
+    const int opt_variant = (debug & SURFEL_OPT_BWD_QUAD) ? 1 : ((debug & SURFEL_OPT_BWD_ROWS) ? 0 : g_opt_bwd_variant);
+    debug &= 0xff;
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (P == 0) return 0;
     if (!scratch_alloc || !geom_buffer || !binning_buffer || !image_buffer) return fail(SURFEL_E_INVALID, "buffer / allocator is NULL");
@@ -412,7 +423,7 @@ int surfel_rasterize_backward(surfel_alloc_fn scratch_alloc, void* scratch_user,
     bb.W = width; bb.H = height; bb.gx = gx; bb.gy = gy;
     bb.ranges = img.ranges; bb.point_list = bin.point_list; bb.rec = geom.rec; bb.bg = background;
     bb.final_T = img.final_T; bb.n_contrib = img.n_contrib; bb.dL_dpix = dL_dout_color; bb.dL_dothers = dL_dout_others;
-    bb.grec = grec;
+    bb.grec = grec; bb.variant = opt_variant; bb.stats = g_blend_stats;
     if (R > 0) {
         tm.begin(ST_BBWD);
         launch_blend_bwd(bb, s);

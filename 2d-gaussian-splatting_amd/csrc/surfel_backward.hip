@@ -1,10 +1,17 @@
-// surfel_backward.hip — backward kernels of the gfx950 surfel rasterizer.
-//   blend_bwd       : per-tile back-to-front replay; per-surfel partial gradients are reduced
-//                     lane->wave with permlane-swap / DPP adds, wave->tile through LDS, and written ONCE per
-//                     (tile, surfel) instance to a gradient record — no global atomics, so the
-//                     result is bit-reproducible and never crosses XCD L2s with device-scope RMWs.
-//                     (A per-DPP-row walk like the forward's was measured slower here: its per-row partial
-//                     sums need LDS float atomics, ~45 LDS cycles each, and the kernel turns LDS-bound.)
+// surfel_backward.hip — blend_bwd: per-tile back-to-front replay of the sorted instance list (gfx950).
+//
+// Per-surfel partial gradients are reduced with DPP adds inside 16-lane rows (+ permlane swaps in the per-wave variant),
+// gathered per tile through LDS in a FIXED order and written ONCE per (tile, surfel) instance to an 80-B gradient record —
+// no global atomics, so the result is bit-reproducible and never crosses XCD L2s with device-scope RMWs.
+//
+// Two variants, bit-identical by construction (same per-pair arithmetic, same summation tree), selected by BlendBwdArgs.variant:
+//   rows (default): every DPP row of 16 lanes owns a 4x4-pixel sub-tile and walks ITS OWN instance bitmask, so a wave works on
+//                   four instances per visit and a small surfel occupies issue slots only in the sub-tiles its alpha >= 1/255
+//                   footprint reaches.  Row totals (20 values, 40 DPP adds, no cross-row traffic) go to private LDS slots —
+//                   one per (instance, overlapped sub-tile), packed by a prefix sum, 256 slots per round — and a flush pass
+//                   adds an instance's slots in the tree order ((r0+r1)+(r2+r3)) per wave, waves 0..3.
+//   quad          : a wave (8x8 pixels) walks the instances its quad overlaps, one per visit, wave-wide reduction
+//                   (40 DPP adds + 5 permlane swaps), per-wave LDS partials.  Kept as the yardstick: it is what round 1 shipped.
 // Semantics: oracle/surfel_oracle.c stages 4-5 (restating the absent diff-surfel-rasterization).
 #include "surfel_common.h"
 #include "surfel_kernels.h"
@@ -29,18 +36,17 @@ __device__ __forceinline__ float fold16(float x, float y) {
     return __uint_as_float(r.x) + __uint_as_float(r.y);
 }
 
-constexpr int BS = 128;   // instances staged per outer batch (one 80-B gather per thread of waves 0-1)
-constexpr int BB = 64;    // instances per accumulate/flush sub-batch
-constexpr int NVP = 20;   // 18 gradient values per instance, padded to 20 for the wave reduction
+constexpr int BS = 128;   // instances staged per outer batch (one 112-B gather per thread of waves 0-1)
+constexpr int BB = 64;    // quad variant: instances per accumulate/flush sub-batch
+constexpr int NVP = 20;   // 18 gradient values per instance, padded to 20 for the reductions
+constexpr int RSLOTS = 256;           // rows variant: (instance, sub-tile) slots per round
+constexpr int NSLOT = RSLOTS + 16;    // the last instance of a round may run 15 slots past the cut
 
-// Wave-wide sum of 20 per-lane values.  Measured issue costs on gfx950 (scripts/ubench/valu_rate.hip, v_fma = 1):
-// v_add_f32_dpp 1.4, v_permlane{16,32}_swap 3.0 — so the lanes are folded INSIDE their 16-lane rows first, where
-// DPP adds can merge two registers into one by writing disjoint lane banks of one destination (bank_mask), and
-// only the 5 surviving registers cross rows through permlane swaps:
-//   fold8 x10 (20 DPP) -> fold4 x5 (10 DPP) -> quad sum x5 (10 DPP) -> fold16 x3, fold32 x2 (5 swaps + 5 adds)
-// = 40 DPP adds + 5 swaps + 5 adds (~76 issue units; folding across rows first costs 15 swaps, ~100 units).
-// Result: u0 holds in quad q (lanes 4q..4q+3) of row r the total of value 4r + {0,2,1,3}[q]; u1 holds in quad q
-// of row 0 the total of value 16 + {0,2,1,3}[q].
+// Sum of 20 per-lane values over each 16-lane row.  Measured issue costs on gfx950 (scripts/ubench/valu_rate.hip, v_fma = 1):
+// v_add_f32_dpp 1.4, v_permlane{16,32}_swap 3.0 — so lanes are folded INSIDE their rows, where DPP adds can merge two
+// registers into one by writing disjoint lane banks of one destination (bank_mask):
+//   fold8 x10 (20 DPP) -> fold4 x5 (10 DPP) -> quad sum x5 (10 DPP)  = 40 DPP adds
+// Result: z[m] holds, in every lane of quad q (lanes 4q..4q+3) of a row, that row's total of value 4m + {0,2,1,3}[q].
 //   fold8 : out = [lanes 0-7 : a(l)+a(l+8) | lanes 8-15 : b(l)+b(l-8)]
 //   fold4 : out = [bank0 : c(l)+c(l+4) | bank1 : d(l)+d(l-4) | bank2 : c | bank3 : d]
 // The s_nop covers the 2 wait states a DPP source needs after a VALU write (the compiler cannot see into the asm).
@@ -60,27 +66,340 @@ __device__ __forceinline__ float row_fold4(float c, float d) {
                  : "=&v"(out) : "v"(c), "v"(d));
     return out;
 }
-__device__ __forceinline__ void wave_reduce20(const float (&v)[NVP], float& u0, float& u1) {
-    float a[10], z[5];
+// sum over the 4 lanes of every quad, result in all 4 lanes (two fused DPP adds)
+__device__ __forceinline__ float quad_sum(float t) {
+    float u, out;
+    asm volatile("s_nop 1\n\t"
+                 "v_add_f32_dpp %0, %2, %2 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\t"
+                 "v_add_f32_dpp %1, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf"
+                 : "=&v"(u), "=&v"(out) : "v"(t));
+    return out;
+}
+__device__ __forceinline__ void row_reduce20(const float (&v)[NVP], float (&z)[5]) {
+    float a[10];
 #pragma unroll
     for (int i = 0; i < 10; i++) a[i] = row_fold8(v[2 * i], v[2 * i + 1]);
 #pragma unroll
-    for (int m = 0; m < 5; m++) {
-        float t = row_fold4(a[2 * m], a[2 * m + 1]);
-        t = row_ror_add<0xB1>(t);      // quad_perm [1,0,3,2]
-        t = row_ror_add<0x4E>(t);      // quad_perm [2,3,0,1]
-        z[m] = t;
-    }
+    for (int m = 0; m < 5; m++) z[m] = quad_sum(row_fold4(a[2 * m], a[2 * m + 1]));
+}
+// Wave-wide: the 5 row totals cross rows through permlane swaps (5 swaps + 5 adds): (r0 + r1) + (r2 + r3).
+// u0 holds in quad q of row r the wave total of value 4r + {0,2,1,3}[q]; u1 holds in quad q of row 0 value 16 + {0,2,1,3}[q].
+__device__ __forceinline__ void wave_reduce20(const float (&v)[NVP], float& u0, float& u1) {
+    float z[5];
+    row_reduce20(v, z);
     const float t0 = fold16(z[0], z[1]), t1 = fold16(z[2], z[3]), t2 = fold16(z[4], z[4]);
     u0 = fold32(t0, t1);
     u1 = fold32(t2, t2);
 }
 
 // ---------------------------------------------------------------------------------------------
-// blend_bwd
+// per-pixel state and the per-(pixel, surfel) arithmetic shared by both variants
 // ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(BLOCK) blend_bwd_kernel(BlendBwdArgs a) {
-    __shared__ float4 s_rec[BS * 5];                 // 20 KB
+struct Pixel {
+    float pxf, pyf;
+    float gC0, gC1, gC2, g_depth, g_alpha, gN0, gN1, gN2, g_med, g_dist;     // upstream gradients
+    float fM1, fM2, final_A;
+    int last, medc;
+    float T, X;      // running transmittance and the suffix sum (see pair_gradients)
+};
+
+__device__ __forceinline__ Pixel load_pixel(const BlendBwdArgs& a, int pxi, int pyi) {
+    Pixel p;
+    p.pxf = (float)pxi; p.pyf = (float)pyi;
+    const bool inside = pxi < a.W && pyi < a.H;
+    const size_t HW = (size_t)a.H * a.W;
+    const size_t pix = (size_t)pyi * a.W + pxi;
+    float T_final = 0.f;
+    p.fM1 = 0.f; p.fM2 = 0.f; p.last = 0; p.medc = 0;
+    p.gC0 = p.gC1 = p.gC2 = p.g_depth = p.g_alpha = p.gN0 = p.gN1 = p.gN2 = p.g_med = p.g_dist = 0.f;
+    if (inside) {
+        T_final = a.final_T[pix]; p.fM1 = a.final_T[HW + pix]; p.fM2 = a.final_T[2 * HW + pix];
+        p.last = (int)a.n_contrib[pix]; p.medc = (int)a.n_contrib[HW + pix];
+        p.gC0 = a.dL_dpix[pix]; p.gC1 = a.dL_dpix[HW + pix]; p.gC2 = a.dL_dpix[2 * HW + pix];
+        p.g_depth = a.dL_dothers[pix]; p.g_alpha = a.dL_dothers[HW + pix];
+        p.gN0 = a.dL_dothers[2 * HW + pix]; p.gN1 = a.dL_dothers[3 * HW + pix]; p.gN2 = a.dL_dothers[4 * HW + pix];
+        p.g_med = a.dL_dothers[5 * HW + pix]; p.g_dist = a.dL_dothers[6 * HW + pix];
+    }
+    p.final_A = 1.f - T_final;
+    p.T = T_final;
+    p.X = T_final * __builtin_fmaf(a.bg[2], p.gC2, __builtin_fmaf(a.bg[1], p.gC1, a.bg[0] * p.gC0));     // suffix sum, seeded with the background term
+    return p;
+}
+
+struct Hit {     // ray-splat intersection of one (pixel, surfel) pair
+    float kx, ky, kz, lx, ly, lz, sx, sy, ip, dx, dy, depth, G, alpha, Twx, Twy, opa;
+    bool use3d;
+};
+
+// This file is compiled with -ffp-contract=off and every fused multiply-add below is spelled out, so the two kernel variants
+// (and any future one) execute the SAME rounding sequence per (pixel, surfel) pair — that is what makes them bit-identical.
+#define FMA(a, b, c) __builtin_fmaf((a), (b), (c))
+
+// branch-free intersection; returns whether the pair was composited by the forward (pos <= last and the forward's tests)
+__device__ __forceinline__ bool pair_hit(const Pixel& p, const float4 q0, const float4 q1, const float4 q2, int pos, Hit& h) {
+    const float Tux = q0.x, Tuy = q0.y, Tuz = q0.z, Tvx = q0.w, Tvy = q1.x, Tvz = q1.y;
+    const float Twx = q1.z, Twy = q1.w, Twz = q2.x;
+    h.Twx = Twx; h.Twy = Twy; h.opa = q2.w;
+    h.kx = FMA(p.pxf, Twx, -Tux); h.ky = FMA(p.pxf, Twy, -Tuy); h.kz = FMA(p.pxf, Twz, -Tuz);
+    h.lx = FMA(p.pyf, Twx, -Tvx); h.ly = FMA(p.pyf, Twy, -Tvy); h.lz = FMA(p.pyf, Twz, -Tvz);
+    const float p0 = FMA(h.ky, h.lz, -(h.kz * h.ly)), p1 = FMA(h.kz, h.lx, -(h.kx * h.lz)), p2 = FMA(h.kx, h.ly, -(h.ky * h.lx));
+    h.ip = __builtin_amdgcn_rcpf(p2);
+    h.sx = p0 * h.ip; h.sy = p1 * h.ip;
+    const float rho3d = FMA(h.sx, h.sx, h.sy * h.sy);
+    h.dx = q2.y - p.pxf; h.dy = q2.z - p.pyf;
+    const float rho2d = FILTER_INV_SQUARE * FMA(h.dx, h.dx, h.dy * h.dy);
+    h.use3d = rho3d <= rho2d;
+    const float rho = fminf(rho3d, rho2d);
+    h.depth = h.use3d ? FMA(h.sx, Twx, h.sy * Twy) + Twz : Twz;
+    h.G = __expf(-0.5f * rho);
+    h.alpha = fminf(ALPHA_MAX, h.opa * h.G);
+    return (pos <= p.last) & (p2 != 0.f) & (h.depth >= NEAR_N) & (h.alpha >= ALPHA_MIN);
+}
+
+// Sequential per-pixel state + the 18 per-pair gradient values.  Every upstream gradient enters dL/dalpha only through its
+// dot product with this surfel's attributes, so the back-to-front recurrences (colour, depth, alpha, normal, distortion,
+// background) collapse into ONE scalar suffix sum
+//     X_k = T_final*bg.gC + sum_{i>k} w_i u_i ,  u_i = c_i.gC + d_i g_D + g_A + n_i.gN + dDist/dw_i
+//     dL/dalpha_k = T_k u_k - X_k / (1 - alpha_k)
+// (algebraically identical to the per-channel "accum_rec" recurrences, 2 state floats instead of 17).
+__device__ __forceinline__ void pair_gradients(Pixel& p, const Hit& h, const float4 q3, const float4 q4, bool ok, int pos, float (&gv)[NVP]) {
+    constexpr float MC1 = FAR_N / (FAR_N - NEAR_N), MC2 = (FAR_N * NEAR_N) / (FAR_N - NEAR_N);
+    // Branch-free: a pair that was not composited runs the same instructions with alpha = 0 and depth = 1, which leaves T and X
+    // unchanged (x 1, + 0); its u and dL/dalpha are forced to zero.
+    const float alpha = ok ? h.alpha : 0.f, depth = ok ? h.depth : 1.f;
+    const float i1a = __builtin_amdgcn_rcpf(1.f - alpha);
+    p.T = p.T * i1a;
+    const float w = alpha * p.T;
+    const float inv_d = __builtin_amdgcn_rcpf(depth);
+    const float mm = FMA(-(MC1 * NEAR_N), inv_d, MC1);
+    float u = FMA(FMA(mm, FMA(mm, p.final_A, -2.f * p.fM1), p.fM2), p.g_dist, p.g_alpha);
+    u = FMA(q3.w, p.gC0, u); u = FMA(q4.x, p.gC1, u); u = FMA(q4.y, p.gC2, u);
+    u = FMA(depth, p.g_depth, u);
+    u = FMA(q3.x, p.gN0, u); u = FMA(q3.y, p.gN1, u); u = FMA(q3.z, p.gN2, u);
+    u = ok ? u : 0.f;          // an idle row may be looking at a stale LDS record: nothing of it may reach the pixel's state
+    const float dL_dalpha = ok ? FMA(p.T, u, -(p.X * i1a)) : 0.f;
+    p.X = FMA(w, u, p.X);
+    float dL_dz = FMA((2.f * w * p.g_dist) * FMA(mm, p.final_A, -p.fM1), MC2 * inv_d * inv_d, w * p.g_depth);
+    dL_dz += (ok & (pos == p.medc)) ? p.g_med : 0.f;
+    gv[15] = w * p.gC0; gv[16] = w * p.gC1; gv[17] = w * p.gC2;
+    gv[11] = w * p.gN0; gv[12] = w * p.gN1; gv[13] = w * p.gN2;
+    gv[14] = h.G * dL_dalpha;
+    gv[18] = 0.f; gv[19] = 0.f;
+    const float nGG = -h.G * (h.opa * dL_dalpha);      // dL/dG * dG/drho*2 ; 0.99 clamp is pass-through
+    // low-pass branch: no gradient reaches the intersection.  The selects zero (s, 1/p2) themselves —
+    // they may be inf there (p2 ~ 0 on edge-on discs) and 0 * inf must not enter the sums.
+    const float sxg = h.use3d ? h.sx : 0.f, syg = h.use3d ? h.sy : 0.f, ipg = h.use3d ? h.ip : 0.f;
+    const float g2 = h.use3d ? 0.f : nGG * FILTER_INV_SQUARE;
+    const float ax = FMA(nGG, sxg, dL_dz * h.Twx) * ipg, ay = FMA(nGG, syg, dL_dz * h.Twy) * ipg;
+    const float dp2 = -FMA(ax, sxg, ay * syg);
+    // -dk = dp x l ,  -dl = k x dp
+    const float nk0 = FMA(ay, h.lz, -(dp2 * h.ly)), nk1 = FMA(dp2, h.lx, -(ax * h.lz)), nk2 = FMA(ax, h.ly, -(ay * h.lx));
+    const float nl0 = FMA(h.ky, dp2, -(h.kz * ay)), nl1 = FMA(h.kz, ax, -(h.kx * dp2)), nl2 = FMA(h.kx, ay, -(h.ky * ax));
+    gv[0] = nk0; gv[1] = nk1; gv[2] = nk2;
+    gv[3] = nl0; gv[4] = nl1; gv[5] = nl2;
+    gv[6] = FMA(dL_dz, sxg, -FMA(p.pxf, nk0, p.pyf * nl0));
+    gv[7] = FMA(dL_dz, syg, -FMA(p.pxf, nk1, p.pyf * nl1));
+    gv[8] = dL_dz - FMA(p.pxf, nk2, p.pyf * nl2);
+    gv[9] = g2 * h.dx; gv[10] = g2 * h.dy;
+}
+
+// gradient-record slot of the (tile, surfel) instance whose staged record holds q4
+__device__ __forceinline__ size_t grec_slot(const float4 q4, int tx, int ty) {
+    const uint32_t basei = __float_as_uint(q4.z), rectbits = __float_as_uint(q4.w);
+    const int x0 = rectbits & 1023, y0 = (rectbits >> 10) & 1023, rw = rectbits >> 20;
+    return (size_t)basei + (size_t)((ty - y0) * rw + (tx - x0));
+}
+
+__device__ __forceinline__ int block_max(int v, int* s_max) {
+    if (threadIdx.x == 0) *s_max = 0;
+    __syncthreads();
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o));
+    if ((threadIdx.x & 63) == 0) atomicMax(s_max, v);
+    __syncthreads();
+    return *s_max;
+}
+
+// instances behind every pixel's last contributor are never staged: their records are zero
+__device__ __forceinline__ void zero_tail(const BlendBwdArgs& a, const uint2 range, int maxc, int tx, int ty) {
+    for (int pos = maxc + 1 + (int)threadIdx.x; pos <= (int)(range.y - range.x); pos += BLOCK) {
+        const uint32_t id = a.point_list[range.x + pos - 1];
+        const float4 q4 = reinterpret_cast<const float4*>(a.rec + (size_t)id * REC_F)[4];
+        float4* __restrict__ dst = reinterpret_cast<float4*>(a.grec + grec_slot(q4, tx, ty) * GREC_F);
+        const float4 zz = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int q = 0; q < 5; q++) dst[q] = zz;
+    }
+}
+
+__device__ __forceinline__ float4 add4(const float4 a, const float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+
+// ---------------------------------------------------------------------------------------------
+// blend_bwd, rows variant
+// ---------------------------------------------------------------------------------------------
+template <bool STATS>
+__global__ void __launch_bounds__(BLOCK) blend_bwd_rows_kernel(BlendBwdArgs a) {
+    __shared__ float4 s_rec[BS * 5];                          // 10 KB: q0-q4 of the staged instances
+    __shared__ float4 s_slot[NSLOT * 5];                      // 21.25 KB: row totals, one 80-B slot per (instance, sub-tile)
+    __shared__ uint32_t s_info[BS];                           // overlap bits (row order) | wave-local exclusive slot prefix << 16
+    __shared__ unsigned long long s_rmask[16][BS / 64];       // per row: the staged instances that reach its sub-tile
+    __shared__ uint32_t s_wtot[BS / 64];                      // slots of each staging wave's 64 instances
+    __shared__ int s_rowlast[16];                             // per row: the largest `last` of its 16 pixels
+    __shared__ int s_max;
+    const int tile = xcd_tile(blockIdx.x, a.gx * a.gy);
+    const int tx = tile % a.gx, ty = tile / a.gx;
+    int lx, ly, sub;
+    thread_pixel(threadIdx.x, lx, ly, sub);
+    (void)sub;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int srow = threadIdx.x >> 4;                        // this lane's DPP row among the tile's 16 = its sub-tile's bit
+    const uint32_t below = (1u << srow) - 1u;
+    const uint2 range = a.ranges[tile];
+    Pixel px = load_pixel(a, tx * TILE + lx, ty * TILE + ly);
+    {   // a row never visits an instance behind the last contributor of all its pixels
+        int m = px.last;
+        m = max(m, __shfl_xor(m, 1)); m = max(m, __shfl_xor(m, 2)); m = max(m, __shfl_xor(m, 4)); m = max(m, __shfl_xor(m, 8));
+        if ((threadIdx.x & 15) == 0) s_rowlast[srow] = m;
+    }
+    const int maxc = block_max(px.last, &s_max);              // (its barriers also publish s_rowlast)
+
+    // which value of the row total this lane stores (row_reduce20): lane t of quad q holds value 4t + {0,2,1,3}[q] of z[t]
+    const int t4 = lane & 3, quad = (lane >> 2) & 3;
+    const int pq = ((quad & 1) << 1) | (quad >> 1);
+    float* const s_slotf = reinterpret_cast<float*>(s_slot);
+
+    for (int hi = maxc; hi > 0; hi -= BS) {
+        const int mb = min(BS, hi);
+        __syncthreads();                      // previous batch fully flushed
+        if (wave < BS / 64) {
+            unsigned ovr = 0;
+            if ((int)threadIdx.x < mb) {
+                const int pos = hi - (int)threadIdx.x;
+                const uint32_t id = a.point_list[range.x + pos - 1];
+                const float4* __restrict__ src = reinterpret_cast<const float4*>(a.rec + (size_t)id * REC_F);
+                const float4 v0 = src[0], v1 = src[1], v2 = src[2], v3 = src[3], v4 = src[4], v5 = src[5], v6 = src[6];
+                s_rec[threadIdx.x * 5 + 0] = v0; s_rec[threadIdx.x * 5 + 1] = v1; s_rec[threadIdx.x * 5 + 2] = v2;
+                s_rec[threadIdx.x * 5 + 3] = v3; s_rec[threadIdx.x * 5 + 4] = v4;
+                ovr = subtile_overlap_rows(make_foot(v2, v5, v6), tx * TILE, ty * TILE);
+                unsigned live = 0;
+#pragma unroll
+                for (int s = 0; s < 16; s++) live |= (pos <= s_rowlast[s]) ? (1u << s) : 0u;
+                ovr &= live;
+            }
+            const int cnt = __popc(ovr);
+            int incl = cnt;                   // inclusive prefix of the slot counts over the wave
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(incl, o); if (lane >= o) incl += v; }
+            s_info[threadIdx.x] = ovr | ((uint32_t)(incl - cnt) << 16);
+            if (lane == 63) s_wtot[wave] = (uint32_t)incl;
+#pragma unroll
+            for (int s = 0; s < 16; s++) {
+                const unsigned long long b = __ballot((ovr >> s) & 1u);
+                if (lane == 0) s_rmask[s][wave] = b;
+            }
+        }
+        __syncthreads();
+        const int off1 = (int)s_wtot[0];                      // slots ahead of the second staging wave's instances
+        const int tot = off1 + (int)s_wtot[1];
+        const int nrounds = max(1, (tot + RSLOTS - 1) / RSLOTS);
+        // round of every staged instance (lane -> instances lane and 64 + lane): the one its first slot falls into; an instance
+        // without slots belongs to the round of its position (clamped) and only gets its zero record written there
+        const int rnd0 = min((int)(s_info[lane] >> 16) >> 8, nrounds - 1);
+        const int rnd1 = min(((int)(s_info[64 + lane] >> 16) + off1) >> 8, nrounds - 1);
+        const unsigned long long c0 = s_rmask[srow][0], c1 = s_rmask[srow][1];
+        for (int r = 0; r < nrounds; r++) {
+            const unsigned long long m0 = __ballot((lane < mb) & (rnd0 == r)), m1 = __ballot((64 + lane < mb) & (rnd1 == r));
+            // ---- walk: every row visits, in list order, its instances of round r; the next visit's record is fetched from LDS
+            // while the current one is being processed
+            unsigned long long cur = c0 & m0, nxt = c1 & m1;
+            int wbase = 0;
+            if (cur == 0ull) { cur = nxt; nxt = 0ull; wbase = 64; }
+            bool act = cur != 0ull;
+            int j = wbase + __builtin_ctzll(cur | (1ull << 63));
+            uint32_t info = s_info[j];
+            float4 q0 = s_rec[j * 5 + 0], q1 = s_rec[j * 5 + 1], q2 = s_rec[j * 5 + 2], q3 = s_rec[j * 5 + 3], q4 = s_rec[j * 5 + 4];
+            while (__any(act)) {
+                const bool actc = act;
+                const int jc = j;
+                const uint32_t infoc = info;
+                const float4 c_q0 = q0, c_q1 = q1, c_q2 = q2, c_q3 = q3, c_q4 = q4;
+                // advance + prefetch
+                if (act) cur &= cur - 1ull;
+                if (cur == 0ull) { cur = nxt; nxt = 0ull; wbase = 64; }
+                act = cur != 0ull;
+                j = wbase + __builtin_ctzll(cur | (1ull << 63));
+                info = s_info[j];
+                q0 = s_rec[j * 5 + 0]; q1 = s_rec[j * 5 + 1]; q2 = s_rec[j * 5 + 2]; q3 = s_rec[j * 5 + 3]; q4 = s_rec[j * 5 + 4];
+                // current visit
+                Hit h;
+                const int pos = hi - jc;      // 1-based position in the tile's list
+                const bool ok = pair_hit(px, c_q0, c_q1, c_q2, pos, h) & actc;
+                float gv[NVP], z[5];
+                pair_gradients(px, h, c_q3, c_q4, ok, pos, gv);
+                row_reduce20(gv, z);
+                if (STATS) {
+                    const unsigned long long okb = __ballot(ok), ab = __ballot(actc);
+                    if (lane == 0) {
+                        atomicAdd(&a.stats[0], 64ull); atomicAdd(&a.stats[1], (unsigned long long)__popcll(okb));
+                        atomicAdd(&a.stats[2], 1ull); atomicAdd(&a.stats[3], (unsigned long long)(__popcll(ab) >> 4));
+                        const int hitrows = ((okb & 0xffffull) != 0) + (((okb >> 16) & 0xffffull) != 0) + (((okb >> 32) & 0xffffull) != 0) + ((okb >> 48) != 0);
+                        atomicAdd(&a.stats[4], (unsigned long long)hitrows);
+                    }
+                }
+                if (actc) {
+                    const int E = (int)(infoc >> 16) + (jc >= 64 ? off1 : 0);
+                    const int slot = (E & (RSLOTS - 1)) + __popc(infoc & below);
+                    float* sp = s_slotf + slot * NVP;
+                    const float v = t4 == 0 ? z[0] : (t4 == 1 ? z[1] : (t4 == 2 ? z[2] : z[3]));
+                    sp[4 * t4 + pq] = v;
+                    if (t4 == 0) sp[16 + pq] = z[4];
+                }
+            }
+            __syncthreads();
+            // ---- flush round r: its instances are a contiguous run of the staged list.  One thread per (instance, float4 of its
+            // record): the instance's slots are added in the fixed order ((r0+r1)+(r2+r3)) per wave, waves 0..3 — the summation
+            // tree of the quad variant, so both variants give the same bits.
+            {
+                const int n = __popcll(m0) + __popcll(m1);
+                const int t0 = m0 ? __builtin_ctzll(m0) : 64 + (m1 ? __builtin_ctzll(m1) : 0);
+                for (int item = threadIdx.x; item < 5 * n; item += BLOCK) {
+                    const int k = (item * 13108) >> 16;       // item / 5 for item < 640
+                    const int q = item - 5 * k;
+                    const int t = t0 + k;
+                    const uint32_t inf = s_info[t];
+                    const int E = (int)(inf >> 16) + (t >= 64 ? off1 : 0);
+                    const float4* sp = s_slot + (E & (RSLOTS - 1)) * 5 + q;
+                    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                    for (int w = 0; w < 4; w++) {
+                        const unsigned m = (inf >> (4 * w)) & 15u;
+                        if (m) {
+                            const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+                            float4 v0 = zero, v1 = zero, v2 = zero, v3 = zero;
+                            if (m & 1u) { v0 = *sp; sp += 5; }
+                            if (m & 2u) { v1 = *sp; sp += 5; }
+                            if (m & 4u) { v2 = *sp; sp += 5; }
+                            if (m & 8u) { v3 = *sp; sp += 5; }
+                            acc = add4(acc, add4(add4(v0, v1), add4(v2, v3)));
+                        }
+                    }
+                    const float4 r4 = s_rec[t * 5 + 4];
+                    reinterpret_cast<float4*>(a.grec + grec_slot(r4, tx, ty) * GREC_F)[q] = acc;
+                }
+            }
+            __syncthreads();                  // slots reusable
+        }
+    }
+    zero_tail(a, range, maxc, tx, ty);
+}
+
+// ---------------------------------------------------------------------------------------------
+// blend_bwd, quad variant (round 1's kernel on the shared per-pair arithmetic)
+// ---------------------------------------------------------------------------------------------
+template <bool STATS>
+__global__ void __launch_bounds__(BLOCK) blend_bwd_quad_kernel(BlendBwdArgs a) {
+    __shared__ float4 s_rec[BS * 5];                 // 10 KB
     __shared__ float s_acc[4][BB][NVP];              // 20 KB: per-wave partial sums of the current sub-batch
     __shared__ unsigned long long s_mask[4];         // which sub-batch slots each wave wrote
     __shared__ unsigned long long s_qmask[4][4];     // [quad][staging wave] overlap bitmasks of the staged batch
@@ -91,40 +410,10 @@ __global__ void __launch_bounds__(BLOCK) blend_bwd_kernel(BlendBwdArgs a) {
     thread_pixel(threadIdx.x, lx, ly, sub);
     (void)sub;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int pxi = tx * TILE + lx, pyi = ty * TILE + ly;
-    const bool inside = pxi < a.W && pyi < a.H;
-    const float pxf = (float)pxi, pyf = (float)pyi;
     const uint2 range = a.ranges[tile];
-    const size_t HW = (size_t)a.H * a.W;
-    const size_t pix = (size_t)pyi * a.W + pxi;
+    Pixel px = load_pixel(a, tx * TILE + lx, ty * TILE + ly);
+    const int maxc = block_max(px.last, &s_max);
 
-    float T_final = 0.f, fM1 = 0.f, fM2 = 0.f;
-    int last = 0, medc = 0;
-    float gC0 = 0.f, gC1 = 0.f, gC2 = 0.f, g_depth = 0.f, g_alpha = 0.f, gN0 = 0.f, gN1 = 0.f, gN2 = 0.f, g_med = 0.f, g_dist = 0.f;
-    if (inside) {
-        T_final = a.final_T[pix]; fM1 = a.final_T[HW + pix]; fM2 = a.final_T[2 * HW + pix];
-        last = (int)a.n_contrib[pix]; medc = (int)a.n_contrib[HW + pix];
-        gC0 = a.dL_dpix[pix]; gC1 = a.dL_dpix[HW + pix]; gC2 = a.dL_dpix[2 * HW + pix];
-        g_depth = a.dL_dothers[pix]; g_alpha = a.dL_dothers[HW + pix];
-        gN0 = a.dL_dothers[2 * HW + pix]; gN1 = a.dL_dothers[3 * HW + pix]; gN2 = a.dL_dothers[4 * HW + pix];
-        g_med = a.dL_dothers[5 * HW + pix]; g_dist = a.dL_dothers[6 * HW + pix];
-    }
-    const float final_A = 1.f - T_final;
-
-    if (threadIdx.x == 0) s_max = 0;
-    __syncthreads();
-    {
-        int m = last;
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) m = max(m, __shfl_xor(m, o));
-        if (lane == 0) atomicMax(&s_max, m);
-    }
-    __syncthreads();
-    const int maxc = s_max;
-
-    float T = T_final;
-    float X = T_final * (a.bg[0] * gC0 + a.bg[1] * gC1 + a.bg[2] * gC2);     // suffix sum, seeded with the background term
-    constexpr float MC1 = FAR_N / (FAR_N - NEAR_N), MC2 = (FAR_N * NEAR_N) / (FAR_N - NEAR_N);
     // after wave_reduce20 the quad leaders hold the totals: u0 -> value 4*row + {0,2,1,3}[quad], u1 (row 0) -> 16 + ...
     const int row = lane >> 4, quad = (lane >> 2) & 3;
     const int vslot = 4 * row + (((quad & 1) << 1) | (quad >> 1));      // value index this lane's u0 holds
@@ -156,70 +445,22 @@ __global__ void __launch_bounds__(BLOCK) blend_bwd_kernel(BlendBwdArgs a) {
                 const int j = sb * BB + jj;
                 const int pos = hi - j;           // 1-based position in the tile's list
                 const float4 q0 = s_rec[j * 5 + 0], q1 = s_rec[j * 5 + 1], q2 = s_rec[j * 5 + 2];
-                // ---- ray-splat intersection, branch-free
-                const float Tux = q0.x, Tuy = q0.y, Tuz = q0.z, Tvx = q0.w, Tvy = q1.x, Tvz = q1.y;
-                const float Twx = q1.z, Twy = q1.w, Twz = q2.x, opa = q2.w;
-                const float kx = pxf * Twx - Tux, ky = pxf * Twy - Tuy, kz = pxf * Twz - Tuz;
-                const float lx_ = pyf * Twx - Tvx, ly_ = pyf * Twy - Tvy, lz_ = pyf * Twz - Tvz;
-                const float p0 = ky * lz_ - kz * ly_, p1 = kz * lx_ - kx * lz_, p2 = kx * ly_ - ky * lx_;
-                const float ip = __builtin_amdgcn_rcpf(p2);
-                const float sx = p0 * ip, sy = p1 * ip;
-                const float rho3d = sx * sx + sy * sy;
-                const float dx = q2.y - pxf, dy = q2.z - pyf;
-                const float rho2d = FILTER_INV_SQUARE * (dx * dx + dy * dy);
-                const bool use3d = rho3d <= rho2d;
-                const float rho = fminf(rho3d, rho2d);
-                const float depth = use3d ? (sx * Twx + sy * Twy) + Twz : Twz;
-                const float G = __expf(-0.5f * rho);
-                const float alpha = fminf(ALPHA_MAX, opa * G);
-                const bool ok = (pos <= last) & (p2 != 0.f) & (depth >= NEAR_N) & (alpha >= ALPHA_MIN);
-                if (__ballot(ok) == 0ull) continue;      // wave-uniform
-                // Sequential per-pixel state.  Every upstream gradient enters dL/dalpha only through its dot product
-                // with this surfel's attributes, so the back-to-front recurrences (colour, depth, alpha, normal,
-                // distortion, background) collapse into ONE scalar suffix sum
-                //     X_k = T_final*bg.gC + sum_{i>k} w_i u_i ,  u_i = c_i.gC + d_i g_D + g_A + n_i.gN + dDist/dw_i
-                //     dL/dalpha_k = T_k u_k - X_k / (1 - alpha_k)
-                // (algebraically identical to the per-channel "accum_rec" recurrences, 2 state floats instead of 17).
+                Hit h;
+                const bool ok = pair_hit(px, q0, q1, q2, pos, h);
+                const unsigned long long okb = __ballot(ok);
+                if (STATS) {
+                    if (lane == 0) {
+                        atomicAdd(&a.stats[0], 64ull); atomicAdd(&a.stats[1], (unsigned long long)__popcll(okb));
+                        atomicAdd(&a.stats[2], 1ull); atomicAdd(&a.stats[3], 1ull);
+                        atomicAdd(&a.stats[4], (unsigned long long)(okb != 0ull));
+                        const int hitrows = ((okb & 0xffffull) != 0) + (((okb >> 16) & 0xffffull) != 0) + (((okb >> 32) & 0xffffull) != 0) + ((okb >> 48) != 0);
+                        atomicAdd(&a.stats[5], (unsigned long long)hitrows);
+                    }
+                }
+                if (okb == 0ull) continue;      // wave-uniform
                 const float4 q3 = s_rec[j * 5 + 3], q4 = s_rec[j * 5 + 4];
-                float w = 0.f, dL_dalpha = 0.f, dL_dz = 0.f;
-                if (ok) {
-                    const float i1a = __builtin_amdgcn_rcpf(1.f - alpha);
-                    T = T * i1a;
-                    w = alpha * T;
-                    const float inv_d = __builtin_amdgcn_rcpf(depth);
-                    const float mm = MC1 - (MC1 * NEAR_N) * inv_d;
-                    float u = (fM2 + mm * (mm * final_A - 2.f * fM1)) * g_dist + g_alpha;
-                    u += q3.w * gC0; u += q4.x * gC1; u += q4.y * gC2;
-                    u += depth * g_depth;
-                    u += q3.x * gN0; u += q3.y * gN1; u += q3.z * gN2;
-                    dL_dalpha = T * u - X * i1a;
-                    X += w * u;
-                    dL_dz = (2.f * w * g_dist) * (mm * final_A - fM1) * (MC2 * inv_d * inv_d) + w * g_depth;
-                    dL_dz += (pos == medc) ? g_med : 0.f;
-                }
                 float gv[NVP];
-                gv[15] = w * gC0; gv[16] = w * gC1; gv[17] = w * gC2;
-                gv[11] = w * gN0; gv[12] = w * gN1; gv[13] = w * gN2;
-                gv[14] = G * dL_dalpha;
-                gv[18] = 0.f; gv[19] = 0.f;
-                {
-                    const float nGG = -G * (opa * dL_dalpha);      // dL/dG * dG/drho*2 ; 0.99 clamp is pass-through
-                    // low-pass branch: no gradient reaches the intersection.  The selects zero (s, 1/p2) themselves —
-                    // they may be inf there (p2 ~ 0 on edge-on discs) and 0 * inf must not enter the sums.
-                    const float sxg = use3d ? sx : 0.f, syg = use3d ? sy : 0.f, ipg = use3d ? ip : 0.f;
-                    const float g2 = use3d ? 0.f : nGG * FILTER_INV_SQUARE;
-                    const float ax = (nGG * sxg + dL_dz * Twx) * ipg, ay = (nGG * syg + dL_dz * Twy) * ipg;
-                    const float dp2 = -(ax * sxg + ay * syg);
-                    // -dk = dp x l ,  -dl = k x dp
-                    const float nk0 = ay * lz_ - dp2 * ly_, nk1 = dp2 * lx_ - ax * lz_, nk2 = ax * ly_ - ay * lx_;
-                    const float nl0 = ky * dp2 - kz * ay, nl1 = kz * ax - kx * dp2, nl2 = kx * ay - ky * ax;
-                    gv[0] = nk0; gv[1] = nk1; gv[2] = nk2;
-                    gv[3] = nl0; gv[4] = nl1; gv[5] = nl2;
-                    gv[6] = dL_dz * sxg - (pxf * nk0 + pyf * nl0);
-                    gv[7] = dL_dz * syg - (pxf * nk1 + pyf * nl1);
-                    gv[8] = dL_dz - (pxf * nk2 + pyf * nl2);
-                    gv[9] = g2 * dx; gv[10] = g2 * dy;
-                }
+                pair_gradients(px, h, q3, q4, ok, pos, gv);
                 float u0, u1;
                 wave_reduce20(gv, u0, u1);
                 if (writer) {
@@ -235,44 +476,36 @@ __global__ void __launch_bounds__(BLOCK) blend_bwd_kernel(BlendBwdArgs a) {
             if ((int)threadIdx.x < min(BB, mb - sb * BB)) {
                 const int jj = threadIdx.x;
                 const unsigned long long bit = 1ull << jj;
-                const bool h0 = s_mask[0] & bit, h1 = s_mask[1] & bit, h2 = s_mask[2] & bit, h3 = s_mask[3] & bit;
                 float4 out[5];
 #pragma unroll
-                for (int q = 0; q < 5; q++) {
-                    float4 sacc = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (h0) { const float4 t4 = *reinterpret_cast<const float4*>(&s_acc[0][jj][4 * q]); sacc.x += t4.x; sacc.y += t4.y; sacc.z += t4.z; sacc.w += t4.w; }
-                    if (h1) { const float4 t4 = *reinterpret_cast<const float4*>(&s_acc[1][jj][4 * q]); sacc.x += t4.x; sacc.y += t4.y; sacc.z += t4.z; sacc.w += t4.w; }
-                    if (h2) { const float4 t4 = *reinterpret_cast<const float4*>(&s_acc[2][jj][4 * q]); sacc.x += t4.x; sacc.y += t4.y; sacc.z += t4.z; sacc.w += t4.w; }
-                    if (h3) { const float4 t4 = *reinterpret_cast<const float4*>(&s_acc[3][jj][4 * q]); sacc.x += t4.x; sacc.y += t4.y; sacc.z += t4.z; sacc.w += t4.w; }
-                    out[q] = sacc;
+                for (int q = 0; q < 5; q++) out[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                for (int w = 0; w < 4; w++) {
+                    if (s_mask[w] & bit) {
+#pragma unroll
+                        for (int q = 0; q < 5; q++) out[q] = add4(out[q], *reinterpret_cast<const float4*>(&s_acc[w][jj][4 * q]));
+                    }
                 }
                 const float4 q4 = s_rec[(sb * BB + jj) * 5 + 4];
-                const uint32_t basei = __float_as_uint(q4.z), rectbits = __float_as_uint(q4.w);
-                const int x0 = rectbits & 1023, y0 = (rectbits >> 10) & 1023, rw = rectbits >> 20;
-                const size_t dest = (size_t)basei + (size_t)((ty - y0) * rw + (tx - x0));
-                float4* __restrict__ dst = reinterpret_cast<float4*>(a.grec + dest * GREC_F);
+                float4* __restrict__ dst = reinterpret_cast<float4*>(a.grec + grec_slot(q4, tx, ty) * GREC_F);
 #pragma unroll
                 for (int q = 0; q < 5; q++) dst[q] = out[q];
             }
             __syncthreads();                  // s_acc / s_mask reusable
         }
     }
-    // instances behind every pixel's last contributor were never staged: their records are zero
-    for (int pos = maxc + 1 + (int)threadIdx.x; pos <= (int)(range.y - range.x); pos += BLOCK) {
-        const uint32_t id = a.point_list[range.x + pos - 1];
-        const float4 q4 = reinterpret_cast<const float4*>(a.rec + (size_t)id * REC_F)[4];
-        const uint32_t basei = __float_as_uint(q4.z), rectbits = __float_as_uint(q4.w);
-        const int x0 = rectbits & 1023, y0 = (rectbits >> 10) & 1023, rw = rectbits >> 20;
-        const size_t dest = (size_t)basei + (size_t)((ty - y0) * rw + (tx - x0));
-        float4* __restrict__ dst = reinterpret_cast<float4*>(a.grec + dest * GREC_F);
-        const float4 zz = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-        for (int q = 0; q < 5; q++) dst[q] = zz;
-    }
+    zero_tail(a, range, maxc, tx, ty);
 }
 
 void launch_blend_bwd(const BlendBwdArgs& a, hipStream_t s) {
-    hipLaunchKernelGGL(blend_bwd_kernel, dim3(a.gx * a.gy), dim3(BLOCK), 0, s, a);
+    const dim3 grid(a.gx * a.gy), block(BLOCK);
+    if (a.variant == 1) {
+        if (a.stats) hipLaunchKernelGGL(blend_bwd_quad_kernel<true>, grid, block, 0, s, a);
+        else hipLaunchKernelGGL(blend_bwd_quad_kernel<false>, grid, block, 0, s, a);
+    } else {
+        if (a.stats) hipLaunchKernelGGL(blend_bwd_rows_kernel<true>, grid, block, 0, s, a);
+        else hipLaunchKernelGGL(blend_bwd_rows_kernel<false>, grid, block, 0, s, a);
+    }
 }
 
 }  // namespace surfel

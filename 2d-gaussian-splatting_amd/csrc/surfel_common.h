@@ -112,6 +112,22 @@ __device__ __forceinline__ unsigned subtile_overlap(const Foot& f, int tile_x0, 
     }
     return ov;
 }
+// The same 16 bits in ROW order: bit 4*w + r <-> the sub-tile owned by DPP row r of wave w (thread_pixel), i.e. bit (tid >> 4).
+__device__ __forceinline__ unsigned subtile_overlap_rows(const Foot& f, int tile_x0, int tile_y0) {
+    unsigned ov = 0;
+#pragma unroll
+    for (int by = 0; by < 4; by++) {
+        float xmin, xmax;
+        foot_strip(f, (float)(tile_y0 + 4 * by), (float)(tile_y0 + 4 * by + 3), xmin, xmax);
+        xmin -= (float)tile_x0; xmax -= (float)tile_x0;
+#pragma unroll
+        for (int bx = 0; bx < 4; bx++) {
+            const int rowbit = 4 * (((by >> 1) << 1) | (bx >> 1)) + (((by & 1) << 1) | (bx & 1));
+            ov |= (xmin <= (float)(4 * bx + 3) && xmax >= (float)(4 * bx)) ? (1u << rowbit) : 0u;
+        }
+    }
+    return ov;
+}
 // 4-bit mask of the tile's 8x8 quads (= backward waves; quad id = 2*(y half) + (x half)) the footprint can touch.
 __device__ __forceinline__ unsigned quad_overlap(const Foot& f, int tile_x0, int tile_y0) {
     unsigned ov = 0;

@@ -29,7 +29,9 @@ struct BlendBwdArgs {
     const uint2* ranges; const uint32_t* point_list; const float* rec; const float* bg;
     const float* final_T; const uint32_t* n_contrib;
     const float* dL_dpix; const float* dL_dothers;
-    float* grec;      // [R][GREC_F] per-instance gradient records (pre-zeroed)
+    float* grec;      // [R][GREC_F] per-instance gradient records (every record written exactly once)
+    int variant;      // 0: per-DPP-row walk (default), 1: per-wave (8x8 quad) walk; bit-identical results
+    unsigned long long* stats;   // optional [4]: lane slots issued, useful (pixel, surfel) lanes, wave visits, row / quad visits
 };
 
 struct PreprocessBwdArgs {

@@ -175,7 +175,7 @@ __device__ __forceinline__ uint32_t preprocess_one(const PreprocessArgs& a, cons
         //   {rho2d <= rmax}: disc of radius sqrt(rmax/2) about (cx,cy);
         //   {rho3d <= rmax}: the projected sqrt(rmax)-sigma ellipse = the conic whose dual is M diag(rmax,rmax,-1) M^T
         //   (M = rows Tu,Tv,Tw), i.e. centre e = (D02,D12)/D22 and "covariance" S = e e^T - D[0:2,0:2]/D22.
-        // S is evaluated in a frame shifted to (cx,cy) so that e e^T - D/D22 does not cancel ~1e6-sized terms, then
+        // S is evaluated in a frame shifted to the projected disc centre so that e e^T - D/D22 does not cancel ~1e6-sized terms, then
         // inflated (x1.002 + 0.3 px on the diagonal) for fp32; unbounded when the ellipse meets the camera plane.
         float bx0 = 1.f, bx1 = 0.f, by0 = 1.f, by1 = 0.f;       // bbox of the footprint (tile-level cull); empty
         float ecx = cx, ecy = cy, Sxx = FOOT_UNBOUNDED, Sxy = 0.f, Syy = FOOT_UNBOUNDED, r2sq = 0.f, Sdet = 1.f;
@@ -191,8 +191,12 @@ __device__ __forceinline__ uint32_t preprocess_one(const PreprocessArgs& a, cons
                 bool bounded = dc < -1e-3f * tw2;
                 if (bounded) {
                     const float g0 = rmax / dc, g2 = -1.f / dc;
-                    const float U0 = T[0] - cx * T[6], U1 = T[1] - cx * T[7], U2 = T[2] - cx * T[8];
-                    const float V0 = T[3] - cy * T[6], V1 = T[4] - cy * T[7], V2 = T[5] - cy * T[8];
+                    // frame origin = the projected disc centre (u = v = 0), which always lies inside this ellipse.  (cx, cy) — the
+                    // centre of the 3-sigma box — does not: it runs off to ~1e5 px when the 3-sigma ellipse grazes the camera plane
+                    // while this smaller one is still bounded, and the shifted form then cancels catastrophically.
+                    const float ox = T[2] / T[8], oy = T[5] / T[8];
+                    const float U0 = T[0] - ox * T[6], U1 = T[1] - ox * T[7], U2 = T[2] - ox * T[8];
+                    const float V0 = T[3] - oy * T[6], V1 = T[4] - oy * T[7], V2 = T[5] - oy * T[8];
                     const float ex_ = g0 * U0 * T[6] + g0 * U1 * T[7] + g2 * U2 * T[8];
                     const float ey_ = g0 * V0 * T[6] + g0 * V1 * T[7] + g2 * V2 * T[8];
                     const float sxx = ex_ * ex_ - (g0 * U0 * U0 + g0 * U1 * U1 + g2 * U2 * U2);
@@ -205,7 +209,7 @@ __device__ __forceinline__ uint32_t preprocess_one(const PreprocessArgs& a, cons
                     const float det = fmaxf(ixx * iyy - sxy * sxy, EPS * (ixx + iyy - 2.f * EPS)) + 4e-7f * ixx * iyy;
                     bounded = (ex_ == ex_) && (ey_ == ey_) && (det == det) && (ixx < 1e12f) && (iyy < 1e12f) && (fabsf(sxy) < 1e12f);
                     if (bounded) {
-                        ecx = cx + ex_; ecy = cy + ey_; Sxx = ixx; Sxy = sxy; Syy = iyy; Sdet = det;
+                        ecx = ox + ex_; ecy = oy + ey_; Sxx = ixx; Sxy = sxy; Syy = iyy; Sdet = det;
                         const float mx = sqrtf(ixx) + 1e-4f * fabsf(ecx) + 0.01f, my = sqrtf(iyy) + 1e-4f * fabsf(ecy) + 0.01f;
                         bx0 = fminf(bx0, ecx - mx); bx1 = fmaxf(bx1, ecx + mx);
                         by0 = fminf(by0, ecy - my); by1 = fmaxf(by1, ecy + my);

@@ -35,6 +35,14 @@ extern "C" {
 #define SURFEL_E_HIP     (-3)   /* a HIP call or kernel failed (message has the hipError string) */
 #define SURFEL_E_LIMIT   (-4)   /* size exceeds an internal limit (e.g. > 2^32-1 tile instances) */
 
+/* The `debug` argument of the rasterizer entry points: low byte = debug mode (0 off, 1 synchronise + check after every stage,
+ * 2 / 3 record stage timing events), upper bits = PER-CALL option overrides, so callers (tests above all) need not flip the
+ * process-wide defaults of surfel_set_option().  All overrides leave results bit-identical. */
+#define SURFEL_OPT_NO_CULL        (1 << 8)             /* forward: "cull" = 0 for this call */
+#define SURFEL_OPT_TILE_SORT(m)   ((((m) + 1) & 3) << 9)   /* forward: "tile_depth_sort" = m (0, 1, 2) for this call */
+#define SURFEL_OPT_BWD_QUAD       (1 << 11)            /* backward: per-quad walk ("bwd_variant" = 1) for this call */
+#define SURFEL_OPT_BWD_ROWS       (1 << 12)            /* backward: per-row walk ("bwd_variant" = 0) for this call */
+
 /* Allocator callback: return a device pointer to `bytes` bytes, 256-byte aligned, valid until the
  * caller frees it.  Replaces the resize functors the reference's binding hands to the native
  * rasterizer (geometry / binning / image buffers; SURVEY.md §8b "ownership"). */
@@ -134,8 +142,20 @@ int surfel_debug_sort_pairs(surfel_alloc_fn scratch_alloc, void* scratch_user, u
  *   "tile_depth_sort" (default 1 = auto): binning path — 2: always order every tile's instance run by depth in LDS after an
  *          index-order emission (no P-sized depth sort; fastest for small / medium frames), 0: always depth-presort the surfels
  *          (large frames), 1: choose by the previous frame's instances per tile.  Results are bit-identical
- *          (tests/test_gpu_parity.py::test_binning_paths_are_identical). */
+ *          (tests/test_gpu_parity.py::test_binning_paths_are_identical).
+ *   "bwd_variant" (default 0): blend-backward walk — 0: every DPP row of 16 lanes (a 4x4-pixel sub-tile) walks its own instance
+ *          list, row totals gathered through private LDS slots; 1: every wave (8x8 pixels) walks one list (round 1's kernel).
+ *          Same per-pair arithmetic and the same summation tree: gradients are bit-identical
+ *          (tests/test_gpu_parity.py::test_backward_variants_are_identical).
+ * Threading: the library keeps one pinned read-back buffer and one event per host thread, created on the device that is current
+ * at first use — one process (or at least one host thread) per GPU, the layout torch.distributed.run gives. */
 int surfel_set_option(const char* name, int value);
+
+/* Debug: a device buffer of 8 uint64 (caller-zeroed) that every following blend-backward launch accumulates into
+ * — [0] lane slots issued (64 per wave visit), [1] lanes that held a composited (pixel, surfel) pair, [2] wave visits,
+ * [3] (sub-tile | quad, instance) visits, [4] of those, the ones with at least one composited pair, [5] quad variant: 4x4 sub-tiles
+ * with a composited pair — or NULL to switch the instrumented kernels off again. */
+int surfel_debug_set_blend_stats(void* dev_u64x8);
 
 #ifdef __cplusplus
 }

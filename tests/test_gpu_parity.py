@@ -270,13 +270,16 @@ def _stress_scene(kind, seed):
         q = np.stack([w, (R[:, 2, 1] - R[:, 1, 2]) / (4 * w), (R[:, 0, 2] - R[:, 2, 0]) / (4 * w), (R[:, 1, 0] - R[:, 0, 1]) / (4 * w)], 1)
         sc["rotations"] = (q / np.linalg.norm(q, axis=1, keepdims=True)).astype(np.float32)
         sc["scales"] = (sc["scales"] * 3.0).astype(np.float32)
+    elif kind == "huge_faint":   # wide, nearly transparent discs close to the camera: the 3-sigma box centre runs far off screen
+        sc = synthetic.make_scene(4000, 96, 64, seed=seed, px_radius=30.0, z_near=2.0, z_far=8.0)
+        sc["opacities"] = np.full_like(sc["opacities"], 0.02)
     elif kind == "opaque_faint":  # opacities at both ends: 1/255-ish (empty footprints) and ~1 (widest footprints)
         sc["opacities"] = rng.choice([0.0035, 0.0045, 0.02, 0.999], size=(P, 1)).astype(np.float32)
     sc["bg"] = np.array([0.1, 0.3, 0.7], np.float32)
     return sc
 
 
-@pytest.mark.parametrize("kind", ["plain", "needles", "huge", "tiny", "grazing", "opaque_faint"])
+@pytest.mark.parametrize("kind", ["plain", "needles", "huge", "tiny", "grazing", "opaque_faint", "huge_faint"])
 def test_culling_is_exact(kind):
     """Every cull (footprint-restricted tile emission, per-quad / per-sub-tile instance masks) only ever removes
     (pixel, surfel) pairs that contribute nothing: images and gradients must be BIT-IDENTICAL with culling on and off,
@@ -351,6 +354,63 @@ def test_binning_paths_are_identical(kind):
         assert np.array_equal(c0, c2) and np.array_equal(o0, o2), "%s: images differ between the binning paths (%d)" % (kind, m)
         for k in g0:
             assert np.array_equal(g0[k], g2[k]), "%s: dL/d%s differs between the binning paths (%d)" % (kind, k, m)
+
+
+@pytest.mark.parametrize("kind", ["plain", "needles", "huge", "tiny", "grazing", "opaque_faint", "crowded", "C1"])
+def test_backward_variants_are_identical(kind):
+    """blend_bwd per-row walk (default) vs per-quad walk (round 1's kernel): same per-pair arithmetic, same summation tree
+    ((r0+r1)+(r2+r3) per wave, waves 0..3) -> BIT-IDENTICAL gradients, selected per call through the debug word's option bits.
+    'crowded' piles thousands of instances on every tile (many slot rounds per batch, big footprints: 16 slots per instance)."""
+    import surfel_native as n
+    import synthetic
+    if kind == "C1":
+        sc = _scene("C1", seed=2)
+    elif kind == "crowded":
+        sc = synthetic.make_scene(9000, 96, 64, seed=6, px_radius=30.0, z_near=2.0, z_far=8.0)
+        sc["opacities"] = np.full_like(sc["opacities"], 0.02)
+    else:
+        sc = _stress_scene(kind, 31)
+    a = scene_args(sc)
+    rng = np.random.default_rng(8)
+    gC = rng.normal(size=(3, a["H"], a["W"])).astype(np.float32); gO = rng.normal(size=(7, a["H"], a["W"])).astype(np.float32)
+    run = HipRun(a).forward()
+    res = []
+    for flag in (n.OPT_BWD_ROWS, n.OPT_BWD_QUAD, n.OPT_BWD_ROWS):
+        run.debug = flag
+        res.append(run.backward(gC, gO))
+    for k in res[0]:
+        assert np.isfinite(res[0][k]).all(), k
+        assert np.array_equal(res[0][k], res[2][k]), "rows variant not reproducible: %s" % k
+        d = np.abs(res[0][k].astype(np.float64) - res[1][k])
+        assert np.array_equal(res[0][k], res[1][k]), "%s: dL/d%s differs between the variants (max |d| %.3e, %d elements)" % (
+            kind, k, d.max(), int((d > 0).sum()))
+
+
+def test_blend_stats_counters():
+    """surfel_debug_set_blend_stats: the instrumented kernels count lane slots issued and lanes that held a composited pair;
+    the per-row walk must waste fewer lanes than the per-quad walk on small footprints and see exactly the same useful pairs."""
+    import torch
+    import surfel_native as n
+    lib = n.load()
+    sc = _scene("C1", seed=3)
+    a = scene_args(sc)
+    rng = np.random.default_rng(1)
+    gC = rng.normal(size=(3, a["H"], a["W"])).astype(np.float32); gO = rng.normal(size=(7, a["H"], a["W"])).astype(np.float32)
+    run = HipRun(a).forward()
+    out = {}
+    try:
+        for name, flag in (("rows", n.OPT_BWD_ROWS), ("quad", n.OPT_BWD_QUAD)):
+            st = torch.zeros(8, dtype=torch.int64, device="cuda:0")
+            assert lib.surfel_debug_set_blend_stats(n.ptr(st)) == 0
+            run.debug = flag
+            run.backward(gC, gO)
+            out[name] = st.cpu().numpy().copy()
+    finally:
+        lib.surfel_debug_set_blend_stats(None)
+    assert out["rows"][1] == out["quad"][1] > 0                 # identical set of composited pairs
+    fr, fq = out["rows"][1] / out["rows"][0], out["quad"][1] / out["quad"][0]
+    print("useful lanes: rows %.3f (%d wave visits), quad %.3f (%d wave visits)" % (fr, out["rows"][2], fq, out["quad"][2]))
+    assert fr > fq and out["rows"][2] < out["quad"][2]
 
 
 @pytest.mark.parametrize("n,bits", [(1, (0, 32)), (63, (0, 32)), (2047, (0, 12)), (2048, (0, 32)), (2049, (3, 17)), (300_000, (0, 32)),
