@@ -21,7 +21,7 @@ namespace {
 thread_local std::string g_err;
 int g_opt_cull = 1;        // surfel_set_option("cull", .)
 int g_opt_tile_sort = 1;   // surfel_set_option("tile_depth_sort", .): 0 never, 1 auto (by last frame's R / tiles), 2 always
-int g_opt_bwd_variant = 0; // surfel_set_option("bwd_variant", .): 0 per-row walk, 1 per-quad walk (bit-identical)
+int g_opt_bwd_variant = 2; // surfel_set_option("bwd_variant", .): 0 per-row walk, 1 per-quad walk, 2 auto (bit-identical)
 unsigned long long* g_blend_stats = nullptr;   // surfel_debug_set_blend_stats
 thread_local int64_t g_last_R = -1; thread_local int g_last_W = 0, g_last_H = 0;   // auto heuristic (speed only; results identical)
 thread_local float g_stage_ms[16];
@@ -100,7 +100,7 @@ struct ImgState {    // per-pixel / per-tile state ("imgBuffer")
     static ImgState carve(void* base, int W, int H, size_t* total) {
         Carver c(base); ImgState im;
         const size_t tiles = (size_t)((W + TILE - 1) / TILE) * ((H + TILE - 1) / TILE);
-        im.ranges = c.take<uint2>(tiles + R_SLOTS / 2);       // [tiles] ranges + R_SLOTS partial instance totals (zeroed together)
+        im.ranges = c.take<uint2>(tiles + R_SLOTS);           // [tiles] ranges + R_SLOTS partial instance totals + R_SLOTS partial visible-surfel counts (zeroed together)
         im.total = reinterpret_cast<uint32_t*>(im.ranges + tiles);
         im.final_T = c.take<float>((size_t)3 * W * H);
         im.n_contrib = c.take<uint32_t>((size_t)2 * W * H);
@@ -215,7 +215,7 @@ int surfel_debug_sort_pairs(surfel_alloc_fn scratch_alloc, void* scratch_user, u
 int surfel_set_option(const char* name, int value) {
     if (name && std::strcmp(name, "cull") == 0) { g_opt_cull = value ? 1 : 0; return 0; }
     if (name && std::strcmp(name, "tile_depth_sort") == 0) { g_opt_tile_sort = value < 0 ? 0 : (value > 2 ? 2 : value); return 0; }
-    if (name && std::strcmp(name, "bwd_variant") == 0) { g_opt_bwd_variant = value ? 1 : 0; return 0; }
+    if (name && std::strcmp(name, "bwd_variant") == 0) { g_opt_bwd_variant = value < 0 ? 0 : (value > 2 ? 2 : value); return 0; }
     return fail(SURFEL_E_INVALID, "unknown option");
 }
 
@@ -269,7 +269,7 @@ int64_t surfel_rasterize_forward(surfel_alloc_fn geom_alloc, void* geom_user, su
     void* img_base = image_alloc(image_user, img_bytes);
     if (!img_base) return fail(SURFEL_E_ALLOC, "image buffer allocation failed");
     ImgState img = ImgState::carve(img_base, width, height, nullptr);
-    HIP_TRY(hipMemsetAsync(img.ranges, 0, sizeof(uint2) * ((size_t)gx * gy + R_SLOTS / 2), s));
+    HIP_TRY(hipMemsetAsync(img.ranges, 0, sizeof(uint2) * ((size_t)gx * gy + R_SLOTS), s));
 
     StageTimer tm(debug, s);
     int64_t R = 0;
@@ -399,7 +399,7 @@ int surfel_rasterize_backward(surfel_alloc_fn scratch_alloc, void* scratch_user,
                               float* dL_drots, int debug, void* stream) {
     (void)tan_fovx; (void)tan_fovy; (void)colors_precomp;
     g_stage_n = 0;
-    const int opt_variant = (debug & SURFEL_OPT_BWD_QUAD) ? 1 : ((debug & SURFEL_OPT_BWD_ROWS) ? 0 : g_opt_bwd_variant);
+    const int opt_variant = (debug & SURFEL_OPT_BWD_QUAD) ? 1 : ((debug & SURFEL_OPT_BWD_ROWS) ? 0 : g_opt_bwd_variant);   // 2 = auto
     debug &= 0xff;
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (P == 0) return 0;
@@ -423,7 +423,7 @@ int surfel_rasterize_backward(surfel_alloc_fn scratch_alloc, void* scratch_user,
     bb.W = width; bb.H = height; bb.gx = gx; bb.gy = gy;
     bb.ranges = img.ranges; bb.point_list = bin.point_list; bb.rec = geom.rec; bb.bg = background;
     bb.final_T = img.final_T; bb.n_contrib = img.n_contrib; bb.dL_dpix = dL_dout_color; bb.dL_dothers = dL_dout_others;
-    bb.grec = grec; bb.variant = opt_variant; bb.stats = g_blend_stats;
+    bb.grec = grec; bb.variant = opt_variant; bb.stats = g_blend_stats; bb.totals = img.total;
     if (R > 0) {
         tm.begin(ST_BBWD);
         launch_blend_bwd(bb, s);

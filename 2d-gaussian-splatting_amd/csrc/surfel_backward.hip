@@ -211,6 +211,18 @@ __device__ __forceinline__ size_t grec_slot(const float4 q4, int tx, int ty) {
     return (size_t)basei + (size_t)((ty - y0) * rw + (tx - x0));
 }
 
+// variant == 2: both kernels are launched and each decides on the device, from the frame's totals, whether it is the one to run.
+// Small footprints (few tile instances per emitting surfel) favour the per-row walk — it wastes fewer lanes; on wide footprints
+// the per-quad walk's cheaper visit wins (profiles/r02_blend_bwd_variants.md).  Every workgroup reaches the same verdict.
+constexpr int AUTO_ROWS_MAX_INST_PER_SURFEL = 4;
+__device__ __forceinline__ bool auto_picks_rows(const BlendBwdArgs& a) {
+    const int lane = threadIdx.x & 63;
+    uint32_t r = a.totals[lane], v = a.totals[R_SLOTS + lane];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { r += __shfl_xor(r, o); v += __shfl_xor(v, o); }
+    return (unsigned long long)r <= (unsigned long long)AUTO_ROWS_MAX_INST_PER_SURFEL * v;
+}
+
 __device__ __forceinline__ int block_max(int v, int* s_max) {
     if (threadIdx.x == 0) *s_max = 0;
     __syncthreads();
@@ -247,6 +259,7 @@ __global__ void __launch_bounds__(BLOCK) blend_bwd_rows_kernel(BlendBwdArgs a) {
     __shared__ uint32_t s_wtot[BS / 64];                      // slots of each staging wave's 64 instances
     __shared__ int s_rowlast[16];                             // per row: the largest `last` of its 16 pixels
     __shared__ int s_max;
+    if (a.variant == 2 && !auto_picks_rows(a)) return;
     const int tile = xcd_tile(blockIdx.x, a.gx * a.gy);
     const int tx = tile % a.gx, ty = tile / a.gx;
     int lx, ly, sub;
@@ -404,6 +417,7 @@ __global__ void __launch_bounds__(BLOCK) blend_bwd_quad_kernel(BlendBwdArgs a) {
     __shared__ unsigned long long s_mask[4];         // which sub-batch slots each wave wrote
     __shared__ unsigned long long s_qmask[4][4];     // [quad][staging wave] overlap bitmasks of the staged batch
     __shared__ int s_max;
+    if (a.variant == 2 && auto_picks_rows(a)) return;
     const int tile = xcd_tile(blockIdx.x, a.gx * a.gy);
     const int tx = tile % a.gx, ty = tile / a.gx;
     int lx, ly, sub;
@@ -499,12 +513,13 @@ __global__ void __launch_bounds__(BLOCK) blend_bwd_quad_kernel(BlendBwdArgs a) {
 
 void launch_blend_bwd(const BlendBwdArgs& a, hipStream_t s) {
     const dim3 grid(a.gx * a.gy), block(BLOCK);
-    if (a.variant == 1) {
-        if (a.stats) hipLaunchKernelGGL(blend_bwd_quad_kernel<true>, grid, block, 0, s, a);
-        else hipLaunchKernelGGL(blend_bwd_quad_kernel<false>, grid, block, 0, s, a);
-    } else {
+    if (a.variant != 1) {
         if (a.stats) hipLaunchKernelGGL(blend_bwd_rows_kernel<true>, grid, block, 0, s, a);
         else hipLaunchKernelGGL(blend_bwd_rows_kernel<false>, grid, block, 0, s, a);
+    }
+    if (a.variant != 0) {
+        if (a.stats) hipLaunchKernelGGL(blend_bwd_quad_kernel<true>, grid, block, 0, s, a);
+        else hipLaunchKernelGGL(blend_bwd_quad_kernel<false>, grid, block, 0, s, a);
     }
 }
 

@@ -13,7 +13,7 @@ struct PreprocessArgs {
     const float* transMat_precomp; const float* colors_precomp; const float* shs;
     const float* viewmatrix; const float* projmatrix; const float* campos;
     float* rec; float* depths; uint32_t* depth_keys; uint32_t* ident; int* radii; uint32_t* tiles_touched; uint8_t* clamped;
-    uint32_t* total_instances;     // [R_SLOTS], zeroed by the caller; sum over slots = sum(tiles_touched)
+    uint32_t* total_instances;     // [2 * R_SLOTS], zeroed by the caller: partial sums of tiles_touched | of (tiles_touched > 0)
     uint32_t* zero_a; uint32_t zero_a_words;   // scratch words this kernel clears for the launches that follow
     uint32_t* zero_b; uint32_t zero_b_words;   // (sort head, scan state) — saves two memset launches
 };
@@ -30,7 +30,8 @@ struct BlendBwdArgs {
     const float* final_T; const uint32_t* n_contrib;
     const float* dL_dpix; const float* dL_dothers;
     float* grec;      // [R][GREC_F] per-instance gradient records (every record written exactly once)
-    int variant;      // 0: per-DPP-row walk (default), 1: per-wave (8x8 quad) walk; bit-identical results
+    int variant;      // 0: per-DPP-row walk, 1: per-wave (8x8 quad) walk, 2: chosen on the device from the frame's totals; bit-identical results
+    const uint32_t* totals;      // [2 * R_SLOTS] partial sums written by preprocess: tile instances | visible surfels
     unsigned long long* stats;   // optional [4]: lane slots issued, useful (pixel, surfel) lanes, wave visits, row / quad visits
 };
 

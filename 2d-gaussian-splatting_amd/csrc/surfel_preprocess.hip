@@ -261,18 +261,23 @@ __device__ __forceinline__ uint32_t preprocess_one(const PreprocessArgs& a, cons
 // the rest of the forward WHILE the device is still depth-sorting.  One atomic per workgroup, spread over
 // R_SLOTS counters (same-address device-scope atomics serialise at ~10 ns each); the host adds the slots.
 __global__ void __launch_bounds__(256) preprocess_fwd_kernel(PreprocessArgs a) {
-    __shared__ uint32_t s_tot[4];
+    __shared__ uint32_t s_tot[4], s_vis[4];
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     for (uint32_t w = (uint32_t)i; w < a.zero_a_words; w += gridDim.x * blockDim.x) a.zero_a[w] = 0u;
     for (uint32_t w = (uint32_t)i; w < a.zero_b_words; w += gridDim.x * blockDim.x) a.zero_b[w] = 0u;
     uint32_t tiles = i < a.P ? preprocess_one(a, i) : 0u;
+    const uint32_t vis = (uint32_t)__popcll(__ballot(tiles != 0u));     // surfels that emit at least one instance
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) tiles += __shfl_xor(tiles, o);
-    if ((threadIdx.x & 63) == 0) s_tot[threadIdx.x >> 6] = tiles;
+    if ((threadIdx.x & 63) == 0) { s_tot[threadIdx.x >> 6] = tiles; s_vis[threadIdx.x >> 6] = vis; }
     __syncthreads();
     if (threadIdx.x == 0) {
         const uint32_t t = s_tot[0] + s_tot[1] + s_tot[2] + s_tot[3];
-        if (t) atomicAdd(a.total_instances + (blockIdx.x % R_SLOTS), t);
+        if (t) {
+            atomicAdd(a.total_instances + (blockIdx.x % R_SLOTS), t);
+            // the blend-backward picks its walk variant from instances per emitting surfel (surfel_backward.hip)
+            atomicAdd(a.total_instances + R_SLOTS + (blockIdx.x % R_SLOTS), s_vis[0] + s_vis[1] + s_vis[2] + s_vis[3]);
+        }
     }
 }
 

@@ -1,6 +1,7 @@
 """A/B of the two blend_bwd variants on the GPU box: kernel time (HIP events on the launch stream, debug mode 2) and the
 instrumented useful-lane fraction (surfel_debug_set_blend_stats).   python scripts/bwd_ab.py [workload ...]
-Workloads: synthetic.CONFIGS names, or  name:px_radius  to override the median 1-sigma radius (e.g. C2:7 = heavy footprints)."""
+Workloads: synthetic.CONFIGS names, or  name:px_radius[:P]  to override the median 1-sigma radius / the surfel count
+(e.g. C2:7 = heavy footprints, C2::900000 = three times the surfels)."""
 import json
 import os
 import sys
@@ -20,8 +21,11 @@ def main():
     lib = n.load()
     out = []
     for spec in (sys.argv[1:] or ["C2", "C4"]):
-        name, _, rad = spec.partition(":")
+        parts = spec.split(":")          # name[:px_radius[:P]]
+        name, rad = parts[0], (parts[1] if len(parts) > 1 else "")
         P, W, H, zf = synthetic.CONFIGS[name]
+        if len(parts) > 2:
+            P = int(parts[2])
         sc = synthetic.make_scene(P, W, H, seed=0, z_far=zf, px_radius=float(rad) if rad else None)
         a = scene_args(sc)
         rng = np.random.default_rng(0)
@@ -53,6 +57,14 @@ def main():
                 ref = g
             else:
                 row["bit_identical"] = all(np.array_equal(ref[k], g[k]) for k in ref)
+        run.debug = 2          # library default: variant chosen on the device
+        for _ in range(3):
+            run.backward(gC, gO)
+        n.collect_stage_times()
+        for _ in range(10):
+            run.backward(gC, gO)
+        t = n.collect_stage_times()
+        row["auto_us"] = round(1e3 * t["blend_bwd"][0] / t["blend_bwd"][1], 1)
         row["speedup"] = round(row["quad_us"] / row["rows_us"], 3)
         print(json.dumps(row), flush=True)
         out.append(row)
