@@ -27,18 +27,22 @@ def _stale(out, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, verbose=False):
+def build(force=False, verbose=False, ieee=False):
+    """ieee=True: the diagnostic twin lib/libsurfel_hip_ieee.so (-DSURFEL_IEEE_MATH: IEEE division and libm expf in the blend kernels);
+    never loaded by the product (surfel_native loads it only when SURFEL_LIB points at it)."""
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     os.makedirs(os.path.join(HERE, "lib"), exist_ok=True)
-    os.makedirs(os.path.join(HERE, "build"), exist_ok=True)
+    bdir = os.path.join(HERE, "build_ieee" if ieee else "build")
+    os.makedirs(bdir, exist_ok=True)
+    LIB = os.path.join(HERE, "lib", "libsurfel_hip_ieee.so" if ieee else "libsurfel_hip.so")
     hdrs = [os.path.join(CSRC, h) for h in HEADERS]
     objs = []
     for src in SOURCES:
         sp = os.path.join(CSRC, src)
-        obj = os.path.join(HERE, "build", src + ".o")
+        obj = os.path.join(bdir, src + ".o")
         objs.append(obj)
         if force or _stale(obj, [sp] + hdrs):
-            cmd = [hipcc] + FLAGS + EXTRA.get(src, []) + ["-c", sp, "-o", obj]
+            cmd = [hipcc] + FLAGS + (["-DSURFEL_IEEE_MATH"] if ieee else []) + EXTRA.get(src, []) + ["-c", sp, "-o", obj]
             if verbose:
                 print(" ".join(cmd))
             subprocess.check_call(cmd)
@@ -51,4 +55,4 @@ def build(force=False, verbose=False):
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    print(build(force="--force" in sys.argv, verbose=True, ieee="--ieee" in sys.argv))

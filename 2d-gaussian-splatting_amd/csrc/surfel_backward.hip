@@ -144,7 +144,7 @@ __device__ __forceinline__ bool pair_hit(const Pixel& p, const float4 q0, const 
     h.kx = FMA(p.pxf, Twx, -Tux); h.ky = FMA(p.pxf, Twy, -Tuy); h.kz = FMA(p.pxf, Twz, -Tuz);
     h.lx = FMA(p.pyf, Twx, -Tvx); h.ly = FMA(p.pyf, Twy, -Tvy); h.lz = FMA(p.pyf, Twz, -Tvz);
     const float p0 = FMA(h.ky, h.lz, -(h.kz * h.ly)), p1 = FMA(h.kz, h.lx, -(h.kx * h.lz)), p2 = FMA(h.kx, h.ly, -(h.ky * h.lx));
-    h.ip = __builtin_amdgcn_rcpf(p2);
+    h.ip = SURFEL_RCP(p2);
     h.sx = p0 * h.ip; h.sy = p1 * h.ip;
     const float rho3d = FMA(h.sx, h.sx, h.sy * h.sy);
     h.dx = q2.y - p.pxf; h.dy = q2.z - p.pyf;
@@ -152,7 +152,7 @@ __device__ __forceinline__ bool pair_hit(const Pixel& p, const float4 q0, const 
     h.use3d = rho3d <= rho2d;
     const float rho = fminf(rho3d, rho2d);
     h.depth = h.use3d ? FMA(h.sx, Twx, h.sy * Twy) + Twz : Twz;
-    h.G = __expf(-0.5f * rho);
+    h.G = SURFEL_EXP(-0.5f * rho);
     h.alpha = fminf(ALPHA_MAX, h.opa * h.G);
     return (pos <= p.last) & (p2 != 0.f) & (h.depth >= NEAR_N) & (h.alpha >= ALPHA_MIN);
 }
@@ -168,10 +168,10 @@ __device__ __forceinline__ void pair_gradients(Pixel& p, const Hit& h, const flo
     // Branch-free: a pair that was not composited runs the same instructions with alpha = 0 and depth = 1, which leaves T and X
     // unchanged (x 1, + 0); its u and dL/dalpha are forced to zero.
     const float alpha = ok ? h.alpha : 0.f, depth = ok ? h.depth : 1.f;
-    const float i1a = __builtin_amdgcn_rcpf(1.f - alpha);
+    const float i1a = SURFEL_RCP(1.f - alpha);
     p.T = p.T * i1a;
     const float w = alpha * p.T;
-    const float inv_d = __builtin_amdgcn_rcpf(depth);
+    const float inv_d = SURFEL_RCP(depth);
     const float mm = FMA(-(MC1 * NEAR_N), inv_d, MC1);
     float u = FMA(FMA(mm, FMA(mm, p.final_A, -2.f * p.fM1), p.fM2), p.g_dist, p.g_alpha);
     u = FMA(q3.w, p.gC0, u); u = FMA(q4.x, p.gC1, u); u = FMA(q4.y, p.gC2, u);

@@ -38,6 +38,17 @@ constexpr int REC_Q = REC_F / 4;
 //   [15..17] dL/drgb  [18..19] pad
 constexpr int GREC_F = 20;
 
+// The blend kernels use the hardware's approximate reciprocal (v_rcp_f32, 1 ulp) and exp2-based exponential (v_exp_f32);
+// -DSURFEL_IEEE_MATH (python build.py --ieee -> lib/libsurfel_hip_ieee.so, diagnostics only) swaps in correctly rounded division
+// and libm-grade expf so that what the fast forms cost in parity can be measured (profiles/r02_fast_intrinsics_cost.md).
+#ifdef SURFEL_IEEE_MATH
+#define SURFEL_RCP(x) (1.0f / (x))
+#define SURFEL_EXP(x) expf(x)
+#else
+#define SURFEL_RCP(x) __builtin_amdgcn_rcpf(x)
+#define SURFEL_EXP(x) __expf(x)
+#endif
+
 struct Rect { int x0, y0, x1, y1; };
 
 __device__ __forceinline__ Rect tile_rect(float px, float py, int r, int gx, int gy) {

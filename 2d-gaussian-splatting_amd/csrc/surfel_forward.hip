@@ -76,13 +76,13 @@ __global__ void __launch_bounds__(BLOCK) blend_fwd_kernel(BlendFwdArgs a) {
             const float kx = pxf * Twx - q0.x, ky = pxf * Twy - q0.y, kz = pxf * Twz - q0.z;
             const float lx_ = pyf * Twx - q0.w, ly_ = pyf * Twy - q1.x, lz_ = pyf * Twz - q1.y;
             const float p0 = ky * lz_ - kz * ly_, p1 = kz * lx_ - kx * lz_, p2 = kx * ly_ - ky * lx_;
-            const float ip = __builtin_amdgcn_rcpf(p2);
+            const float ip = SURFEL_RCP(p2);
             const float sx = p0 * ip, sy = p1 * ip;
             const float rho3d = sx * sx + sy * sy;
             const float dx = q2.y - pxf, dy = q2.z - pyf;
             const float rho2d = FILTER_INV_SQUARE * (dx * dx + dy * dy);
             const float depth = (rho3d <= rho2d) ? (sx * Twx + sy * Twy) + Twz : Twz;
-            const float alpha = fminf(ALPHA_MAX, q2.w * __expf(-0.5f * fminf(rho3d, rho2d)));
+            const float alpha = fminf(ALPHA_MAX, q2.w * SURFEL_EXP(-0.5f * fminf(rho3d, rho2d)));
             const bool ok = act & (!done) & (p2 != 0.f) & (depth >= NEAR_N) & (alpha >= ALPHA_MIN);
             if (__any(ok)) {
                 if (ok) {
@@ -92,7 +92,7 @@ __global__ void __launch_bounds__(BLOCK) blend_fwd_kernel(BlendFwdArgs a) {
                         const uint32_t contributor = base + j + 1;
                         const float4 q3 = s_rec[j * 5 + 3], q4 = s_rec[j * 5 + 4];
                         const float w = alpha * T;
-                        const float mm = MC1 - (MC1 * NEAR_N) * __builtin_amdgcn_rcpf(depth);
+                        const float mm = MC1 - (MC1 * NEAR_N) * SURFEL_RCP(depth);
                         dist += (mm * (mm * (1.f - T) - 2.f * M1) + M2) * w;
                         D += depth * w;
                         M1 += mm * w;

@@ -12,7 +12,8 @@ import threading
 import torch  # noqa: F401  (must precede the CDLL below, see module doc)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libsurfel_hip.so")
+# SURFEL_LIB: diagnostics only (e.g. the -DSURFEL_IEEE_MATH twin built by `python build.py --ieee`)
+LIB_PATH = os.environ.get("SURFEL_LIB") or os.path.join(_HERE, "lib", "libsurfel_hip.so")
 
 ALLOC_FN = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_size_t)
 
