@@ -16,6 +16,17 @@ import surfel_native as _n
 _n.load()  # fail loudly at import time if the HIP extension is missing
 
 last_num_rendered = 0   # instance count R of the most recent forward (introspection for bench / tests)
+_last_image = None      # (image buffer, tiles x, tiles y) of the most recent forward
+
+
+def tile_row_instances():
+    """[tile rows] int64 device tensor: tile instances per 16-row tile row of the most recent forward (read from its tile
+    ranges) — the weights surfel_dist.band_bounds balances the row bands with.  None before the first forward."""
+    if _last_image is None:
+        return None
+    buf, gx, gy = _last_image
+    r = buf[:gx * gy * 8].view(torch.int32).view(gy, gx, 2).to(torch.int64)
+    return (r[..., 1] - r[..., 0]).sum(1)
 
 _grad_arena = None
 
@@ -23,7 +34,7 @@ _grad_arena = None
 def set_grad_arena(arena):
     """Optional (multi-GPU): a dict of preallocated fp32 tensors — any of means3D [P,3], sh [P,M,3], opacities [P,1],
     scales [P,2], rotations [P,4], colors [P,3] (dL/dcolour; in SH mode the clamp-masked dL/d(SH colour) that
-    surfel_sh_grad_gather exchanges) — that the backward writes its gradients into and returns, instead of fresh tensors.
+    surfel_sh_grad_gather exchanges), means2D [P,3] (the densification statistic) — that the backward writes its gradients into and returns, instead of fresh tensors.
     surfel_dist.GradBucket.arena() hands out views of ONE flat buffer, so the gradient all-reduce needs no packing pass.
     The kernels write every element, so the tensors need no zeroing.  An explicit `sh=None` entry makes the backward skip the
     SH-coefficient gradients altogether (their autograd gradient is then None).  None restores the default."""
@@ -88,8 +99,9 @@ class _RasterizeGaussians(torch.autograd.Function):
                                              _n.current_stream_ptr(dev))
         if R < 0:
             raise RuntimeError("surfel_rasterize_forward failed (%d): %s" % (R, _n.last_error()))
-        global last_num_rendered
+        global last_num_rendered, _last_image
         last_num_rendered = int(R)
+        _last_image = (ia.last(), (W + 15) // 16, (H + 15) // 16)
         ctx.raster_settings = rs
         ctx.num_rendered = int(R)
         ctx.dims = (P, M, H, W)
@@ -122,7 +134,7 @@ class _RasterizeGaussians(torch.autograd.Function):
             if tuple(t.shape) != shape or t.dtype != torch.float32 or t.device != dev or not t.is_contiguous():
                 raise RuntimeError("grad arena tensor %r does not match %s fp32 contiguous on %s" % (name, shape, dev))
             return t
-        g_means2D, g_normal, g_colors = z(P, 3), z(P, 3), out("colors", P, 3)
+        g_means2D, g_normal, g_colors = out("means2D", P, 3), z(P, 3), out("colors", P, 3)
         g_opac = out("opacities", P, 1)
         g_means3D, g_trans = out("means3D", P, 3), z(P, 9)
         skip_sh = has_sh and "sh" in arena and arena["sh"] is None     # caller rebuilds dL/dSH from dL/dcolour (include/surfel_train.h)

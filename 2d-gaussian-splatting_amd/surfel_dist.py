@@ -117,20 +117,28 @@ def broadcast_parameters(params: Sequence[torch.Tensor], src: int = 0, group=Non
 
 
 # ------------------------------------------------------------------------------------------- tile bands
-def band_bounds(H: int, world: int, weights: Optional[Sequence[float]] = None) -> List[tuple]:
-    """Split image rows into `world` contiguous bands whose edges are multiples of 16 (tile rows).  `weights`
-    (one per tile row, e.g. last frame's instance counts) balances the bands; default = equal tile rows."""
-    rows = (H + 15) // 16
-    w = [1.0] * rows if weights is None else [float(x) + 1e-6 for x in weights]
-    assert len(w) == rows and world >= 1
+def band_bounds(H: int, world: int, weights: Optional[Sequence[float]] = None, multiple: int = 16) -> List[tuple]:
+    """Split image rows into `world` contiguous bands whose edges are multiples of `multiple` rows (16 = tile rows; the
+    halo-sharded loss uses 32 so that band edges also coincide with the loss kernels' 32-row blocks).  `weights` (one per
+    16-row tile row, e.g. the previous frames' instance counts) balances the bands; default = equal rows."""
+    assert multiple % 16 == 0 and world >= 1
+    k = multiple // 16
+    rows16 = (H + 15) // 16
+    w16 = [1.0] * rows16 if weights is None else [float(x) + 1e-6 for x in weights]
+    assert len(w16) == rows16
+    rows = (rows16 + k - 1) // k                       # band granules of `multiple` rows
+    w = [sum(w16[i * k:(i + 1) * k]) for i in range(rows)]
     total = sum(w)
     cuts, acc, r = [0], 0.0, 0
-    for k in range(1, world):
-        while r < rows and acc + w[r] <= total * k / world + 1e-9:
+    for b in range(1, world):
+        while r < rows and acc + w[r] <= total * b / world + 1e-9:
             acc += w[r]; r += 1
-        cuts.append(max(r, cuts[-1]))
+        r_min = cuts[-1] + 1 if rows >= world else cuts[-1]      # every band gets at least one granule when there are enough
+        cuts.append(min(max(r, r_min), rows - (world - b) if rows >= world else rows))
+        if cuts[-1] > r:
+            acc += sum(w[r:cuts[-1]]); r = cuts[-1]
     cuts.append(rows)
-    return [(min(cuts[i] * 16, H), min(cuts[i + 1] * 16, H)) for i in range(world)]
+    return [(min(cuts[i] * multiple, H), min(cuts[i + 1] * multiple, H)) for i in range(world)]
 
 
 def band_settings(raster_settings, y0: int, y1: int):
@@ -177,3 +185,92 @@ class _GatherBands(torch.autograd.Function):
 def gather_bands(band: torch.Tensor, bounds: Sequence[tuple], group=None) -> torch.Tensor:
     """Assemble the full image from every rank's rows (bounds = band_bounds(H, world)); differentiable w.r.t. the own band."""
     return _GatherBands.apply(band, list(bounds), group)
+
+
+# ------------------------------------------------------------------------------------------- halo-sharded loss
+HALO = 32      # rows: >= 10 for the 11x11 SSIM window applied twice (S_q, then dS_q/dimg_p), >= 2 for the depth-to-normal stencil,
+               # and a multiple of the loss kernels' 32-row blocks so that band-only partial sums can be picked out
+
+
+def halo_rows(bounds: Sequence[tuple], rank: int, H: int, halo: int = HALO):
+    y0, y1 = bounds[rank]
+    return min(halo, y0), min(halo, H - y1)
+
+
+class _ExchangeHalo(torch.autograd.Function):
+    """[C, Hb, W] band of this rank -> [C, top + Hb + bottom, W]: the band plus up to `halo` rows of the neighbouring bands
+    (point-to-point with the two neighbours; backends without device send/recv gather the edge strips instead).  The halo rows are
+    inputs of THIS rank's loss terms only as context: every pixel's gradient is computed once, by the rank that owns the pixel
+    (its own extended region holds every loss term the pixel takes part in), so the backward just hands the own rows on."""
+
+    @staticmethod
+    def forward(ctx, band, bounds, H, halo, group):
+        world = dist.get_world_size(group); rank = dist.get_rank(group)
+        C, Hb, W = band.shape
+        top, bot = halo_rows(bounds, rank, H, halo)
+        for r in range(world):
+            if bounds[r][1] - bounds[r][0] < halo and world > 1:
+                raise ValueError("band %d has %d rows, fewer than the %d-row halo" % (r, bounds[r][1] - bounds[r][0], halo))
+        src = band.detach()
+        ext = src.new_empty((C, top + Hb + bot, W))
+        ext[:, top:top + Hb].copy_(src)
+        send_up = src[:, :halo].contiguous() if rank > 0 else None               # my first rows -> bottom halo of rank - 1
+        send_dn = src[:, Hb - halo:].contiguous() if rank < world - 1 else None  # my last rows  -> top halo of rank + 1
+        recv_up = src.new_empty((C, top, W)) if top else None
+        recv_dn = src.new_empty((C, bot, W)) if bot else None
+        if dist.get_backend(group) == "nccl":
+            ops = []
+            if rank > 0:
+                ops += [dist.P2POp(dist.isend, send_up, rank - 1, group), dist.P2POp(dist.irecv, recv_up, rank - 1, group)]
+            if rank < world - 1:
+                ops += [dist.P2POp(dist.isend, send_dn, rank + 1, group), dist.P2POp(dist.irecv, recv_dn, rank + 1, group)]
+            for w in (dist.batch_isend_irecv(ops) if ops else []):
+                w.wait()
+        else:           # rehearsal backends: all-gather of the (first, last) strips of every band
+            z = src.new_zeros((C, halo, W))
+            strips = torch.stack([send_up if send_up is not None else z, send_dn if send_dn is not None else z]).contiguous()
+            allst = [torch.empty_like(strips) for _ in range(world)]
+            dist.all_gather(allst, strips, group=group)
+            if top:
+                recv_up.copy_(allst[rank - 1][1])
+            if bot:
+                recv_dn.copy_(allst[rank + 1][0])
+        if top:
+            ext[:, :top].copy_(recv_up)
+        if bot:
+            ext[:, top + Hb:].copy_(recv_dn)
+        ctx.rows = (top, top + Hb)
+        return ext
+
+    @staticmethod
+    def backward(ctx, g_ext):
+        a, b = ctx.rows
+        return g_ext[:, a:b].contiguous(), None, None, None, None
+
+
+def exchange_halo(band: torch.Tensor, bounds: Sequence[tuple], H: int, halo: int = HALO, group=None) -> torch.Tensor:
+    """Band + neighbour rows for the halo-sharded loss (see _ExchangeHalo); differentiable w.r.t. the own band."""
+    return _ExchangeHalo.apply(band, list(bounds), int(H), int(halo), group)
+
+
+def halo_bytes(bounds: Sequence[tuple], rank: int, H: int, W: int, channels: int, halo: int = HALO) -> int:
+    """Bytes this rank receives per halo exchange (= sends, by symmetry of interior bands)."""
+    top, bot = halo_rows(bounds, rank, H, halo)
+    return 4 * channels * W * (top + bot)
+
+
+def wire_bytes_per_step(P: int, world: int, sharding: str, stats_live: bool, halo_b: int = 0) -> dict:
+    """Bytes on the wire per GPU per training step (ring algorithms: all-reduce 2 (N-1)/N x payload, all-gather (N-1) x own
+    payload), by collective.  views: all-gather of 12 B/surfel colour gradients + all-reduce of the 40 B/surfel geometry prefix;
+    bands: ONE all-reduce of 52 B/surfel (+ 12 B/surfel while the densification statistic is live) + the halo strips."""
+    f = 2.0 * (world - 1) / world
+    if world <= 1:
+        return {"total": 0}
+    if sharding == "bands":
+        d = {"all_reduce_per_surfel_B": 52 + (12 if stats_live else 0), "all_reduce": int(f * P * (52 + (12 if stats_live else 0))),
+             "radii_max_all_reduce": int(f * P * 4) if stats_live else 0, "halo_p2p": int(halo_b), "loss_scalars": int(f * 16)}
+    else:
+        d = {"all_gather_colour": int((world - 1) * P * 12), "all_reduce_geometry": int(f * P * 40)}
+    d["total"] = int(sum(v for k, v in d.items() if not k.endswith("_B")))
+    d["per_surfel_B"] = round(d["total"] / P, 1)
+    return d

@@ -203,3 +203,93 @@ def train_loss(image, allmap, gt_image, cam_consts, depth_ratio, lambda_dssim, l
         cam_consts = torch.empty(0, device=image.device)
         allmap = None
     return _TrainLoss.apply(image, allmap, gt_image, cam_consts, depth_ratio, lambda_dssim, lambda_normal, lambda_dist)
+
+
+class _TrainLossBand(torch.autograd.Function):
+    """The training loss of ONE ROW BAND of the image, for tile-band sharded training (surfel_dist, BASELINE config 5).
+
+    Inputs are the band extended by halo rows of the neighbouring bands (surfel_dist.exchange_halo): [3, He, W] image,
+    [7, He, W] allmap, the same rows of the target.  The loss kernels run on the extended region as if it were an image; the
+    band's share of the full-image sums is read from the per-block partial sums of the blocks that lie inside the band (band and
+    halo edges are multiples of the kernels' 32 / 16-row blocks), and the backward scales by the FULL image's pixel count.  Every
+    band pixel sits >= 32 rows away from an artificial edge of the extended region, farther than the reach of any loss term it
+    takes part in (SSIM: 2 x 5 rows; depth-to-normal stencil: 2 rows), so its gradient equals the unsharded one; gradients that
+    land on halo rows are dropped — the rank owning those rows computes them itself.
+    Returns (band share of the total loss, sums = [sum |img-gt|, sum SSIM, sum normal error, sum distortion] over the band)."""
+
+    @staticmethod
+    def forward(ctx, image, allmap, gt, cam, depth_ratio, lambda_dssim, lambda_normal, lambda_dist, rows, full_hw):
+        planes, He, W = _planes(image, gt)
+        x = image.detach().contiguous().float(); y = gt.detach().contiguous().float()
+        dev = x.device
+        lib = _n.load()
+        reg = (lambda_normal != 0.0 or lambda_dist != 0.0) and allmap is not None
+        a, b = int(rows[0]), int(rows[1])
+        if a % 32 != 0 or (b % 32 != 0 and b != He):
+            raise ValueError("band rows (%d, %d) of the %d-row extended region must sit on 32-row blocks" % (a, b, He))
+        Hf, Wf = int(full_hw[0]), int(full_hw[1])
+        nbx, nby = (W + 31) // 32, (He + 31) // 32
+        dmaps = torch.empty((3, planes, He, W), dtype=torch.float32, device=dev)
+        partials = torch.empty((planes * nbx * nby, 2), dtype=torch.float32, device=dev)
+        s = _n.current_stream_ptr(dev)
+        am = pb = None
+        with torch.cuda.device(dev):
+            _check(lib.surfel_l1_ssim_forward(planes, He, W, _n.ptr(x), _n.ptr(y), _n.ptr(dmaps), _n.ptr(partials), s), "surfel_l1_ssim_forward")
+            if reg:
+                am = allmap.detach().contiguous().float()
+                maps = torch.empty((9, He, W), dtype=torch.float32, device=dev)
+                pb = torch.empty((((W + 15) // 16) * ((He + 15) // 16), 2), dtype=torch.float32, device=dev)
+                _check(lib.surfel_render_post_forward(He, W, _n.ptr(am), _n.ptr(cam), float(depth_ratio), _n.ptr(maps), _n.ptr(pb), s),
+                       "surfel_render_post_forward")
+        sums = torch.zeros((4,), dtype=torch.float32, device=dev)
+        sums[0:2] = partials.view(planes, nby, nbx, 2)[:, a // 32:(b + 31) // 32].sum((0, 1, 2))
+        if reg:
+            sums[2:4] = pb.view((He + 15) // 16, (W + 15) // 16, 2)[a // 16:(b + 15) // 16].sum((0, 1))
+        N3, N1 = float(planes * Hf * Wf), float(Hf * Wf)
+        share = ((1.0 - lambda_dssim) * sums[0] - lambda_dssim * sums[1]) / N3 + (lambda_normal * sums[2] + lambda_dist * sums[3]) / N1
+        ctx.set_materialize_grads(False)
+        ctx.k = (planes, He, W, float(depth_ratio), float(lambda_dssim), float(lambda_normal), float(lambda_dist), reg, N3, N1)
+        ctx.shapes = (tuple(image.shape), None if allmap is None else tuple(allmap.shape))
+        ctx.save_for_backward(x, y, dmaps, am, cam)
+        ctx.mark_non_differentiable(sums)
+        return share, sums
+
+    @staticmethod
+    def backward(ctx, g_share, g_sums):
+        planes, He, W, ratio, lam, ln, ld, reg, N3, N1 = ctx.k
+        x, y, dmaps, am, cam = ctx.saved_tensors
+        if g_share is None:
+            return (None,) * 10
+        dev = x.device
+        lib = _n.load()
+        g = g_share.contiguous().float().reshape(1)
+        grad_img = torch.empty_like(x)
+        grad_am = None
+        s = _n.current_stream_ptr(dev)
+        with torch.cuda.device(dev):
+            _check(lib.surfel_l1_ssim_backward(planes, He, W, _n.ptr(x), _n.ptr(y), _n.ptr(dmaps), (1.0 - lam) / N3, -lam / N3, _n.ptr(g), _n.ptr(g),
+                                               _n.ptr(grad_img), s), "surfel_l1_ssim_backward")
+            if reg:
+                grad_am = torch.empty_like(am)
+                _check(lib.surfel_render_post_backward(He, W, _n.ptr(am), _n.ptr(cam), ratio, None, ln / N1, ld / N1, _n.ptr(g),
+                                                       _n.ptr(grad_am), s), "surfel_render_post_backward")
+        return (grad_img.view(ctx.shapes[0]), grad_am) + (None,) * 8
+
+
+def train_loss_band(image_ext, allmap_ext, gt_ext, cam_consts_ext, depth_ratio, lambda_dssim, lambda_normal, lambda_dist, rows, full_hw):
+    """Band share of train.py:72-88's loss for tile-band sharding: the shares of all ranks add up to the full-image loss
+    (without the constant lambda_dssim term), their gradients are the unsharded ones.  rows = (first, end) band rows inside the
+    extended region, full_hw = (H, W) of the whole image, cam_consts_ext = surfel_render.post_consts_rows(...)."""
+    if cam_consts_ext is None:
+        if lambda_normal != 0.0 or lambda_dist != 0.0:
+            raise ValueError("regularisers need the camera constants")
+        cam_consts_ext = torch.empty(0, device=image_ext.device)
+        allmap_ext = None
+    return _TrainLossBand.apply(image_ext, allmap_ext, gt_ext, cam_consts_ext, depth_ratio, lambda_dssim, lambda_normal, lambda_dist, rows, full_hw)
+
+
+def scalars_from_band_sums(sums, planes_hw, hw, lambda_dssim, lambda_normal, lambda_dist):
+    """[Ll1, ssim, normal_err, dist, photometric, total] (the layout of train_loss's scalars) from the all-reduced band sums."""
+    l1, ss, ne, di = sums[0] / planes_hw, sums[1] / planes_hw, sums[2] / hw, sums[3] / hw
+    photo = (1.0 - lambda_dssim) * l1 + lambda_dssim * (1.0 - ss)
+    return torch.stack([l1, ss, ne, di, photo, photo + lambda_normal * ne + lambda_dist * di])

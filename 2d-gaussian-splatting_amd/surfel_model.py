@@ -78,6 +78,17 @@ def _views(buf, P):
     return out
 
 
+COLOUR_FLOATS = 3    # the clamp-masked dL/dcolour rides right behind the geometry prefix (fused SH mode): 13 floats = 52 B / surfel
+
+
+def exchange_same_view(grad, P, group=None, async_op=False):
+    """Tile-band sharding: every rank rendered rows of the SAME view, so the SH gradient of the summed loss is
+    basis(dir) (x) sum_r g_r — the colour gradients are simply ADDED.  With the colour block aliased behind the geometry prefix
+    (GaussianModel.bind(sh_grad=False)) the whole per-surfel exchange is ONE all-reduce of 13 floats = 52 B / surfel."""
+    import torch.distributed as dist
+    return dist.all_reduce(grad[:(GEOM_FLOATS + COLOUR_FLOATS) * P], op=dist.ReduceOp.SUM, group=group, async_op=async_op)
+
+
 def exchange_collectives(grad, gcol, P, group=None, async_op=False):
     """The two data-path collectives of a view-parallel step: all-gather of the per-rank colour gradients -> [world, P, 3] and
     all-reduce(SUM) of the geometry prefix of the flat gradient store (in place).  The gather is issued first: with
@@ -129,8 +140,15 @@ class GaussianModel:
         self.grad = torch.zeros(P * FLOATS, dtype=torch.float32, device=dev)
         self.m = torch.zeros(P * FLOATS, dtype=torch.float32, device=dev)
         self.v = torch.zeros(P * FLOATS, dtype=torch.float32, device=dev)
-        self.gcol = torch.zeros((P, 3), dtype=torch.float32, device=dev)     # clamp-masked dL/dcolour of this rank's view
         self._gv = _views(self.grad, P)
+        self._gcol_own = None
+        self.gcol = self._gcol_alias()       # clamp-masked dL/dcolour of this rank's view
+
+    def _gcol_alias(self):
+        """[P,3] view of the first 3P floats of the gradient store's SH section: in fused-SH mode nothing else lives there (the SH
+        gradients are rebuilt in registers), and geometry prefix + colour block form one contiguous 52 B/surfel exchange buffer."""
+        P = self.P
+        return self.grad[GEOM_FLOATS * P:(GEOM_FLOATS + COLOUR_FLOATS) * P].view(P, 3)
 
     def _set(self, xyz, f_dc, f_rest, opacity, scaling, rotation):
         P = xyz.shape[0]
@@ -238,6 +256,12 @@ class GaussianModel:
         192 B/surfel SH gradients; optimizer_step(colour_grads=...) rebuilds them in registers from the colour gradients."""
         import diff_surfel_rasterization as dsr
         gv = self._gv
+        if sh_grad:       # explicit SH gradients occupy the SH section: the colour gradients need a tensor of their own
+            if self._gcol_own is None or self._gcol_own.shape[0] != self.P:
+                self._gcol_own = torch.zeros((self.P, 3), dtype=torch.float32, device=self.device)
+            self.gcol = self._gcol_own
+        else:
+            self.gcol = self._gcol_alias()
         dsr.set_grad_arena(dict(means3D=gv["xyz"], sh=gv["sh"].view(self.P, 16, 3) if sh_grad else None, opacities=gv["opacity"],
                                 scales=gv["scaling"], rotations=gv["rotation"], colors=self.gcol))
 
@@ -277,6 +301,8 @@ class GaussianModel:
     def sh_grad_from_colours(self, campos_all, gcol_all):
         """grad.sh = sum_r basis(dir(xyz, campos_all[r])) (x) gcol_all[r]  for the active SH degree (one HIP launch)."""
         c = campos_all.contiguous().float(); g = gcol_all.contiguous().float()
+        if g.untyped_storage().data_ptr() == self.grad.untyped_storage().data_ptr():
+            g = g.clone()        # the fused-mode colour block lives inside the SH section this call overwrites
         with torch.cuda.device(self.device):
             rc = _n.load().surfel_sh_grad_gather(self.P, int(self.active_sh_degree), int(g.shape[0]), _n.ptr(self._pv["xyz"]), _n.ptr(c),
                                                  _n.ptr(g), _n.ptr(self._gv["sh"]), _n.current_stream_ptr(self.device))
@@ -329,8 +355,9 @@ class GaussianModel:
         if m is not None:
             self.m, self.v = m, v
             self.grad = torch.zeros(Pn * FLOATS, dtype=torch.float32, device=self.device)
-            self.gcol = torch.zeros((Pn, 3), dtype=torch.float32, device=self.device)
             self._gv = _views(self.grad, Pn)
+            self._gcol_own = None
+            self.gcol = self._gcol_alias()
             self.bind()
         self._activate_host_or_device()
         return idx

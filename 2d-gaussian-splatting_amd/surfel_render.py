@@ -62,6 +62,16 @@ def post_consts(world_view_transform, full_proj_transform, W, H):
     return out
 
 
+def post_consts_rows(consts, row0):
+    """The camera block for a sub-image that starts at image row `row0` (tile-band sharding): the pixel ray of local row y is
+    (x, y + row0, 1) @ K, i.e. K's third row gains row0 x its second row; everything else is unchanged."""
+    if row0 == 0:
+        return consts
+    c = consts.clone()
+    c[15:18] = consts[15:18] + float(row0) * consts[12:15]
+    return c
+
+
 class Camera:
     """Same attributes as the reference's Camera (scene/cameras.py:17-59): R = C2W rotation, T = W2C translation,
     matrices stored transposed (row-vector convention) on the device, znear 0.01 / zfar 100."""

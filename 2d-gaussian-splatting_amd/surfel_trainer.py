@@ -23,9 +23,9 @@ import torch
 import torch.distributed as dist
 
 import surfel_dist
-from surfel_losses import train_loss
-from surfel_model import GaussianModel, exchange_collectives
-from surfel_render import Camera, rasterize, render
+from surfel_losses import scalars_from_band_sums, train_loss, train_loss_band
+from surfel_model import COLOUR_FLOATS, GEOM_FLOATS, GaussianModel, exchange_collectives, exchange_same_view
+from surfel_render import Camera, post_consts_rows, rasterize, render
 
 
 def optimization_params(**over):
@@ -120,9 +120,11 @@ def capture_views(gt_model, cams, background, pipe=None):
 class Trainer:
     def __init__(self, model, cams, opt=None, pipe=None, white_background=False, extent=None, seed=0, sharding="views"):
         """sharding (N > 1): "views" = every rank trains on its own view per step (default, BASELINE config 4); "bands" = all ranks
-        render row bands of the SAME view (tile-band sharding, BASELINE config 5): the bands are all-gathered into the full image,
-        the loss is evaluated on it by every rank, each rank back-propagates its own rows, and the per-surfel gradients of the bands
-        ADD UP to the single-GPU gradient (same exchange, no averaging)."""
+        render row bands of the SAME view (tile-band sharding, BASELINE config 5): every rank evaluates the loss on ITS band plus a
+        32-row halo received from its two neighbours (surfel_losses.train_loss_band), back-propagates its own rows, and the
+        per-surfel gradients of the bands ADD UP to the single-GPU gradient — ONE all-reduce of 52 B/surfel (geometry + colour
+        gradients; the camera is shared, so the SH gradients are rebuilt from the SUM of the colour gradients), no averaging.
+        Band edges follow the previous frames' instances per tile row (re-balanced every `rebalance_every` iterations)."""
         if sharding not in ("views", "bands"):
             raise ValueError("sharding must be 'views' or 'bands'")
         self.sharding = sharding
@@ -141,6 +143,11 @@ class Trainer:
         self.last = {}
         self._epoch, self._epoch_views, self._epoch_campos, self._centers = -1, None, None, None
         self._one = torch.ones((), dtype=torch.float32, device=model.device)
+        self.rebalance_every = 8        # bands: iterations between re-balancing the band edges (one small all-gather + D2H)
+        self._row_weights = None        # bands: running mean of tile instances per 16-row tile row (host list)
+        self.wire = {"total": 0}        # bytes on the wire per GPU of the most recent step, by collective (surfel_dist.wire_bytes_per_step)
+        self.time_exchange = False      # bench: bracket the stream waits on the exchange with events -> self.exchange_events
+        self.exchange_events = []
         # RCCL: asynchronous collectives with stream-level waits (SH-block Adam overlaps the geometry all-reduce); other backends
         # (gloo rehearsals stage through the host and block) take the plain synchronous form
         self._async_exchange = self.world > 1 and dist.get_backend() == "nccl"
@@ -189,28 +196,52 @@ class Trainer:
         cam = self._next_camera()
         m.bind(sh_grad=not self.fused_sh)      # fused: the SH gradients are rebuilt inside the optimiser kernel from the colour gradients
         bands = self.world > 1 and self.sharding == "bands"
-        if bands:
-            bounds = surfel_dist.band_bounds(int(cam.image_height), self.world)
-            image, radii, allmap, means2D = rasterize(cam, m, self.pipe, self.background, zero_means2D=False, band=bounds[self.rank])
-            image = surfel_dist.gather_bands(image, bounds)
-            allmap = surfel_dist.gather_bands(allmap, bounds)
-        else:
-            image, radii, allmap, means2D = rasterize(cam, m, self.pipe, self.background, zero_means2D=False)
         lam_n = opt.lambda_normal if it > opt.normal_from_iter else 0.0
         lam_d = opt.lambda_dist if it > opt.dist_from_iter else 0.0
         reg = lam_n > 0.0 or lam_d > 0.0
-        loss, scalars = train_loss(image, allmap if reg else None, cam.original_image, cam.post_consts() if reg else None,
-                                   self.pipe.depth_ratio, opt.lambda_dssim, lam_n, lam_d)
+        stats_live = it < opt.densify_until_iter
+        if bands:
+            H, W = int(cam.image_height), int(cam.image_width)
+            bounds = surfel_dist.band_bounds(H, self.world, self._row_weights, multiple=surfel_dist.HALO)
+            y0, y1 = bounds[self.rank]
+            # the densification statistic of the view = norm of the SUM over bands: it rides in the same all-reduce, right
+            # behind the colour block (both live in the SH section of the gradient store, unused in fused-SH mode)
+            arena2d = m.grad[(GEOM_FLOATS + COLOUR_FLOATS) * m.P:(GEOM_FLOATS + COLOUR_FLOATS + 3) * m.P].view(m.P, 3)
+            import diff_surfel_rasterization as dsr
+            dsr._grad_arena["means2D"] = arena2d
+            image_b, radii, allmap_b, means2D = rasterize(cam, m, self.pipe, self.background, zero_means2D=False, band=(y0, y1))
+            ext = surfel_dist.exchange_halo(torch.cat([image_b, allmap_b], 0) if reg else image_b, bounds, H)
+            top, bot = surfel_dist.halo_rows(bounds, self.rank, H)
+            gt_ext = cam.original_image[:, y0 - top:y1 + bot]
+            consts = post_consts_rows(cam.post_consts(), y0 - top) if reg else None
+            loss, sums = train_loss_band(ext[:3], ext[3:] if reg else None, gt_ext, consts, self.pipe.depth_ratio, opt.lambda_dssim, lam_n, lam_d,
+                                         (top, top + (y1 - y0)), (H, W))
+            sums = sums.clone()
+            dist.all_reduce(sums, op=dist.ReduceOp.SUM)           # 16 bytes: the full-image loss terms, for logging
+            scalars = scalars_from_band_sums(sums, float(3 * H * W), float(H * W), opt.lambda_dssim, lam_n, lam_d)
+            halo_b = surfel_dist.halo_bytes(bounds, self.rank, H, W, 10 if reg else 3)
+        else:
+            image, radii, allmap, means2D = rasterize(cam, m, self.pipe, self.background, zero_means2D=False)
+            loss, scalars = train_loss(image, allmap if reg else None, cam.original_image, cam.post_consts() if reg else None,
+                                       self.pipe.depth_ratio, opt.lambda_dssim, lam_n, lam_d)
+            halo_b = 0
+        self.wire = surfel_dist.wire_bytes_per_step(m.P, self.world, self.sharding, stats_live, halo_b)
         torch.autograd.backward(loss, grad_tensors=self._one)        # cached seed gradient: no ones_like fill per iteration
         self.last = dict(loss=scalars[5], scalars=scalars, points=m.P, radii=radii)     # [Ll1, ssim, normal_err, dist, photometric, total] on the device
         with torch.no_grad():
             rebuilt = False
-            if it < opt.densify_until_iter:
-                g2d = means2D.grad
-                if bands:      # one view: the statistic is the norm of the SUM over bands, visibility the union of the bands
-                    dist.all_reduce(g2d, op=dist.ReduceOp.SUM)
-                    radii = radii.clone(); dist.all_reduce(radii, op=dist.ReduceOp.MAX)
-                m.add_densification_stats(g2d, radii=radii)
+            w_same = None
+            if bands:
+                # ONE all-reduce: geometry 10 | colour 3 (| means2D statistic 3) floats per surfel
+                n_f = GEOM_FLOATS + COLOUR_FLOATS + (3 if stats_live else 0)
+                w_same = dist.all_reduce(m.grad[:n_f * m.P], op=dist.ReduceOp.SUM, async_op=self._async_exchange)
+                if stats_live:
+                    radii = radii.clone(); dist.all_reduce(radii, op=dist.ReduceOp.MAX)      # visibility = union of the bands
+                if self._async_exchange:
+                    self._timed_wait(w_same)
+                self._rebalance_bands(cam)
+            if stats_live:
+                m.add_densification_stats(arena2d if bands else means2D.grad, radii=radii)
                 if it > opt.densify_from_iter and it % opt.densification_interval == 0:
                     if self.world > 1 and not bands:
                         self._reduce_stats()
@@ -225,16 +256,19 @@ class Trainer:
                     if not rebuilt:      # the reference re-creates only the opacity parameter: its update is skipped this iteration
                         m._gv["opacity"].zero_()
             if it < opt.iterations and not rebuilt:     # re-created parameters carry no gradient in the reference: no update
-                if self.world > 1:
+                if bands:
+                    # partial gradients of one view add up (no averaging); the SH block is rebuilt from the summed colour gradients
+                    m.optimizer_step(grad_scale=1.0, colour_grads=(cam.camera_center[None], m.gcol[None]))
+                elif self.world > 1:
                     # all-reduce of the 40 B/surfel geometry prefix + all-gather of 12 B/surfel/rank colour gradients; the 192 B/surfel
                     # SH gradients are rebuilt from them (exact, rank-ordered sum) instead of being all-reduced
-                    campos_all = cam.camera_center[None].expand(self.world, 3).contiguous() if bands else self._step_views()[1]
-                    scale = 1.0 if bands else 1.0 / self.world      # bands: partial gradients of one view add up; views: average
+                    campos_all = self._step_views()[1]
+                    scale = 1.0 / self.world      # views: average
                     if self._async_exchange:
                         gcol_all, w_gather, w_reduce = exchange_collectives(m.grad, m.gcol, m.P, async_op=True)
-                        w_gather.wait()          # stream-level wait: the SH block updates while the geometry all-reduce is in flight
+                        self._timed_wait(w_gather)   # stream-level wait: the SH block updates while the geometry all-reduce is in flight
                         m.optimizer_step(grad_scale=scale, colour_grads=(campos_all, gcol_all), parts=1)
-                        w_reduce.wait()
+                        self._timed_wait(w_reduce)
                         m.optimizer_step(grad_scale=scale, colour_grads=(campos_all, gcol_all), parts=2)
                     else:
                         gcol_all = exchange_collectives(m.grad, m.gcol, m.P)
@@ -243,6 +277,31 @@ class Trainer:
                     if self.fused_sh:
                         campos_all, gcol_all = cam.camera_center[None], m.gcol[None]
                     m.optimizer_step(grad_scale=1.0, colour_grads=(campos_all, gcol_all) if self.fused_sh else None)
+
+    def _timed_wait(self, work):
+        """Stream-level wait on an asynchronous collective; with time_exchange the wait is bracketed by events on the compute
+        stream — the elapsed time is what the exchange was NOT hidden behind compute (resolved by the caller after the run)."""
+        if self.time_exchange:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(); work.wait(); e1.record()
+            self.exchange_events.append((e0, e1))
+        else:
+            work.wait()
+
+    def _rebalance_bands(self, cam):
+        """bands: every `rebalance_every` iterations gather the ranks' tile instances per tile row (a few hundred bytes) into a
+        running mean that the next iterations' band_bounds use as weights."""
+        if self.rebalance_every <= 0 or self.iteration % self.rebalance_every != 0:
+            return
+        import diff_surfel_rasterization as dsr
+        rows16 = (int(cam.image_height) + 15) // 16
+        mine = dsr.tile_row_instances()
+        full = torch.zeros((rows16,), dtype=torch.int64, device=self.model.device)
+        y0 = surfel_dist.band_bounds(int(cam.image_height), self.world, self._row_weights, multiple=surfel_dist.HALO)[self.rank][0]
+        full[y0 // 16:y0 // 16 + mine.numel()] = mine
+        dist.all_reduce(full, op=dist.ReduceOp.SUM)
+        w = full.to(torch.float64).cpu().tolist()
+        self._row_weights = w if self._row_weights is None else [0.5 * a + 0.5 * b for a, b in zip(self._row_weights, w)]
 
     def evaluate(self, cams=None):
         """Mean PSNR / L1 over views (training_report, train.py:201-232)."""

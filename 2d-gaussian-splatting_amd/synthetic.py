@@ -21,6 +21,10 @@ CONFIGS = {
     "1080p_1M": (1_000_000, 1920, 1080, 12.0),
     "1080p_2M": (2_000_000, 1920, 1080, 12.0),
 }
+# median projected 1-sigma radius in px where it is not the default 4 px x W / 1920 (heavy-footprint stand-in for a trained scene:
+# R / P ~ 10 tile instances per surfel instead of ~2)
+PX_RADIUS = {"C2H": 7.0}
+CONFIGS["C2H"] = (300_000, 800, 800, 12.0)
 
 
 def projection_matrix(znear, zfar, fovx, fovy):
@@ -60,25 +64,31 @@ def _rot(axis, ang):
     return np.eye(3) + math.sin(ang) * K + (1 - math.cos(ang)) * K @ K
 
 
+def _base_pose(tilt=True):
+    if tilt:
+        return _rot([0.3, 1.0, 0.2], 0.15), np.array([0.1, -0.05, 0.2])
+    return np.eye(3), np.zeros(3)
+
+
+def view_camera(W, H, view_index=0, tilt=True):
+    """Camera of training view `view_index` of a make_scene() scene (view 0 = the camera the surfels are laid out for; the others
+    add a small rotation + shift, so view-parallel ranks see different images of the SAME surfels)."""
+    Rcw, t = _base_pose(tilt)
+    if view_index:
+        Rcw = _rot([0.1, 1.0, 0.0], 0.02 * view_index) @ Rcw
+        t = t + np.array([0.05 * view_index, 0.0, 0.02 * view_index])
+    return look_at_camera(W, H, Rcw=Rcw, t=t)
+
+
 def make_scene(P, W, H, seed=0, z_near=2.0, z_far=12.0, px_radius=None, tilt=True, sh_degree=3, view_index=0):
     """Random surfels filling 110 % of the frustum slab z in [z_near, z_far] (≈9 % culled off-screen).
     Scales are chosen so the median projected 1-sigma radius is `px_radius` px (default: 4 px at 1080p,
     scaled with resolution). Camera is slightly rotated/translated so no matrix entry is trivially 0."""
     rng = np.random.default_rng(seed)
-    if tilt:
-        Rcw = _rot([0.3, 1.0, 0.2], 0.15)
-        t = np.array([0.1, -0.05, 0.2])
-    else:
-        Rcw, t = np.eye(3), np.zeros(3)
-    cam = look_at_camera(W, H, Rcw=Rcw, t=t)
+    Rcw, t = _base_pose(tilt)
+    cam0 = look_at_camera(W, H, Rcw=Rcw, t=t)       # surfels are laid out in the base camera's frustum
+    cam = view_camera(W, H, view_index, tilt)
     f = 1.2 * W
-    cam0 = cam
-    if view_index:
-        # another training view of the SAME surfels (view-parallel ranks): small extra rotation + shift
-        Rv = _rot([0.1, 1.0, 0.0], 0.02 * view_index) @ Rcw
-        tv = t + np.array([0.05 * view_index, 0.0, 0.02 * view_index])
-        cam = look_at_camera(W, H, Rcw=Rv, t=tv)
-    cam0 = cam0  # surfels are laid out in the base camera's frustum
     if px_radius is None:
         px_radius = 4.0 * W / 1920.0 * 1.0
         px_radius = max(px_radius, 1.5)
@@ -92,11 +102,11 @@ def make_scene(P, W, H, seed=0, z_near=2.0, z_far=12.0, px_radius=None, tilt=Tru
     rots = rng.normal(size=(P, 4)); rots /= np.linalg.norm(rots, axis=1, keepdims=True)
     opac = 1.0 / (1.0 + np.exp(-rng.normal(0.0, 2.0, (P, 1))))
     M = 16
-    sh = np.zeros((P, M, 3))
+    sh = np.zeros((P, M, 3), np.float32)
     sh[:, 0] = rng.normal(0.0, 1.0, (P, 3))
     sh[:, 1:] = rng.normal(0.0, 0.1, (P, M - 1, 3))
     scene = dict(means3D=pw.astype(np.float32), scales=scales.astype(np.float32), rotations=rots.astype(np.float32),
-                 opacities=opac.astype(np.float32), shs=sh.astype(np.float32), sh_degree=sh_degree,
+                 opacities=opac.astype(np.float32), shs=sh, sh_degree=sh_degree,
                  bg=np.zeros(3, np.float32), scale_modifier=1.0)
     scene.update(cam)
     return scene
@@ -104,4 +114,4 @@ def make_scene(P, W, H, seed=0, z_near=2.0, z_far=12.0, px_radius=None, tilt=Tru
 
 def make_config(name, seed=0):
     P, W, H, zf = CONFIGS[name]
-    return make_scene(P, W, H, seed=seed, z_far=zf)
+    return make_scene(P, W, H, seed=seed, z_far=zf, px_radius=PX_RADIUS.get(name))

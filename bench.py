@@ -87,6 +87,8 @@ def main():
     ap.add_argument("--no-1080p", action="store_true")
     ap.add_argument("--no-raster-only", action="store_true")
     ap.add_argument("--no-train-iter", action="store_true", help="(kept for older scripts; the timed step IS the training iteration)")
+    ap.add_argument("--no-legs", action="store_true", help="skip the extra N = 1 workload legs (C4-synthetic, heavy-footprint C2H, trained state)")
+    ap.add_argument("--quick", action="store_true", help="headline leg only (= --no-legs --no-cpu-baseline --no-1080p --no-raster-only)")
     ap.add_argument("--sharding", choices=("views", "bands"), default="views",
                     help="N > 1: 'views' = one view per GPU per iteration (weak scaling, default); 'bands' = tile-band sharding of ONE view "
                          "per iteration across the GPUs (strong scaling; BASELINE config 5: --workload C5)")
@@ -96,6 +98,8 @@ def main():
 
     # ---- launch contract: `python bench.py --gpus N` run DIRECTLY must time N ranks.  Without a torch.distributed.run
     # environment this process re-executes itself under it (one rank per GPU, rendezvous on 127.0.0.1) and relays the result.
+    if args.quick:
+        args.no_legs = args.no_cpu_baseline = args.no_1080p = args.no_raster_only = True
     if "WORLD_SIZE" not in os.environ:
         if args.gpus > 1:
             raise SystemExit(_respawn(args.gpus))
@@ -136,6 +140,7 @@ def main():
     for _ in range(PRIME):
         tr.step()
     tr.pipe.debug = 3       # HIP events around the dominant kernel only (blend_bwd), resolved after the timed region, no sync
+    tr.time_exchange = world > 1     # N > 1: events around the stream waits on the collectives -> exposed exchange time
 
     def fence():
         torch.cuda.synchronize()
@@ -148,12 +153,16 @@ def main():
     fence()
     loss_first = float(tr.last["loss"])
     surfel_native.collect_stage_times()     # drop warm-up events
+    tr.exchange_events = []
     t0 = time.perf_counter()
     for _ in range(args.steps):
         tr.step()
     fence()
     dt = time.perf_counter() - t0
     dom_stage = surfel_native.collect_stage_times()        # {"blend_bwd": (total_ms, launches)} from the timed region itself
+    exposed_ms = (sum(e0.elapsed_time(e1) for e0, e1 in tr.exchange_events) / args.steps) if tr.exchange_events else None
+    tr.time_exchange = False
+    wire = dict(tr.wire)
     loss_last = float(tr.last["loss"])
     # per-stage breakdown of the rasterizer: a second, untimed pass with every stage bracketed by events
     # (bracketing all ~9 stages costs ~10 us each, which would perturb the timed region by ~9 % at this size)
@@ -187,11 +196,15 @@ def main():
         if dom:
             B = algorithmic_bytes(dom, P, V, R, W, H, n_pass)
             ach = B / (per_kernel[dom] * 1e-3) / 1e9
-            traffic = None
+            # HBM traffic of the dominant kernel: PMC counters cannot be read from inside the process, so this is the figure of the
+            # committed rocprofv3 pass over this same command (scripts/profile_gpu.sh), labelled as such
+            traffic, traffic_src = None, None
             tf = os.path.join(REPO, "profiles", "pmc_traffic.json")
             if os.path.exists(tf):
                 try:
-                    traffic = json.load(open(tf)).get(args.workload, {}).get(dom)
+                    tj = json.load(open(tf))
+                    traffic = tj.get(args.workload, {}).get(dom)
+                    traffic_src = "profiles/pmc_traffic.json (%s): separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over `python bench.py`, not read in this run" % tj.get("_tag", "committed")
                 except Exception:
                     traffic = None
             # second yardstick for the VALU-bound blend kernels: issued VALU wave-instructions per launch (SQ_INSTS_VALU from the
@@ -208,7 +221,7 @@ def main():
             except Exception:
                 valu = None
             roof = {"bound": "hbm", "kernel": dom, "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic, "algorithmic_bytes": int(B),
+                    "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_src, "algorithmic_bytes": int(B),
                     "kernel_ms": round(per_kernel[dom], 4), "valu_issue": valu,
                     "all_kernels_ms": {k: round(v, 4) for k, v in per_kernel.items()},
                     "all_kernels_GBps": {k: round(algorithmic_bytes(k, P, V, R, W, H, n_pass) / (v * 1e-3) / 1e9, 1)
@@ -225,6 +238,10 @@ def main():
                           "parallelism": ("tile-band sharding of one view over %d GPUs (image bands all-gathered, same gradient exchange)" % world) if bands
                           else ("view-parallel dp%d; per iteration 1 all-reduce of 40 B/surfel (geometry gradients) + 1 all-gather of "
                                 "12 B/surfel/rank (colour gradients -> SH gradients rebuilt locally)" % world)},
+               "world_size_seen": world, "backend": backend if world > 1 else None,
+               "exchange": None if world == 1 else {"wire_bytes_per_step_per_gpu": wire, "exposed_ms_per_step": None if exposed_ms is None else round(exposed_ms, 4),
+                                                     "note": "wire bytes = ring-algorithm bytes per GPU per step by collective; exposed = mean time the "
+                                                             "compute stream spent waiting on the collectives (events around the stream waits)"},
                "loss_first": round(loss_first, 5), "loss_last": round(loss_last, 5),
                "train_Msplats_per_s": round((1 if bands else world) * P * args.steps / dt / 1e6, 2), "roofline": roof}
 
@@ -245,10 +262,21 @@ def main():
         from helpers_bench import fwd_1080p
         out["fwd_1080p"] = fwd_1080p(dev)
 
-    # ---- CPU baseline: the oracle's fp32 OpenMP port of the rasterizer, same workload shape, rank 0 / N=1 only
+    # ---- more workloads through the same full iteration (N=1 only): BASELINE configs[3]'s per-GPU shape, a heavy-footprint
+    # synthetic, and a TRAINED state (post-densification statistics) — VERDICT r1 weak #5
+    if rank == 0 and world == 1 and not args.no_legs:
+        from helpers_bench import config_leg, copy_bandwidth, trained_leg
+        out["hbm_copy_probe"] = copy_bandwidth(dev)
+        out["legs"] = {"C4": config_leg(dev, "C4", steps=20, warmup=5), "C2H": config_leg(dev, "C2H", steps=30, warmup=5),
+                       "trained": trained_leg(dev)}
+
+    # ---- CPU baselines, rank 0 / N=1 only: the oracle's fp32 OpenMP port of the rasterizer on the headline workload shape, and
+    # BASELINE configs[0]: the dense pure-PyTorch rasterizer at C1
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        from helpers_bench import cpu_baseline
+        sys.path.insert(0, os.path.join(REPO, "tests"))
+        from helpers_bench import cpu_baseline, cpu_dense_c1
         out["cpu_baseline"] = cpu_baseline(args.workload)
+        out["cpu_baseline_dense_torch_C1"] = cpu_dense_c1()
 
     if rank == 0:
         print(json.dumps(out))

@@ -79,10 +79,10 @@ def make_trainer(dev, workload="C2", n_views=8, regularizers=True, sharding="vie
     import surfel_trainer as TR
     from surfel_render import Camera
     P, W, H, zf = synthetic.CONFIGS[workload]
-    cams, sc0 = [], None
+    sc0 = synthetic.make_scene(P, W, H, seed=0, z_far=zf, px_radius=synthetic.PX_RADIUS.get(workload))
+    cams = []
     for k in range(n_views):
-        sc = synthetic.make_scene(P, W, H, seed=0, z_far=zf, view_index=k)
-        sc0 = sc0 or sc
+        sc = synthetic.view_camera(W, H, k)           # the same surfels seen from view k (no second 2 M-surfel generation per view)
         w2c = sc["viewmatrix"].T.astype(np.float64)
         cams.append(Camera(colmap_id=k, R=w2c[:3, :3].T, T=w2c[:3, 3], FoVx=2 * math.atan(sc["tanfovx"]), FoVy=2 * math.atan(sc["tanfovy"]),
                            image=torch.zeros(3, H, W), image_name="bench_%d" % k, uid=k, data_device=dev))
@@ -100,10 +100,141 @@ def make_trainer(dev, workload="C2", n_views=8, regularizers=True, sharding="vie
                          raw["opacity"] - 0.5, raw["scaling"] + 0.1 * torch.randn(raw["scaling"].shape, generator=g), raw["rotation"])
     model.active_sh_degree = 3
     model.spatial_lr_scale = TR.cameras_extent(cams) if n_views > 1 else 1.0
+    return TR.Trainer(model, cams, _frozen_schedule(TR, regularizers), TR.pipeline_params(depth_ratio=1.0), sharding=sharding)
+
+
+def _frozen_schedule(TR, regularizers=True):
+    """Steady-state iteration: every loss term on, no densification / opacity reset inside the timed window."""
     far = 10 ** 9
-    opt = TR.optimization_params(iterations=far, densify_from_iter=far, opacity_reset_interval=far, dist_from_iter=0 if regularizers else far,
-                                 normal_from_iter=0 if regularizers else far, lambda_dist=1000.0, lambda_normal=0.05)
-    return TR.Trainer(model, cams, opt, TR.pipeline_params(depth_ratio=1.0), sharding=sharding)
+    return TR.optimization_params(iterations=far, densify_from_iter=far, opacity_reset_interval=far, dist_from_iter=0 if regularizers else far,
+                                  normal_from_iter=0 if regularizers else far, lambda_dist=1000.0, lambda_normal=0.05)
+
+
+def time_trainer(tr, steps, warmup, prime=15):
+    """ms per full training iteration of an existing Trainer + the rasterizer's per-stage kernel times (second, untimed pass)."""
+    import torch
+    import surfel_native
+    import diff_surfel_rasterization as dsr
+    for _ in range(prime + warmup):
+        tr.step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        tr.step()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    surfel_native.collect_stage_times()
+    tr.pipe.debug = 2
+    for _ in range(max(5, steps // 2)):
+        tr.step()
+    torch.cuda.synchronize()
+    st = surfel_native.collect_stage_times()
+    tr.pipe.debug = 0
+    cam = tr.cams[0]
+    tiles = ((int(cam.image_width) + 15) // 16) * ((int(cam.image_height) + 15) // 16)
+    R = int(dsr.last_num_rendered)
+    return {"ms_per_step": round(dt / steps * 1e3, 4), "iters_per_s": round(steps / dt, 2), "steps": steps, "P": int(tr.model.P),
+            "visible": int((tr.last["radii"] > 0).sum().item()), "instances_R": R, "inst_per_tile": round(R / tiles, 1),
+            "inst_per_surfel": round(R / max(1, int(tr.model.P)), 2), "loss": round(float(tr.last["loss"]), 5),
+            "kernels_ms": {k: round(v[0] / v[1], 4) for k, v in st.items()}}
+
+
+def config_leg(dev, workload, steps=20, warmup=5):
+    """One more synthetic configuration through the same full training iteration (C4 = BASELINE configs[3] per-GPU shape,
+    C2H = heavy footprints)."""
+    import torch
+    import synthetic
+    import diff_surfel_rasterization as dsr
+    P, W, H, zf = synthetic.CONFIGS[workload]
+    tr = make_trainer(dev, workload, n_views=8)
+    out = time_trainer(tr, steps, warmup)
+    out["workload"] = ("%s-synthetic: %d random surfels, %dx%d, median 1-sigma radius %.1f px, full iteration as the headline leg"
+                       % (workload, P, W, H, synthetic.PX_RADIUS.get(workload) or max(4.0 * W / 1920.0, 1.5)))
+    del tr
+    dsr.set_grad_arena(None)
+    torch.cuda.empty_cache()
+    return out
+
+
+def trained_leg(dev, train_iters=6000, n_gt=200_000, n_views=48, res=800, steps=30, warmup=5):
+    """A TRAINED state instead of random surfels: run the reference's default schedule (random-point initialisation, densification
+    500 -> every 100, opacity resets, lambda_dist after 3000) on a synthetic capture for `train_iters` iterations — untimed —
+    then time the steady-state iteration on the resulting model (post-densification scale / opacity statistics, every loss on)."""
+    import torch
+    import surfel_model
+    import surfel_trainer as TR
+    import diff_surfel_rasterization as dsr
+    torch.manual_seed(0)
+    bg = torch.zeros(3, device=dev)
+    gt = TR.synthetic_object(n_gt, dev, seed=0, px_scale=0.035)
+    cams = TR.capture_views(gt, TR.orbit_cameras(n_views + 8, res, res, device=dev), bg)
+    del gt
+    train_cams, test_cams = cams[:n_views], cams[n_views:]
+    extent = TR.cameras_extent(train_cams)
+    rng = np.random.default_rng(0)
+    pcd = type("PCD", (), {})()
+    pcd.points = (rng.random((n_gt, 3)) * 2.6 - 1.3).astype(np.float32)
+    pcd.colors = rng.random((n_gt, 3)).astype(np.float32)
+    model = surfel_model.GaussianModel(3, device=dev)
+    model.create_from_pcd(pcd, spatial_lr_scale=extent)
+    opt = TR.optimization_params(iterations=train_iters, lambda_dist=100.0, position_lr_max_steps=train_iters)
+    tr = TR.Trainer(model, train_cams, opt, TR.pipeline_params(depth_ratio=1.0), extent=extent)
+    p0 = tr.evaluate(train_cams[:8])[0]
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(train_iters - 1):       # the schedule's last iteration takes no optimiser step (train.py:136)
+        tr.step()
+    torch.cuda.synchronize(); t_train = time.perf_counter() - t0
+    psnr_train, psnr_test = tr.evaluate(train_cams[:8])[0], tr.evaluate(test_cams)[0]
+    sc = model._av["scaling"]; op = model._av["opacity"]
+    stats = {"median_scale": round(float(sc.median()), 5), "median_opacity": round(float(op.median()), 4), "frac_opacity_gt_0.5": round(float((op > 0.5).float().mean()), 4)}
+    tr2 = TR.Trainer(model, train_cams, _frozen_schedule(TR), TR.pipeline_params(depth_ratio=1.0), extent=extent)
+    tr2.iteration = train_iters
+    out = time_trainer(tr2, steps, warmup, prime=5)
+    out.update({"workload": "trained synthetic capture: %d random points -> %d surfels after %d iterations of the reference schedule, %d views of %dx%d"
+                            % (n_gt, int(model.P), train_iters, n_views, res, res),
+                "train_wall_s": round(t_train, 2), "train_iters_per_s": round((train_iters - 1) / t_train, 1), "psnr_init": round(p0, 2),
+                "psnr_train": round(psnr_train, 2), "psnr_heldout": round(psnr_test, 2), "model_stats": stats})
+    del tr, tr2, model
+    dsr.set_grad_arena(None)
+    torch.cuda.empty_cache()
+    return out
+
+
+def copy_bandwidth(dev, mbytes=1024, iters=10):
+    """Same-run HBM copy probe (SURVEY 8d): device-to-device copy of a buffer far larger than the 256 MB Infinity Cache;
+    GB/s counts bytes read + written."""
+    import torch
+    n = mbytes * 1024 * 1024 // 4
+    a = torch.empty(n, dtype=torch.float32, device=dev).normal_()
+    b = torch.empty_like(a)
+    for _ in range(2):
+        b.copy_(a)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        b.copy_(a)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / iters
+    del a, b
+    torch.cuda.empty_cache()
+    return {"buffer_MB": mbytes, "ms": round(ms, 4), "GBps_read_plus_write": round(2 * mbytes * 1.048576 / ms, 1)}
+
+
+def cpu_dense_c1(max_seconds=25.0):
+    """BASELINE configs[0]: the dense pure-PyTorch surfel rasterizer (oracle/dense_autograd.py — every surfel against every pixel,
+    the algorithm of the reference's linked Python notebook, README.md:3,7) forward on the host CPU at C1 (10 k surfels, 256x256),
+    on a bounded sample of pixel rows, extrapolated linearly to the full image (the work is uniform per pixel row)."""
+    import torch
+    import synthetic
+    from oracle import dense_autograd as da
+    from oracle.surfel_oracle import Oracle
+    from helpers import oracle_forward, scene_args      # tests/helpers.py (sys.path is set by bench.py)
+    P, W, H, zf = synthetic.CONFIGS["C1"]
+    sc = synthetic.make_scene(P, W, H, seed=0, z_far=zf)
+    a = scene_args(sc)
+    _, _, _, radii, st = oracle_forward(Oracle("f64"), a)
+    return da.time_dense_forward(sc, st, max_seconds)
 
 
 def train_iter(dev, workload="C2", iters=60, warmup=15, n_views=8):

@@ -89,10 +89,10 @@ def aabb_center(T):
 
 def render_dense(means3D, scales, rotations, opacities, shs, colors_precomp, transMat_precomp, *, bg, viewmatrix,
                  projmatrix, campos, W, H, sh_degree, scale_modifier, radii, rects, depth_key, detach_center=False,
-                 T_leaf=None):
+                 T_leaf=None, rows=None):
     """All tensors fp64 torch.  `radii` [P] int and `rects` [P,4] (x0,y0,x1,y1 tile rect) come from the C
     oracle's preprocess (non-differentiable culling/binning decisions); `depth_key` [P] is the float32
-    depth used as sort key.  Returns color[3,H,W], allmap[7,H,W], T[P,9]."""
+    depth used as sort key.  Returns color[3,H,W], allmap[7,H,W] (rows=(y0, y1): only those image rows, [.., y1-y0, W])."""
     dt = means3D.dtype
     vis = torch.as_tensor(radii) > 0
     idx = torch.nonzero(vis).squeeze(1)
@@ -122,7 +122,9 @@ def render_dense(means3D, scales, rotations, opacities, shs, colors_precomp, tra
     T = T[order]; xy = xy[order]; nrm = nrm[order]; rgb = rgb[order]
     opa = opacities.reshape(-1)[order]
     rect = torch.as_tensor(rects)[order]
-    ys, xs = torch.meshgrid(torch.arange(H, dtype=dt), torch.arange(W, dtype=dt), indexing="ij")
+    y0, y1 = (0, H) if rows is None else rows
+    ys, xs = torch.meshgrid(torch.arange(y0, y1, dtype=dt), torch.arange(W, dtype=dt), indexing="ij")
+    H = y1 - y0
     px = xs.reshape(-1, 1); py = ys.reshape(-1, 1)                 # [N,1]
     tx = (px // 16).long(); ty = (py // 16).long()
     in_rect = (tx >= rect[:, 0]) & (tx < rect[:, 2]) & (ty >= rect[:, 1]) & (ty < rect[:, 3])   # [N,S]
@@ -171,3 +173,39 @@ def render_dense(means3D, scales, rotations, opacities, shs, colors_precomp, tra
     color = Ccol.T.reshape(3, H, W)
     allmap = torch.stack([D, 1 - T_final, N[:, 0], N[:, 1], N[:, 2], med, dist], 0).reshape(7, H, W)
     return color, allmap
+
+
+def time_dense_forward(sc, st, max_seconds=25.0, rows_per_chunk=4):
+    """CPU baseline leg of bench.py (BASELINE configs[0]): forward of the dense rasterizer above in fp32 under no_grad on all host
+    cores, over as many 4-row chunks of the image as fit into `max_seconds`, extrapolated linearly to the full image.
+    sc = synthetic scene dict, st = the C oracle's preprocess state (radii / tile rects / depth keys: the non-differentiable
+    binning decisions render_dense takes as inputs)."""
+    import os
+    import time
+    import numpy as np
+    W, H, P = int(sc["W"]), int(sc["H"]), sc["means3D"].shape[0]
+    cores = min(os.cpu_count() or 1, 32)      # intra-op threads actually used: more than ~32 slows these broadcast-heavy ops down
+    torch.set_num_threads(cores)
+    t = lambda x: torch.tensor(np.asarray(x, np.float32))
+    gx, gy = (W + 15) // 16, (H + 15) // 16
+    r = st.radii
+    clampi = lambda v, hi: np.minimum(hi, np.maximum(0, v.astype(np.int64)))
+    rects = np.stack([clampi(np.trunc((st.xy[:, 0] - r) / 16), gx), clampi(np.trunc((st.xy[:, 1] - r) / 16), gy),
+                      clampi(np.trunc((st.xy[:, 0] + r + 15) / 16), gx), clampi(np.trunc((st.xy[:, 1] + r + 15) / 16), gy)], 1)
+    kw = dict(bg=t(sc["bg"]), viewmatrix=t(sc["viewmatrix"]), projmatrix=t(sc["projmatrix"]), campos=t(sc["campos"]), W=W, H=H,
+              sh_degree=int(sc["sh_degree"]), scale_modifier=1.0, radii=st.radii, rects=rects, depth_key=st.depths.astype(np.float32))
+    args = [t(sc[k]) for k in ("means3D", "scales", "rotations", "opacities", "shs")]
+    done_rows, spent = 0, 0.0
+    with torch.no_grad():
+        y = 0
+        while y < H and (spent < max_seconds or done_rows == 0):
+            t0 = time.perf_counter()
+            render_dense(*args, None, None, rows=(y, min(H, y + rows_per_chunk)), **kw)
+            spent += time.perf_counter() - t0
+            done_rows += min(H, y + rows_per_chunk) - y
+            y += rows_per_chunk * max(1, (H // rows_per_chunk) // 16)       # sample chunks spread over the image
+    full = spent * H / done_rows
+    return {"value": round(1.0 / full, 5), "unit": "forward views/s", "cores": cores, "kind": "port",
+            "sample": "C1 (%d surfels, %dx%d), dense pure-PyTorch rasterizer (every surfel x every pixel, fp32, torch threads = %d): %d of %d "
+                      "pixel rows in %.1f s, extrapolated linearly to the full image: %.1f s per forward view" % (P, W, H, cores, done_rows, H, spent, full),
+            "Msplats_per_s": round(P / full / 1e6, 6)}

@@ -214,3 +214,60 @@ def test_gather_bands_world2():
         assert ok_full and ok_grad
         assert bounds[0][0] == 0 and bounds[-1][1] == 80 and bounds[0][1] == bounds[1][0] and bounds[0][1] % 16 == 0
         assert bounds[0][1] - bounds[0][0] != bounds[1][1] - bounds[1][0]          # unequal bands: exercises the padding
+
+
+def _halo_worker(rank, world, port, q):
+    import sys
+    here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(here, "2d-gaussian-splatting_amd"))
+    import surfel_dist as sd
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        H, W, C = 200, 24, 10
+        full = torch.arange(C * H * W, dtype=torch.float32).reshape(C, H, W)
+        bounds = sd.band_bounds(H, world, [1.0, 1.0, 3.0, 3.0, 1.0, 1.0, 1.0, 1.0, 2.0, 2.0, 1.0, 1.0, 1.0], multiple=sd.HALO)
+        y0, y1 = bounds[rank]
+        band = full[:, y0:y1].clone().requires_grad_(True)
+        ext = sd.exchange_halo(band, bounds, H)
+        top, bot = sd.halo_rows(bounds, rank, H)
+        ok = torch.equal(ext.detach(), full[:, y0 - top:y1 + bot])                 # band + the neighbours' rows, in place
+        g = torch.randn(ext.shape, generator=torch.Generator().manual_seed(rank))
+        ext.backward(g)
+        ok &= torch.equal(band.grad, g[:, top:top + y1 - y0])                      # halo gradients are dropped, own rows pass through
+        ok &= sd.halo_bytes(bounds, rank, H, W, C) == 4 * C * W * (top + bot)
+        q.put((rank, bool(ok), bounds))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_halo_exchange(world):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_halo_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, ok, bounds in res:
+        assert ok
+        assert all(y0 % 32 == 0 for y0, _ in bounds) and bounds[0][0] == 0 and bounds[-1][1] == 200
+        assert all(bounds[i][1] == bounds[i + 1][0] for i in range(world - 1)) and all(y1 - y0 >= 32 for y0, y1 in bounds)
+
+
+def test_wire_bytes_accounting():
+    import sys
+    here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(here, "2d-gaussian-splatting_amd"))
+    import surfel_dist as sd
+    P = 1_000_000
+    v = sd.wire_bytes_per_step(P, 8, "views", True)
+    assert v["all_gather_colour"] == 7 * 12 * P and v["all_reduce_geometry"] == int(1.75 * 40 * P) and abs(v["per_surfel_B"] - 154.0) < 0.1
+    b = sd.wire_bytes_per_step(P, 8, "bands", False, halo_b=12345)
+    assert b["all_reduce"] == int(1.75 * 52 * P) and b["halo_p2p"] == 12345 and b["radii_max_all_reduce"] == 0
+    assert sd.wire_bytes_per_step(P, 2, "bands", True)["all_reduce_per_surfel_B"] == 64
+    assert sd.wire_bytes_per_step(P, 1, "views", True)["total"] == 0

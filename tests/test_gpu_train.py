@@ -505,7 +505,10 @@ def test_fused_sh_adam_equals_explicit_sh_gradients():
             m.update_learning_rate(it)
         backward(a, cams[0], True); a.optimizer_step()
         b.grad.fill_(float("nan")); backward(b, cams[0], False)
-        assert torch.isnan(b._gv["sh"]).all() and not torch.isnan(b._gv["xyz"]).any()      # the SH block was not touched
+        # the SH block was not written — except its first 3P floats, where the fused mode keeps the colour gradients (one
+        # contiguous 52 B/surfel exchange buffer behind the geometry prefix)
+        assert torch.isnan(b._gv["sh"].reshape(-1)[3 * b.P:]).all() and not torch.isnan(b._gv["xyz"]).any()
+        assert b.gcol.data_ptr() == b._gv["sh"].data_ptr() and not torch.isnan(b.gcol).any()
         b.optimizer_step(colour_grads=(cams[0].camera_center[None], b.gcol[None]))
         assert torch.allclose(a.theta, b.theta, rtol=1e-5, atol=1e-7), float((a.theta - b.theta).abs().max())
         assert torch.allclose(a.m, b.m, rtol=1e-5, atol=1e-9) and torch.allclose(a.act, b.act, rtol=1e-5, atol=1e-7)
@@ -612,3 +615,44 @@ def test_adam_in_two_parts_equals_one_call():
             b.optimizer_step(grad_scale=0.5, colour_grads=(cam.camera_center[None], b.gcol[None]) if fused else None, parts=2)
             assert a.step_count == b.step_count == it
             assert torch.equal(a.theta, b.theta) and torch.equal(a.m, b.m) and torch.equal(a.v, b.v) and torch.equal(a.act, b.act)
+
+
+def test_band_loss_shares_add_up_to_the_full_loss():
+    """surfel_losses.train_loss_band (tile-band sharding): the band shares computed on band + 32-row halo add up to the full-image
+    loss terms, and the band rows of their gradients equal the unsharded gradients (single process: the halo rows are sliced
+    from the full tensors instead of received from a neighbour)."""
+    import torch
+    import surfel_dist as sd
+    import surfel_losses as L
+    from surfel_render import post_consts_rows
+    d = dev()
+    g = torch.Generator().manual_seed(3)
+    H, W = 200, 144
+    img = torch.rand((3, H, W), generator=g).to(d)
+    gtimg = (img + 0.1 * torch.randn((3, H, W), generator=g).to(d)).clamp(0, 1)
+    am = torch.rand((7, H, W), generator=g).to(d)
+    am[1] = am[1] * 0.5 + 0.5; am[0] = am[0] + 2.0 * am[1]; am[5] = 2.0 + torch.rand((H, W), generator=g).to(d)
+    cam = torch.zeros(24, device=d)
+    cam[0:9] = torch.eye(3, device=d).reshape(-1)
+    cam[9:18] = torch.tensor([[1 / 120.0, 0, 0], [0, 1 / 120.0, 0], [-0.6, -0.8, 1.0]], device=d).reshape(-1)
+    lam, ln, ld, ratio = 0.2, 0.05, 100.0, 1.0
+    x = img.clone().requires_grad_(True); a = am.clone().requires_grad_(True)
+    total, sc = L.train_loss(x, a, gtimg, cam, ratio, lam, ln, ld)
+    total.backward()
+    for world in (2, 3):
+        bounds = sd.band_bounds(H, world, multiple=sd.HALO)
+        acc_sums = torch.zeros(4, device=d); share_sum = 0.0
+        gi = torch.zeros_like(img); ga = torch.zeros_like(am)
+        for r, (y0, y1) in enumerate(bounds):
+            top, bot = sd.halo_rows(bounds, r, H)
+            xe = img[:, y0 - top:y1 + bot].clone().requires_grad_(True); ae = am[:, y0 - top:y1 + bot].clone().requires_grad_(True)
+            share, sums = L.train_loss_band(xe, ae, gtimg[:, y0 - top:y1 + bot], post_consts_rows(cam, y0 - top), ratio, lam, ln, ld,
+                                            (top, top + y1 - y0), (H, W))
+            share.backward()
+            gi[:, y0:y1] = xe.grad[:, top:top + y1 - y0]; ga[:, y0:y1] = ae.grad[:, top:top + y1 - y0]
+            acc_sums += sums; share_sum += float(share)
+        s6 = L.scalars_from_band_sums(acc_sums, float(3 * H * W), float(H * W), lam, ln, ld)
+        assert torch.allclose(s6, sc, rtol=2e-5, atol=1e-6), (s6, sc)
+        assert abs(share_sum + lam - float(total)) < 1e-5 * max(1.0, abs(float(total)))      # the shares omit the constant lambda_dssim term
+        assert torch.allclose(gi, x.grad, rtol=1e-5, atol=1e-9)
+        assert torch.allclose(ga, a.grad, rtol=1e-4, atol=1e-9)
