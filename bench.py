@@ -213,7 +213,8 @@ def main():
             try:
                 import glob
                 pm = sorted(glob.glob(os.path.join(REPO, "profiles", "r*_%s_pmc.json" % args.workload)))[-1]
-                n_inst = json.load(open(pm)).get(dom + "_kernel", {}).get("SQ_INSTS_VALU")
+                pj = json.load(open(pm))
+                n_inst = sum(v.get("SQ_INSTS_VALU", 0.0) for k, v in pj.items() if k.startswith(dom)) or None   # blend_bwd = rows + quad launch
                 if n_inst:
                     rate = n_inst / (per_kernel[dom] * 1e-3) / 1e9
                     valu = {"wave_insts_per_launch": int(n_inst), "achieved_Ginst_per_s": round(rate, 1), "peak_Ginst_per_s": 1228.9,

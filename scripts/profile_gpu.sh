@@ -14,15 +14,19 @@ ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -o kt -- python $ROOT/bench.py --workload $WL --no-raster-only --no-1080p --no-cpu-baseline > $OUT/bench_kt.log 2>&1
-SHORT="--workload $WL --steps 8 --warmup 2 --no-cpu-baseline --no-1080p --no-train-iter"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -o kt -- python $ROOT/bench.py --workload $WL --quick > $OUT/bench_kt.log 2>&1
+SHORT="--workload $WL --steps 8 --warmup 2 --quick"
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -o p -- python $ROOT/bench.py $SHORT > $OUT/bench_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/write -o p -- python $ROOT/bench.py $SHORT > $OUT/bench_write.log 2>&1
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_INST_ANY SQ_LDS_BANK_CONFLICT \
     --output-format csv -d $OUT/sq -o p -- python $ROOT/bench.py $SHORT > $OUT/bench_sq.log 2>&1
+# lanes enabled per VALU instruction (the hardware's VALUUtilization; EXEC-enabled lanes, not lanes doing useful work: see
+# profiles/r02_blend_bwd_variants.md) + wait breakdown
+rocprofv3 --pmc SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_LDS_IDX_ACTIVE \
+    --output-format csv -d $OUT/sq2 -o p -- python $ROOT/bench.py $SHORT > $OUT/bench_sq2.log 2>&1
 cd $ROOT
 # keep what comes back small: kernel_trace of the PMC passes is not needed
 find $OUT -name '*.db' -delete
-find $OUT/fetch $OUT/write $OUT/sq -name '*kernel_trace.csv' -delete
+find $OUT/fetch $OUT/write $OUT/sq $OUT/sq2 -name '*kernel_trace.csv' -delete
 tail -n 1 $OUT/bench_kt.log
 ls -R $OUT | head -40

@@ -22,7 +22,8 @@ import sys
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 STAGE_OF = {"preprocess_fwd_kernel": "preprocess_fwd", "emit_instances_kernel": "emit_instances", "tile_ranges_kernel": "tile_ranges",
-            "blend_fwd_kernel": "blend_fwd", "blend_bwd_kernel": "blend_bwd", "preprocess_bwd_kernel": "preprocess_bwd"}
+            "blend_fwd_kernel": "blend_fwd", "blend_bwd_kernel": "blend_bwd", "blend_bwd_rows_kernel": "blend_bwd", "blend_bwd_quad_kernel": "blend_bwd",
+            "preprocess_bwd_kernel": "preprocess_bwd"}
 
 
 def short(name):
@@ -68,21 +69,25 @@ def main():
             open(os.path.join(dst, "%s_%s_bench_under_rocprof.json" % (tag, wl)), "w").write(lines[-1])
     # 2. PMC
     merged = collections.defaultdict(dict)
-    for sub in ("fetch", "write", "sq"):
+    for sub in ("fetch", "write", "sq", "sq2"):
         for k, cs in pmc_means(os.path.join(src, sub)).items():
             merged[k].update(cs)
     ours = ("rs_", "os_", "scan_", "tile_", "ssim_", "post_", "adam_", "loss_", "densify_", "activate_", "reduce_")
     merged = {k: v for k, v in merged.items() if k in STAGE_OF or k.startswith(ours) or "knn" in k}
     traffic = {}
     for k, cs in merged.items():
+        if "SQ_THREAD_CYCLES_VALU" in cs and cs.get("SQ_ACTIVE_INST_VALU"):
+            cs["VALUUtilization_exec_lanes"] = round(cs["SQ_THREAD_CYCLES_VALU"] / (64.0 * cs["SQ_ACTIVE_INST_VALU"]), 4)
         if "FETCH_SIZE" in cs and "WRITE_SIZE" in cs:
             cs["HBM_bytes_per_launch"] = int(2 * cs["FETCH_SIZE"] * 1024 + cs["WRITE_SIZE"] * 1024)
             if k in STAGE_OF or k.startswith(("ssim_", "post_", "adam_")):
-                traffic[STAGE_OF.get(k, k.replace("_kernel", ""))] = cs["HBM_bytes_per_launch"]
+                st = STAGE_OF.get(k, k.replace("_kernel", ""))
+                traffic[st] = traffic.get(st, 0) + cs["HBM_bytes_per_launch"]      # blend_bwd = rows + quad launch (one of them returns at once)
     json.dump(merged, open(os.path.join(dst, "%s_%s_pmc.json" % (tag, wl)), "w"), indent=1, sort_keys=True)
     tf = os.path.join(dst, "pmc_traffic.json")
     allt = json.load(open(tf)) if os.path.exists(tf) else {}
     allt[wl] = traffic
+    allt["_tag"] = tag
     allt.setdefault("_note", "HBM bytes per launch = (2*FETCH_SIZE + WRITE_SIZE) KiB, separate --pmc passes, gfx950 FETCH_SIZE x2 "
                              "correction (MI355X_MICROARCH.md); produced by scripts/profile_summary.py")
     json.dump(allt, open(tf, "w"), indent=1, sort_keys=True)
