@@ -34,8 +34,28 @@ def optimization_params(**over):
              position_lr_max_steps=30_000, feature_lr=0.0025, opacity_lr=0.05, scaling_lr=0.005, rotation_lr=0.001,
              percent_dense=0.01, lambda_dssim=0.2, lambda_dist=0.0, lambda_normal=0.05, opacity_cull=0.05,
              densification_interval=100, opacity_reset_interval=3000, densify_from_iter=500, densify_until_iter=15_000,
-             densify_grad_threshold=0.0002, dist_from_iter=3000, normal_from_iter=7000)
+             densify_grad_threshold=0.0002, dist_from_iter=3000, normal_from_iter=7000,
+             sh_degree_interval=1000)          # train.py:61-62 hard-codes the 1000
     d.update(over)
+    return SimpleNamespace(**d)
+
+
+def scale_schedule(opt, n, lr="linear"):
+    """View-parallel training sees n views per step.  This returns the schedule with every iteration count divided by n (total
+    iterations, position-lr horizon, densification window / interval, opacity reset, regulariser and SH-degree onsets), so that
+    the run consumes the SAME number of images as the reference's 1-view-per-step schedule and every event happens after the same
+    number of images, and with the learning rates scaled: lr = "linear" (x n, default), "sqrt" (x sqrt n) or "none".
+    PSNR-parity experiment (profiles/r02_psnr_parity.md, N = 2 / 4 / 8): "linear" keeps the train PSNR of the 1-view reference
+    run (+0.05 ... +1.0 dB) in 1/n of the steps; "none" loses 3 - 4 dB at N >= 4; keeping the step count instead (no call to this
+    function, gradients averaged) is never below the reference (+1.9 ... +3.4 dB: it sees n x the images)."""
+    n = max(1, int(n))
+    d = dict(vars(opt))
+    f = {"linear": float(n), "sqrt": float(n) ** 0.5, "none": 1.0}[lr]
+    for k in ("position_lr_init", "position_lr_final", "feature_lr", "opacity_lr", "scaling_lr", "rotation_lr"):
+        d[k] = d[k] * f
+    for k in ("iterations", "position_lr_max_steps", "densification_interval", "opacity_reset_interval", "densify_from_iter",
+              "densify_until_iter", "dist_from_iter", "normal_from_iter", "sh_degree_interval"):
+        d[k] = max(1, int(round(d[k] / n)))
     return SimpleNamespace(**d)
 
 
@@ -143,6 +163,7 @@ class Trainer:
         self.last = {}
         self._epoch, self._epoch_views, self._epoch_campos, self._centers = -1, None, None, None
         self._one = torch.ones((), dtype=torch.float32, device=model.device)
+        self.views_per_step = 1         # single process: > 1 = accumulate that many views per optimiser step (_step_accumulate)
         self.rebalance_every = 8        # bands: iterations between re-balancing the band edges (one small all-gather + D2H)
         self._row_weights = None        # bands: running mean of tile instances per 16-row tile row (host list)
         self.wire = {"total": 0}        # bytes on the wire per GPU of the most recent step, by collective (surfel_dist.wire_bytes_per_step)
@@ -188,10 +209,12 @@ class Trainer:
 
     def step(self):
         """One training iteration (train.py:54-138).  Returns nothing; `self.last` holds device scalars for logging."""
+        if self.world == 1 and self.views_per_step > 1:
+            return self._step_accumulate(self.views_per_step)
         self.iteration += 1
         it, opt, m = self.iteration, self.opt, self.model
         m.update_learning_rate(it)
-        if it % 1000 == 0:
+        if it % getattr(opt, "sh_degree_interval", 1000) == 0:
             m.oneupSHdegree()
         cam = self._next_camera()
         m.bind(sh_grad=not self.fused_sh)      # fused: the SH gradients are rebuilt inside the optimiser kernel from the colour gradients
@@ -242,19 +265,7 @@ class Trainer:
                 self._rebalance_bands(cam)
             if stats_live:
                 m.add_densification_stats(arena2d if bands else means2D.grad, radii=radii)
-                if it > opt.densify_from_iter and it % opt.densification_interval == 0:
-                    if self.world > 1 and not bands:
-                        self._reduce_stats()
-                    size_threshold = 20 if it > opt.opacity_reset_interval else None
-                    gen = None
-                    if self.world > 1:       # identical split samples on every rank
-                        gen = torch.Generator(device=m.device); gen.manual_seed(self.seed * 1_000_003 + it)
-                    m.densify_and_prune(opt.densify_grad_threshold, opt.opacity_cull, self.extent, size_threshold, generator=gen)
-                    rebuilt = True
-                if it % opt.opacity_reset_interval == 0 or (self.white_background and it == opt.densify_from_iter):
-                    m.reset_opacity()
-                    if not rebuilt:      # the reference re-creates only the opacity parameter: its update is skipped this iteration
-                        m._gv["opacity"].zero_()
+                rebuilt = self._schedule_events(it, bands)
             if it < opt.iterations and not rebuilt:     # re-created parameters carry no gradient in the reference: no update
                 if bands:
                     # partial gradients of one view add up (no averaging); the SH block is rebuilt from the summed colour gradients
@@ -277,6 +288,62 @@ class Trainer:
                     if self.fused_sh:
                         campos_all, gcol_all = cam.camera_center[None], m.gcol[None]
                     m.optimizer_step(grad_scale=1.0, colour_grads=(campos_all, gcol_all) if self.fused_sh else None)
+
+    def _schedule_events(self, it, bands=False):
+        """Densification and opacity reset when due (train.py:129-135); returns whether the parameters were re-created."""
+        opt, m = self.opt, self.model
+        rebuilt = False
+        if it > opt.densify_from_iter and it % opt.densification_interval == 0:
+            if self.world > 1 and not bands:
+                self._reduce_stats()
+            size_threshold = 20 if it > opt.opacity_reset_interval else None
+            gen = None
+            if self.world > 1:       # identical split samples on every rank
+                gen = torch.Generator(device=m.device); gen.manual_seed(self.seed * 1_000_003 + it)
+            m.densify_and_prune(opt.densify_grad_threshold, opt.opacity_cull, self.extent, size_threshold, generator=gen)
+            rebuilt = True
+        if it % opt.opacity_reset_interval == 0 or (self.white_background and it == opt.densify_from_iter):
+            m.reset_opacity()
+            if not rebuilt:      # the reference re-creates only the opacity parameter: its update is skipped this iteration
+                m._gv["opacity"].zero_()
+        return rebuilt
+
+    def _step_accumulate(self, n):
+        """One optimiser step on the AVERAGED gradients of n views rendered one after the other on this GPU — the optimisation
+        semantics of n view-parallel ranks (same view schedule: surfel_dist.epoch_schedule; per-view densification statistics;
+        SH gradients rebuilt from the n views' colour gradients) without the processes.  Used by the PSNR-parity experiment."""
+        self.iteration += 1
+        it, opt, m = self.iteration, self.opt, self.model
+        m.update_learning_rate(it)
+        if it % getattr(opt, "sh_degree_interval", 1000) == 0:
+            m.oneupSHdegree()
+        per_epoch = max(1, len(self.cams) // n)
+        epoch, k = divmod(it - 1, per_epoch)
+        if self._epoch != epoch:
+            self._epoch, self._epoch_views = epoch, surfel_dist.epoch_schedule(len(self.cams), n, epoch, self.seed)
+        views = [self.cams[v] for v in self._epoch_views[k]]
+        lam_n = opt.lambda_normal if it > opt.normal_from_iter else 0.0
+        lam_d = opt.lambda_dist if it > opt.dist_from_iter else 0.0
+        reg = lam_n > 0.0 or lam_d > 0.0
+        geo = torch.zeros(GEOM_FLOATS * m.P, device=m.device)
+        gcols = torch.empty((n, m.P, 3), device=m.device)
+        for r, cam in enumerate(views):
+            m.bind(sh_grad=False)
+            image, radii, allmap, means2D = rasterize(cam, m, self.pipe, self.background, zero_means2D=False)
+            loss, scalars = train_loss(image, allmap if reg else None, cam.original_image, cam.post_consts() if reg else None,
+                                       self.pipe.depth_ratio, opt.lambda_dssim, lam_n, lam_d)
+            torch.autograd.backward(loss, grad_tensors=self._one)
+            with torch.no_grad():
+                geo += m.grad[:GEOM_FLOATS * m.P]; gcols[r].copy_(m.gcol)
+                if it < opt.densify_until_iter:
+                    m.add_densification_stats(means2D.grad, radii=radii)
+        self.last = dict(loss=scalars[5], scalars=scalars, points=m.P, radii=radii)
+        with torch.no_grad():
+            rebuilt = self._schedule_events(it) if it < opt.densify_until_iter else False
+            if it < opt.iterations and not rebuilt:
+                m.grad[:GEOM_FLOATS * m.P].copy_(geo)
+                campos = torch.stack([c.camera_center for c in views]).contiguous()
+                m.optimizer_step(grad_scale=1.0 / n, colour_grads=(campos, gcols))
 
     def _timed_wait(self, work):
         """Stream-level wait on an asynchronous collective; with time_exchange the wait is bracketed by events on the compute
