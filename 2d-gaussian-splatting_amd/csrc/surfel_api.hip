@@ -23,7 +23,8 @@ int g_opt_cull = 1;        // surfel_set_option("cull", .)
 int g_opt_tile_sort = 1;   // surfel_set_option("tile_depth_sort", .): 0 never, 1 auto (by last frame's R / tiles), 2 always
 int g_opt_bwd_variant = 2; // surfel_set_option("bwd_variant", .): 0 per-row walk, 1 per-quad walk, 2 auto (bit-identical)
 unsigned long long* g_blend_stats = nullptr;   // surfel_debug_set_blend_stats
-thread_local int64_t g_last_R = -1; thread_local int g_last_W = 0, g_last_H = 0;   // auto heuristic (speed only; results identical)
+thread_local int64_t g_last_R = -1; thread_local int g_last_W = 0, g_last_H = 0;   // auto heuristic (speed only; results identical; a stale
+                                                                                    // value from another device / stream only costs one slower frame)
 thread_local float g_stage_ms[16];
 thread_local int g_stage_n = 0;
 thread_local int g_stage_id[16];
@@ -115,6 +116,7 @@ struct ImgState {    // per-pixel / per-tile state ("imgBuffer")
 //                     so a timed region is not perturbed by host synchronisation.
 struct PendingStage { int stage; hipEvent_t e0, e1; };
 std::vector<PendingStage> g_pending;   // process-wide: autograd runs backward on its own thread
+constexpr size_t kMaxPending = 8192;   // debug >= 2 without surfel_collect_stage_ms(): bounded (oldest timings are dropped)
 std::mutex g_pending_mu;
 
 struct StageTimer {
@@ -134,7 +136,15 @@ struct StageTimer {
         if (!armed) return 0;
         armed = false;
         (void)hipEventRecord(e1, s);
-        if (mode >= 2) { std::lock_guard<std::mutex> lk(g_pending_mu); g_pending.push_back({stage, e0, e1}); return 0; }
+        if (mode >= 2) {
+            std::lock_guard<std::mutex> lk(g_pending_mu);
+            if (g_pending.size() >= kMaxPending) {       // nobody collects: drop the oldest pair instead of growing without bound
+                (void)hipEventDestroy(g_pending.front().e0); (void)hipEventDestroy(g_pending.front().e1);
+                g_pending.erase(g_pending.begin());
+            }
+            g_pending.push_back({stage, e0, e1});
+            return 0;
+        }
         hipError_t e = hipEventSynchronize(e1);
         if (e != hipSuccess) return (int)e;
         e = hipGetLastError();
@@ -150,16 +160,31 @@ struct StageTimer {
         if (_e) return fail(SURFEL_E_HIP, kStageNames[st], (hipError_t)_e);                \
     } while (0)
 
+// One event + one pinned read-back buffer per (host thread, device): a thread that rasterizes on a second GPU gets its own pair
+// instead of recording an event created on another device.
+constexpr int kMaxDevices = 32;
+struct PerDevice { hipEvent_t ev = nullptr; uint32_t* pinned = nullptr; };
+PerDevice* per_device() {
+    thread_local PerDevice tab[kMaxDevices];
+    int d = 0;
+    if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= kMaxDevices) return nullptr;
+    return &tab[d];
+}
+
 hipEvent_t r_event() {
-    thread_local hipEvent_t e = nullptr;
-    if (!e) { if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) e = nullptr; }
-    return e;
+    PerDevice* pd = per_device();
+    if (!pd) return nullptr;
+    if (!pd->ev) { if (hipEventCreateWithFlags(&pd->ev, hipEventDisableTiming) != hipSuccess) pd->ev = nullptr; }
+    return pd->ev;
 }
 
 uint32_t* pinned_u32() {
-    thread_local uint32_t* p = nullptr;
-    if (!p) { if (hipHostMalloc(reinterpret_cast<void**>(&p), sizeof(uint32_t) * R_SLOTS, hipHostMallocDefault) != hipSuccess) p = nullptr; }
-    return p;
+    PerDevice* pd = per_device();
+    if (!pd) return nullptr;
+    if (!pd->pinned) {
+        if (hipHostMalloc(reinterpret_cast<void**>(&pd->pinned), sizeof(uint32_t) * R_SLOTS, hipHostMallocDefault) != hipSuccess) pd->pinned = nullptr;
+    }
+    return pd->pinned;
 }
 
 int higher_msb(uint32_t n) {   // number of bits needed to represent values < n

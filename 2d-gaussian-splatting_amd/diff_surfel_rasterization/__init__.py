@@ -37,7 +37,9 @@ def set_grad_arena(arena):
     surfel_sh_grad_gather exchanges), means2D [P,3] (the densification statistic) — that the backward writes its gradients into and returns, instead of fresh tensors.
     surfel_dist.GradBucket.arena() hands out views of ONE flat buffer, so the gradient all-reduce needs no packing pass.
     The kernels write every element, so the tensors need no zeroing.  An explicit `sh=None` entry makes the backward skip the
-    SH-coefficient gradients altogether (their autograd gradient is then None).  None restores the default."""
+    SH-coefficient gradients altogether (their autograd gradient is then None).  An optional `_owner` tensor scopes the arena to
+    one model: it is used only by backwards whose means3D shares that tensor's storage (GaussianModel.bind passes its parameter
+    store), every other caller — and any tensor that does not match in shape — gets fresh gradient tensors.  None restores the default."""
     global _grad_arena
     _grad_arena = arena
 
@@ -126,13 +128,14 @@ class _RasterizeGaussians(torch.autograd.Function):
         dev = means3D.device
         z = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)   # the kernels write every element
         arena = _grad_arena or {}
+        owner = arena.get("_owner")
+        if owner is not None and owner.untyped_storage().data_ptr() != means3D.untyped_storage().data_ptr():
+            arena = {}      # this backward belongs to another model / caller than the one that bound the arena: plain fresh tensors
 
         def out(name, *shape):
             t = arena.get(name)
-            if t is None:
-                return z(*shape)
-            if tuple(t.shape) != shape or t.dtype != torch.float32 or t.device != dev or not t.is_contiguous():
-                raise RuntimeError("grad arena tensor %r does not match %s fp32 contiguous on %s" % (name, shape, dev))
+            if t is None or tuple(t.shape) != shape or t.dtype != torch.float32 or t.device != dev or not t.is_contiguous():
+                return z(*shape)          # no (matching) arena tensor: the default behaviour
             return t
         g_means2D, g_normal, g_colors = out("means2D", P, 3), z(P, 3), out("colors", P, 3)
         g_opac = out("opacities", P, 1)

@@ -77,12 +77,54 @@ def l1_loss(network_output, gt):
     return _means(network_output, gt)[0]
 
 
+class _SSIMPerImage(torch.autograd.Function):
+    """size_average=False (utils/loss_utils.py:70-73): one mean SSIM per batch element of a [B,C,H,W] input."""
+
+    @staticmethod
+    def forward(ctx, img, gt):
+        B, C, H, W = (int(v) for v in img.shape)
+        x = img.detach().contiguous().float(); y = gt.detach().contiguous().float()
+        dev = x.device
+        lib = _n.load()
+        nblk = ((W + 31) // 32) * ((H + 31) // 32)
+        dmaps = torch.empty((3, B * C, H, W), dtype=torch.float32, device=dev)
+        partials = torch.empty((B * C * nblk, 2), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            _check(lib.surfel_l1_ssim_forward(B * C, H, W, _n.ptr(x), _n.ptr(y), _n.ptr(dmaps), _n.ptr(partials), _n.current_stream_ptr(dev)),
+                   "surfel_l1_ssim_forward")
+        ctx.dims = (B, C, H, W)
+        ctx.save_for_backward(x, y, dmaps)
+        return partials.view(B, C * nblk, 2)[:, :, 1].sum(1) / float(C * H * W)
+
+    @staticmethod
+    def backward(ctx, g):
+        B, C, H, W = ctx.dims
+        x, y, dmaps = ctx.saved_tensors
+        dev = x.device
+        lib = _n.load()
+        g = g.contiguous().float()
+        grad = torch.empty_like(x)
+        s = _n.current_stream_ptr(dev)
+        with torch.cuda.device(dev):
+            for b in range(B):        # one launch per batch element: its own upstream scalar
+                dm = dmaps[:, b * C:(b + 1) * C].contiguous()
+                _check(lib.surfel_l1_ssim_backward(C, H, W, _n.ptr(x[b]), _n.ptr(y[b]), _n.ptr(dm), 0.0, 1.0 / float(C * H * W), None, _n.ptr(g[b:b + 1]),
+                                                   _n.ptr(grad[b]), s), "surfel_l1_ssim_backward")
+        return grad, None
+
+
 def ssim(img1, img2, window_size=11, size_average=True):
-    """Mean SSIM with the reference's 11x11 sigma-1.5 window and zero padding (utils/loss_utils.py:43-73)."""
+    """SSIM with the reference's 11x11 sigma-1.5 window and zero padding (utils/loss_utils.py:43-73): the mean over everything
+    (size_average=True, what train.py uses) or one mean per batch element of a [B,C,H,W] input (size_average=False).
+    Other window sizes are not implemented by the HIP kernel (the reference never passes one) and raise."""
     if window_size != 11:
-        raise NotImplementedError("the HIP kernel implements the reference's window_size=11 only")
+        raise NotImplementedError("the HIP kernel implements the reference's window_size=11 only (utils/loss_utils.py:43 default)")
     if not size_average:
-        raise NotImplementedError("size_average=False is not used by the reference's training loop")
+        if img1.dim() != 4:
+            raise ValueError("size_average=False needs a [B,C,H,W] input (the reference reduces dims 1..3)")
+        if img1.shape != img2.shape or img1.device.type != "cuda":
+            raise RuntimeError("surfel_losses.ssim: shapes differ or tensors are not on a HIP device")
+        return _SSIMPerImage.apply(img1, img2)
     return _means(img1, img2)[1]
 
 

@@ -70,6 +70,24 @@ class _ParamGate(torch.autograd.Function):
         return None, None
 
 
+class _ParamSink(torch.autograd.Function):
+    """Marks a store view as a differentiable input of ordinary PyTorch code (the compute_cov3D_python homography of
+    gaussian_renderer/__init__.py:64-75) and ADDS the gradient autograd hands back into the gradient store's section — the
+    counterpart of _ParamGate for gradients that do not come out of the rasterizer's own backward."""
+
+    @staticmethod
+    def forward(ctx, anchor, t, dst):
+        ctx.dst = dst
+        ctx.set_materialize_grads(False)
+        return t.view_as(t)
+
+    @staticmethod
+    def backward(ctx, g):
+        if g is not None:
+            ctx.dst.add_(g.reshape(ctx.dst.shape))
+        return None, None, None
+
+
 def _views(buf, P):
     out, off = {}, 0
     for name, n in SECTIONS:
@@ -109,8 +127,11 @@ class GaussianModel:
     def __init__(self, sh_degree: int, device="cuda"):
         self.active_sh_degree = 0
         self.max_sh_degree = sh_degree
-        if (sh_degree + 1) ** 2 != 16:
-            raise NotImplementedError("the store holds 16 SH coefficients per surfel (sh_degree 3, the reference's default)")
+        if not 0 <= sh_degree <= 3:
+            raise ValueError("sh_degree must be 0..3 (/root/reference/arguments/__init__.py:49)")
+        # the store always holds 16 coefficients per surfel; with --sh_degree d < 3 only the first (d+1)^2 are ever active: the rest
+        # stay zero (zero gradient -> zero Adam update) and are neither written to nor read from .ply / checkpoints
+        self.n_coef = (sh_degree + 1) ** 2
         self.device = torch.device(device)
         self.P = 0
         self.theta = self.act = self.grad = self.m = self.v = None
@@ -156,7 +177,12 @@ class GaussianModel:
         pv = self._pv
         pv["xyz"].copy_(xyz.reshape(P, 3))
         sh = pv["sh"].view(P, 16, 3)
-        sh[:, :1].copy_(f_dc.reshape(P, 1, 3)); sh[:, 1:].copy_(f_rest.reshape(P, 15, 3))
+        sh.zero_()
+        sh[:, :1].copy_(f_dc.reshape(P, 1, 3))
+        n_rest = f_rest.numel() // (3 * P) if P else 0
+        if n_rest not in (self.n_coef - 1, 15):
+            raise ValueError("f_rest holds %d coefficients per surfel, expected %d (sh_degree %d)" % (n_rest, self.n_coef - 1, self.max_sh_degree))
+        sh[:, 1:1 + n_rest].copy_(f_rest.reshape(P, n_rest, 3))
         pv["opacity"].copy_(opacity.reshape(P, 1)); pv["scaling"].copy_(scaling.reshape(P, 2)); pv["rotation"].copy_(rotation.reshape(P, 4))
         self.refresh_activations()
 
@@ -175,7 +201,7 @@ class GaussianModel:
     @property
     def _features_dc(self): return self._pv["sh"].view(self.P, 16, 3)[:, :1]
     @property
-    def _features_rest(self): return self._pv["sh"].view(self.P, 16, 3)[:, 1:]
+    def _features_rest(self): return self._pv["sh"].view(self.P, 16, 3)[:, 1:self.n_coef]
     @property
     def _opacity(self): return self._pv["opacity"]
     @property
@@ -201,15 +227,24 @@ class GaussianModel:
     def get_rotation(self): return self._gate(self._av["rotation"])
 
     def get_covariance(self, scaling_modifier=1):
-        """splat2world [P,4,4] as the reference builds it (scene/gaussian_model.py:27-33), for compute_cov3D_python."""
+        """splat2world [P,4,4] as the reference builds it (scene/gaussian_model.py:27-33), for compute_cov3D_python.
+        While training (gradient store bound) the matrix is built from differentiable views: autograd carries the rasterizer's
+        dL/dcov3D_precomp back through this PyTorch code and _ParamSink adds it into the store's xyz / scaling / rotation
+        sections (w.r.t. the activated scaling / rotation, as the optimiser kernel expects) — the reference trains this path
+        through autograd as well."""
         P = self.P
-        s = torch.cat([self._av["scaling"] * scaling_modifier, torch.ones_like(self._av["scaling"])], dim=-1)[:, :3]
-        RS = (quat_to_rotmat(self._pv["rotation"]) * s[:, None, :]).permute(0, 2, 1)
-        trans = torch.zeros((P, 4, 4), dtype=torch.float32, device=self.device)
-        trans[:, :3, :3] = RS
-        trans[:, 3, :3] = self._pv["xyz"]
-        trans[:, 3, 3] = 1
-        return trans
+        scaling, rotation, xyz = self._av["scaling"], self._av["rotation"], self._pv["xyz"]
+        if torch.is_grad_enabled() and self.grad is not None:
+            gv = self._gv
+            gv["scaling"].zero_(); gv["rotation"].zero_()        # the rasterizer's backward does not write them on this path
+            scaling = _ParamSink.apply(self._anchor, scaling, gv["scaling"])
+            rotation = _ParamSink.apply(self._anchor, rotation, gv["rotation"])
+            xyz = _ParamSink.apply(self._anchor, xyz, gv["xyz"])  # added AFTER the rasterizer's backward has written its own share
+        s = torch.cat([scaling * scaling_modifier, torch.ones_like(scaling)], dim=-1)[:, :3]
+        RS = (quat_to_rotmat(rotation) * s[:, None, :]).permute(0, 2, 1)
+        top = torch.cat([RS, torch.zeros((P, 3, 1), dtype=torch.float32, device=self.device)], dim=2)
+        bottom = torch.cat([xyz, torch.ones((P, 1), dtype=torch.float32, device=self.device)], dim=1)[:, None, :]
+        return torch.cat([top, bottom], dim=1)
 
     def oneupSHdegree(self):
         if self.active_sh_degree < self.max_sh_degree:
@@ -229,7 +264,7 @@ class GaussianModel:
         scales = torch.log(torch.sqrt(dist2))[..., None].repeat(1, 2)
         rots = torch.rand((P, 4), device=dev)
         opac = inverse_sigmoid(0.1 * torch.ones((P, 1), dtype=torch.float32, device=dev))
-        self._set(pts, col.reshape(P, 1, 3), torch.zeros((P, 15, 3), device=dev), opac, scales, rots)
+        self._set(pts, col.reshape(P, 1, 3), torch.zeros((P, self.n_coef - 1, 3), device=dev), opac, scales, rots)
         self.max_radii2D = torch.zeros((P,), device=dev)
 
     def set_parameters(self, xyz, f_dc, f_rest, opacity, scaling, rotation):
@@ -263,7 +298,7 @@ class GaussianModel:
         else:
             self.gcol = self._gcol_alias()
         dsr.set_grad_arena(dict(means3D=gv["xyz"], sh=gv["sh"].view(self.P, 16, 3) if sh_grad else None, opacities=gv["opacity"],
-                                scales=gv["scaling"], rotations=gv["rotation"], colors=self.gcol))
+                                scales=gv["scaling"], rotations=gv["rotation"], colors=self.gcol, _owner=self.theta))
 
     def update_learning_rate(self, iteration):
         lr = expon_lr(iteration, **self._lr_args)
@@ -429,7 +464,7 @@ class GaussianModel:
     def _group_tensors(self, buf):
         v = _views(buf, self.P)
         sh = v["sh"].view(self.P, 16, 3)
-        return [v["xyz"], sh[:, :1], sh[:, 1:], v["opacity"], v["scaling"], v["rotation"]]
+        return [v["xyz"], sh[:, :1], sh[:, 1:self.n_coef], v["opacity"], v["scaling"], v["rotation"]]
 
     def capture(self):
         """The reference's checkpoint tuple; the optimiser entry has torch.optim.Adam's state_dict layout."""
@@ -460,7 +495,7 @@ class GaussianModel:
 
     # ------------------------------------------------------------------ point_cloud.ply (scene/gaussian_model.py:176-255)
     def construct_list_of_attributes(self):
-        names = ["x", "y", "z", "nx", "ny", "nz"] + ["f_dc_%d" % i for i in range(3)] + ["f_rest_%d" % i for i in range(45)]
+        names = ["x", "y", "z", "nx", "ny", "nz"] + ["f_dc_%d" % i for i in range(3)] + ["f_rest_%d" % i for i in range(3 * (self.n_coef - 1))]
         return names + ["opacity", "scale_0", "scale_1"] + ["rot_%d" % i for i in range(4)]
 
     def save_ply(self, path):
@@ -482,9 +517,11 @@ class GaussianModel:
         xyz = np.stack([col("x"), col("y"), col("z")], axis=1)
         f_dc = np.stack([col("f_dc_%d" % i) for i in range(3)], axis=1)[:, None, :]                     # [P,1,3]
         rest_names = sorted((n for n in props if n.startswith("f_rest_")), key=lambda s: int(s.split("_")[-1]))
-        if len(rest_names) != 45:
-            raise ValueError("%s holds %d f_rest properties, expected 45 (sh_degree 3)" % (path, len(rest_names)))
-        f_rest = np.stack([col(n) for n in rest_names], axis=1).reshape(-1, 3, 15).transpose(0, 2, 1)   # channel-major -> [P,15,3]
+        n_rest = self.n_coef - 1
+        if len(rest_names) != 3 * n_rest:        # scene/gaussian_model.py:231: assert len(extra_f_names) == 3*(max_sh_degree + 1)**2 - 3
+            raise ValueError("%s holds %d f_rest properties, expected %d (sh_degree %d)" % (path, len(rest_names), 3 * n_rest, self.max_sh_degree))
+        f_rest = (np.stack([col(n) for n in rest_names], axis=1).reshape(-1, 3, n_rest).transpose(0, 2, 1) if n_rest
+                  else np.zeros((xyz.shape[0], 0, 3), np.float32))                                       # channel-major -> [P,n_rest,3]
         scale_names = sorted((n for n in props if n.startswith("scale_")), key=lambda s: int(s.split("_")[-1]))
         rot_names = sorted((n for n in props if n.startswith("rot")), key=lambda s: int(s.split("_")[-1]))
         scales = np.stack([col(n) for n in scale_names], axis=1)

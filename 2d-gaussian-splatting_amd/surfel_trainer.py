@@ -138,7 +138,7 @@ def capture_views(gt_model, cams, background, pipe=None):
 
 # ------------------------------------------------------------------------------------------------ the loop
 class Trainer:
-    def __init__(self, model, cams, opt=None, pipe=None, white_background=False, extent=None, seed=0, sharding="views"):
+    def __init__(self, model, cams, opt=None, pipe=None, white_background=False, extent=None, seed=0, sharding="views", first_iter=0):
         """sharding (N > 1): "views" = every rank trains on its own view per step (default, BASELINE config 4); "bands" = all ranks
         render row bands of the SAME view (tile-band sharding, BASELINE config 5): every rank evaluates the loss on ITS band plus a
         32-row halo received from its two neighbours (surfel_losses.train_loss_band), back-propagates its own rows, and the
@@ -159,7 +159,7 @@ class Trainer:
         self.seed = seed
         self._rng = random.Random(seed)
         self._stack = []
-        self.iteration = 0
+        self.iteration = int(first_iter)      # resume: the checkpoint's iteration (train.py:37-39), so that the lr / SH / densify schedules continue
         self.last = {}
         self._epoch, self._epoch_views, self._epoch_campos, self._centers = -1, None, None, None
         self._one = torch.ones((), dtype=torch.float32, device=model.device)
@@ -177,6 +177,23 @@ class Trainer:
         self.fused_sh = self.world > 1 or os.environ.get("SURFEL_SH_FUSED", "1") != "0"
         if model.grad is None:
             model.training_setup(self.opt)
+        if self.world > 1:
+            self._sync_replicas()
+
+    def _sync_replicas(self):
+        """N > 1: every rank must start from the same model.  Surfel count and optimiser step are checked (a mismatch would make
+        the fixed-size collectives hang or corrupt memory), then parameters, Adam moments and densification statistics are
+        broadcast from rank 0 (create_from_pcd draws its rotations from the global RNG, so differently seeded ranks differ)."""
+        m = self.model
+        chk = torch.tensor([m.P, m.step_count, self.iteration], dtype=torch.int64, device=m.device)
+        lo, hi = chk.clone(), chk.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN); dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        if not torch.equal(lo, hi):
+            raise RuntimeError("view-parallel ranks disagree on (surfels, optimiser step, iteration): min %s max %s" % (lo.tolist(), hi.tolist()))
+        for t in (m.theta, m.m, m.v, m.xyz_gradient_accum, m.denom, m.max_radii2D):
+            if t is not None and t.numel():
+                dist.broadcast(t, src=0)
+        m.refresh_activations()
 
     def _step_views(self):
         """(camera indices of ALL ranks for the current iteration, their camera centres [world,3] on the device).  Every rank

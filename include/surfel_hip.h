@@ -147,8 +147,9 @@ int surfel_debug_sort_pairs(surfel_alloc_fn scratch_alloc, void* scratch_user, u
  *          list, row totals gathered through private LDS slots; 1: every wave (8x8 pixels) walks one list (round 1's kernel).
  *          Same per-pair arithmetic and the same summation tree: gradients are bit-identical
  *          (tests/test_gpu_parity.py::test_backward_variants_are_identical).
- * Threading: the library keeps one pinned read-back buffer and one event per host thread, created on the device that is current
- * at first use — one process (or at least one host thread) per GPU, the layout torch.distributed.run gives. */
+ * Threading: the library keeps one pinned read-back buffer and one event per (host thread, device); calls are not re-entrant
+ * per thread, and the intended layout is one process per GPU (torch.distributed.run).  Stage-timing events recorded with
+ * debug >= 2 are kept until surfel_collect_stage_ms() (at most 8192 pairs; older ones are dropped). */
 int surfel_set_option(const char* name, int value);
 
 /* Debug: a device buffer of 8 uint64 (caller-zeroed) that every following blend-backward launch accumulates into

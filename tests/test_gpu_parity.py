@@ -174,19 +174,14 @@ def test_config_sizes(name):
         assert cs >= 0.999 or cs >= cs32 - 1e-3, "%s cosine hip %.7f, cpu-fp32 %.7f" % (k, cs, cs32)
         print("%s %s: frac hip %.5f cpu-fp32 %.5f | cosine hip %.7f cpu-fp32 %.7f" % (name, k, f, f32, cs, cs32))
     if name in ("C3", "C4"):
-        lib = n.load()
         base = (run.R, c, o, run.radii.cpu().numpy(), g)
-        try:
-            for mode in (0, 2):      # depth-presorted emission | per-tile depth sort
-                assert lib.surfel_set_option(b"tile_depth_sort", mode) == 0
-                r2 = HipRun(a).forward()
-                g2 = r2.backward(gC, gO)
-                assert r2.R == base[0] and np.array_equal(r2.radii.cpu().numpy(), base[3])
-                assert np.array_equal(r2.color.cpu().numpy(), base[1]) and np.array_equal(r2.others.cpu().numpy(), base[2]), mode
-                for k in g2:
-                    assert np.array_equal(g2[k], base[4][k]), "%s: dL/d%s differs on binning path %d" % (name, k, mode)
-        finally:
-            lib.surfel_set_option(b"tile_depth_sort", 1)
+        for mode in (0, 2):      # depth-presorted emission | per-tile depth sort
+            r2 = HipRun(a, debug=n.opt_tile_sort(mode)).forward()
+            g2 = r2.backward(gC, gO)
+            assert r2.R == base[0] and np.array_equal(r2.radii.cpu().numpy(), base[3])
+            assert np.array_equal(r2.color.cpu().numpy(), base[1]) and np.array_equal(r2.others.cpu().numpy(), base[2]), mode
+            for k in g2:
+                assert np.array_equal(g2[k], base[4][k]), "%s: dL/d%s differs on binning path %d" % (name, k, mode)
 
 
 def test_config_c5_stress():
@@ -293,14 +288,10 @@ def test_culling_is_exact(kind):
         rng = np.random.default_rng(seed)
         gC = rng.normal(size=(3, a["H"], a["W"])).astype(np.float32); gO = rng.normal(size=(7, a["H"], a["W"])).astype(np.float32)
         res = []
-        try:
-            for cull in (1, 0):
-                assert lib.surfel_set_option(b"cull", cull) == 0
-                run = HipRun(a).forward()
-                g = run.backward(gC, gO)
-                res.append((run.R, run.color.cpu().numpy(), run.others.cpu().numpy(), run.radii.cpu().numpy(), g))
-        finally:
-            lib.surfel_set_option(b"cull", 1)
+        for cull in (1, 0):          # per-call option bit of the debug word: no process-wide switch is touched
+            run = HipRun(a, debug=0 if cull else n.OPT_NO_CULL).forward()
+            g = run.backward(gC, gO)
+            res.append((run.R, run.color.cpu().numpy(), run.others.cpu().numpy(), run.radii.cpu().numpy(), g))
         (R1, c1, o1, r1, g1), (R0, c0, o0, r0, g0) = res
         assert R1 <= R0 and np.array_equal(r1, r0)
         assert np.array_equal(c1, c0), "%s/%d: colour differs with culling" % (kind, seed)
@@ -336,14 +327,10 @@ def test_binning_paths_are_identical(kind):
     rng = np.random.default_rng(3)
     gC = rng.normal(size=(3, a["H"], a["W"])).astype(np.float32); gO = rng.normal(size=(7, a["H"], a["W"])).astype(np.float32)
     res = []
-    try:
-        for mode in (0, 2, 1, 1):          # presorted | per-tile depth sort | auto (twice: first-frame and steady-state decisions)
-            assert lib.surfel_set_option(b"tile_depth_sort", mode) == 0
-            run = HipRun(a).forward()
-            g = run.backward(gC, gO)
-            res.append((run.R, run.color.cpu().numpy(), run.others.cpu().numpy(), run.radii.cpu().numpy(), g))
-    finally:
-        lib.surfel_set_option(b"tile_depth_sort", 1)
+    for mode in (0, 2, 1, 1):          # presorted | per-tile depth sort | auto (twice: first-frame and steady-state decisions)
+        run = HipRun(a, debug=n.opt_tile_sort(mode)).forward()
+        g = run.backward(gC, gO)
+        res.append((run.R, run.color.cpu().numpy(), run.others.cpu().numpy(), run.radii.cpu().numpy(), g))
     R0, c0, o0, r0, g0 = res[0]
     assert R0 > 0
     if kind == "crowded":

@@ -656,3 +656,101 @@ def test_band_loss_shares_add_up_to_the_full_loss():
         assert abs(share_sum + lam - float(total)) < 1e-5 * max(1.0, abs(float(total)))      # the shares omit the constant lambda_dssim term
         assert torch.allclose(gi, x.grad, rtol=1e-5, atol=1e-9)
         assert torch.allclose(ga, a.grad, rtol=1e-4, atol=1e-9)
+
+
+def test_compute_cov3D_python_trains_like_the_native_path():
+    """pipe.compute_cov3D_python (gaussian_renderer/__init__.py:64-75): the homography built by PyTorch code from the store must
+    deliver the same xyz / scaling / rotation gradients into the gradient store as the kernel's own homography (this
+    path used to freeze scaling and rotation).  Rotation: compared after the optimiser's normalisation Jacobian (tangential part)."""
+    import torch
+    import surfel_render as R
+    import surfel_trainer as TR
+    from surfel_losses import train_loss
+    d = dev()
+    cams = TR.orbit_cameras(2, 112, 96, device=d)
+    bg = torch.zeros(3, device=d)
+    gtm = TR.synthetic_object(3000, d, seed=4, px_scale=0.07)
+    TR.capture_views(gtm, cams, bg)
+    cam = cams[1]
+    out = {}
+    for python_cov in (False, True):
+        m = TR.synthetic_object(3000, d, seed=4, px_scale=0.07)
+        m._pv["xyz"].add_(0.01); m.refresh_activations()
+        m.spatial_lr_scale = 1.0
+        m.training_setup(TR.optimization_params())
+        m.bind(sh_grad=True)
+        m.grad.fill_(float("nan"))
+        pipe = TR.pipeline_params(depth_ratio=1.0, compute_cov3D_python=python_cov)
+        img, radii, allmap, m2 = R.rasterize(cam, m, pipe, bg)
+        loss, _ = train_loss(img, allmap, cam.original_image, cam.post_consts(), 1.0, 0.2, 0.05, 10.0)
+        loss.backward()
+        assert torch.isfinite(m.grad).all()
+        q = m._av["rotation"]
+        grot = m._gv["rotation"] - (m._gv["rotation"] * q).sum(1, keepdim=True) * q
+        out[python_cov] = dict(xyz=m._gv["xyz"].clone(), scaling=m._gv["scaling"].clone(), rotation=grot.clone(), opacity=m._gv["opacity"].clone(),
+                               sh=m._gv["sh"].clone())
+    for k in out[False]:
+        a, b = out[False][k].cpu().numpy(), out[True][k].cpu().numpy()
+        assert np.abs(a).max() > 0
+        assert cosine(a, b) > 0.9999, (k, cosine(a, b))
+
+
+def test_ssim_per_image_matches_torch():
+    """ssim(..., size_average=False) on [B,C,H,W] (utils/loss_utils.py:70-73) against a plain PyTorch fp32 statement of the
+    reference's _ssim (grouped 11x11 Gaussian conv, zero padding), value and gradient."""
+    import torch
+    import torch.nn.functional as F
+    import surfel_losses as L
+    d = dev()
+    g = torch.Generator().manual_seed(1)
+    B, C, H, W = 3, 3, 70, 90
+    a = torch.rand((B, C, H, W), generator=g).to(d).requires_grad_(True)
+    b = (a.detach() + 0.1 * torch.randn((B, C, H, W), generator=g).to(d)).clamp(0, 1)
+    got = L.ssim(a, b, size_average=False)
+    wts = torch.randn(B, generator=g).to(d)
+    (got * wts).sum().backward()
+    ga = a.grad.clone(); a.grad = None
+    k1 = torch.tensor([math.exp(-(x - 5) ** 2 / (2 * 1.5 ** 2)) for x in range(11)], device=d); k1 = k1 / k1.sum()
+    win = (k1[:, None] * k1[None, :]).expand(C, 1, 11, 11).contiguous()
+    conv = lambda t: F.conv2d(t, win, padding=5, groups=C)
+    mu1, mu2 = conv(a), conv(b)
+    s1, s2, s12 = conv(a * a) - mu1 * mu1, conv(b * b) - mu2 * mu2, conv(a * b) - mu1 * mu2
+    C1, C2 = 0.01 ** 2, 0.03 ** 2
+    ref = (((2 * mu1 * mu2 + C1) * (2 * s12 + C2)) / ((mu1 * mu1 + mu2 * mu2 + C1) * (s1 + s2 + C2))).mean(1).mean(1).mean(1)
+    (ref * wts).sum().backward()
+    assert got.shape == (B,) and torch.allclose(got, ref, rtol=1e-4, atol=2e-5)
+    grad_ok(ga.cpu().numpy(), a.grad.cpu().numpy(), frac=0.999, cos=0.9999)
+
+
+def test_sh_degree_below_three(tmp_path):
+    """--sh_degree 0..2 (/root/reference/arguments/__init__.py:49): the store keeps 16 coefficients, the inactive ones stay zero
+    through training, and .ply / checkpoint hold (d+1)^2 - 1 f_rest coefficients like the reference's."""
+    import torch
+    import surfel_model
+    import surfel_trainer as TR
+    d = dev()
+    for deg in (0, 1, 2):
+        nc = (deg + 1) ** 2
+        rng = np.random.default_rng(deg)
+        pcd = type("PCD", (), {})(); pcd.points = rng.normal(size=(1500, 3)).astype(np.float32) * 0.6; pcd.colors = rng.random((1500, 3)).astype(np.float32)
+        m = surfel_model.GaussianModel(deg, device=d)
+        m.create_from_pcd(pcd, spatial_lr_scale=1.0)
+        assert m._features_rest.shape == (1500, nc - 1, 3)
+        gtm = TR.synthetic_object(1500, d, seed=1, px_scale=0.08)
+        cams = TR.capture_views(gtm, TR.orbit_cameras(3, 64, 48, device=d), torch.zeros(3, device=d))
+        tr = TR.Trainer(m, cams, TR.optimization_params(sh_degree_interval=2, densify_from_iter=10 ** 6), TR.pipeline_params())
+        for _ in range(8):
+            tr.step()
+        assert m.active_sh_degree == deg                                   # oneupSHdegree stops at max_sh_degree
+        sh = m._pv["sh"].view(m.P, 16, 3)
+        assert float(sh[:, nc:].abs().max()) == 0.0 if nc < 16 else True   # inactive coefficients never move
+        if deg > 0:
+            assert float(sh[:, 1:nc].abs().max()) > 0.0                    # active ones train
+        path = str(tmp_path / ("pc%d.ply" % deg))
+        m.save_ply(path)
+        m2 = surfel_model.GaussianModel(deg, device=d); m2.load_ply(path)
+        assert torch.equal(m2._pv["sh"], m._pv["sh"]) and torch.equal(m2._xyz, m._xyz)
+        cap = m.capture()
+        assert cap[3].shape == (m.P, nc - 1, 3)
+        m3 = surfel_model.GaussianModel(deg, device=d); m3.restore(cap, TR.optimization_params())
+        assert torch.equal(m3.theta, m.theta) and torch.allclose(m3.m, m.m)

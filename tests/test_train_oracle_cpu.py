@@ -119,5 +119,6 @@ def test_rotation_and_splat2world_match_reference(gt):
     m = M.GaussianModel.__new__(M.GaussianModel)          # no device store: only the pure-torch covariance builder is exercised
     m.P, m.device = 64, torch.device("cpu")
     m._pv = {"xyz": torch.tensor(gt["cov_xyz"]), "rotation": q}
-    m._av = {"scaling": torch.exp(torch.tensor(gt["cov_scaling"]))}
+    m._av = {"scaling": torch.exp(torch.tensor(gt["cov_scaling"])), "rotation": q / q.norm(dim=1, keepdim=True)}      # activated values
+    m.grad = None
     assert np.allclose(m.get_covariance(1.7).numpy(), gt["cov_splat2world"], rtol=1e-5, atol=1e-6)
