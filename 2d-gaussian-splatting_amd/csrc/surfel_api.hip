@@ -240,6 +240,7 @@ int surfel_debug_sort_pairs(surfel_alloc_fn scratch_alloc, void* scratch_user, u
 int surfel_set_option(const char* name, int value) {
     if (name && std::strcmp(name, "cull") == 0) { g_opt_cull = value ? 1 : 0; return 0; }
     if (name && std::strcmp(name, "tile_depth_sort") == 0) { g_opt_tile_sort = value < 0 ? 0 : (value > 2 ? 2 : value); return 0; }
+    if (name && std::strcmp(name, "large_sort") == 0) { set_large_sort_impl(value); return 0; }
     if (name && std::strcmp(name, "bwd_variant") == 0) { g_opt_bwd_variant = value < 0 ? 0 : (value > 2 ? 2 : value); return 0; }
     return fail(SURFEL_E_INVALID, "unknown option");
 }
@@ -372,7 +373,7 @@ int64_t surfel_rasterize_forward(surfel_alloc_fn geom_alloc, void* geom_user, su
         if (R > 0) {
             // (3) stable sort on the tile-id bits only: depth order inside every tile is preserved.  The value buffers
             // are assigned so that the ping-pong ends in bin.point_list.
-            const bool odd = radix_sort_passes((size_t)R, 0, end_bit) & 1;
+            const bool odd = radix_sort_result_buffer((size_t)R, 0, end_bit) == 1;      // result lands in the b buffers
             uint32_t* va = odd ? bin.vals_alt : bin.point_list;
             uint32_t* vb = odd ? bin.point_list : bin.vals_alt;
             tm.begin();

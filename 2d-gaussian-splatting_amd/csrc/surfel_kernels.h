@@ -57,7 +57,9 @@ void launch_preprocess_bwd(const PreprocessBwdArgs& a, hipStream_t s);
 void launch_knn(int P, const float* points, float* out, void* scratch, size_t scratch_bytes, hipStream_t s);
 size_t knn_scratch_bytes(int P);
 size_t radix_sort_scratch_bytes(size_t n);
+void set_large_sort_impl(int v);      // for n > 2^20 — 0: three launches per pass (own), 1: rocprim::radix_sort_pairs, 2: auto (default)
 int radix_sort_passes(size_t n, int begin_bit, int end_bit);
+int radix_sort_result_buffer(size_t n, int begin_bit, int end_bit);
 int radix_sort_pairs_u32(uint32_t* keys_a, uint32_t* vals_a, uint32_t* keys_b, uint32_t* vals_b, size_t n, int begin_bit, int end_bit,
                          void* scratch, hipStream_t s, bool head_zeroed = false);
 size_t radix_sort_head_words(size_t n);       // words at the start of the sort scratch that must be zero (head_zeroed callers)

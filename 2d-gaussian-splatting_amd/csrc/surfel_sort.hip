@@ -21,9 +21,34 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <cstring>
+#include <rocprim/device/device_radix_sort.hpp>
+
 #include "surfel_kernels.h"
 
 namespace surfel {
+
+constexpr size_t RS_ONESWEEP_MAX_ITEMS = (size_t)1 << 20;
+// Large inputs (n > RS_ONESWEEP_MAX: the P-sized depth sort at C4 / C5 and the R-sized tile sort of 1e7 - 1e8 instances) can be
+// handed to rocprim::radix_sort_pairs (the north star names rocPRIM for the global key sort) instead of the three-launch path
+// below: surfel_set_option("large_sort", 1).  Both are stable LSD sorts on [begin_bit, end_bit): results are identical.
+// Measured choice: profiles/r02_large_sort.md.
+int g_large_sort_impl = 2;      // 0 own, 1 rocPRIM, 2 auto
+void set_large_sort_impl(int v) { g_large_sort_impl = v < 0 ? 0 : (v > 2 ? 2 : v); }
+// auto (measured on MI355X, profiles/r02_large_sort.md): rocPRIM for the R-sized tile-id sorts (<= 16 key bits: 2.1 vs 1.2 TB/s per
+// pass at 1.3e8 items, 1.5 vs 1.3 at 8e6) and for 32-bit sorts of >= 4 M items (10 M surfels: 0.66 vs 0.76 ms); the library's
+// own passes for 32-bit sorts below that (2 M surfels: 0.19 vs 0.22 ms).
+static inline bool use_rocprim(size_t n, int begin_bit, int end_bit) {
+    if (n <= RS_ONESWEEP_MAX_ITEMS) return false;
+    if (g_large_sort_impl != 2) return g_large_sort_impl == 1;
+    return (end_bit - begin_bit) <= 16 || n >= ((size_t)4 << 20);
+}
+static size_t rocprim_sort_temp_bytes(size_t n) {
+    size_t bytes = 0;
+    uint32_t* nul = nullptr;
+    (void)rocprim::radix_sort_pairs(nullptr, bytes, nul, nul, nul, nul, n, 0u, 32u, (hipStream_t)0);
+    return bytes;
+}
 
 constexpr int RS_THREADS = 256;
 // items per thread: 8 (2048-item tiles) for large inputs — long same-digit store runs, 1 KB of status per 16 KB of
@@ -32,7 +57,7 @@ constexpr int RS_THREADS = 256;
 // (512-item tiles were measured 2x SLOWER at 0.3-0.6 M items: 4x the tickets, status words and look-back depth.)
 constexpr int RS_IPT = 8;
 constexpr int RS_TILE = RS_THREADS * RS_IPT;
-constexpr size_t RS_ONESWEEP_MAX = (size_t)1 << 20;
+constexpr size_t RS_ONESWEEP_MAX = RS_ONESWEEP_MAX_ITEMS;
 static inline bool rs_onesweep(size_t n) { return n <= RS_ONESWEEP_MAX; }
 constexpr int RS_BITS = 8;
 constexpr int RS_RADIX = 1 << RS_BITS;
@@ -46,10 +71,21 @@ constexpr size_t RS_HEAD_WORDS = RS_MAX_PASSES * RS_RADIX + 64;
 static inline uint32_t rs_nblocks(size_t n) { return (uint32_t)((n + RS_TILE - 1) / RS_TILE); }
 
 size_t radix_sort_scratch_bytes(size_t n) {
-    if (!rs_onesweep(n)) return ((size_t)RS_RADIX * rs_nblocks(n) + RS_RADIX) * sizeof(uint32_t) + 256;   // hist[digit][tile] | total[digit]
+    if (!rs_onesweep(n)) {
+        const size_t own = ((size_t)RS_RADIX * rs_nblocks(n) + RS_RADIX) * sizeof(uint32_t) + 256;   // hist[digit][tile] | total[digit]
+        const size_t rp = rocprim_sort_temp_bytes(n) + 256;
+        return own > rp ? own : rp;
+    }
     return (RS_HEAD_WORDS + (size_t)RS_MAX_PASSES * rs_nblocks(n) * RS_RADIX) * sizeof(uint32_t) + 256;
 }
 int radix_sort_passes(size_t, int begin_bit, int end_bit) { return (end_bit - begin_bit + RS_BITS - 1) / RS_BITS; }
+// which buffer pair radix_sort_pairs_u32 will leave the result in (0: a, 1: b) — callers that need it in a particular buffer
+// assign a / b accordingly BEFORE the call
+int radix_sort_result_buffer(size_t n, int begin_bit, int end_bit) {
+    if (n == 0) return 0;
+    if (use_rocprim(n, begin_bit, end_bit)) return 1;
+    return radix_sort_passes(n, begin_bit, end_bit) & 1;
+}
 size_t radix_sort_head_bytes() { return RS_HEAD_WORDS * sizeof(uint32_t); }
 
 __device__ __forceinline__ uint32_t ld_agent(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -434,6 +470,11 @@ int radix_sort_pairs_u32(uint32_t* keys_a, uint32_t* vals_a, uint32_t* keys_b, u
     const int passes = radix_sort_passes(n, begin_bit, end_bit);
     if (passes > RS_MAX_PASSES) return -1;
     int cur = 0;
+    if (use_rocprim(n, begin_bit, end_bit)) {
+        size_t bytes = rocprim_sort_temp_bytes(n);
+        if (rocprim::radix_sort_pairs(scratch, bytes, keys_a, keys_b, vals_a, vals_b, n, (unsigned)begin_bit, (unsigned)end_bit, s) != hipSuccess) return -1;
+        return 1;
+    }
     if (!rs_onesweep(n)) {
         uint32_t* hist = static_cast<uint32_t*>(scratch);
         uint32_t* total = hist + (size_t)RS_RADIX * nblocks;

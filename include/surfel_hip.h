@@ -143,6 +143,10 @@ int surfel_debug_sort_pairs(surfel_alloc_fn scratch_alloc, void* scratch_user, u
  *          index-order emission (no P-sized depth sort; fastest for small / medium frames), 0: always depth-presort the surfels
  *          (large frames), 1: choose by the previous frame's instances per tile.  Results are bit-identical
  *          (tests/test_gpu_parity.py::test_binning_paths_are_identical).
+ *   "large_sort": sorts of more than 2^20 items (the P-sized depth sort and the R-sized tile sort of large frames) — 0: the library's
+ *          three-launches-per-pass radix sort, 1: rocprim::radix_sort_pairs, 2 (default): rocPRIM for key fields of <= 16 bits and for
+ *          >= 4 M items, the library's passes otherwise (profiles/r02_large_sort.md).  Both stable: identical results
+ *          (tests/test_gpu_parity.py::test_radix_sort_is_stable_and_exact runs both).
  *   "bwd_variant" (default 2 = chosen on the device per frame from tile instances per emitting surfel): blend-backward walk — 0: every DPP row of 16 lanes (a 4x4-pixel sub-tile) walks its own instance
  *          list, row totals gathered through private LDS slots; 1: every wave (8x8 pixels) walks one list (round 1's kernel).
  *          Same per-pair arithmetic and the same summation tree: gradients are bit-identical

@@ -23,6 +23,7 @@ from helpers import HipRun, cosine, frac_close, oracle_forward, scene_args
 pytestmark = pytest.mark.gpu
 
 IMG_ATOL, IMG_RTOL, IMG_FRAC = 1e-4, 1e-4, 0.999
+LARGE_SORT_DEFAULT = 2          # surfel_set_option("large_sort") default of the library (profiles/r02_large_sort.md)
 G_RTOL, G_FRAC, G_COS = 2e-3, 0.999, 0.9999
 
 
@@ -410,7 +411,10 @@ def test_radix_sort_is_stable_and_exact(n, bits):
     dev = torch.device("cuda:0")
     rng = np.random.default_rng(n)
     lo, hi = bits
-    for trial in range(3):
+    impls = (0, 1) if n > (1 << 20) else (0,)          # large inputs: the library's own passes and rocprim::radix_sort_pairs
+    for trial in [(t, i) for i in impls for t in range(3)]:
+        trial, impl = trial
+        assert lib.surfel_set_option(b"large_sort", impl) == 0
         if trial == 0:
             keys = rng.integers(0, 2 ** 32, n, dtype=np.uint64).astype(np.uint32)
         elif trial == 1:   # few distinct keys: long same-digit runs, every tie must keep input order
@@ -425,8 +429,9 @@ def test_radix_sort_is_stable_and_exact(n, bits):
         torch.cuda.synchronize()
         field = (keys >> np.uint32(lo)) & np.uint32((1 << (hi - lo)) - 1 if hi - lo < 32 else 0xffffffff)
         order = np.argsort(field, kind="stable")
-        assert np.array_equal(v.cpu().numpy().view(np.uint32), vals[order]), "trial %d: order differs" % trial
+        assert np.array_equal(v.cpu().numpy().view(np.uint32), vals[order]), "trial %d impl %d: order differs" % (trial, impl)
         assert np.array_equal(k.cpu().numpy().view(np.uint32), keys[order])
+    lib.surfel_set_option(b"large_sort", LARGE_SORT_DEFAULT)
 
 
 def test_grad_arena_is_zero_copy_and_identical():
