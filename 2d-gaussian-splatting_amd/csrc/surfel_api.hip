@@ -425,6 +425,7 @@ int surfel_rasterize_backward(surfel_alloc_fn scratch_alloc, void* scratch_user,
                               float* dL_drots, int debug, void* stream) {
     (void)tan_fovx; (void)tan_fovy; (void)colors_precomp;
     g_stage_n = 0;
+    const int debug_in = debug;
     const int opt_variant = (debug & SURFEL_OPT_BWD_QUAD) ? 1 : ((debug & SURFEL_OPT_BWD_ROWS) ? 0 : g_opt_bwd_variant);   // 2 = auto
     debug &= 0xff;
     hipStream_t s = static_cast<hipStream_t>(stream);
@@ -458,6 +459,8 @@ int surfel_rasterize_backward(surfel_alloc_fn scratch_alloc, void* scratch_user,
 
     PreprocessBwdArgs pb{};
     pb.P = P; pb.D = D; pb.M = M; pb.W = width; pb.H = height; pb.scale_modifier = scale_modifier;
+    // record gather: per thread while a surfel holds a few records, by the wave when it holds many (bit-identical sums)
+    pb.coop = (debug_in & SURFEL_OPT_PBWD_COOP) ? 1 : ((debug_in & SURFEL_OPT_PBWD_THREAD) ? 0 : (R >= (int64_t)6 * P ? 1 : 0));
     pb.means3D = means3D; pb.radii = radii; pb.shs = shs; pb.clamped = geom.clamped; pb.scales = scales; pb.rotations = rotations;
     pb.transMat_precomp = transMat_precomp; pb.viewmatrix = viewmatrix; pb.projmatrix = projmatrix; pb.campos = cam_pos;
     pb.rec = geom.rec; pb.tiles_touched = geom.tiles_touched; pb.grec = grec;

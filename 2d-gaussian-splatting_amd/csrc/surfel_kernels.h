@@ -37,6 +37,7 @@ struct BlendBwdArgs {
 
 struct PreprocessBwdArgs {
     int P, D, M, W, H;
+    int coop;                 // 1: wave-cooperative gather of the instance gradient records (many records per surfel)
     float scale_modifier;
     const float* means3D; const int* radii; const float* shs; const uint8_t* clamped;
     const float* scales; const float* rotations; const float* transMat_precomp;

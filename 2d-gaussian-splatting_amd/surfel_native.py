@@ -28,6 +28,8 @@ EXPORTS = ["surfel_abi_version", "surfel_last_error", "surfel_rasterize_forward"
 OPT_NO_CULL = 1 << 8
 OPT_BWD_QUAD = 1 << 11
 OPT_BWD_ROWS = 1 << 12
+OPT_PBWD_COOP = 1 << 13
+OPT_PBWD_THREAD = 1 << 14
 
 
 def opt_tile_sort(mode):

@@ -130,13 +130,26 @@ def time_trainer(tr, steps, warmup, prime=15):
     torch.cuda.synchronize()
     st = surfel_native.collect_stage_times()
     tr.pipe.debug = 0
+    # both blend_bwd walks on this very state (the library default picks one per frame on the device): data for that choice
+    ab = {}
+    lib = surfel_native.load()
+    for name, v in (("rows", 0), ("quad", 1)):
+        lib.surfel_set_option(b"bwd_variant", v)
+        tr.pipe.debug = 2
+        for _ in range(6):
+            tr.step()
+        torch.cuda.synchronize()
+        t = surfel_native.collect_stage_times()
+        ab[name] = round(t["blend_bwd"][0] / t["blend_bwd"][1], 4)
+    lib.surfel_set_option(b"bwd_variant", 2)
+    tr.pipe.debug = 0
     cam = tr.cams[0]
     tiles = ((int(cam.image_width) + 15) // 16) * ((int(cam.image_height) + 15) // 16)
     R = int(dsr.last_num_rendered)
     return {"ms_per_step": round(dt / steps * 1e3, 4), "iters_per_s": round(steps / dt, 2), "steps": steps, "P": int(tr.model.P),
             "visible": int((tr.last["radii"] > 0).sum().item()), "instances_R": R, "inst_per_tile": round(R / tiles, 1),
             "inst_per_surfel": round(R / max(1, int(tr.model.P)), 2), "loss": round(float(tr.last["loss"]), 5),
-            "kernels_ms": {k: round(v[0] / v[1], 4) for k, v in st.items()}}
+            "kernels_ms": {k: round(v[0] / v[1], 4) for k, v in st.items()}, "blend_bwd_ms_by_walk": ab}
 
 
 def config_leg(dev, workload, steps=20, warmup=5):

@@ -65,6 +65,15 @@ def main():
             run.backward(gC, gO)
         t = n.collect_stage_times()
         row["auto_us"] = round(1e3 * t["blend_bwd"][0] / t["blend_bwd"][1], 1)
+        for nm, flag in (("pbwd_thread_us", n.OPT_PBWD_THREAD), ("pbwd_coop_us", n.OPT_PBWD_COOP)):
+            run.debug = 2 | flag
+            for _ in range(3):
+                run.backward(gC, gO)
+            n.collect_stage_times()
+            for _ in range(8):
+                run.backward(gC, gO)
+            t = n.collect_stage_times()
+            row[nm] = round(1e3 * t["preprocess_bwd"][0] / t["preprocess_bwd"][1], 1)
         row["speedup"] = round(row["quad_us"] / row["rows_us"], 3)
         print(json.dumps(row), flush=True)
         out.append(row)

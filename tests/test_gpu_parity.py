@@ -374,6 +374,32 @@ def test_backward_variants_are_identical(kind):
             kind, k, d.max(), int((d > 0).sum()))
 
 
+@pytest.mark.parametrize("kind", ["plain", "huge", "crowded", "C1"])
+def test_record_gather_variants_are_identical(kind):
+    """preprocess_bwd sums a surfel's instance gradient records either per thread or wave-cooperatively (groups of 5 lanes read
+    one 80-B record; chosen by R / P): both add every value over the records in emission order -> BIT-IDENTICAL gradients."""
+    import surfel_native as n
+    import synthetic
+    if kind == "C1":
+        sc = _scene("C1", seed=4)
+    elif kind == "crowded":
+        sc = synthetic.make_scene(9000, 96, 64, seed=6, px_radius=30.0, z_near=2.0, z_far=8.0)
+        sc["opacities"] = np.full_like(sc["opacities"], 0.02)
+    else:
+        sc = _stress_scene(kind, 41)
+    a = scene_args(sc)
+    rng = np.random.default_rng(2)
+    gC = rng.normal(size=(3, a["H"], a["W"])).astype(np.float32); gO = rng.normal(size=(7, a["H"], a["W"])).astype(np.float32)
+    run = HipRun(a).forward()
+    res = []
+    for flag in (n.OPT_PBWD_THREAD, n.OPT_PBWD_COOP):
+        run.debug = flag
+        res.append(run.backward(gC, gO))
+    for k in res[0]:
+        assert np.isfinite(res[1][k]).all(), k
+        assert np.array_equal(res[0][k], res[1][k]), "%s: dL/d%s differs between the record-gather variants" % (kind, k)
+
+
 def test_blend_stats_counters():
     """surfel_debug_set_blend_stats: the instrumented kernels count lane slots issued and lanes that held a composited pair;
     the per-row walk must waste fewer lanes than the per-quad walk on small footprints and see exactly the same useful pairs."""
