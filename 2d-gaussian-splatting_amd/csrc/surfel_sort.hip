@@ -34,11 +34,12 @@ constexpr size_t RS_ONESWEEP_MAX_ITEMS = (size_t)1 << 20;
 // below: surfel_set_option("large_sort", 1).  Both are stable LSD sorts on [begin_bit, end_bit): results are identical.
 // Measured choice: profiles/r02_large_sort.md.
 int g_large_sort_impl = 2;      // 0 own, 1 rocPRIM, 2 auto
-void set_large_sort_impl(int v) { g_large_sort_impl = v < 0 ? 0 : (v > 2 ? 2 : v); }
+void set_large_sort_impl(int v) { g_large_sort_impl = v < 0 ? 0 : (v > 3 ? 2 : v); }      // 3: rocPRIM for every size (measurement only)
 // auto (measured on MI355X, profiles/r02_large_sort.md): rocPRIM for the R-sized tile-id sorts (<= 16 key bits: 2.1 vs 1.2 TB/s per
 // pass at 1.3e8 items, 1.5 vs 1.3 at 8e6) and for 32-bit sorts of >= 4 M items (10 M surfels: 0.66 vs 0.76 ms); the library's
 // own passes for 32-bit sorts below that (2 M surfels: 0.19 vs 0.22 ms).
 static inline bool use_rocprim(size_t n, int begin_bit, int end_bit) {
+    if (g_large_sort_impl == 3) return true;
     if (n <= RS_ONESWEEP_MAX_ITEMS) return false;
     if (g_large_sort_impl != 2) return g_large_sort_impl == 1;
     return (end_bit - begin_bit) <= 16 || n >= ((size_t)4 << 20);
@@ -76,7 +77,9 @@ size_t radix_sort_scratch_bytes(size_t n) {
         const size_t rp = rocprim_sort_temp_bytes(n) + 256;
         return own > rp ? own : rp;
     }
-    return (RS_HEAD_WORDS + (size_t)RS_MAX_PASSES * rs_nblocks(n) * RS_RADIX) * sizeof(uint32_t) + 256;
+    const size_t own = (RS_HEAD_WORDS + (size_t)RS_MAX_PASSES * rs_nblocks(n) * RS_RADIX) * sizeof(uint32_t) + 256;
+    const size_t rp = g_large_sort_impl == 3 ? rocprim_sort_temp_bytes(n) + 256 : 0;
+    return own > rp ? own : rp;
 }
 int radix_sort_passes(size_t, int begin_bit, int end_bit) { return (end_bit - begin_bit + RS_BITS - 1) / RS_BITS; }
 // which buffer pair radix_sort_pairs_u32 will leave the result in (0: a, 1: b) — callers that need it in a particular buffer

@@ -17,7 +17,7 @@ for name in (sys.argv[1:] or ["C4", "C5"]):
     tiles = ((W + 15) // 16) * ((H + 15) // 16)
     row = {"workload": name, "P": P, "tiles": tiles, "tile_id_bits": max(1, (tiles - 1).bit_length())}
     ref = None
-    for impl, nm in ((0, "own"), (1, "rocprim")):
+    for impl, nm in ((0, "own"), (3, "rocprim")):
         lib.surfel_set_option(b"large_sort", impl)
         for mode in (0, 2):                      # depth-presorted emission (P-sized 32-bit sort + R-sized tile sort) | per-tile depth sort (R-sized tile sort only)
             run = HipRun(a, debug=2 | n.opt_tile_sort(mode))
