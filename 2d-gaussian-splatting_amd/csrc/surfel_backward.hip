@@ -416,6 +416,7 @@ __global__ void __launch_bounds__(BLOCK) blend_bwd_quad_kernel(BlendBwdArgs a) {
     __shared__ float s_acc[4][BB][NVP];              // 20 KB: per-wave partial sums of the current sub-batch
     __shared__ unsigned long long s_mask[4];         // which sub-batch slots each wave wrote
     __shared__ unsigned long long s_qmask[4][4];     // [quad][staging wave] overlap bitmasks of the staged batch
+    __shared__ int s_quadlast[4];                    // per quad (= wave): the largest `last` of its 64 pixels
     __shared__ int s_max;
     if (a.variant == 2 && auto_picks_rows(a)) return;
     const int tile = xcd_tile(blockIdx.x, a.gx * a.gy);
@@ -426,7 +427,13 @@ __global__ void __launch_bounds__(BLOCK) blend_bwd_quad_kernel(BlendBwdArgs a) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const uint2 range = a.ranges[tile];
     Pixel px = load_pixel(a, tx * TILE + lx, ty * TILE + ly);
-    const int maxc = block_max(px.last, &s_max);
+    {   // a quad never visits an instance behind the last contributor of all its pixels (those visits would find no lane to work on)
+        int m = px.last;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) m = max(m, __shfl_xor(m, o));
+        if (lane == 0) s_quadlast[wave] = m;
+    }
+    const int maxc = block_max(px.last, &s_max);              // (its barriers also publish s_quadlast)
 
     // after wave_reduce20 the quad leaders hold the totals: u0 -> value 4*row + {0,2,1,3}[quad], u1 (row 0) -> 16 + ...
     const int row = lane >> 4, quad = (lane >> 2) & 3;
@@ -445,6 +452,9 @@ __global__ void __launch_bounds__(BLOCK) blend_bwd_quad_kernel(BlendBwdArgs a) {
                 s_rec[threadIdx.x * 5 + 0] = v0; s_rec[threadIdx.x * 5 + 1] = v1; s_rec[threadIdx.x * 5 + 2] = v2;
                 s_rec[threadIdx.x * 5 + 3] = v3; s_rec[threadIdx.x * 5 + 4] = v4;
                 ov = quad_overlap(make_foot(v2, v5, v6), tx * TILE, ty * TILE);
+                const int pos = hi - (int)threadIdx.x;
+#pragma unroll
+                for (int qd = 0; qd < 4; qd++) ov &= (pos <= s_quadlast[qd]) ? ~0u : ~(1u << qd);
             }
             const unsigned long long b0 = __ballot(ov & 1u), b1 = __ballot(ov & 2u), b2 = __ballot(ov & 4u), b3 = __ballot(ov & 8u);
             if (lane == 0) { s_qmask[0][wave] = b0; s_qmask[1][wave] = b1; s_qmask[2][wave] = b2; s_qmask[3][wave] = b3; }
