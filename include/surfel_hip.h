@@ -42,7 +42,7 @@ extern "C" {
 #define SURFEL_OPT_TILE_SORT(m)   ((((m) + 1) & 3) << 9)   /* forward: "tile_depth_sort" = m (0, 1, 2) for this call */
 #define SURFEL_OPT_BWD_QUAD       (1 << 11)            /* backward: per-quad walk ("bwd_variant" = 1) for this call */
 #define SURFEL_OPT_BWD_ROWS       (1 << 12)            /* backward: per-row walk ("bwd_variant" = 0) for this call */
-#define SURFEL_OPT_PBWD_COOP      (1 << 13)            /* backward: wave-cooperative gather of the gradient records (default: R >= 6 P) */
+#define SURFEL_OPT_PBWD_COOP      (1 << 13)            /* backward: wave-cooperative gather of the gradient records (default: R >= 6 P and R >= 2^25) */
 #define SURFEL_OPT_PBWD_THREAD    (1 << 14)            /* backward: per-thread gather of the gradient records */
 
 /* Allocator callback: return a device pointer to `bytes` bytes, 256-byte aligned, valid until the
