@@ -22,6 +22,7 @@ thread_local std::string g_err;
 int g_opt_cull = 1;        // surfel_set_option("cull", .)
 int g_opt_tile_sort = 1;   // surfel_set_option("tile_depth_sort", .): 0 never, 1 auto (by last frame's R / tiles), 2 always
 int g_opt_bwd_variant = 2; // surfel_set_option("bwd_variant", .): 0 per-row walk, 1 per-quad walk, 2 auto (bit-identical)
+int g_opt_bwd_tune = 1;    // surfel_set_option("bwd_tune", .): auto = timed probes (1) or the device-side rule alone (0)
 unsigned long long* g_blend_stats = nullptr;   // surfel_debug_set_blend_stats
 thread_local int64_t g_last_R = -1; thread_local int g_last_W = 0, g_last_H = 0;   // auto heuristic (speed only; results identical; a stale
                                                                                     // value from another device / stream only costs one slower frame)
@@ -160,6 +161,74 @@ struct StageTimer {
         if (_e) return fail(SURFEL_E_HIP, kStageNames[st], (hipError_t)_e);                \
     } while (0)
 
+// Online choice of the blend_bwd walk (bwd_variant = 2, the default).  The two walks are bit-identical, so the choice only
+// changes speed, and which one is faster depends on footprint statistics that no cheap formula captured: the same instances per
+// surfel gave rows -8 % on one C4 frame and +10 % on another (profiles/r02_blend_bwd_variants.md).  So it is measured: per
+// (device, width, height, octave of tile instances per surfel), two backward calls out of every kTunePeriod are timed with HIP
+// events on the launch stream — one per walk, never the first two calls of an entry (cold code and caches); the events are polled
+// by later calls, never synchronised — and the walk with the lower time per tile instance (running mean over probes) is launched
+// alone until the next probe.  Until both walks have been timed, and while the stream is being
+// captured into a graph, both kernels are launched and the device-side rule (R <= 4 V) picks.
+struct WalkTuner {
+    int dev = -1, W = 0, H = 0, octave = 0;
+    unsigned calls = 0;
+    int choice = -1;
+    float ns_per_inst[2] = {0.f, 0.f};
+    bool have[2] = {false, false}, pending[2] = {false, false};
+    int64_t pend_R[2] = {0, 0};
+    hipEvent_t e0[2] = {nullptr, nullptr}, e1[2] = {nullptr, nullptr};
+};
+constexpr int kTuners = 8;
+constexpr unsigned kTunePeriod = 32;
+constexpr unsigned kTuneFirst = 2;      // phase of the first probe
+WalkTuner g_tuners[kTuners];
+unsigned g_tuner_next = 0;
+std::mutex g_tuner_mu;
+
+// returns the variant to launch (0 rows, 1 quad, 2 both + device rule); *probe = the walk being timed by this call, or -1
+int walk_octave(int P, int64_t R) {
+    int o = 0;
+    for (int64_t x = R / (P > 0 ? P : 1); x > 1 && o < 15; x >>= 1) o++;
+    return o;
+}
+int walk_tuner_pick(int P, int W, int H, int64_t R, hipStream_t s, WalkTuner** out, int* probe) {
+    *out = nullptr; *probe = -1;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 2;
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) return 2;
+    WalkTuner* t = nullptr;
+    const int octave = walk_octave(P, R);
+    for (auto& c : g_tuners) if (c.dev == dev && c.W == W && c.H == H && c.octave == octave) { t = &c; break; }
+    if (!t) {
+        t = &g_tuners[g_tuner_next++ % kTuners];
+        for (int v = 0; v < 2; v++) {
+            if (t->pending[v]) (void)hipEventSynchronize(t->e1[v]);        // an evicted entry: its events are about to be reused
+            t->pending[v] = false; t->have[v] = false; t->ns_per_inst[v] = 0.f;
+        }
+        t->dev = dev; t->W = W; t->H = H; t->octave = octave; t->calls = 0; t->choice = -1;
+    }
+    for (int v = 0; v < 2; v++) {
+        if (!t->pending[v] || hipEventQuery(t->e1[v]) != hipSuccess) continue;
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, t->e0[v], t->e1[v]) == hipSuccess && t->pend_R[v] > 0) {
+            const float x = 1e6f * ms / (float)t->pend_R[v];
+            t->ns_per_inst[v] = t->have[v] ? 0.5f * (t->ns_per_inst[v] + x) : x;
+            t->have[v] = true;
+        }
+        t->pending[v] = false;
+    }
+    if (t->have[0] && t->have[1]) t->choice = t->ns_per_inst[1] < t->ns_per_inst[0] ? 1 : 0;
+    const unsigned phase = t->calls++ % kTunePeriod;
+    if (phase >= kTuneFirst && phase < kTuneFirst + 2 && !t->pending[phase - kTuneFirst]) {
+        const int v = (int)(phase - kTuneFirst);
+        if (!t->e0[v] && (hipEventCreate(&t->e0[v]) != hipSuccess || hipEventCreate(&t->e1[v]) != hipSuccess)) { t->e0[v] = nullptr; return t->choice >= 0 ? t->choice : 2; }
+        *out = t; *probe = v;
+        return v;
+    }
+    return t->choice >= 0 ? t->choice : 2;
+}
+
 // One event + one pinned read-back buffer per (host thread, device): a thread that rasterizes on a second GPU gets its own pair
 // instead of recording an event created on another device.
 constexpr int kMaxDevices = 32;
@@ -242,9 +311,19 @@ int surfel_set_option(const char* name, int value) {
     if (name && std::strcmp(name, "tile_depth_sort") == 0) { g_opt_tile_sort = value < 0 ? 0 : (value > 2 ? 2 : value); return 0; }
     if (name && std::strcmp(name, "large_sort") == 0) { set_large_sort_impl(value); return 0; }
     if (name && std::strcmp(name, "bwd_variant") == 0) { g_opt_bwd_variant = value < 0 ? 0 : (value > 2 ? 2 : value); return 0; }
+    if (name && std::strcmp(name, "bwd_tune") == 0) { g_opt_bwd_tune = value != 0; return 0; }
     return fail(SURFEL_E_INVALID, "unknown option");
 }
 
+int surfel_debug_walk_choice(int width, int height) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return -1;
+    std::lock_guard<std::mutex> lk(g_tuner_mu);
+    int choice = -1;
+    unsigned best = 0;
+    for (auto& c : g_tuners) if (c.dev == dev && c.W == width && c.H == height && c.calls >= best) { best = c.calls; choice = c.choice; }
+    return choice;
+}
 int surfel_debug_set_blend_stats(void* dev_u64x8) { g_blend_stats = static_cast<unsigned long long*>(dev_u64x8); return 0; }
 
 int surfel_collect_stage_ms(float* sum_ms, int* count, int cap) {
@@ -452,9 +531,21 @@ int surfel_rasterize_backward(surfel_alloc_fn scratch_alloc, void* scratch_user,
     bb.final_T = img.final_T; bb.n_contrib = img.n_contrib; bb.dL_dpix = dL_dout_color; bb.dL_dothers = dL_dout_others;
     bb.grec = grec; bb.variant = opt_variant; bb.stats = g_blend_stats; bb.totals = img.total;
     if (R > 0) {
+        WalkTuner* tuner = nullptr;
+        int probe = -1;
+        std::unique_lock<std::mutex> tl(g_tuner_mu, std::defer_lock);
+        if (opt_variant == 2 && !g_blend_stats && g_opt_bwd_tune) {
+            tl.lock();
+            bb.variant = walk_tuner_pick(P, width, height, R, s, &tuner, &probe);
+            if (probe >= 0) (void)hipEventRecord(tuner->e0[probe], s);
+        }
         tm.begin(ST_BBWD);
         launch_blend_bwd(bb, s);
         STAGE_END(tm, ST_BBWD);
+        if (probe >= 0) {
+            tuner->pending[probe] = hipEventRecord(tuner->e1[probe], s) == hipSuccess;
+            tuner->pend_R[probe] = R;
+        }
     }
 
     PreprocessBwdArgs pb{};

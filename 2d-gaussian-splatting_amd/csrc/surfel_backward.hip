@@ -39,8 +39,15 @@ __device__ __forceinline__ float fold16(float x, float y) {
 constexpr int BS = 128;   // instances staged per outer batch (one 112-B gather per thread of waves 0-1)
 constexpr int BB = 64;    // quad variant: instances per accumulate/flush sub-batch
 constexpr int NVP = 20;   // 18 gradient values per instance, padded to 20 for the reductions
-constexpr int RSLOTS = 256;           // rows variant: (instance, sub-tile) slots per round
-constexpr int NSLOT = RSLOTS + 16;    // the last instance of a round may run 15 slots past the cut
+#ifndef ROWS_RSHIFT
+#define ROWS_RSHIFT 8
+#endif
+#ifndef ROWS_WAVES
+#define ROWS_WAVES 5
+#endif
+constexpr int RSHIFT = ROWS_RSHIFT;
+constexpr int RSLOTS = 1 << RSHIFT;   // rows variant: (instance, sub-tile) slots per round
+constexpr int NSLOT = RSLOTS + 15;    // the last instance of a round may run 15 slots past the cut (271 slots: LDS stays <= 32 KB -> 5 workgroups / CU)
 
 // Sum of 20 per-lane values over each 16-lane row.  Measured issue costs on gfx950 (scripts/ubench/valu_rate.hip, v_fma = 1):
 // v_add_f32_dpp 1.4, v_permlane{16,32}_swap 3.0 — so lanes are folded INSIDE their rows, where DPP adds can merge two
@@ -77,11 +84,55 @@ __device__ __forceinline__ float quad_sum(float t) {
     return out;
 }
 __device__ __forceinline__ void row_reduce20(const float (&v)[NVP], float (&z)[5]) {
-    float a[10];
-#pragma unroll
-    for (int i = 0; i < 10; i++) a[i] = row_fold8(v[2 * i], v[2 * i + 1]);
-#pragma unroll
-    for (int m = 0; m < 5; m++) z[m] = quad_sum(row_fold4(a[2 * m], a[2 * m + 1]));
+    // One block, all in place: value 2i folds value 2i+1 into its upper lanes, then 4m folds 4m+2, then the quads are summed.
+    // Every DPP source was written >= 5 instructions earlier, so only the leading s_nop (2 wait states after whatever VALU
+    // produced v[]) is needed — the per-step s_nops of a fold-at-a-time formulation cost 24 issue slots per visit.
+    float w0 = v[0], w1 = v[1], w2 = v[2], w3 = v[3], w4 = v[4], w5 = v[5], w6 = v[6], w7 = v[7], w8 = v[8], w9 = v[9];
+    float w10 = v[10], w11 = v[11], w12 = v[12], w13 = v[13], w14 = v[14], w15 = v[15], w16 = v[16], w17 = v[17], w18 = v[18], w19 = v[19];
+    asm volatile("s_nop 1\n\t"
+                 "v_add_f32_dpp %[w0], %[w0], %[w0] row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_add_f32_dpp %[w2], %[w2], %[w2] row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_add_f32_dpp %[w4], %[w4], %[w4] row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_add_f32_dpp %[w6], %[w6], %[w6] row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_add_f32_dpp %[w8], %[w8], %[w8] row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_add_f32_dpp %[w10], %[w10], %[w10] row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_add_f32_dpp %[w12], %[w12], %[w12] row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_add_f32_dpp %[w14], %[w14], %[w14] row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_add_f32_dpp %[w16], %[w16], %[w16] row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_add_f32_dpp %[w18], %[w18], %[w18] row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_add_f32_dpp %[w0], %[w1], %[w1] row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+                 "v_add_f32_dpp %[w2], %[w3], %[w3] row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+                 "v_add_f32_dpp %[w4], %[w5], %[w5] row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+                 "v_add_f32_dpp %[w6], %[w7], %[w7] row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+                 "v_add_f32_dpp %[w8], %[w9], %[w9] row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+                 "v_add_f32_dpp %[w10], %[w11], %[w11] row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+                 "v_add_f32_dpp %[w12], %[w13], %[w13] row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+                 "v_add_f32_dpp %[w14], %[w15], %[w15] row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+                 "v_add_f32_dpp %[w16], %[w17], %[w17] row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+                 "v_add_f32_dpp %[w18], %[w19], %[w19] row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+                 "v_add_f32_dpp %[w0], %[w0], %[w0] row_ror:12 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_add_f32_dpp %[w4], %[w4], %[w4] row_ror:12 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_add_f32_dpp %[w8], %[w8], %[w8] row_ror:12 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_add_f32_dpp %[w12], %[w12], %[w12] row_ror:12 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_add_f32_dpp %[w16], %[w16], %[w16] row_ror:12 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_add_f32_dpp %[w0], %[w2], %[w2] row_ror:4 row_mask:0xf bank_mask:0xa\n\t"
+                 "v_add_f32_dpp %[w4], %[w6], %[w6] row_ror:4 row_mask:0xf bank_mask:0xa\n\t"
+                 "v_add_f32_dpp %[w8], %[w10], %[w10] row_ror:4 row_mask:0xf bank_mask:0xa\n\t"
+                 "v_add_f32_dpp %[w12], %[w14], %[w14] row_ror:4 row_mask:0xf bank_mask:0xa\n\t"
+                 "v_add_f32_dpp %[w16], %[w18], %[w18] row_ror:4 row_mask:0xf bank_mask:0xa\n\t"
+                 "v_add_f32_dpp %[w0], %[w0], %[w0] quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+                 "v_add_f32_dpp %[w4], %[w4], %[w4] quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+                 "v_add_f32_dpp %[w8], %[w8], %[w8] quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+                 "v_add_f32_dpp %[w12], %[w12], %[w12] quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+                 "v_add_f32_dpp %[w16], %[w16], %[w16] quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+                 "v_add_f32_dpp %[w0], %[w0], %[w0] quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+                 "v_add_f32_dpp %[w4], %[w4], %[w4] quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+                 "v_add_f32_dpp %[w8], %[w8], %[w8] quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+                 "v_add_f32_dpp %[w12], %[w12], %[w12] quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+                 "v_add_f32_dpp %[w16], %[w16], %[w16] quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf"
+                 : [w0] "+v"(w0), [w2] "+v"(w2), [w4] "+v"(w4), [w6] "+v"(w6), [w8] "+v"(w8), [w10] "+v"(w10), [w12] "+v"(w12), [w14] "+v"(w14), [w16] "+v"(w16), [w18] "+v"(w18)
+                 : [w1] "v"(w1), [w3] "v"(w3), [w5] "v"(w5), [w7] "v"(w7), [w9] "v"(w9), [w11] "v"(w11), [w13] "v"(w13), [w15] "v"(w15), [w17] "v"(w17), [w19] "v"(w19));
+    z[0] = w0; z[1] = w4; z[2] = w8; z[3] = w12; z[4] = w16;
 }
 // Wave-wide: the 5 row totals cross rows through permlane swaps (5 swaps + 5 adds): (r0 + r1) + (r2 + r3).
 // u0 holds in quad q of row r the wave total of value 4r + {0,2,1,3}[q]; u1 holds in quad q of row 0 value 16 + {0,2,1,3}[q].
@@ -251,7 +302,7 @@ __device__ __forceinline__ float4 add4(const float4 a, const float4 b) { return 
 // blend_bwd, rows variant
 // ---------------------------------------------------------------------------------------------
 template <bool STATS>
-__global__ void __launch_bounds__(BLOCK) blend_bwd_rows_kernel(BlendBwdArgs a) {
+__global__ void __launch_bounds__(BLOCK, ROWS_WAVES) blend_bwd_rows_kernel(BlendBwdArgs a) {
     __shared__ float4 s_rec[BS * 5];                          // 10 KB: q0-q4 of the staged instances
     __shared__ float4 s_slot[NSLOT * 5];                      // 21.25 KB: row totals, one 80-B slot per (instance, sub-tile)
     __shared__ uint32_t s_info[BS];                           // overlap bits (row order) | wave-local exclusive slot prefix << 16
@@ -260,6 +311,9 @@ __global__ void __launch_bounds__(BLOCK) blend_bwd_rows_kernel(BlendBwdArgs a) {
     __shared__ int s_rowlast[16];                             // per row: the largest `last` of its 16 pixels
     __shared__ int s_max;
     if (a.variant == 2 && !auto_picks_rows(a)) return;
+#ifdef ROWS_TIMING
+    const long long tm_start = __builtin_readcyclecounter();
+#endif
     const int tile = xcd_tile(blockIdx.x, a.gx * a.gy);
     const int tx = tile % a.gx, ty = tile / a.gx;
     int lx, ly, sub;
@@ -282,8 +336,20 @@ __global__ void __launch_bounds__(BLOCK) blend_bwd_rows_kernel(BlendBwdArgs a) {
     const int pq = ((quad & 1) << 1) | (quad >> 1);
     float* const s_slotf = reinterpret_cast<float*>(s_slot);
 
+    // -DROWS_TIMING (diagnostic build, see DESIGN.md "blend_bwd"): the instrumented kernel accumulates s_memtime ticks per phase
+    // of every wave instead of the lane counters — stats[5] staging (kernel start / batch top -> first round, barrier waits
+    // included), [6] walk, [7] wait at the barrier after the walk, [4] flush, [2] wave visits (scripts/bwd_ab.py: rows_raw).
+#ifdef ROWS_TIMING
+    long long tm_stage = 0, tm_walk = 0, tm_bar = 0, tm_flush = 0, tm_nvis = 0, tm_t = tm_start;
+#define TM(acc) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); const long long t_ = __builtin_readcyclecounter(); acc += t_ - tm_t; tm_t = t_; }
+#else
+#define TM(acc)
+#endif
+    float pf_touch = 0.f;                     // landing register of the prefetch touches (never read)
+    uint32_t pf_id = 0;
     for (int hi = maxc; hi > 0; hi -= BS) {
         const int mb = min(BS, hi);
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(pf_touch) :: "memory");      // the previous touch has landed: pf_touch may be rewritten
         __syncthreads();                      // previous batch fully flushed
         if (wave < BS / 64) {
             unsigned ovr = 0;
@@ -311,39 +377,42 @@ __global__ void __launch_bounds__(BLOCK) blend_bwd_rows_kernel(BlendBwdArgs a) {
                 const unsigned long long b = __ballot((ovr >> s) & 1u);
                 if (lane == 0) s_rmask[s][wave] = b;
             }
+        } else if (hi > BS) {
+            // waves 2-3 have nothing to stage: they fetch the NEXT batch's ids, and after the barrier (while everybody walks)
+            // pull those records towards this XCD's L2 with one dword load each, so that the gathers of the next staging pass
+            // overlap this batch's arithmetic instead of forming one burst with every other workgroup's
+            const int t = (int)threadIdx.x - BS;
+            if (t < min(BS, hi - BS)) pf_id = a.point_list[range.x + (hi - BS - t) - 1];
         }
         __syncthreads();
+        if (wave >= BS / 64 && hi > BS && (int)threadIdx.x - BS < min(BS, hi - BS)) {
+            const float* ptr = a.rec + (size_t)pf_id * REC_F;
+            asm volatile("global_load_dword %0, %1, off" : "+v"(pf_touch) : "v"(ptr) : "memory");
+        }
         const int off1 = (int)s_wtot[0];                      // slots ahead of the second staging wave's instances
         const int tot = off1 + (int)s_wtot[1];
         const int nrounds = max(1, (tot + RSLOTS - 1) / RSLOTS);
         // round of every staged instance (lane -> instances lane and 64 + lane): the one its first slot falls into; an instance
         // without slots belongs to the round of its position (clamped) and only gets its zero record written there
-        const int rnd0 = min((int)(s_info[lane] >> 16) >> 8, nrounds - 1);
-        const int rnd1 = min(((int)(s_info[64 + lane] >> 16) + off1) >> 8, nrounds - 1);
+        const int rnd0 = min((int)(s_info[lane] >> 16) >> RSHIFT, nrounds - 1);
+        const int rnd1 = min(((int)(s_info[64 + lane] >> 16) + off1) >> RSHIFT, nrounds - 1);
         const unsigned long long c0 = s_rmask[srow][0], c1 = s_rmask[srow][1];
+        TM(tm_stage)
         for (int r = 0; r < nrounds; r++) {
             const unsigned long long m0 = __ballot((lane < mb) & (rnd0 == r)), m1 = __ballot((64 + lane < mb) & (rnd1 == r));
-            // ---- walk: every row visits, in list order, its instances of round r; the next visit's record is fetched from LDS
-            // while the current one is being processed
+            // ---- walk: every row visits, in list order, its instances of round r.  (No software prefetch of the next record:
+            // the VALU pipe is the bound and other waves cover the LDS latency — the pipelined form cost 22 VGPRs and 5 %.)
             unsigned long long cur = c0 & m0, nxt = c1 & m1;
             int wbase = 0;
             if (cur == 0ull) { cur = nxt; nxt = 0ull; wbase = 64; }
-            bool act = cur != 0ull;
-            int j = wbase + __builtin_ctzll(cur | (1ull << 63));
-            uint32_t info = s_info[j];
-            float4 q0 = s_rec[j * 5 + 0], q1 = s_rec[j * 5 + 1], q2 = s_rec[j * 5 + 2], q3 = s_rec[j * 5 + 3], q4 = s_rec[j * 5 + 4];
-            while (__any(act)) {
-                const bool actc = act;
-                const int jc = j;
-                const uint32_t infoc = info;
-                const float4 c_q0 = q0, c_q1 = q1, c_q2 = q2, c_q3 = q3, c_q4 = q4;
-                // advance + prefetch
-                if (act) cur &= cur - 1ull;
+            for (;;) {
                 if (cur == 0ull) { cur = nxt; nxt = 0ull; wbase = 64; }
-                act = cur != 0ull;
-                j = wbase + __builtin_ctzll(cur | (1ull << 63));
-                info = s_info[j];
-                q0 = s_rec[j * 5 + 0]; q1 = s_rec[j * 5 + 1]; q2 = s_rec[j * 5 + 2]; q3 = s_rec[j * 5 + 3]; q4 = s_rec[j * 5 + 4];
+                const bool actc = cur != 0ull;
+                if (!__any(actc)) break;
+                const int jc = wbase + __builtin_ctzll(cur | (1ull << 63));
+                if (actc) cur &= cur - 1ull;
+                const uint32_t infoc = s_info[jc];
+                const float4 c_q0 = s_rec[jc * 5 + 0], c_q1 = s_rec[jc * 5 + 1], c_q2 = s_rec[jc * 5 + 2], c_q3 = s_rec[jc * 5 + 3], c_q4 = s_rec[jc * 5 + 4];
                 // current visit
                 Hit h;
                 const int pos = hi - jc;      // 1-based position in the tile's list
@@ -351,6 +420,9 @@ __global__ void __launch_bounds__(BLOCK) blend_bwd_rows_kernel(BlendBwdArgs a) {
                 float gv[NVP], z[5];
                 pair_gradients(px, h, c_q3, c_q4, ok, pos, gv);
                 row_reduce20(gv, z);
+#ifdef ROWS_TIMING
+                tm_nvis++;
+#else
                 if (STATS) {
                     const unsigned long long okb = __ballot(ok), ab = __ballot(actc);
                     if (lane == 0) {
@@ -360,6 +432,7 @@ __global__ void __launch_bounds__(BLOCK) blend_bwd_rows_kernel(BlendBwdArgs a) {
                         atomicAdd(&a.stats[4], (unsigned long long)hitrows);
                     }
                 }
+#endif
                 if (actc) {
                     const int E = (int)(infoc >> 16) + (jc >= 64 ? off1 : 0);
                     const int slot = (E & (RSLOTS - 1)) + __popc(infoc & below);
@@ -369,7 +442,9 @@ __global__ void __launch_bounds__(BLOCK) blend_bwd_rows_kernel(BlendBwdArgs a) {
                     if (t4 == 0) sp[16 + pq] = z[4];
                 }
             }
+            TM(tm_walk)
             __syncthreads();
+            TM(tm_bar)
             // ---- flush round r: its instances are a contiguous run of the staged list.  One thread per (instance, float4 of its
             // record): the instance's slots are added in the fixed order ((r0+r1)+(r2+r3)) per wave, waves 0..3 — the summation
             // tree of the quad variant, so both variants give the same bits.
@@ -402,8 +477,16 @@ __global__ void __launch_bounds__(BLOCK) blend_bwd_rows_kernel(BlendBwdArgs a) {
                 }
             }
             __syncthreads();                  // slots reusable
+            TM(tm_flush)
         }
     }
+#ifdef ROWS_TIMING
+    if (STATS && lane == 0) {
+        atomicAdd(&a.stats[2], (unsigned long long)tm_nvis); atomicAdd(&a.stats[4], (unsigned long long)tm_flush);
+        atomicAdd(&a.stats[5], (unsigned long long)tm_stage); atomicAdd(&a.stats[6], (unsigned long long)tm_walk);
+        atomicAdd(&a.stats[7], (unsigned long long)tm_bar);
+    }
+#endif
     zero_tail(a, range, maxc, tx, ty);
 }
 

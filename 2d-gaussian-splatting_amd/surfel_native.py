@@ -19,7 +19,7 @@ ALLOC_FN = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_size_t)
 
 EXPORTS = ["surfel_abi_version", "surfel_last_error", "surfel_rasterize_forward", "surfel_rasterize_backward",
            "surfel_mark_visible", "surfel_knn_dist2", "surfel_last_stage_ms", "surfel_last_stage_ids", "surfel_stage_name",
-           "surfel_collect_stage_ms", "surfel_set_option", "surfel_debug_sort_pairs", "surfel_debug_set_blend_stats",
+           "surfel_collect_stage_ms", "surfel_set_option", "surfel_debug_sort_pairs", "surfel_debug_set_blend_stats", "surfel_debug_walk_choice",
            # include/surfel_train.h
            "surfel_l1_ssim_forward", "surfel_l1_ssim_backward", "surfel_render_post_forward", "surfel_render_post_backward",
            "surfel_reduce_partials", "surfel_loss_finalize", "surfel_activate", "surfel_adam_step", "surfel_sh_grad_gather", "surfel_densify_stats"]
@@ -77,6 +77,8 @@ def load():
         lib.surfel_debug_sort_pairs.argtypes = [ALLOC_FN, vp, vp, vp, i64, i, i, vp]
         lib.surfel_debug_set_blend_stats.restype = i
         lib.surfel_debug_set_blend_stats.argtypes = [vp]
+        lib.surfel_debug_walk_choice.restype = i
+        lib.surfel_debug_walk_choice.argtypes = [i, i]
         lib.surfel_set_option.restype = i
         lib.surfel_set_option.argtypes = [C.c_char_p, i]
         # ---- include/surfel_train.h

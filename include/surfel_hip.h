@@ -149,10 +149,15 @@ int surfel_debug_sort_pairs(surfel_alloc_fn scratch_alloc, void* scratch_user, u
  *          three-launches-per-pass radix sort, 1: rocprim::radix_sort_pairs, 2 (default): rocPRIM for key fields of <= 16 bits and for
  *          >= 4 M items, the library's passes otherwise (profiles/r02_large_sort.md).  Both stable: identical results
  *          (tests/test_gpu_parity.py::test_radix_sort_is_stable_and_exact runs both).
- *   "bwd_variant" (default 2 = chosen on the device per frame from tile instances per emitting surfel): blend-backward walk — 0: every DPP row of 16 lanes (a 4x4-pixel sub-tile) walks its own instance
- *          list, row totals gathered through private LDS slots; 1: every wave (8x8 pixels) walks one list (round 1's kernel).
- *          Same per-pair arithmetic and the same summation tree: gradients are bit-identical
- *          (tests/test_gpu_parity.py::test_backward_variants_are_identical).
+ *   "bwd_variant" (default 2 = auto): blend-backward walk — 0: every DPP row of 16 lanes (a 4x4-pixel sub-tile) walks its own
+ *          instance list, row totals gathered through private LDS slots; 1: every wave (8x8 pixels) walks one list (round 1's
+ *          kernel).  Same per-pair arithmetic and the same summation tree: gradients are bit-identical
+ *          (tests/test_gpu_parity.py::test_backward_variants_are_identical), so auto only ever changes speed.
+ *   "bwd_tune" (default 1): how auto chooses.  1: per (device, width, height, octave of tile instances per surfel), two backward
+ *          calls in every 32 are timed with HIP events on the launch stream (one per walk; polled later, never synchronised) and
+ *          the faster walk per tile instance is launched alone in between; 0: both kernels are launched every call and the device decides from the frame's
+ *          totals (rows iff tile instances <= 4 x emitting surfels) — also what happens before both walks have been timed and
+ *          while the stream is being captured into a graph.
  * Threading: the library keeps one pinned read-back buffer and one event per (host thread, device); calls are not re-entrant
  * per thread, and the intended layout is one process per GPU (torch.distributed.run).  Stage-timing events recorded with
  * debug >= 2 are kept until surfel_collect_stage_ms() (at most 8192 pairs; older ones are dropped). */
@@ -163,6 +168,10 @@ int surfel_set_option(const char* name, int value);
  * [3] (sub-tile | quad, instance) visits, [4] of those, the ones with at least one composited pair, [5] quad variant: 4x4 sub-tiles
  * with a composited pair — or NULL to switch the instrumented kernels off again. */
 int surfel_debug_set_blend_stats(void* dev_u64x8);
+
+/* Debug: the walk the "bwd_tune" probes currently favour for frames of this size on the current device (the most used entry of
+ * that size) — 0 per-row, 1 per-quad, -1 not decided yet (fewer than two timed calls have completed). */
+int surfel_debug_walk_choice(int width, int height);
 
 #ifdef __cplusplus
 }

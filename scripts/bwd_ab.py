@@ -52,7 +52,7 @@ def main():
             s = st.cpu().numpy()
             row[vname + "_useful_lane_frac"] = round(float(s[1]) / max(1, float(s[0])), 4)
             row[vname + "_wave_visits"] = int(s[2]); row[vname + "_unit_visits"] = int(s[3]); row["useful_pairs"] = int(s[1])
-            row[vname + "_units_with_hits"] = int(s[4]); row[vname + "_s5"] = int(s[5])
+            row[vname + "_units_with_hits"] = int(s[4]); row[vname + "_s5"] = int(s[5]); row[vname + "_raw"] = [int(x) for x in s]
             if ref is None:
                 ref = g
             else:

@@ -400,6 +400,37 @@ def test_record_gather_variants_are_identical(kind):
         assert np.array_equal(res[0][k], res[1][k]), "%s: dL/d%s differs between the record-gather variants" % (kind, k)
 
 
+def test_walk_tuner_settles_and_keeps_the_bits():
+    """"bwd_tune": with bwd_variant = auto the library times one call per walk out of every 64 and then launches the faster walk
+    alone.  The gradients of every call — probes, the both-kernels fallback before a verdict, the settled choice — are the bits of
+    the forced walks, and a verdict exists after a handful of calls; with "bwd_tune" = 0 the device-side rule alone decides."""
+    import torch
+    import surfel_native as n
+    lib = n.load()
+    sc = _scene((6000, 208, 144), seed=5)          # a frame size no other test uses: this test owns its tuner entry
+    a = scene_args(sc)
+    rng = np.random.default_rng(2)
+    gC = rng.normal(size=(3, a["H"], a["W"])).astype(np.float32); gO = rng.normal(size=(7, a["H"], a["W"])).astype(np.float32)
+    run = HipRun(a).forward()
+    run.debug = n.OPT_BWD_ROWS
+    ref = run.backward(gC, gO)
+    run.debug = 0
+    assert lib.surfel_debug_walk_choice(a["W"], a["H"]) == -1
+    try:
+        for it in range(8):
+            g = run.backward(gC, gO)
+            torch.cuda.synchronize()
+            for k in ref:
+                assert np.array_equal(ref[k], g[k]), (it, k)
+        assert lib.surfel_debug_walk_choice(a["W"], a["H"]) in (0, 1)
+        assert lib.surfel_set_option(b"bwd_tune", 0) == 0
+        g = run.backward(gC, gO)
+        for k in ref:
+            assert np.array_equal(ref[k], g[k]), k
+    finally:
+        lib.surfel_set_option(b"bwd_tune", 1)
+
+
 def test_blend_stats_counters():
     """surfel_debug_set_blend_stats: the instrumented kernels count lane slots issued and lanes that held a composited pair;
     the per-row walk must waste fewer lanes than the per-quad walk on small footprints and see exactly the same useful pairs."""
