@@ -22,6 +22,8 @@ thread_local std::string g_err;
 int g_opt_cull = 1;        // surfel_set_option("cull", .)
 int g_opt_tile_sort = 1;   // surfel_set_option("tile_depth_sort", .): 0 never, 1 auto (by last frame's R / tiles), 2 always
 int g_opt_bwd_variant = 2; // surfel_set_option("bwd_variant", .): 0 per-row walk, 1 per-quad walk, 2 auto (bit-identical)
+surfel_hook_fn g_colour_hook = nullptr;   // surfel_set_backward_hook
+void* g_colour_hook_user = nullptr;
 int g_opt_bwd_tune = 1;    // surfel_set_option("bwd_tune", .): auto = timed probes (1) or the device-side rule alone (0)
 unsigned long long* g_blend_stats = nullptr;   // surfel_debug_set_blend_stats
 thread_local int64_t g_last_R = -1; thread_local int g_last_W = 0, g_last_H = 0;   // auto heuristic (speed only; results identical; a stale
@@ -315,6 +317,11 @@ int surfel_set_option(const char* name, int value) {
     return fail(SURFEL_E_INVALID, "unknown option");
 }
 
+int surfel_set_backward_hook(surfel_hook_fn colour_ready, void* user) {
+    g_colour_hook = colour_ready; g_colour_hook_user = user;
+    return 0;
+}
+
 int surfel_debug_walk_choice(int width, int height) {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return -1;
@@ -559,6 +566,11 @@ int surfel_rasterize_backward(surfel_alloc_fn scratch_alloc, void* scratch_user,
     pb.dL_dtransMat = dL_dtransMat; pb.dL_dnormal = dL_dnormal; pb.dL_dopacity = dL_dopacity; pb.dL_dcolors = dL_dcolors;
     pb.dL_dsh = dL_dsh; pb.dL_dmeans2D = dL_dmeans2D; pb.dL_dmeans3D = dL_dmeans3D; pb.dL_dscales = dL_dscales; pb.dL_drots = dL_drots;
     tm.begin();
+    if (g_colour_hook) {      // dL/dcolour first, so the caller can start moving it while the geometry chain rule runs
+        launch_colour_gradients(pb, s);
+        pb.keep_colors = 1;
+        g_colour_hook(g_colour_hook_user);
+    }
     launch_preprocess_bwd(pb, s);
     STAGE_END(tm, ST_PBWD);
     HIP_TRY(hipGetLastError());

@@ -38,6 +38,7 @@ struct BlendBwdArgs {
 struct PreprocessBwdArgs {
     int P, D, M, W, H;
     int coop;                 // 1: wave-cooperative gather of the instance gradient records (many records per surfel)
+    int keep_colors;          // 1: dL_dcolors was already written by launch_colour_gradients (and may be on the wire): leave it alone
     float scale_modifier;
     const float* means3D; const int* radii; const float* shs; const uint8_t* clamped;
     const float* scales; const float* rotations; const float* transMat_precomp;
@@ -55,6 +56,9 @@ void launch_blend_fwd(const BlendFwdArgs& a, hipStream_t s);
 void launch_mark_visible(int P, const float* means3D, const float* vm, uint8_t* present, hipStream_t s);
 void launch_blend_bwd(const BlendBwdArgs& a, hipStream_t s);
 void launch_preprocess_bwd(const PreprocessBwdArgs& a, hipStream_t s);
+// dL/dcolour alone (the sum of three floats of every gradient record, same order as preprocess_bwd -> the same bits), so that a
+// caller can put it on the wire while preprocess_bwd still runs the geometry chain rule (surfel_set_backward_hook)
+void launch_colour_gradients(const PreprocessBwdArgs& a, hipStream_t s);
 void launch_knn(int P, const float* points, float* out, void* scratch, size_t scratch_bytes, hipStream_t s);
 size_t knn_scratch_bytes(int P);
 size_t radix_sort_scratch_bytes(size_t n);

@@ -446,7 +446,8 @@ __global__ void __launch_bounds__(256) preprocess_bwd_kernel(PreprocessBwdArgs a
     float4* __restrict__ gshq = (a.shs && a.dL_dsh) ? reinterpret_cast<float4*>(a.dL_dsh + (size_t)i * a.M * 3) : nullptr;
     if (!vis) {
         a.dL_dopacity[i] = 0.f;
-        store3(a.dL_dnormal, i, 0.f, 0.f, 0.f); store3(a.dL_dcolors, i, 0.f, 0.f, 0.f);
+        store3(a.dL_dnormal, i, 0.f, 0.f, 0.f);
+        if (!a.keep_colors) store3(a.dL_dcolors, i, 0.f, 0.f, 0.f);
         store3(a.dL_dmeans2D, i, 0.f, 0.f, 0.f); store3(a.dL_dmeans3D, i, 0.f, 0.f, 0.f);
 #pragma unroll
         for (int q = 0; q < 9; q++) a.dL_dtransMat[9 * (size_t)i + q] = 0.f;
@@ -505,7 +506,7 @@ __global__ void __launch_bounds__(256) preprocess_bwd_kernel(PreprocessBwdArgs a
     }
     a.dL_dopacity[i] = g[14];
     store3(a.dL_dnormal, i, g[11], g[12], g[13]);
-    store3(a.dL_dcolors, i, g[15], g[16], g[17]);
+    if (!a.keep_colors) store3(a.dL_dcolors, i, g[15], g[16], g[17]);
 
     const float T[9] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w, r2.x};
     float gT[9];
@@ -592,7 +593,7 @@ __global__ void __launch_bounds__(256) preprocess_bwd_kernel(PreprocessBwdArgs a
         const float x = dox * il, y = doy * il, z = doz * il;
         const uint8_t cb = a.clamped[i];
         const float gR[3] = {(cb & 1) ? 0.f : g[15], (cb & 2) ? 0.f : g[16], (cb & 4) ? 0.f : g[17]};
-        store3(a.dL_dcolors, i, gR[0], gR[1], gR[2]);      // SH mode: gradient w.r.t. the pre-clamp SH colour (include/surfel_hip.h)
+        if (!a.keep_colors) store3(a.dL_dcolors, i, gR[0], gR[1], gR[2]);      // SH mode: gradient w.r.t. the pre-clamp SH colour (include/surfel_hip.h)
         // SH basis B[k] and its direction derivatives dB[k]/d{x,y,z} for the active degree (zero above it)
         float B[16], Bx[16], By[16], Bz[16];
 #pragma unroll
@@ -677,6 +678,34 @@ void launch_tile_ranges(int64_t R, const uint32_t* keys, uint2* ranges, hipStrea
 void launch_mark_visible(int P, const float* means3D, const float* vm, uint8_t* present, hipStream_t s) {
     if (P > 0) hipLaunchKernelGGL(mark_visible_kernel, dim3((P + 255) / 256), dim3(256), 0, s, P, means3D, vm, present);
 }
+// dL/dcolour of every surfel = sum over its gradient records (emission order, one record at a time: the additions of
+// preprocess_bwd's gather in the same order) of floats 15-17, clamp-masked in SH mode.  12 of the 80 record bytes are used, but the records of a surfel are
+// contiguous, so the lines fetched here are the ones preprocess_bwd reads next.
+__global__ void __launch_bounds__(256) colour_gradients_kernel(PreprocessBwdArgs a) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.P) return;
+    float c0 = 0.f, c1 = 0.f, c2 = 0.f;
+    if (a.radii[i] > 0) {
+        const uint32_t beg = __float_as_uint(a.rec[(size_t)i * REC_F + 18]);
+        const uint32_t end = beg + a.tiles_touched[i];
+        for (uint32_t k = beg; k < end; k++) {
+            const float* __restrict__ src = a.grec + (size_t)k * GREC_F;
+            const float v0 = src[15];
+            const float2 v1 = *reinterpret_cast<const float2*>(src + 16);
+            c0 += v0; c1 += v1.x; c2 += v1.y;
+        }
+        if (a.shs != nullptr) {      // SH mode: gradient w.r.t. the pre-clamp SH colour, as preprocess_bwd stores it
+            const uint8_t cb = a.clamped[i];
+            c0 = (cb & 1) ? 0.f : c0; c1 = (cb & 2) ? 0.f : c1; c2 = (cb & 4) ? 0.f : c2;
+        }
+    }
+    store3(a.dL_dcolors, i, c0, c1, c2);
+}
+
+void launch_colour_gradients(const PreprocessBwdArgs& a, hipStream_t s) {
+    if (a.P > 0) hipLaunchKernelGGL(colour_gradients_kernel, dim3((a.P + 255) / 256), dim3(256), 0, s, a);
+}
+
 void launch_preprocess_bwd(const PreprocessBwdArgs& a, hipStream_t s) {
     if (a.P <= 0) return;
     if (a.coop) hipLaunchKernelGGL(preprocess_bwd_kernel<true>, dim3((a.P + 255) / 256), dim3(256), 0, s, a);

@@ -16,10 +16,11 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SURFEL_LIB") or os.path.join(_HERE, "lib", "libsurfel_hip.so")
 
 ALLOC_FN = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_size_t)
+HOOK_FN = C.CFUNCTYPE(None, C.c_void_p)
 
 EXPORTS = ["surfel_abi_version", "surfel_last_error", "surfel_rasterize_forward", "surfel_rasterize_backward",
            "surfel_mark_visible", "surfel_knn_dist2", "surfel_last_stage_ms", "surfel_last_stage_ids", "surfel_stage_name",
-           "surfel_collect_stage_ms", "surfel_set_option", "surfel_debug_sort_pairs", "surfel_debug_set_blend_stats", "surfel_debug_walk_choice",
+           "surfel_collect_stage_ms", "surfel_set_option", "surfel_debug_sort_pairs", "surfel_debug_set_blend_stats", "surfel_debug_walk_choice", "surfel_set_backward_hook",
            # include/surfel_train.h
            "surfel_l1_ssim_forward", "surfel_l1_ssim_backward", "surfel_render_post_forward", "surfel_render_post_backward",
            "surfel_reduce_partials", "surfel_loss_finalize", "surfel_activate", "surfel_adam_step", "surfel_sh_grad_gather", "surfel_densify_stats"]
@@ -79,6 +80,8 @@ def load():
         lib.surfel_debug_set_blend_stats.argtypes = [vp]
         lib.surfel_debug_walk_choice.restype = i
         lib.surfel_debug_walk_choice.argtypes = [i, i]
+        lib.surfel_set_backward_hook.restype = i
+        lib.surfel_set_backward_hook.argtypes = [HOOK_FN, vp]
         lib.surfel_set_option.restype = i
         lib.surfel_set_option.argtypes = [C.c_char_p, i]
         # ---- include/surfel_train.h
@@ -98,8 +101,30 @@ def load():
             fn.argtypes = args
         if lib.surfel_abi_version() != 1:
             raise ImportError("libsurfel_hip.so ABI version mismatch")
+        # SURFEL_OPTIONS="name=value,..." -> surfel_set_option (A/B runs of an unmodified caller, e.g. bench.py)
+        for kv in filter(None, os.environ.get("SURFEL_OPTIONS", "").split(",")):
+            name, _, value = kv.partition("=")
+            if lib.surfel_set_option(name.strip().encode(), int(value)) != 0:
+                raise ValueError("SURFEL_OPTIONS: unknown option %r" % name)
         _lib = lib
     return _lib
+
+
+_hook_keepalive = None
+
+
+def set_backward_hook(fn):
+    """surfel_set_backward_hook: fn() is called inside every rasterizer backward once dL/dcolour is final on the stream (None
+    removes the hook).  The ctypes thunk is kept alive here for as long as the hook is installed."""
+    global _hook_keepalive
+    lib = load()
+    if fn is None:
+        lib.surfel_set_backward_hook(HOOK_FN(), None)
+        _hook_keepalive = None
+        return
+    thunk = HOOK_FN(lambda user: fn())
+    lib.surfel_set_backward_hook(thunk, None)
+    _hook_keepalive = thunk
 
 
 def last_error():

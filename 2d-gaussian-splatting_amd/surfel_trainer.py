@@ -23,6 +23,7 @@ import torch
 import torch.distributed as dist
 
 import surfel_dist
+import surfel_native as _n
 from surfel_losses import scalars_from_band_sums, train_loss, train_loss_band
 from surfel_model import COLOUR_FLOATS, GEOM_FLOATS, GaussianModel, exchange_collectives, exchange_same_view
 from surfel_render import Camera, post_consts_rows, rasterize, render
@@ -138,13 +139,16 @@ def capture_views(gt_model, cams, background, pipe=None):
 
 # ------------------------------------------------------------------------------------------------ the loop
 class Trainer:
-    def __init__(self, model, cams, opt=None, pipe=None, white_background=False, extent=None, seed=0, sharding="views", first_iter=0):
+    def __init__(self, model, cams, opt=None, pipe=None, white_background=False, extent=None, seed=0, sharding="views", first_iter=0,
+                 rehearse_exchange=False):
         """sharding (N > 1): "views" = every rank trains on its own view per step (default, BASELINE config 4); "bands" = all ranks
         render row bands of the SAME view (tile-band sharding, BASELINE config 5): every rank evaluates the loss on ITS band plus a
         32-row halo received from its two neighbours (surfel_losses.train_loss_band), back-propagates its own rows, and the
         per-surfel gradients of the bands ADD UP to the single-GPU gradient — ONE all-reduce of 52 B/surfel (geometry + colour
         gradients; the camera is shared, so the SH gradients are rebuilt from the SUM of the colour gradients), no averaging.
-        Band edges follow the previous frames' instances per tile row (re-balanced every `rebalance_every` iterations)."""
+        Band edges follow the previous frames' instances per tile row (re-balanced every `rebalance_every` iterations).
+        rehearse_exchange: take the view-parallel step (schedule, collectives, split optimiser) even with a single rank — the
+        N > 1 code path run against the real backend on one GPU (tests/test_gpu_train.py, scripts/rccl_selfcheck.py)."""
         if sharding not in ("views", "bands"):
             raise ValueError("sharding must be 'views' or 'bands'")
         self.sharding = sharding
@@ -171,10 +175,15 @@ class Trainer:
         self.exchange_events = []
         # RCCL: asynchronous collectives with stream-level waits (SH-block Adam overlaps the geometry all-reduce); other backends
         # (gloo rehearsals stage through the host and block) take the plain synchronous form
-        self._async_exchange = self.world > 1 and dist.get_backend() == "nccl"
+        self._exchange = self.world > 1 or (bool(rehearse_exchange) and dist.is_available() and dist.is_initialized())
+        self._async_exchange = self._exchange and dist.get_backend() == "nccl"
+        # views + RCCL: the all-gather of the colour gradients starts inside the rasterizer's backward, as soon as the kernel that
+        # finalises them is on the stream (surfel_set_backward_hook), and overlaps the per-surfel geometry chain rule
+        self.early_gather = True
+        self._early, self._early_err = None, None
         # fused SH path (default): the rasterizer's backward skips the 192 B/surfel SH gradients, the optimiser kernel rebuilds them
         # from the 12 B/surfel colour gradients.  Always on under view-parallel training (that is how the gradients are exchanged).
-        self.fused_sh = self.world > 1 or os.environ.get("SURFEL_SH_FUSED", "1") != "0"
+        self.fused_sh = self._exchange or os.environ.get("SURFEL_SH_FUSED", "1") != "0"
         if model.grad is None:
             model.training_setup(self.opt)
         if self.world > 1:
@@ -211,7 +220,7 @@ class Trainer:
         return self._epoch_views[k], self._epoch_campos[k]
 
     def _next_camera(self):
-        if self.world > 1 and self.sharding == "views":
+        if self._exchange and self.sharding == "views":
             return self.cams[self._step_views()[0][self.rank]]
         if not self._stack:                       # train.py:64-67: pop a random view from a refilled stack
             self._stack = list(range(len(self.cams)))
@@ -266,7 +275,17 @@ class Trainer:
                                        self.pipe.depth_ratio, opt.lambda_dssim, lam_n, lam_d)
             halo_b = 0
         self.wire = surfel_dist.wire_bytes_per_step(m.P, self.world, self.sharding, stats_live, halo_b)
-        torch.autograd.backward(loss, grad_tensors=self._one)        # cached seed gradient: no ones_like fill per iteration
+        early = self.early_gather and self._async_exchange and not bands and it < opt.iterations
+        if early:
+            self._early, self._early_err = None, None
+            _n.set_backward_hook(self._on_colour_ready)
+        try:
+            torch.autograd.backward(loss, grad_tensors=self._one)        # cached seed gradient: no ones_like fill per iteration
+        finally:
+            if early:
+                _n.set_backward_hook(None)
+        if self._early_err is not None:
+            raise self._early_err
         self.last = dict(loss=scalars[5], scalars=scalars, points=m.P, radii=radii)     # [Ll1, ssim, normal_err, dist, photometric, total] on the device
         with torch.no_grad():
             rebuilt = False
@@ -287,13 +306,18 @@ class Trainer:
                 if bands:
                     # partial gradients of one view add up (no averaging); the SH block is rebuilt from the summed colour gradients
                     m.optimizer_step(grad_scale=1.0, colour_grads=(cam.camera_center[None], m.gcol[None]))
-                elif self.world > 1:
+                elif self._exchange:
                     # all-reduce of the 40 B/surfel geometry prefix + all-gather of 12 B/surfel/rank colour gradients; the 192 B/surfel
                     # SH gradients are rebuilt from them (exact, rank-ordered sum) instead of being all-reduced
                     campos_all = self._step_views()[1]
                     scale = 1.0 / self.world      # views: average
                     if self._async_exchange:
-                        gcol_all, w_gather, w_reduce = exchange_collectives(m.grad, m.gcol, m.P, async_op=True)
+                        if self._early is not None:      # the gather has been in flight since the middle of the backward
+                            gcol_all, w_gather = self._early
+                            self._early = None
+                            w_reduce = dist.all_reduce(m.grad[:GEOM_FLOATS * m.P], op=dist.ReduceOp.SUM, async_op=True)
+                        else:
+                            gcol_all, w_gather, w_reduce = exchange_collectives(m.grad, m.gcol, m.P, async_op=True)
                         self._timed_wait(w_gather)   # stream-level wait: the SH block updates while the geometry all-reduce is in flight
                         m.optimizer_step(grad_scale=scale, colour_grads=(campos_all, gcol_all), parts=1)
                         self._timed_wait(w_reduce)
@@ -305,6 +329,20 @@ class Trainer:
                     if self.fused_sh:
                         campos_all, gcol_all = cam.camera_center[None], m.gcol[None]
                     m.optimizer_step(grad_scale=1.0, colour_grads=(campos_all, gcol_all) if self.fused_sh else None)
+            if self._early is not None:      # an iteration without an optimiser step (parameters re-created): retire the gather
+                self._early[1].wait()
+                self._early = None
+
+    def _on_colour_ready(self):
+        """Called by the C library inside the rasterizer's backward (autograd's thread, the forward's stream) once dL/dcolour is
+        final on the stream: launch the all-gather of this rank's colour gradients now.  Exceptions cannot cross the C frame:
+        they are parked and re-raised by step()."""
+        try:
+            m = self.model
+            gall = torch.empty((dist.get_world_size(), m.P, 3), dtype=torch.float32, device=m.device)
+            self._early = (gall, dist.all_gather_into_tensor(gall, m.gcol, async_op=True))
+        except Exception as e:      # noqa: BLE001
+            self._early, self._early_err = None, e
 
     def _schedule_events(self, it, bands=False):
         """Densification and opacity reset when due (train.py:129-135); returns whether the parameters were re-created."""

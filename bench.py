@@ -217,8 +217,12 @@ def main():
                 n_inst = sum(v.get("SQ_INSTS_VALU", 0.0) for k, v in pj.items() if k.startswith(dom)) or None   # blend_bwd = rows + quad launch
                 if n_inst:
                     rate = n_inst / (per_kernel[dom] * 1e-3) / 1e9
+                    # measured_ceiling: what independent v_fma_f32 streams reach on this chip with 8 waves / SIMD — 1.44 ns per
+                    # wave-instruction per SIMD (scripts/ubench/valu_rate.hip, profiles/r02_valu_rate_ubench.txt) = 711 G/s over
+                    # 1024 SIMDs; DPP adds / compares / selects run at 0.75x of that, v_exp / v_rcp at 0.35x
                     valu = {"wave_insts_per_launch": int(n_inst), "achieved_Ginst_per_s": round(rate, 1), "peak_Ginst_per_s": 1228.9,
-                            "frac": round(rate / 1228.9, 4), "source": os.path.basename(pm)}
+                            "frac": round(rate / 1228.9, 4), "measured_ceiling_Ginst_per_s": 711.0,
+                            "frac_of_measured_ceiling": round(rate / 711.0, 4), "source": os.path.basename(pm)}
             except Exception:
                 valu = None
             roof = {"bound": "hbm", "kernel": dom, "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",

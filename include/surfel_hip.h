@@ -163,6 +163,15 @@ int surfel_debug_sort_pairs(surfel_alloc_fn scratch_alloc, void* scratch_user, u
  * debug >= 2 are kept until surfel_collect_stage_ms() (at most 8192 pairs; older ones are dropped). */
 int surfel_set_option(const char* name, int value);
 
+/* Multi-GPU overlap hook (process-wide; NULL removes it).  When set, surfel_rasterize_backward enqueues, after the blend
+ * backward, a small kernel that finalises dL_dcolors (bit-identical to what the single-kernel path writes), calls
+ * colour_ready(user) on the calling thread — the caller typically launches its all-gather of dL_dcolors there, ordered behind that
+ * kernel on `stream` — and only then enqueues the per-surfel chain rule, which no longer touches dL_dcolors.  All other outputs
+ * are unchanged.  Reference counterpart: none (the reference trains on one GPU); this serves the view-parallel exchange of
+ * surfel_trainer.py. */
+typedef void (*surfel_hook_fn)(void* user);
+int surfel_set_backward_hook(surfel_hook_fn colour_ready, void* user);
+
 /* Debug: a device buffer of 8 uint64 (caller-zeroed) that every following blend-backward launch accumulates into
  * — [0] lane slots issued (64 per wave visit), [1] lanes that held a composited (pixel, surfel) pair, [2] wave visits,
  * [3] (sub-tile | quad, instance) visits, [4] of those, the ones with at least one composited pair, [5] quad variant: 4x4 sub-tiles

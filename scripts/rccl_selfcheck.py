@@ -35,5 +35,15 @@ tr._reduce_stats(); ok["reduce_stats"] = True
 r = torch.arange(5, dtype=torch.int32, device=dev); dist.all_reduce(r, op=dist.ReduceOp.MAX); ok["max_int32"] = bool(r[4] == 4)
 dist.barrier(); torch.cuda.synchronize()
 tr.step(); ok["step_after"] = bool(torch.isfinite(tr.last["scalars"]).all())
+# the whole view-parallel step against RCCL (world 1): early all-gather from inside the backward, split Adam
+m2 = TR.synthetic_object(5000, dev, seed=3, px_scale=0.05); m2.spatial_lr_scale = 1.0
+tr2 = TR.Trainer(m2, cams, TR.optimization_params(dist_from_iter=0, normal_from_iter=0, lambda_dist=10.0), TR.pipeline_params(depth_ratio=1.0),
+                 rehearse_exchange=True)
+tr2.time_exchange = True
+for _ in range(5):
+    tr2.step()
+torch.cuda.synchronize()
+ok["rehearsed_steps_finite"] = bool(torch.isfinite(tr2.last["scalars"]).all() and torch.isfinite(m2.theta).all())
+ok["rehearsed_exposed_ms_per_step"] = round(sum(a.elapsed_time(b) for a, b in tr2.exchange_events) / 5, 4)
 print(json.dumps(ok))
 dist.destroy_process_group()

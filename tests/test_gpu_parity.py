@@ -400,6 +400,35 @@ def test_record_gather_variants_are_identical(kind):
         assert np.array_equal(res[0][k], res[1][k]), "%s: dL/d%s differs between the record-gather variants" % (kind, k)
 
 
+def test_backward_hook_splits_off_the_colour_gradients():
+    """surfel_set_backward_hook: with a hook installed the backward finalises dL/dcolour in a kernel of its own, calls the hook
+    (where a multi-GPU caller starts its all-gather), then runs the chain rule without touching dL/dcolour again — every output
+    keeps the bits of the single-kernel path, with SH gradients and with precomputed colours."""
+    import surfel_native as n
+    sc = _stress_scene("plain", 33)
+    a = scene_args(sc)
+    rng = np.random.default_rng(4)
+    gC = rng.normal(size=(3, a["H"], a["W"])).astype(np.float32); gO = rng.normal(size=(7, a["H"], a["W"])).astype(np.float32)
+    P = sc["means3D"].shape[0]
+    for kw in ({}, {"colors_precomp": rng.uniform(0, 1, (P, 3)).astype(np.float32)}):
+        run = HipRun(a, **kw).forward()
+        ref = run.backward(gC, gO)
+        calls = []
+        # the hook snapshots dL/dcolour on the stream: it must already be final there (that is what goes on the wire)
+        n.set_backward_hook(lambda: calls.append(run.g["colors"].clone()))
+        try:
+            got = run.backward(gC, gO)
+        finally:
+            n.set_backward_hook(None)
+        assert len(calls) == 1 and np.array_equal(calls[0].cpu().numpy(), ref["colors"])
+        calls = [1]
+        for k in ref:
+            assert np.array_equal(ref[k], got[k], equal_nan=True), k      # (outputs the call does not produce keep their NaN poison)
+        assert np.abs(got["colors"]).max() > 0
+        again = run.backward(gC, gO)          # hook removed: the single-kernel path again
+        assert calls == [1] and all(np.array_equal(ref[k], again[k], equal_nan=True) for k in ref)
+
+
 def test_walk_tuner_settles_and_keeps_the_bits():
     """"bwd_tune": with bwd_variant = auto the library times one call per walk out of every 64 and then launches the faster walk
     alone.  The gradients of every call — probes, the both-kernels fallback before a verdict, the settled choice — are the bits of

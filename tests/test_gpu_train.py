@@ -756,3 +756,43 @@ def test_sh_degree_below_three(tmp_path):
         assert cap[3].shape == (m.P, nc - 1, 3)
         m3 = surfel_model.GaussianModel(deg, device=d); m3.restore(cap, TR.optimization_params())
         assert torch.equal(m3.theta, m.theta) and torch.allclose(m3.m, m.m)
+
+
+def test_view_parallel_step_rehearsed_on_rccl_with_early_gather():
+    """The N > 1 view-parallel step run against the real backend (RCCL, world_size 1) on this GPU: view schedule, asynchronous
+    all-gather / all-reduce with stream-level waits, Adam in two parts.  With `early_gather` the colour-gradient all-gather is
+    launched from INSIDE the rasterizer's backward (surfel_set_backward_hook) while the geometry chain rule still runs; it must
+    take exactly the steps of the gather-after-backward form.  (Halo p2p and > 1 rank: gloo tests in tests/test_dist_cpu.py.)"""
+    import torch
+    import torch.distributed as dist
+    import surfel_trainer as TR
+    d = dev()
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29541")
+    assert not dist.is_initialized()
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=d)
+    try:
+        bg = torch.zeros(3, device=d)
+        gt_model = TR.synthetic_object(4000, d, seed=1, px_scale=0.06)
+        cams = TR.capture_views(gt_model, TR.orbit_cameras(4, 128, 96, device=d), bg)
+        thetas = []
+        for early in (False, True):
+            m = TR.synthetic_object(4000, d, seed=2, px_scale=0.05)
+            m.spatial_lr_scale = 1.0
+            tr = TR.Trainer(m, cams, TR.optimization_params(dist_from_iter=0, normal_from_iter=0, lambda_dist=10.0, densify_from_iter=10 ** 9),
+                            TR.pipeline_params(depth_ratio=1.0), rehearse_exchange=True)
+            assert tr._exchange and tr._async_exchange and tr.fused_sh
+            tr.early_gather = early
+            calls = []
+            if early:
+                inner = tr._on_colour_ready
+                tr._on_colour_ready = lambda: (calls.append(1), inner())[1]
+            for _ in range(4):
+                tr.step()
+            torch.cuda.synchronize()
+            assert torch.isfinite(tr.last["scalars"]).all() and torch.isfinite(m.theta).all()
+            assert len(calls) == (4 if early else 0) and tr._early is None
+            thetas.append((m.theta.clone(), m.m.clone(), m.v.clone()))
+        for a, b in zip(*thetas):
+            assert torch.equal(a, b)
+    finally:
+        dist.destroy_process_group()
