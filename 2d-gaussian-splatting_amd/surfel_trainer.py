@@ -178,8 +178,10 @@ class Trainer:
         self._exchange = self.world > 1 or (bool(rehearse_exchange) and dist.is_available() and dist.is_initialized())
         self._async_exchange = self._exchange and dist.get_backend() == "nccl"
         # views + RCCL: the all-gather of the colour gradients starts inside the rasterizer's backward, as soon as the kernel that
-        # finalises them is on the stream (surfel_set_backward_hook), and overlaps the per-surfel geometry chain rule
-        self.early_gather = True
+        # finalises them is on the stream (surfel_set_backward_hook), and overlaps the per-surfel geometry chain rule.  The split
+        # costs a second pass over the gradient records (measured +15 us at C2, +208 us at C4: scripts/hook_cost.py) and buys up to
+        # min(gather time, chain-rule time): worth it once the gather is long, i.e. from 4 ranks on (12 B/surfel/rank received)
+        self.early_gather = self.world >= 4 or bool(rehearse_exchange)
         self._early, self._early_err = None, None
         # fused SH path (default): the rasterizer's backward skips the 192 B/surfel SH gradients, the optimiser kernel rebuilds them
         # from the 12 B/surfel colour gradients.  Always on under view-parallel training (that is how the gradients are exchanged).
