@@ -214,7 +214,9 @@ def main():
                 import glob
                 pm = sorted(glob.glob(os.path.join(REPO, "profiles", "r*_%s_pmc.json" % args.workload)))[-1]
                 pj = json.load(open(pm))
-                n_inst = sum(v.get("SQ_INSTS_VALU", 0.0) for k, v in pj.items() if k.startswith(dom)) or None   # blend_bwd = rows + quad launch
+                # blend_bwd = blend_bwd_rows_kernel | blend_bwd_quad_kernel: the walk that ran (the other one is launched for the
+                # tuner's probes only, its per-launch mean mixes probes and idle launches)
+                n_inst = max([v.get("SQ_INSTS_VALU", 0.0) for k, v in pj.items() if k.startswith(dom)] or [0.0]) or None
                 if n_inst:
                     rate = n_inst / (per_kernel[dom] * 1e-3) / 1e9
                     # measured_ceiling: what independent v_fma_f32 streams reach on this chip with 8 waves / SIMD — 1.44 ns per

@@ -82,7 +82,9 @@ def main():
             cs["HBM_bytes_per_launch"] = int(2 * cs["FETCH_SIZE"] * 1024 + cs["WRITE_SIZE"] * 1024)
             if k in STAGE_OF or k.startswith(("ssim_", "post_", "adam_")):
                 st = STAGE_OF.get(k, k.replace("_kernel", ""))
-                traffic[st] = traffic.get(st, 0) + cs["HBM_bytes_per_launch"]      # blend_bwd = rows + quad launch (one of them returns at once)
+                # blend_bwd = the walk that ran (rows | quad): the other kernel is launched for the tuner's probes and the
+                # pre-verdict calls only, so its per-launch mean is a mix of full and idle launches — not a summand
+                traffic[st] = max(traffic.get(st, 0), cs["HBM_bytes_per_launch"]) if st == "blend_bwd" else traffic.get(st, 0) + cs["HBM_bytes_per_launch"]
     json.dump(merged, open(os.path.join(dst, "%s_%s_pmc.json" % (tag, wl)), "w"), indent=1, sort_keys=True)
     tf = os.path.join(dst, "pmc_traffic.json")
     allt = json.load(open(tf)) if os.path.exists(tf) else {}
