@@ -86,9 +86,9 @@ __device__ __forceinline__ float quad_sum(float t) {
 __device__ __forceinline__ void row_reduce20(const float (&v)[NVP], float (&z)[5]) {
     // One block, all in place: value 2i folds value 2i+1 into its upper lanes, then 4m folds 4m+2, then the quads are summed.
     // Every DPP source was written >= 5 instructions earlier, so only the leading s_nop (2 wait states after whatever VALU
-    // produced v[]) is needed — the per-step s_nops of a fold-at-a-time formulation cost 24 issue slots per visit.
+    // produced v[]) is needed — the per-step s_nops of a fold-at-a-time formulation cost 24 issue slots per visit.  38 DPP adds.
     float w0 = v[0], w1 = v[1], w2 = v[2], w3 = v[3], w4 = v[4], w5 = v[5], w6 = v[6], w7 = v[7], w8 = v[8], w9 = v[9];
-    float w10 = v[10], w11 = v[11], w12 = v[12], w13 = v[13], w14 = v[14], w15 = v[15], w16 = v[16], w17 = v[17], w18 = v[18], w19 = v[19];
+    float w10 = v[10], w11 = v[11], w12 = v[12], w13 = v[13], w14 = v[14], w15 = v[15], w16 = v[16], w17 = v[17], w18 = v[18];      // v[18] = v[19] = 0 (padding): their own fold is skipped
     asm volatile("s_nop 1\n\t"
                  "v_add_f32_dpp %[w0], %[w0], %[w0] row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
                  "v_add_f32_dpp %[w2], %[w2], %[w2] row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
@@ -99,7 +99,6 @@ __device__ __forceinline__ void row_reduce20(const float (&v)[NVP], float (&z)[5
                  "v_add_f32_dpp %[w12], %[w12], %[w12] row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
                  "v_add_f32_dpp %[w14], %[w14], %[w14] row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
                  "v_add_f32_dpp %[w16], %[w16], %[w16] row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
-                 "v_add_f32_dpp %[w18], %[w18], %[w18] row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
                  "v_add_f32_dpp %[w0], %[w1], %[w1] row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
                  "v_add_f32_dpp %[w2], %[w3], %[w3] row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
                  "v_add_f32_dpp %[w4], %[w5], %[w5] row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
@@ -109,7 +108,6 @@ __device__ __forceinline__ void row_reduce20(const float (&v)[NVP], float (&z)[5
                  "v_add_f32_dpp %[w12], %[w13], %[w13] row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
                  "v_add_f32_dpp %[w14], %[w15], %[w15] row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
                  "v_add_f32_dpp %[w16], %[w17], %[w17] row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
-                 "v_add_f32_dpp %[w18], %[w19], %[w19] row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
                  "v_add_f32_dpp %[w0], %[w0], %[w0] row_ror:12 row_mask:0xf bank_mask:0xf\n\t"
                  "v_add_f32_dpp %[w4], %[w4], %[w4] row_ror:12 row_mask:0xf bank_mask:0xf\n\t"
                  "v_add_f32_dpp %[w8], %[w8], %[w8] row_ror:12 row_mask:0xf bank_mask:0xf\n\t"
@@ -131,7 +129,7 @@ __device__ __forceinline__ void row_reduce20(const float (&v)[NVP], float (&z)[5
                  "v_add_f32_dpp %[w12], %[w12], %[w12] quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
                  "v_add_f32_dpp %[w16], %[w16], %[w16] quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf"
                  : [w0] "+v"(w0), [w2] "+v"(w2), [w4] "+v"(w4), [w6] "+v"(w6), [w8] "+v"(w8), [w10] "+v"(w10), [w12] "+v"(w12), [w14] "+v"(w14), [w16] "+v"(w16), [w18] "+v"(w18)
-                 : [w1] "v"(w1), [w3] "v"(w3), [w5] "v"(w5), [w7] "v"(w7), [w9] "v"(w9), [w11] "v"(w11), [w13] "v"(w13), [w15] "v"(w15), [w17] "v"(w17), [w19] "v"(w19));
+                 : [w1] "v"(w1), [w3] "v"(w3), [w5] "v"(w5), [w7] "v"(w7), [w9] "v"(w9), [w11] "v"(w11), [w13] "v"(w13), [w15] "v"(w15), [w17] "v"(w17));
     z[0] = w0; z[1] = w4; z[2] = w8; z[3] = w12; z[4] = w16;
 }
 // Wave-wide: the 5 row totals cross rows through permlane swaps (5 swaps + 5 adds): (r0 + r1) + (r2 + r3).
