@@ -131,6 +131,20 @@ def last_error():
     return load().surfel_last_error().decode()
 
 
+def bucket_bytes(n):
+    """Size actually requested from torch for an n-byte scratch buffer.  The R-sized buffers (binning state, the 80 B/instance
+    gradient records: ~10 GB at 1.3e8 instances) change by a few per cent from frame to frame; the caching allocator cannot grow
+    a cached block, so every new maximum cost a fresh hipMalloc of the whole buffer (290 ms at 10 GB, measured) while the slightly
+    smaller block stayed cached — reserved memory ratcheted up by the buffer size each time.  Sizes of 64 MiB and more are
+    therefore rounded up to the next multiple of 1/16 .. 1/8 of themselves (a power of two), so a fluctuating size settles in one or
+    two blocks; smaller requests are left to the allocator's own 2 MiB rounding."""
+    n = int(n)
+    if n < (1 << 26):
+        return max(n, 1)
+    step = 1 << (n.bit_length() - 4)
+    return (n + step - 1) // step * step
+
+
 class TorchAllocator:
     """Allocator callback backed by torch's caching allocator (uint8 tensors kept alive in `held`).
     The ctypes callback closes over the `held` list only — not over `self` — so there is no reference cycle and the
@@ -142,7 +156,7 @@ class TorchAllocator:
 
         def _alloc(user, nbytes):
             try:
-                t = torch.empty(max(int(nbytes), 1), dtype=torch.uint8, device=device)
+                t = torch.empty(bucket_bytes(nbytes), dtype=torch.uint8, device=device)
             except Exception:  # out of memory -> NULL -> SURFEL_E_ALLOC
                 return None
             held.append(t)

@@ -121,3 +121,19 @@ def test_ply_roundtrip_and_reference_layout(tmp_path):
         f.write("ply\nformat ascii 1.0\ncomment x\nelement vertex 2\nproperty float x\nproperty double y\nend_header\n1 2\n3 4\n")
     b2 = surfel_io.read_ply(p)
     assert b2["x"].tolist() == [1.0, 3.0] and b2["y"].tolist() == [2.0, 4.0]
+
+
+def test_scratch_sizes_are_bucketed():
+    """surfel_native.bucket_bytes: large scratch requests are rounded up to a multiple of 1/16..1/8 of their size, so the R-sized
+    buffers of consecutive frames (sizes a few per cent apart) land in the same cached block instead of forcing a fresh hipMalloc at
+    every new maximum (measured at 10 M surfels: 290 ms per new maximum and +9.6 GB reserved each time)."""
+    import surfel_native as n
+    assert n.bucket_bytes(0) == 1 and n.bucket_bytes(1000) == 1000 and n.bucket_bytes((1 << 26) - 1) == (1 << 26) - 1
+    prev = 0
+    for size in [1 << 26, (1 << 26) + 1, 100_000_000, 129_137_928 * 80, 129_770_365 * 80, 10 ** 11]:
+        b = n.bucket_bytes(size)
+        assert size <= b <= size * 1.125 + 1 and b >= prev
+        assert n.bucket_bytes(b) == b          # a bucket maps to itself
+        prev = b
+    # the creeping maxima of the C5 bench (instances x 80 B) share one bucket
+    assert len({n.bucket_bytes(r * 80) for r in (129_137_928, 129_394_610, 129_434_296, 129_655_849, 129_770_365)}) == 1
