@@ -44,7 +44,7 @@ def pmc_means(d):
         return {}
     for r in csv.DictReader(open(f)):
         acc[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
-    return {k: {c: sum(v) / len(v) for c, v in cs.items()} for k, cs in acc.items()}
+    return {k: dict({c: sum(v) / len(v) for c, v in cs.items()}, launches=max(len(v) for v in cs.values())) for k, cs in acc.items()}
 
 
 def main():
@@ -75,6 +75,7 @@ def main():
     ours = ("rs_", "os_", "scan_", "tile_", "ssim_", "post_", "adam_", "loss_", "densify_", "activate_", "reduce_")
     merged = {k: v for k, v in merged.items() if k in STAGE_OF or k.startswith(ours) or "knn" in k}
     traffic = {}
+    bwd_launches = -1
     for k, cs in merged.items():
         if "SQ_THREAD_CYCLES_VALU" in cs and cs.get("SQ_ACTIVE_INST_VALU"):
             cs["VALUUtilization_exec_lanes"] = round(cs["SQ_THREAD_CYCLES_VALU"] / (64.0 * cs["SQ_ACTIVE_INST_VALU"]), 4)
@@ -82,9 +83,14 @@ def main():
             cs["HBM_bytes_per_launch"] = int(2 * cs["FETCH_SIZE"] * 1024 + cs["WRITE_SIZE"] * 1024)
             if k in STAGE_OF or k.startswith(("ssim_", "post_", "adam_")):
                 st = STAGE_OF.get(k, k.replace("_kernel", ""))
-                # blend_bwd = the walk that ran (rows | quad): the other kernel is launched for the tuner's probes and the
-                # pre-verdict calls only, so its per-launch mean is a mix of full and idle launches — not a summand
-                traffic[st] = max(traffic.get(st, 0), cs["HBM_bytes_per_launch"]) if st == "blend_bwd" else traffic.get(st, 0) + cs["HBM_bytes_per_launch"]
+                # blend_bwd = the walk that ran most (rows | quad): the other kernel is launched for the tuner's probes and the
+                # pre-verdict calls, so its per-launch mean is a mix of full and idle launches — not a summand
+                if st == "blend_bwd":
+                    if cs.get("launches", 0) >= bwd_launches:
+                        bwd_launches = cs.get("launches", 0)
+                        traffic[st] = cs["HBM_bytes_per_launch"]
+                else:
+                    traffic[st] = traffic.get(st, 0) + cs["HBM_bytes_per_launch"]
     json.dump(merged, open(os.path.join(dst, "%s_%s_pmc.json" % (tag, wl)), "w"), indent=1, sort_keys=True)
     tf = os.path.join(dst, "pmc_traffic.json")
     allt = json.load(open(tf)) if os.path.exists(tf) else {}
