@@ -14,6 +14,7 @@ namespace {
 constexpr int ST = 32;             // output tile edge
 constexpr int SR = 5;              // window radius
 constexpr int SHALO = ST + 2 * SR; // 42
+constexpr int NSTAGE = (SHALO * SHALO + 255) / 256;   // staged elements per thread (7)
 constexpr float SSIM_C1 = 0.01f * 0.01f;
 constexpr float SSIM_C2 = 0.03f * 0.03f;
 
@@ -50,11 +51,23 @@ __global__ __launch_bounds__(256) void ssim_fwd_kernel(int H, int W, const float
     const size_t poff = (size_t)plane * H * W;
     const float* X = img + poff;
     const float* Y = gt + poff;
-    for (int i = tid; i < SHALO * SHALO; i += 256) {
-        const int r = i / SHALO, c = i - r * SHALO;
-        const int gy = y0 + r - SR, gx = x0 + c - SR;
-        const bool in = gy >= 0 && gy < H && gx >= 0 && gx < W;
-        sxy[r * XP + c] = in ? make_float2(X[(size_t)gy * W + gx], Y[(size_t)gy * W + gx]) : make_float2(0.f, 0.f);
+    {   // stage the 42x42 tile: ALL of a thread's 7 x 2 loads are issued before the first one is consumed (as a rolled loop this
+        // was seven dependent global round trips per workgroup — most of the kernel's time)
+        float2 v[NSTAGE];
+#pragma unroll
+        for (int k = 0; k < NSTAGE; k++) {
+            const int i = tid + 256 * k;
+            const int r = i / SHALO, c = i - r * SHALO;
+            const int gy = y0 + r - SR, gx = x0 + c - SR;
+            const bool in = i < SHALO * SHALO && gy >= 0 && gy < H && gx >= 0 && gx < W;
+            v[k] = in ? make_float2(X[(size_t)gy * W + gx], Y[(size_t)gy * W + gx]) : make_float2(0.f, 0.f);
+        }
+#pragma unroll
+        for (int k = 0; k < NSTAGE; k++) {
+            const int i = tid + 256 * k;
+            const int r = i / SHALO, c = i - r * SHALO;
+            if (i < SHALO * SHALO) sxy[r * XP + c] = v[k];
+        }
     }
     __syncthreads();
     // horizontal pass: item = (row r of 42, group of 4 output columns)
@@ -150,13 +163,25 @@ __global__ __launch_bounds__(256) void ssim_bwd_kernel(int H, int W, const float
     const int plane = lin / ntile, tile = lin - plane * ntile;
     const int x0 = (tile % gxt) * ST, y0 = (tile / gxt) * ST;
     const size_t poff = (size_t)plane * H * W;
-    for (int i = tid; i < SHALO * SHALO; i += 256) {
-        const int r = i / SHALO, c = i - r * SHALO;
-        const int gy = y0 + r - SR, gx = x0 + c - SR;
-        const bool in = gy >= 0 && gy < H && gx >= 0 && gx < W;
-        const size_t o = poff + (size_t)gy * W + gx;
-        s12[r * XP + c] = in ? make_float2(dmaps[o], dmaps[map_stride + o]) : make_float2(0.f, 0.f);
-        s3[r * XP + c] = in ? dmaps[2 * map_stride + o] : 0.f;
+    {   // all 7 x 3 loads of a thread in flight before the first LDS store (see ssim_fwd_kernel)
+        float2 v12[NSTAGE];
+        float v3[NSTAGE];
+#pragma unroll
+        for (int k = 0; k < NSTAGE; k++) {
+            const int i = tid + 256 * k;
+            const int r = i / SHALO, c = i - r * SHALO;
+            const int gy = y0 + r - SR, gx = x0 + c - SR;
+            const bool in = i < SHALO * SHALO && gy >= 0 && gy < H && gx >= 0 && gx < W;
+            const size_t o = poff + (size_t)gy * W + gx;
+            v12[k] = in ? make_float2(dmaps[o], dmaps[map_stride + o]) : make_float2(0.f, 0.f);
+            v3[k] = in ? dmaps[2 * map_stride + o] : 0.f;
+        }
+#pragma unroll
+        for (int k = 0; k < NSTAGE; k++) {
+            const int i = tid + 256 * k;
+            const int r = i / SHALO, c = i - r * SHALO;
+            if (i < SHALO * SHALO) { s12[r * XP + c] = v12[k]; s3[r * XP + c] = v3[k]; }
+        }
     }
     __syncthreads();
     for (int it = tid; it < SHALO * (ST / 4); it += 256) {
