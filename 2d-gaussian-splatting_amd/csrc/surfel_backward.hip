@@ -7,11 +7,12 @@
 // Two variants, bit-identical by construction (same per-pair arithmetic, same summation tree), selected by BlendBwdArgs.variant:
 //   rows (default): every DPP row of 16 lanes owns a 4x4-pixel sub-tile and walks ITS OWN instance bitmask, so a wave works on
 //                   four instances per visit and a small surfel occupies issue slots only in the sub-tiles its alpha >= 1/255
-//                   footprint reaches.  Row totals (20 values, 40 DPP adds, no cross-row traffic) go to private LDS slots —
+//                   footprint reaches.  Row totals (18 values, 38 DPP adds in one block, no cross-row traffic) go to private LDS slots —
 //                   one per (instance, overlapped sub-tile), packed by a prefix sum, 256 slots per round — and a flush pass
 //                   adds an instance's slots in the tree order ((r0+r1)+(r2+r3)) per wave, waves 0..3.
 //   quad          : a wave (8x8 pixels) walks the instances its quad overlaps, one per visit, wave-wide reduction
-//                   (40 DPP adds + 5 permlane swaps), per-wave LDS partials.  Kept as the yardstick: it is what round 1 shipped.
+//                   (38 DPP adds + 5 permlane swaps), per-wave LDS partials.  Round 1's kernel; the faster walk on wide footprints.
+// Which of the two runs is decided by the caller (surfel_api.hip: timed probes, `bwd_tune`) or, for variant 2, on the device.
 // Semantics: oracle/surfel_oracle.c stages 4-5 (restating the absent diff-surfel-rasterization).
 #include "surfel_common.h"
 #include "surfel_kernels.h"

@@ -30,7 +30,7 @@ struct BlendBwdArgs {
     const float* final_T; const uint32_t* n_contrib;
     const float* dL_dpix; const float* dL_dothers;
     float* grec;      // [R][GREC_F] per-instance gradient records (every record written exactly once)
-    int variant;      // 0: per-DPP-row walk, 1: per-wave (8x8 quad) walk, 2: chosen on the device from the frame's totals; bit-identical results
+    int variant;      // 0: per-DPP-row walk, 1: per-wave (8x8 quad) walk, 2: both launched, the device picks from the frame's totals; bit-identical results
     const uint32_t* totals;      // [2 * R_SLOTS] partial sums written by preprocess: tile instances | visible surfels
     unsigned long long* stats;   // optional [4]: lane slots issued, useful (pixel, surfel) lanes, wave visits, row / quad visits
 };
