@@ -287,7 +287,11 @@ class Trainer:
             if early:
                 _n.set_backward_hook(None)
         if self._early_err is not None:
-            raise self._early_err
+            # the early all-gather could not be launched from inside the backward: dL/dcolour is final regardless (the split
+            # kernel ran), so the step continues with the gather-after-backward form and the early form stays off
+            import warnings
+            warnings.warn("early colour all-gather disabled after: %r" % (self._early_err,))
+            self.early_gather, self._early, self._early_err = False, None, None
         self.last = dict(loss=scalars[5], scalars=scalars, points=m.P, radii=radii)     # [Ll1, ssim, normal_err, dist, photometric, total] on the device
         with torch.no_grad():
             rebuilt = False
