@@ -19,18 +19,30 @@ inline int launched(const char* what) {
 
 extern "C" {
 
-int surfel_l1_ssim_forward(int planes, int H, int W, const float* img, const float* gt, float* dmaps, float* partials, void* stream) {
+int surfel_l1_ssim_forward_w(int window_size, int planes, int H, int W, const float* img, const float* gt, float* dmaps, float* partials,
+                             void* stream) {
     if (planes <= 0 || H <= 0 || W <= 0 || !img || !gt || !partials) return api_fail(SURFEL_E_INVALID, "l1_ssim_forward: bad arguments");
-    launch_ssim_fwd(planes, H, W, img, gt, dmaps, partials, static_cast<hipStream_t>(stream));
+    if (!launch_ssim_fwd(window_size, planes, H, W, img, gt, dmaps, partials, static_cast<hipStream_t>(stream)))
+        return api_fail(SURFEL_E_INVALID, "l1_ssim_forward: window_size must be odd and in 3..15");
     const int rc = launched("ssim_fwd_kernel");
     return rc < 0 ? rc : ssim_blocks(H, W);
 }
 
+int surfel_l1_ssim_backward_w(int window_size, int planes, int H, int W, const float* img, const float* gt, const float* dmaps, float c_l1,
+                              float c_ssim, const float* g_l1_dev, const float* g_ssim_dev, float* grad_img, void* stream) {
+    if (planes <= 0 || H <= 0 || W <= 0 || !img || !gt || !dmaps || !grad_img) return api_fail(SURFEL_E_INVALID, "l1_ssim_backward: bad arguments");
+    if (!launch_ssim_bwd(window_size, planes, H, W, img, gt, dmaps, c_l1, c_ssim, g_l1_dev, g_ssim_dev, grad_img, static_cast<hipStream_t>(stream)))
+        return api_fail(SURFEL_E_INVALID, "l1_ssim_backward: window_size must be odd and in 3..15");
+    return launched("ssim_bwd_kernel");
+}
+
+int surfel_l1_ssim_forward(int planes, int H, int W, const float* img, const float* gt, float* dmaps, float* partials, void* stream) {
+    return surfel_l1_ssim_forward_w(11, planes, H, W, img, gt, dmaps, partials, stream);
+}
+
 int surfel_l1_ssim_backward(int planes, int H, int W, const float* img, const float* gt, const float* dmaps, float c_l1, float c_ssim,
                             const float* g_l1_dev, const float* g_ssim_dev, float* grad_img, void* stream) {
-    if (planes <= 0 || H <= 0 || W <= 0 || !img || !gt || !dmaps || !grad_img) return api_fail(SURFEL_E_INVALID, "l1_ssim_backward: bad arguments");
-    launch_ssim_bwd(planes, H, W, img, gt, dmaps, c_l1, c_ssim, g_l1_dev, g_ssim_dev, grad_img, static_cast<hipStream_t>(stream));
-    return launched("ssim_bwd_kernel");
+    return surfel_l1_ssim_backward_w(11, planes, H, W, img, gt, dmaps, c_l1, c_ssim, g_l1_dev, g_ssim_dev, grad_img, stream);
 }
 
 int surfel_render_post_forward(int H, int W, const float* allmap, const float* cam, float depth_ratio, float* maps, float* partials,

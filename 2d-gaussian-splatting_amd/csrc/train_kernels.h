@@ -8,8 +8,9 @@
 namespace surfel {
 
 int ssim_blocks(int H, int W);
-void launch_ssim_fwd(int planes, int H, int W, const float* img, const float* gt, float* dmaps, float* partials, hipStream_t s);
-void launch_ssim_bwd(int planes, int H, int W, const float* img, const float* gt, const float* dmaps, float c_l1, float c_ssim,
+// window = the reference's window_size (odd, 3..15; loss_utils.py:43 default 11); false = unsupported size, nothing launched
+bool launch_ssim_fwd(int window, int planes, int H, int W, const float* img, const float* gt, float* dmaps, float* partials, hipStream_t s);
+bool launch_ssim_bwd(int window, int planes, int H, int W, const float* img, const float* gt, const float* dmaps, float c_l1, float c_ssim,
                      const float* g_l1_dev, const float* g_ssim_dev, float* grad_img, hipStream_t s);
 void launch_reduce_partials(const float* partials, int groups, int n, int stride, float scale, float* out, hipStream_t s);
 void launch_loss_finalize(const float* pa, int na, float scale_a, const float* pb, int nb, float scale_b, float lambda_dssim,

@@ -1,8 +1,11 @@
 // train_loss.hip — photometric loss of a training iteration on gfx950: L1 + SSIM forward and backward.
-// Restates utils/loss_utils.py:23-24,43-73 of the reference (11x11 window, sigma 1.5, zero padding, C1 = 0.01^2,
-// C2 = 0.03^2) as two LDS-tiled separable-convolution kernels instead of five grouped conv2d calls + ~20 elementwise
-// kernels per direction.  One workgroup = 4 waves = a 32x32 output tile staged with a 5-pixel halo (42x42).
+// Restates utils/loss_utils.py:23-24,43-73 of the reference (window_size x window_size Gaussian window, sigma 1.5, zero padding,
+// C1 = 0.01^2, C2 = 0.03^2) as two LDS-tiled separable-convolution kernels instead of five grouped conv2d calls + ~20 elementwise
+// kernels per direction.  One workgroup = 4 waves = a 32x32 output tile staged with a halo of the window radius (42x42 for the
+// reference's window_size = 11; the kernels are templates on the radius, odd window sizes 3..15 are instantiated).
 #include <hip/hip_runtime.h>
+
+#include <cmath>
 
 #include "surfel_common.h"
 #include "train_kernels.h"
@@ -12,16 +15,20 @@ namespace surfel {
 namespace {
 
 constexpr int ST = 32;             // output tile edge
-constexpr int SR = 5;              // window radius
-constexpr int SHALO = ST + 2 * SR; // 42
-constexpr int NSTAGE = (SHALO * SHALO + 255) / 256;   // staged elements per thread (7)
+// per window radius SR: SHALO = staged tile edge (42 for SR = 5), NSTAGE = staged elements per thread (7), NE = consecutive
+// elements a thread slides its (2 SR + 1)-tap window over to produce 4 outputs (14), XP = float2 pitch of the staged tile
+// (even: 16-B aligned b128 reads at even columns)
+#define SSIM_GEOMETRY(SR)                                                                                           \
+    constexpr int SHALO = ST + 2 * (SR), NSTAGE = (SHALO * SHALO + 255) / 256, NE = 4 + 2 * (SR), NW = 2 * (SR) + 1, \
+                  XP = SHALO + 4
+struct SsimWin { float w[15]; };     // the normalised 1-D Gaussian window, passed by value
 constexpr float SSIM_C1 = 0.01f * 0.01f;
 constexpr float SSIM_C2 = 0.03f * 0.03f;
 
 // gaussian(11, 1.5) of loss_utils.py:29-31 evaluated in fp32 exactly as torch does (exp in double, stored fp32, fp32 sum)
-__device__ __constant__ float kG[11] = {1.028380124e-03f, 7.598758209e-03f, 3.600077331e-02f, 1.093606874e-01f,
-                                        2.130055279e-01f, 2.660117149e-01f, 2.130055279e-01f, 1.093606874e-01f,
-                                        3.600077331e-02f, 7.598758209e-03f, 1.028380124e-03f};
+constexpr float kG11[11] = {1.028380124e-03f, 7.598758209e-03f, 3.600077331e-02f, 1.093606874e-01f,
+                            2.130055279e-01f, 2.660117149e-01f, 2.130055279e-01f, 1.093606874e-01f,
+                            3.600077331e-02f, 7.598758209e-03f, 1.028380124e-03f};
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
@@ -29,14 +36,15 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
-// LDS layout (42 KB -> 3 workgroups / CU): the staged 42x42 tile as float2 (x,y) with pitch XP, the horizontal moments as
-// float4 (E[x], E[y], E[x^2], E[y^2]) with pitch HZP + float (E[xy]).  Each thread slides an 11-tap window over 14 consecutive
-// elements held in registers (4 outputs per 14 LDS reads instead of 44), horizontally then vertically.
-constexpr int XP = 46;            // float2 pitch of the staged tile (even: 16-B aligned b128 reads at even columns)
+// LDS layout (42 KB at window 11 -> 3 workgroups / CU): the staged tile as float2 (x,y) with pitch XP, the horizontal moments as
+// float4 (E[x], E[y], E[x^2], E[y^2]) with pitch HZP + float (E[xy]).  Each thread slides the window over NE consecutive
+// elements held in registers (window 11: 4 outputs per 14 LDS reads instead of 44), horizontally then vertically.
 constexpr int HZP = ST + 1;       // float4 pitch of the horizontal-pass result
 
+template <int SR>
 __global__ __launch_bounds__(256) void ssim_fwd_kernel(int H, int W, const float* __restrict__ img, const float* __restrict__ gt,
-                                                       float* __restrict__ dmaps, size_t map_stride, float* __restrict__ partials) {
+                                                       float* __restrict__ dmaps, size_t map_stride, float* __restrict__ partials, SsimWin win) {
+    SSIM_GEOMETRY(SR);
     __shared__ float2 sxy[SHALO * XP];
     __shared__ float4 hz4[SHALO * HZP];
     __shared__ float hz1[SHALO * ST];
@@ -51,7 +59,7 @@ __global__ __launch_bounds__(256) void ssim_fwd_kernel(int H, int W, const float
     const size_t poff = (size_t)plane * H * W;
     const float* X = img + poff;
     const float* Y = gt + poff;
-    {   // stage the 42x42 tile: ALL of a thread's 7 x 2 loads are issued before the first one is consumed (as a rolled loop this
+    {   // stage the tile (42x42 at window 11): ALL of a thread's 7 x 2 loads are issued before the first one is consumed (as a rolled loop this
         // was seven dependent global round trips per workgroup — most of the kernel's time)
         float2 v[NSTAGE];
 #pragma unroll
@@ -73,20 +81,20 @@ __global__ __launch_bounds__(256) void ssim_fwd_kernel(int H, int W, const float
     // horizontal pass: item = (row r of 42, group of 4 output columns)
     for (int it = tid; it < SHALO * (ST / 4); it += 256) {
         const int r = it >> 3, c0 = (it & 7) << 2;
-        float xv[14], yv[14];
+        float xv[NE], yv[NE];
         const float4* src = reinterpret_cast<const float4*>(&sxy[r * XP + c0]);
 #pragma unroll
-        for (int k = 0; k < 7; k++) { const float4 t = src[k]; xv[2 * k] = t.x; yv[2 * k] = t.y; xv[2 * k + 1] = t.z; yv[2 * k + 1] = t.w; }
+        for (int k = 0; k < NE / 2; k++) { const float4 t = src[k]; xv[2 * k] = t.x; yv[2 * k] = t.y; xv[2 * k + 1] = t.z; yv[2 * k + 1] = t.w; }
         float a[4] = {0.f, 0.f, 0.f, 0.f}, b[4] = {0.f, 0.f, 0.f, 0.f}, aa[4] = {0.f, 0.f, 0.f, 0.f}, bb[4] = {0.f, 0.f, 0.f, 0.f},
               ab[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int e = 0; e < 14; e++) {
+        for (int e = 0; e < NE; e++) {
             const float x = xv[e], y = yv[e], xx = x * x, yy = y * y, xy = x * y;
 #pragma unroll
             for (int j = 0; j < 4; j++) {
                 const int k = e - j;
-                if (k >= 0 && k < 11) {
-                    const float w = kG[k];
+                if (k >= 0 && k < NW) {
+                    const float w = win.w[k];
                     a[j] += w * x; b[j] += w * y; aa[j] += w * xx; bb[j] += w * yy; ab[j] += w * xy;
                 }
             }
@@ -103,14 +111,14 @@ __global__ __launch_bounds__(256) void ssim_fwd_kernel(int H, int W, const float
     float mu1[4] = {0.f, 0.f, 0.f, 0.f}, mu2[4] = {0.f, 0.f, 0.f, 0.f}, e11[4] = {0.f, 0.f, 0.f, 0.f}, e22[4] = {0.f, 0.f, 0.f, 0.f},
           e12[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int e = 0; e < 14; e++) {
+    for (int e = 0; e < NE; e++) {
         const float4 h = hz4[(4 * g + e) * HZP + c];
         const float h1 = hz1[(4 * g + e) * ST + c];
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             const int k = e - j;
-            if (k >= 0 && k < 11) {
-                const float w = kG[k];
+            if (k >= 0 && k < NW) {
+                const float w = win.w[k];
                 mu1[j] += w * h.x; mu2[j] += w * h.y; e11[j] += w * h.z; e22[j] += w * h.w; e12[j] += w * h1;
             }
         }
@@ -148,10 +156,12 @@ __global__ __launch_bounds__(256) void ssim_fwd_kernel(int H, int W, const float
     }
 }
 
+template <int SR>
 __global__ __launch_bounds__(256) void ssim_bwd_kernel(int H, int W, const float* __restrict__ img, const float* __restrict__ gt,
                                                        const float* __restrict__ dmaps, size_t map_stride, float c_l1, float c_ssim,
                                                        const float* __restrict__ g_l1_dev, const float* __restrict__ g_ssim_dev,
-                                                       float* __restrict__ grad_img) {
+                                                       float* __restrict__ grad_img, SsimWin win) {
+    SSIM_GEOMETRY(SR);
     __shared__ float2 s12[SHALO * XP];      // (M1, M2)
     __shared__ float s3[SHALO * XP];        // M3
     __shared__ float4 hz[SHALO * HZP];      // horizontal pass of (M1, M2, M3, -)
@@ -186,20 +196,20 @@ __global__ __launch_bounds__(256) void ssim_bwd_kernel(int H, int W, const float
     __syncthreads();
     for (int it = tid; it < SHALO * (ST / 4); it += 256) {
         const int r = it >> 3, c0 = (it & 7) << 2;
-        float m1[14], m2[14], m3[14];
+        float m1[NE], m2[NE], m3[NE];
         const float4* src = reinterpret_cast<const float4*>(&s12[r * XP + c0]);
 #pragma unroll
-        for (int k = 0; k < 7; k++) { const float4 t = src[k]; m1[2 * k] = t.x; m2[2 * k] = t.y; m1[2 * k + 1] = t.z; m2[2 * k + 1] = t.w; }
+        for (int k = 0; k < NE / 2; k++) { const float4 t = src[k]; m1[2 * k] = t.x; m2[2 * k] = t.y; m1[2 * k + 1] = t.z; m2[2 * k + 1] = t.w; }
         const float2* src3 = reinterpret_cast<const float2*>(&s3[r * XP + c0]);
 #pragma unroll
-        for (int k = 0; k < 7; k++) { const float2 t = src3[k]; m3[2 * k] = t.x; m3[2 * k + 1] = t.y; }
+        for (int k = 0; k < NE / 2; k++) { const float2 t = src3[k]; m3[2 * k] = t.x; m3[2 * k + 1] = t.y; }
         float a[4] = {0.f, 0.f, 0.f, 0.f}, b[4] = {0.f, 0.f, 0.f, 0.f}, d[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int e = 0; e < 14; e++) {
+        for (int e = 0; e < NE; e++) {
 #pragma unroll
             for (int j = 0; j < 4; j++) {
                 const int k = e - j;
-                if (k >= 0 && k < 11) { const float w = kG[k]; a[j] += w * m1[e]; b[j] += w * m2[e]; d[j] += w * m3[e]; }
+                if (k >= 0 && k < NW) { const float w = win.w[k]; a[j] += w * m1[e]; b[j] += w * m2[e]; d[j] += w * m3[e]; }
             }
         }
 #pragma unroll
@@ -210,12 +220,12 @@ __global__ __launch_bounds__(256) void ssim_bwd_kernel(int H, int W, const float
     const int c = tid & 31, g = tid >> 5;
     float a[4] = {0.f, 0.f, 0.f, 0.f}, b[4] = {0.f, 0.f, 0.f, 0.f}, d[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int e = 0; e < 14; e++) {
+    for (int e = 0; e < NE; e++) {
         const float4 h = hz[(4 * g + e) * HZP + c];
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             const int k = e - j;
-            if (k >= 0 && k < 11) { const float w = kG[k]; a[j] += w * h.x; b[j] += w * h.y; d[j] += w * h.z; }
+            if (k >= 0 && k < NW) { const float w = win.w[k]; a[j] += w * h.x; b[j] += w * h.y; d[j] += w * h.z; }
         }
     }
 #pragma unroll
@@ -287,16 +297,66 @@ __global__ __launch_bounds__(1024) void loss_finalize_kernel(const float* __rest
 
 int ssim_blocks(int H, int W) { return ((W + ST - 1) / ST) * ((H + ST - 1) / ST); }
 
-void launch_ssim_fwd(int planes, int H, int W, const float* img, const float* gt, float* dmaps, float* partials, hipStream_t s) {
-    dim3 grid(ssim_blocks(H, W) * planes);
-    hipLaunchKernelGGL(ssim_fwd_kernel, grid, dim3(256), 0, s, H, W, img, gt, dmaps, (size_t)planes * H * W, partials);
+// The window of loss_utils.py:29-31: exp(-(x - ws/2)^2 / (2 sigma^2)) evaluated in double (Python floats), stored as float32
+// (torch.Tensor), divided by its float32 sum.  window_size 11 uses the table pinned against the reference's own tensor.
+static bool ssim_window(int window, SsimWin* w) {
+    if (window < 3 || window > 15 || (window & 1) == 0) return false;
+    for (int i = 0; i < 15; i++) w->w[i] = 0.f;
+    if (window == 11) { for (int i = 0; i < 11; i++) w->w[i] = kG11[i]; return true; }
+    float g[15], sum = 0.f;
+    for (int i = 0; i < window; i++) {
+        const double d = (double)(i - window / 2);
+        g[i] = (float)exp(-(d * d) / (2.0 * 1.5 * 1.5));
+        sum += g[i];
+    }
+    for (int i = 0; i < window; i++) w->w[i] = g[i] / sum;
+    return true;
 }
 
-void launch_ssim_bwd(int planes, int H, int W, const float* img, const float* gt, const float* dmaps, float c_l1, float c_ssim,
-                     const float* g_l1_dev, const float* g_ssim_dev, float* grad_img, hipStream_t s) {
+template <int SR>
+static void ssim_fwd_launch(dim3 grid, hipStream_t s, int H, int W, const float* img, const float* gt, float* dmaps, size_t stride, float* partials,
+                            const SsimWin& win) {
+    hipLaunchKernelGGL(ssim_fwd_kernel<SR>, grid, dim3(256), 0, s, H, W, img, gt, dmaps, stride, partials, win);
+}
+template <int SR>
+static void ssim_bwd_launch(dim3 grid, hipStream_t s, int H, int W, const float* img, const float* gt, const float* dmaps, size_t stride, float c_l1,
+                            float c_ssim, const float* g_l1_dev, const float* g_ssim_dev, float* grad_img, const SsimWin& win) {
+    hipLaunchKernelGGL(ssim_bwd_kernel<SR>, grid, dim3(256), 0, s, H, W, img, gt, dmaps, stride, c_l1, c_ssim, g_l1_dev, g_ssim_dev, grad_img, win);
+}
+
+bool launch_ssim_fwd(int window, int planes, int H, int W, const float* img, const float* gt, float* dmaps, float* partials, hipStream_t s) {
+    SsimWin win;
+    if (!ssim_window(window, &win)) return false;
     dim3 grid(ssim_blocks(H, W) * planes);
-    hipLaunchKernelGGL(ssim_bwd_kernel, grid, dim3(256), 0, s, H, W, img, gt, dmaps, (size_t)planes * H * W, c_l1, c_ssim, g_l1_dev,
-                       g_ssim_dev, grad_img);
+    const size_t stride = (size_t)planes * H * W;
+    switch (window / 2) {
+        case 1: ssim_fwd_launch<1>(grid, s, H, W, img, gt, dmaps, stride, partials, win); break;
+        case 2: ssim_fwd_launch<2>(grid, s, H, W, img, gt, dmaps, stride, partials, win); break;
+        case 3: ssim_fwd_launch<3>(grid, s, H, W, img, gt, dmaps, stride, partials, win); break;
+        case 4: ssim_fwd_launch<4>(grid, s, H, W, img, gt, dmaps, stride, partials, win); break;
+        case 5: ssim_fwd_launch<5>(grid, s, H, W, img, gt, dmaps, stride, partials, win); break;
+        case 6: ssim_fwd_launch<6>(grid, s, H, W, img, gt, dmaps, stride, partials, win); break;
+        default: ssim_fwd_launch<7>(grid, s, H, W, img, gt, dmaps, stride, partials, win); break;
+    }
+    return true;
+}
+
+bool launch_ssim_bwd(int window, int planes, int H, int W, const float* img, const float* gt, const float* dmaps, float c_l1, float c_ssim,
+                     const float* g_l1_dev, const float* g_ssim_dev, float* grad_img, hipStream_t s) {
+    SsimWin win;
+    if (!ssim_window(window, &win)) return false;
+    dim3 grid(ssim_blocks(H, W) * planes);
+    const size_t stride = (size_t)planes * H * W;
+    switch (window / 2) {
+        case 1: ssim_bwd_launch<1>(grid, s, H, W, img, gt, dmaps, stride, c_l1, c_ssim, g_l1_dev, g_ssim_dev, grad_img, win); break;
+        case 2: ssim_bwd_launch<2>(grid, s, H, W, img, gt, dmaps, stride, c_l1, c_ssim, g_l1_dev, g_ssim_dev, grad_img, win); break;
+        case 3: ssim_bwd_launch<3>(grid, s, H, W, img, gt, dmaps, stride, c_l1, c_ssim, g_l1_dev, g_ssim_dev, grad_img, win); break;
+        case 4: ssim_bwd_launch<4>(grid, s, H, W, img, gt, dmaps, stride, c_l1, c_ssim, g_l1_dev, g_ssim_dev, grad_img, win); break;
+        case 5: ssim_bwd_launch<5>(grid, s, H, W, img, gt, dmaps, stride, c_l1, c_ssim, g_l1_dev, g_ssim_dev, grad_img, win); break;
+        case 6: ssim_bwd_launch<6>(grid, s, H, W, img, gt, dmaps, stride, c_l1, c_ssim, g_l1_dev, g_ssim_dev, grad_img, win); break;
+        default: ssim_bwd_launch<7>(grid, s, H, W, img, gt, dmaps, stride, c_l1, c_ssim, g_l1_dev, g_ssim_dev, grad_img, win); break;
+    }
+    return true;
 }
 
 void launch_reduce_partials(const float* partials, int groups, int n, int stride, float scale, float* out, hipStream_t s) {

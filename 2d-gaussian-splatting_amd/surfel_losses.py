@@ -31,7 +31,7 @@ class _L1SSIM(torch.autograd.Function):
     """Returns the two means (mean |img-gt|, mean SSIM map) as a [2] tensor; backward is one kernel."""
 
     @staticmethod
-    def forward(ctx, img, gt):
+    def forward(ctx, img, gt, window=11):
         planes, H, W = _planes(img, gt)
         x = img.detach().contiguous().float(); y = gt.detach().contiguous().float()
         dev = x.device
@@ -43,10 +43,12 @@ class _L1SSIM(torch.autograd.Function):
         out = torch.empty((2,), dtype=torch.float32, device=dev)
         s = _n.current_stream_ptr(dev)
         with torch.cuda.device(dev):
-            _check(lib.surfel_l1_ssim_forward(planes, H, W, _n.ptr(x), _n.ptr(y), _n.ptr(dmaps), _n.ptr(partials), s), "surfel_l1_ssim_forward")
+            _check(lib.surfel_l1_ssim_forward_w(int(window), planes, H, W, _n.ptr(x), _n.ptr(y), _n.ptr(dmaps), _n.ptr(partials), s),
+                   "surfel_l1_ssim_forward")
             _check(lib.surfel_reduce_partials(_n.ptr(partials), 1, planes * nblk, 2, 1.0 / (planes * H * W), _n.ptr(out), s),
                    "surfel_reduce_partials")
         ctx.dims = (planes, H, W)
+        ctx.window = int(window)
         ctx.in_shape = tuple(img.shape)
         if need:
             ctx.save_for_backward(x, y, dmaps)
@@ -62,13 +64,13 @@ class _L1SSIM(torch.autograd.Function):
         g = g.contiguous().float()          # (dL/d mean|.|, dL/d mean S), stays on the device
         grad = torch.empty_like(x)
         with torch.cuda.device(dev):
-            _check(lib.surfel_l1_ssim_backward(planes, H, W, _n.ptr(x), _n.ptr(y), _n.ptr(dmaps), 1.0 / N, 1.0 / N, _n.ptr(g[0:1]), _n.ptr(g[1:2]),
-                                               _n.ptr(grad), _n.current_stream_ptr(dev)), "surfel_l1_ssim_backward")
-        return grad.view(ctx.in_shape), None
+            _check(lib.surfel_l1_ssim_backward_w(ctx.window, planes, H, W, _n.ptr(x), _n.ptr(y), _n.ptr(dmaps), 1.0 / N, 1.0 / N, _n.ptr(g[0:1]),
+                                                 _n.ptr(g[1:2]), _n.ptr(grad), _n.current_stream_ptr(dev)), "surfel_l1_ssim_backward")
+        return grad.view(ctx.in_shape), None, None
 
 
-def _means(img, gt):
-    out = _L1SSIM.apply(img, gt)
+def _means(img, gt, window=11):
+    out = _L1SSIM.apply(img, gt, window)
     return out
 
 
@@ -81,7 +83,7 @@ class _SSIMPerImage(torch.autograd.Function):
     """size_average=False (utils/loss_utils.py:70-73): one mean SSIM per batch element of a [B,C,H,W] input."""
 
     @staticmethod
-    def forward(ctx, img, gt):
+    def forward(ctx, img, gt, window=11):
         B, C, H, W = (int(v) for v in img.shape)
         x = img.detach().contiguous().float(); y = gt.detach().contiguous().float()
         dev = x.device
@@ -90,9 +92,10 @@ class _SSIMPerImage(torch.autograd.Function):
         dmaps = torch.empty((3, B * C, H, W), dtype=torch.float32, device=dev)
         partials = torch.empty((B * C * nblk, 2), dtype=torch.float32, device=dev)
         with torch.cuda.device(dev):
-            _check(lib.surfel_l1_ssim_forward(B * C, H, W, _n.ptr(x), _n.ptr(y), _n.ptr(dmaps), _n.ptr(partials), _n.current_stream_ptr(dev)),
-                   "surfel_l1_ssim_forward")
+            _check(lib.surfel_l1_ssim_forward_w(int(window), B * C, H, W, _n.ptr(x), _n.ptr(y), _n.ptr(dmaps), _n.ptr(partials),
+                                                _n.current_stream_ptr(dev)), "surfel_l1_ssim_forward")
         ctx.dims = (B, C, H, W)
+        ctx.window = int(window)
         ctx.save_for_backward(x, y, dmaps)
         return partials.view(B, C * nblk, 2)[:, :, 1].sum(1) / float(C * H * W)
 
@@ -108,24 +111,25 @@ class _SSIMPerImage(torch.autograd.Function):
         with torch.cuda.device(dev):
             for b in range(B):        # one launch per batch element: its own upstream scalar
                 dm = dmaps[:, b * C:(b + 1) * C].contiguous()
-                _check(lib.surfel_l1_ssim_backward(C, H, W, _n.ptr(x[b]), _n.ptr(y[b]), _n.ptr(dm), 0.0, 1.0 / float(C * H * W), None, _n.ptr(g[b:b + 1]),
-                                                   _n.ptr(grad[b]), s), "surfel_l1_ssim_backward")
-        return grad, None
+                _check(lib.surfel_l1_ssim_backward_w(ctx.window, C, H, W, _n.ptr(x[b]), _n.ptr(y[b]), _n.ptr(dm), 0.0, 1.0 / float(C * H * W), None,
+                                                     _n.ptr(g[b:b + 1]), _n.ptr(grad[b]), s), "surfel_l1_ssim_backward")
+        return grad, None, None
 
 
 def ssim(img1, img2, window_size=11, size_average=True):
-    """SSIM with the reference's 11x11 sigma-1.5 window and zero padding (utils/loss_utils.py:43-73): the mean over everything
+    """SSIM with the reference's Gaussian window (sigma 1.5) and zero padding (utils/loss_utils.py:43-73): the mean over everything
     (size_average=True, what train.py uses) or one mean per batch element of a [B,C,H,W] input (size_average=False).
-    Other window sizes are not implemented by the HIP kernel (the reference never passes one) and raise."""
-    if window_size != 11:
-        raise NotImplementedError("the HIP kernel implements the reference's window_size=11 only (utils/loss_utils.py:43 default)")
+    window_size: odd, 3..15 (the reference's default and only call-site value is 11)."""
+    window_size = int(window_size)
+    if window_size < 3 or window_size > 15 or window_size % 2 == 0:
+        raise NotImplementedError("window_size must be odd and in 3..15 (the HIP kernels are instantiated for these radii)")
     if not size_average:
         if img1.dim() != 4:
             raise ValueError("size_average=False needs a [B,C,H,W] input (the reference reduces dims 1..3)")
         if img1.shape != img2.shape or img1.device.type != "cuda":
             raise RuntimeError("surfel_losses.ssim: shapes differ or tensors are not on a HIP device")
-        return _SSIMPerImage.apply(img1, img2)
-    return _means(img1, img2)[1]
+        return _SSIMPerImage.apply(img1, img2, window_size)
+    return _means(img1, img2, window_size)[1]
 
 
 class _PhotometricLoss(torch.autograd.Function):

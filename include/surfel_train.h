@@ -50,6 +50,14 @@ int surfel_l1_ssim_backward(int planes, int H, int W, const float* img, const fl
                             float c_l1, float c_ssim, const float* g_l1_dev, const float* g_ssim_dev, float* grad_img,
                             void* stream);
 
+/* The same two with the reference's `window_size` argument (utils/loss_utils.py:43, default 11; sigma stays 1.5): odd sizes
+ * 3..15, anything else returns SURFEL_E_INVALID.  The plain entry points above are these with window_size = 11. */
+int surfel_l1_ssim_forward_w(int window_size, int planes, int H, int W, const float* img, const float* gt, float* dmaps,
+                             float* partials, void* stream);
+int surfel_l1_ssim_backward_w(int window_size, int planes, int H, int W, const float* img, const float* gt, const float* dmaps,
+                              float c_l1, float c_ssim, const float* g_l1_dev, const float* g_ssim_dev, float* grad_img,
+                              void* stream);
+
 /*
  * Camera constants for the post-processing kernels, 24 floats on the device:
  *   [0..8]   A (row-major 3x3) = world_view_transform[:3,:3]: world normal = A * view normal

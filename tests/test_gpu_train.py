@@ -724,6 +724,46 @@ def test_ssim_per_image_matches_torch():
     grad_ok(ga.cpu().numpy(), a.grad.cpu().numpy(), frac=0.999, cos=0.9999)
 
 
+@pytest.mark.parametrize("ws", [3, 5, 7, 9, 13, 15])
+def test_ssim_other_window_sizes_match_torch(ws):
+    """ssim(window_size=ws) (utils/loss_utils.py:43: the reference's argument, default 11): the kernels are templates on the window
+    radius — value and gradient against a plain PyTorch fp32 statement of the reference's _ssim, both reductions; even or
+    out-of-range sizes raise."""
+    import torch
+    import torch.nn.functional as F
+    import surfel_losses as L
+    d = dev()
+    g = torch.Generator().manual_seed(ws)
+    B, C, H, W = 2, 3, 67, 101
+    a = torch.rand((B, C, H, W), generator=g).to(d).requires_grad_(True)
+    b = (a.detach() + 0.1 * torch.randn((B, C, H, W), generator=g).to(d)).clamp(0, 1)
+    k1 = torch.tensor([math.exp(-(x - ws // 2) ** 2 / (2 * 1.5 ** 2)) for x in range(ws)], device=d); k1 = k1 / k1.sum()
+    win = (k1[:, None] * k1[None, :]).expand(C, 1, ws, ws).contiguous()
+    conv = lambda t: F.conv2d(t, win, padding=ws // 2, groups=C)
+
+    def ref_map(x, y):
+        mu1, mu2 = conv(x), conv(y)
+        s1, s2, s12 = conv(x * x) - mu1 * mu1, conv(y * y) - mu2 * mu2, conv(x * y) - mu1 * mu2
+        C1, C2 = 0.01 ** 2, 0.03 ** 2
+        return ((2 * mu1 * mu2 + C1) * (2 * s12 + C2)) / ((mu1 * mu1 + mu2 * mu2 + C1) * (s1 + s2 + C2))
+
+    got = L.ssim(a, b, window_size=ws)                      # size_average=True: one scalar
+    got.backward(); ga = a.grad.clone(); a.grad = None
+    ref = ref_map(a, b).mean(); ref.backward(); gr = a.grad.clone(); a.grad = None
+    assert abs(float(got) - float(ref)) < 2e-5
+    grad_ok(ga.cpu().numpy(), gr.cpu().numpy(), frac=0.999, cos=0.9999)
+    wts = torch.randn(B, generator=g).to(d)
+    got = L.ssim(a, b, window_size=ws, size_average=False)
+    (got * wts).sum().backward(); ga = a.grad.clone(); a.grad = None
+    ref = ref_map(a, b).mean(1).mean(1).mean(1)
+    (ref * wts).sum().backward()
+    assert torch.allclose(got, ref, rtol=1e-4, atol=2e-5)
+    grad_ok(ga.cpu().numpy(), a.grad.cpu().numpy(), frac=0.999, cos=0.9999)
+    for bad in (2, 10, 17, 1):
+        with pytest.raises(NotImplementedError):
+            L.ssim(a, b, window_size=bad)
+
+
 def test_sh_degree_below_three(tmp_path):
     """--sh_degree 0..2 (/root/reference/arguments/__init__.py:49): the store keeps 16 coefficients, the inactive ones stay zero
     through training, and .ply / checkpoint hold (d+1)^2 - 1 f_rest coefficients like the reference's."""
