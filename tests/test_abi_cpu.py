@@ -137,3 +137,15 @@ def test_scratch_sizes_are_bucketed():
         prev = b
     # the creeping maxima of the C5 bench (instances x 80 B) share one bucket
     assert len({n.bucket_bytes(r * 80) for r in (129_137_928, 129_394_610, 129_434_296, 129_655_849, 129_770_365)}) == 1
+
+
+def test_surfel_options_environment_hook():
+    """SURFEL_OPTIONS="name=value,..." is applied through surfel_set_option when the library is loaded (how an unmodified caller
+    such as bench.py is A/B-tested); an unknown option name fails loudly."""
+    import subprocess
+    import sys
+    code = "import sys; sys.path.insert(0, %r); import surfel_native as n; n.load(); print('loaded')" % os.path.join(REPO, "2d-gaussian-splatting_amd")
+    ok = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, SURFEL_OPTIONS="bwd_variant=1, bwd_tune=0,cull=1"), capture_output=True, text=True)
+    assert ok.returncode == 0 and "loaded" in ok.stdout, ok.stderr[-2000:]
+    bad = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, SURFEL_OPTIONS="no_such_option=1"), capture_output=True, text=True)
+    assert bad.returncode != 0 and "no_such_option" in bad.stderr
