@@ -517,8 +517,9 @@ int surfel_rasterize_backward(surfel_alloc_fn scratch_alloc, void* scratch_user,
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (P == 0) return 0;
     if (!scratch_alloc || !geom_buffer || !binning_buffer || !image_buffer) return fail(SURFEL_E_INVALID, "buffer / allocator is NULL");
-    if (!dL_dout_color || !dL_dout_others || !dL_dmeans2D || !dL_dnormal || !dL_dopacity || !dL_dcolors || !dL_dmeans3D || !dL_dtransMat)
+    if (!dL_dout_color || !dL_dout_others || !dL_dmeans2D || !dL_dopacity || !dL_dcolors || !dL_dmeans3D)
         return fail(SURFEL_E_INVALID, "gradient pointer is NULL");
+    if (transMat_precomp && !dL_dtransMat) return fail(SURFEL_E_INVALID, "dL_dtransMat is NULL but transMat_precomp was given");
     if (!transMat_precomp && (!dL_dscales || !dL_drots || !scales || !rotations)) return fail(SURFEL_E_INVALID, "scale/rotation pointers are NULL");
     const int gx = (width + TILE - 1) / TILE, gy = (height + TILE - 1) / TILE;
 

@@ -446,11 +446,13 @@ __global__ void __launch_bounds__(256) preprocess_bwd_kernel(PreprocessBwdArgs a
     float4* __restrict__ gshq = (a.shs && a.dL_dsh) ? reinterpret_cast<float4*>(a.dL_dsh + (size_t)i * a.M * 3) : nullptr;
     if (!vis) {
         a.dL_dopacity[i] = 0.f;
-        store3(a.dL_dnormal, i, 0.f, 0.f, 0.f);
+        if (a.dL_dnormal) store3(a.dL_dnormal, i, 0.f, 0.f, 0.f);
         if (!a.keep_colors) store3(a.dL_dcolors, i, 0.f, 0.f, 0.f);
         store3(a.dL_dmeans2D, i, 0.f, 0.f, 0.f); store3(a.dL_dmeans3D, i, 0.f, 0.f, 0.f);
+        if (a.dL_dtransMat) {
 #pragma unroll
-        for (int q = 0; q < 9; q++) a.dL_dtransMat[9 * (size_t)i + q] = 0.f;
+            for (int q = 0; q < 9; q++) a.dL_dtransMat[9 * (size_t)i + q] = 0.f;
+        }
         if (!precomp) {
             reinterpret_cast<float2*>(a.dL_dscales)[i] = make_float2(0.f, 0.f);
             reinterpret_cast<float4*>(a.dL_drots)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -505,7 +507,7 @@ __global__ void __launch_bounds__(256) preprocess_bwd_kernel(PreprocessBwdArgs a
     }
     }
     a.dL_dopacity[i] = g[14];
-    store3(a.dL_dnormal, i, g[11], g[12], g[13]);
+    if (a.dL_dnormal) store3(a.dL_dnormal, i, g[11], g[12], g[13]);
     if (!a.keep_colors) store3(a.dL_dcolors, i, g[15], g[16], g[17]);
 
     const float T[9] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w, r2.x};
@@ -539,8 +541,10 @@ __global__ void __launch_bounds__(256) preprocess_bwd_kernel(PreprocessBwdArgs a
         for (int q = 0; q < 9; q++) a.dL_dtransMat[9 * (size_t)i + q] = gT[q];
         store3(a.dL_dmeans2D, i, gT[2] * T[8] * 0.5f * (float)a.W, gT[5] * T[8] * 0.5f * (float)a.H, 0.f);
     } else {
+        if (a.dL_dtransMat) {      // an intermediate on this path (the chain rule below continues to scales / rotations): optional
 #pragma unroll
-        for (int q = 0; q < 9; q++) a.dL_dtransMat[9 * (size_t)i + q] = g[q];
+            for (int q = 0; q < 9; q++) a.dL_dtransMat[9 * (size_t)i + q] = g[q];
+        }
         // densification statistic from the blend-stage dL/dT (before the centre term is folded in)
         store3(a.dL_dmeans2D, i, g[2] * T[8] * 0.5f * (float)a.W, g[5] * T[8] * 0.5f * (float)a.H, 0.f);
         const float* __restrict__ vm = a.viewmatrix;

@@ -137,9 +137,10 @@ class _RasterizeGaussians(torch.autograd.Function):
             if t is None or tuple(t.shape) != shape or t.dtype != torch.float32 or t.device != dev or not t.is_contiguous():
                 return z(*shape)          # no (matching) arena tensor: the default behaviour
             return t
-        g_means2D, g_normal, g_colors = out("means2D", P, 3), z(P, 3), out("colors", P, 3)
+        g_means2D, g_normal, g_colors = out("means2D", P, 3), None, out("colors", P, 3)      # dL/dnormal: internal, not requested
         g_opac = out("opacities", P, 1)
-        g_means3D, g_trans = out("means3D", P, 3), z(P, 9)
+        g_means3D = out("means3D", P, 3)
+        g_trans = z(P, 9) if has_cov else None      # an intermediate unless cov3D_precomp carries the gradient
         skip_sh = has_sh and "sh" in arena and arena["sh"] is None     # caller rebuilds dL/dSH from dL/dcolour (include/surfel_train.h)
         g_sh = out("sh", P, M, 3) if (has_sh and not skip_sh) else None
         g_scales = out("scales", P, 2) if has_sr else None

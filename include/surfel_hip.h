@@ -92,7 +92,8 @@ int64_t surfel_rasterize_forward(
  *   dL_dnormal[P,3], dL_dopacity[P], dL_dcolors[P,3] (w.r.t. colors_precomp; in SH mode w.r.t. the SH colour BEFORE the
  *   forward's clamp_min(0), i.e. zero where the forward clamped), dL_dmeans3D[P,3], dL_dtransMat[P,9],
  *   dL_dsh[P,M,3] (may be NULL: skipped — callers that rebuild it from dL_dcolors, include/surfel_train.h), dL_dscales[P,2],
- *   dL_drots[P,4].
+ *   dL_drots[P,4].  dL_dnormal and — unless transMat_precomp is given — dL_dtransMat are intermediates of the chain rule that no
+ *   caller of the reference's Python API receives: either may be NULL and is then not written (saves 48 B/surfel of stores).
  * `scratch_alloc` provides the per-instance gradient records (R * 80 bytes, each written exactly once);
  * gradients are accumulated without atomics, so results are bit-reproducible run to run.
  */

@@ -66,7 +66,8 @@ class HipRun:
         off = (self.P * 112 + 255) // 256 * 256
         return self.ga.last()[off:off + 4 * self.P].view(self.torch.float32).cpu().numpy()
 
-    def backward(self, gC, gO):
+    def backward(self, gC, gO, skip=()):
+        """skip: names of optional outputs ("normal", "transMat") passed as NULL; they are left out of the returned dict."""
         torch, n = self.torch, self.n
         z = lambda *s: torch.full(s, float('nan'), device=self.dev)   # poison: the kernels must write every element
         P, M = self.P, self.M
@@ -82,12 +83,13 @@ class HipRun:
                                                 n.ptr(self.proj), n.ptr(self.campos), a["tanfovx"], a["tanfovy"],
                                                 n.ptr(self.radii), n.ptr(self.ga.last()), n.ptr(self.ba.last()),
                                                 n.ptr(self.ia.last()), n.ptr(gC), n.ptr(gO), n.ptr(g["means2D"]),
-                                                n.ptr(g["normal"]), n.ptr(g["opacity"]), n.ptr(g["colors"]), n.ptr(g["means3D"]),
-                                                n.ptr(g["transMat"]), n.ptr(g["sh"]) if M else None, n.ptr(g["scales"]),
+                                                None if "normal" in skip else n.ptr(g["normal"]), n.ptr(g["opacity"]), n.ptr(g["colors"]),
+                                                n.ptr(g["means3D"]), None if "transMat" in skip else n.ptr(g["transMat"]),
+                                                n.ptr(g["sh"]) if M else None, n.ptr(g["scales"]),
                                                 n.ptr(g["rots"]), self.debug, n.current_stream_ptr(self.dev))
         assert rc >= 0, "backward failed: %s" % n.last_error()
         torch.cuda.synchronize()
-        return {k: v.cpu().numpy() for k, v in g.items()}
+        return {k: v.cpu().numpy() for k, v in g.items() if k not in skip}
 
 
 def frac_close(x, ref, atol, rtol):

@@ -400,6 +400,23 @@ def test_record_gather_variants_are_identical(kind):
         assert np.array_equal(res[0][k], res[1][k]), "%s: dL/d%s differs between the record-gather variants" % (kind, k)
 
 
+def test_optional_gradient_outputs_may_be_null():
+    """dL_dnormal and (without transMat_precomp) dL_dtransMat are intermediates no caller of the Python API receives: NULL skips the
+    stores and leaves every other output's bits alone; with transMat_precomp a NULL dL_dtransMat is an error."""
+    import surfel_native as n
+    sc = _stress_scene("plain", 35)
+    a = scene_args(sc)
+    rng = np.random.default_rng(5)
+    gC = rng.normal(size=(3, a["H"], a["W"])).astype(np.float32); gO = rng.normal(size=(7, a["H"], a["W"])).astype(np.float32)
+    run = HipRun(a).forward()
+    full = run.backward(gC, gO)
+    part = run.backward(gC, gO, skip=("normal", "transMat"))
+    assert set(full) - set(part) == {"normal", "transMat"}
+    for k in part:
+        assert np.array_equal(full[k], part[k], equal_nan=True), k
+    assert np.isfinite(full["transMat"]).all() and np.abs(full["normal"]).max() > 0
+
+
 def test_backward_hook_splits_off_the_colour_gradients():
     """surfel_set_backward_hook: with a hook installed the backward finalises dL/dcolour in a kernel of its own, calls the hook
     (where a multi-GPU caller starts its all-gather), then runs the chain rule without touching dL/dcolour again — every output
