@@ -47,7 +47,7 @@ int surfel_l1_ssim_backward(int planes, int H, int W, const float* img, const fl
 
 int surfel_render_post_forward(int H, int W, const float* allmap, const float* cam, float depth_ratio, float* maps, float* partials,
                                void* stream) {
-    if (H <= 0 || W <= 0 || !allmap || !cam || !maps) return api_fail(SURFEL_E_INVALID, "render_post_forward: bad arguments");
+    if (H <= 0 || W <= 0 || !allmap || !cam || (!maps && !partials)) return api_fail(SURFEL_E_INVALID, "render_post_forward: bad arguments");
     launch_post_fwd(H, W, allmap, cam, depth_ratio, maps, partials, static_cast<hipStream_t>(stream));
     const int rc = launched("post_fwd_kernel");
     return rc < 0 ? rc : post_blocks(H, W);

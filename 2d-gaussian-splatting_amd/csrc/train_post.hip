@@ -114,11 +114,13 @@ __global__ __launch_bounds__(256) void post_fwd_kernel(int H, int W, const float
         }
         const float dist = allmap[6 * HW + o];
         const float sd = surf_depth_at(allmap, HW, o, ratio);      // recomputed: recovering it from the staged point would lose bits
-        maps[o] = alpha;
-        maps[HW + o] = rn[0]; maps[2 * HW + o] = rn[1]; maps[3 * HW + o] = rn[2];
-        maps[4 * HW + o] = dist;
-        maps[5 * HW + o] = sd;
-        maps[6 * HW + o] = sn[0]; maps[7 * HW + o] = sn[1]; maps[8 * HW + o] = sn[2];
+        if (maps) {      // NULL: only the regulariser sums are wanted (the training loss: 36 B/pixel of stores saved)
+            maps[o] = alpha;
+            maps[HW + o] = rn[0]; maps[2 * HW + o] = rn[1]; maps[3 * HW + o] = rn[2];
+            maps[4 * HW + o] = dist;
+            maps[5 * HW + o] = sd;
+            maps[6 * HW + o] = sn[0]; maps[7 * HW + o] = sn[1]; maps[8 * HW + o] = sn[2];
+        }
         e_n = 1.f - (rn[0] * sn[0] + rn[1] * sn[1] + rn[2] * sn[2]);
         e_d = dist;
     }

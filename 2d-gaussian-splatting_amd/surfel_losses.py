@@ -203,9 +203,9 @@ class _TrainLoss(torch.autograd.Function):
             if reg:
                 am = allmap.detach().contiguous().float()
                 npost = ((W + 15) // 16) * ((H + 15) // 16)
-                maps = torch.empty((9, H, W), dtype=torch.float32, device=dev)
                 pb = torch.empty((npost, 2), dtype=torch.float32, device=dev)
-                _check(lib.surfel_render_post_forward(H, W, _n.ptr(am), _n.ptr(cam), float(depth_ratio), _n.ptr(maps), _n.ptr(pb), s),
+                # maps = NULL: only the two regulariser sums are needed (the backward recomputes from allmap)
+                _check(lib.surfel_render_post_forward(H, W, _n.ptr(am), _n.ptr(cam), float(depth_ratio), None, _n.ptr(pb), s),
                        "surfel_render_post_forward")
             _check(lib.surfel_loss_finalize(_n.ptr(partials), planes * nblk, planes * H * W, _n.ptr(pb), npost, H * W, float(lambda_dssim),
                                             float(lambda_normal) if reg else 0.0, float(lambda_dist) if reg else 0.0, _n.ptr(out), _n.ptr(total), s),
@@ -283,9 +283,8 @@ class _TrainLossBand(torch.autograd.Function):
             _check(lib.surfel_l1_ssim_forward(planes, He, W, _n.ptr(x), _n.ptr(y), _n.ptr(dmaps), _n.ptr(partials), s), "surfel_l1_ssim_forward")
             if reg:
                 am = allmap.detach().contiguous().float()
-                maps = torch.empty((9, He, W), dtype=torch.float32, device=dev)
                 pb = torch.empty((((W + 15) // 16) * ((He + 15) // 16), 2), dtype=torch.float32, device=dev)
-                _check(lib.surfel_render_post_forward(He, W, _n.ptr(am), _n.ptr(cam), float(depth_ratio), _n.ptr(maps), _n.ptr(pb), s),
+                _check(lib.surfel_render_post_forward(He, W, _n.ptr(am), _n.ptr(cam), float(depth_ratio), None, _n.ptr(pb), s),
                        "surfel_render_post_forward")
         sums = torch.zeros((4,), dtype=torch.float32, device=dev)
         sums[0:2] = partials.view(planes, nby, nbx, 2)[:, a // 32:(b + 31) // 32].sum((0, 1, 2))

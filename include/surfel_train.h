@@ -69,6 +69,8 @@ int surfel_l1_ssim_backward_w(int window_size, int planes, int H, int W, const f
  * Forward: allmap[7,H,W] (rasterizer output) -> maps[9,H,W]:
  *   0 rend_alpha | 1-3 rend_normal (world) | 4 rend_dist | 5 surf_depth | 6-8 surf_normal (* alpha, detached)
  *   partials [nblk, 2] or NULL: per-workgroup (sum (1 - rend_normal . surf_normal), sum rend_dist)   (train.py:83-85)
+ *   maps may be NULL when only the regulariser sums are wanted (the training loss: the backward recomputes from allmap); at
+ *   least one of maps / partials must be given.
  * Returns nblk.
  */
 int surfel_render_post_forward(int H, int W, const float* allmap, const float* cam, float depth_ratio, float* maps,
