@@ -67,6 +67,7 @@ struct GeomState {   // per-surfel state ("geomBuffer")
     float* rec; float* depths; uint32_t* tiles_touched; uint8_t* clamped;
     uint32_t *dkey_a, *dkey_b, *ord_a, *ord_b;   // depth-bit keys / surfel order (double buffers of the P-sized sort)
     uint32_t* offsets;                            // inclusive scan of tiles_touched in depth order
+    uint32_t* rects;                              // packed tile rect of every surfel (copy of record word 19: emission reads 4 B instead of a record line)
     char* temp; size_t temp_bytes;                // scratch of the P-sized sort, then of the scan
     static GeomState carve(void* base, int P, size_t temp_bytes, size_t* total) {
         Carver c(base); GeomState g;
@@ -77,6 +78,7 @@ struct GeomState {   // per-surfel state ("geomBuffer")
         g.dkey_a = c.take<uint32_t>(P); g.dkey_b = c.take<uint32_t>(P);
         g.ord_a = c.take<uint32_t>(P); g.ord_b = c.take<uint32_t>(P);
         g.offsets = c.take<uint32_t>(P);
+        g.rects = c.take<uint32_t>(P);
         g.temp = c.take<char>(temp_bytes);
         g.temp_bytes = temp_bytes;
         if (total) *total = c.size();
@@ -404,7 +406,7 @@ int64_t surfel_rasterize_forward(surfel_alloc_fn geom_alloc, void* geom_user, su
         pa.transMat_precomp = transMat_precomp; pa.colors_precomp = colors_precomp; pa.shs = shs;
         pa.viewmatrix = viewmatrix; pa.projmatrix = projmatrix; pa.campos = cam_pos;
         pa.rec = geom.rec; pa.depths = geom.depths; pa.depth_keys = geom.dkey_a; pa.ident = geom.ord_a; pa.radii = radii;
-        pa.tiles_touched = geom.tiles_touched; pa.clamped = geom.clamped; pa.total_instances = img.total;
+        pa.tiles_touched = geom.tiles_touched; pa.clamped = geom.clamped; pa.total_instances = img.total; pa.rects = geom.rects;
         uint32_t* scan_state = reinterpret_cast<uint32_t*>(geom.temp + psort_bytes);
         pa.zero_a = reinterpret_cast<uint32_t*>(geom.temp); pa.zero_a_words = (uint32_t)radix_sort_head_words((size_t)P);
         pa.zero_b = scan_state; pa.zero_b_words = (uint32_t)scan_scratch_words((size_t)P);
@@ -463,7 +465,7 @@ int64_t surfel_rasterize_forward(surfel_alloc_fn geom_alloc, void* geom_user, su
             uint32_t* va = odd ? bin.vals_alt : bin.point_list;
             uint32_t* vb = odd ? bin.point_list : bin.vals_alt;
             tm.begin();
-            launch_emit_instances(P, geom.rec, order, geom.offsets, bin.keys_a, va, gx, reinterpret_cast<uint32_t*>(bin.sort_temp),
+            launch_emit_instances(P, geom.rec, geom.rects, order, geom.offsets, bin.keys_a, va, gx, reinterpret_cast<uint32_t*>(bin.sort_temp),
                                   (uint32_t)radix_sort_head_words((size_t)R), s);
             STAGE_END(tm, ST_EMIT);
             tm.begin();

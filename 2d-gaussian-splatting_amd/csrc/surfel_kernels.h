@@ -13,6 +13,7 @@ struct PreprocessArgs {
     const float* transMat_precomp; const float* colors_precomp; const float* shs;
     const float* viewmatrix; const float* projmatrix; const float* campos;
     float* rec; float* depths; uint32_t* depth_keys; uint32_t* ident; int* radii; uint32_t* tiles_touched; uint8_t* clamped;
+    uint32_t* rects;          // packed emission rect per surfel (x0 | y0 << 10 | width << 20), a compact copy of record word 19
     uint32_t* total_instances;     // [2 * R_SLOTS], zeroed by the caller: partial sums of tiles_touched | of (tiles_touched > 0)
     uint32_t* zero_a; uint32_t zero_a_words;   // scratch words this kernel clears for the launches that follow
     uint32_t* zero_b; uint32_t zero_b_words;   // (sort head, scan state) — saves two memset launches
@@ -49,7 +50,7 @@ struct PreprocessBwdArgs {
 };
 
 void launch_preprocess_fwd(const PreprocessArgs& a, hipStream_t s);
-void launch_emit_instances(int P, float* rec, const uint32_t* order, const uint32_t* offsets_sorted, uint32_t* keys,
+void launch_emit_instances(int P, float* rec, const uint32_t* rects, const uint32_t* order, const uint32_t* offsets_sorted, uint32_t* keys,
                            uint32_t* vals, int gx, uint32_t* zero_ptr, uint32_t zero_words, hipStream_t s);
 void launch_tile_ranges(int64_t R, const uint32_t* keys, uint2* ranges, hipStream_t s);
 void launch_blend_fwd(const BlendFwdArgs& a, hipStream_t s);

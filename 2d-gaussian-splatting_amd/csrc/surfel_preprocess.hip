@@ -240,6 +240,7 @@ __device__ __forceinline__ uint32_t preprocess_one(const PreprocessArgs& a, cons
             }
         }
         const uint32_t rectbits = (uint32_t)ex0 | ((uint32_t)ey0 << 10) | ((uint32_t)(ex1 - ex0) << 20);
+        a.rects[i] = rectbits;
         rec[4] = make_float4(g, b, 0.f /* inst_base patched by emit_instances */, __uint_as_float(rectbits));
         rec[5] = make_float4(ecx, ecy, Sxx, Sxy);
         rec[6] = make_float4(Syy, r2sq, Sdet, 0.f);
@@ -293,7 +294,7 @@ __global__ void __launch_bounds__(256) preprocess_fwd_kernel(PreprocessArgs a) {
 // emit_instances also patches the record's inst_base (first instance slot of the surfel), which the
 // atomic-free backward uses to address its gradient records.
 // ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) emit_instances_kernel(int P, float* rec, const uint32_t* __restrict__ order,
+__global__ void __launch_bounds__(256) emit_instances_kernel(int P, float* rec, const uint32_t* __restrict__ rects, const uint32_t* __restrict__ order,
                                                              const uint32_t* __restrict__ offsets_sorted, uint32_t* __restrict__ keys,
                                                              uint32_t* __restrict__ vals, int gx, uint32_t* __restrict__ zero_ptr,
                                                              uint32_t zero_words) {
@@ -306,7 +307,7 @@ __global__ void __launch_bounds__(256) emit_instances_kernel(int P, float* rec, 
         n = (int)(offsets_sorted[k] - off);
         if (n > 0) {
             i = order[k];
-            rectbits = __float_as_uint(rec[(size_t)i * REC_F + 19]);
+            rectbits = rects[i];      // (written by preprocess_fwd for every surfel that emits)
             rec[(size_t)i * REC_F + 18] = __uint_as_float(off);
         }
     }
@@ -671,10 +672,10 @@ __global__ void __launch_bounds__(256) preprocess_bwd_kernel(PreprocessBwdArgs a
 void launch_preprocess_fwd(const PreprocessArgs& a, hipStream_t s) {
     if (a.P > 0) hipLaunchKernelGGL(preprocess_fwd_kernel, dim3((a.P + 255) / 256), dim3(256), 0, s, a);
 }
-void launch_emit_instances(int P, float* rec, const uint32_t* order, const uint32_t* offsets_sorted, uint32_t* keys, uint32_t* vals,
-                           int gx, uint32_t* zero_ptr, uint32_t zero_words, hipStream_t s) {
-    if (P > 0) hipLaunchKernelGGL(emit_instances_kernel, dim3((P + 255) / 256), dim3(256), 0, s, P, rec, order, offsets_sorted, keys, vals, gx,
-                                  zero_ptr, zero_words);
+void launch_emit_instances(int P, float* rec, const uint32_t* rects, const uint32_t* order, const uint32_t* offsets_sorted, uint32_t* keys,
+                           uint32_t* vals, int gx, uint32_t* zero_ptr, uint32_t zero_words, hipStream_t s) {
+    if (P > 0) hipLaunchKernelGGL(emit_instances_kernel, dim3((P + 255) / 256), dim3(256), 0, s, P, rec, rects, order, offsets_sorted, keys, vals,
+                                  gx, zero_ptr, zero_words);
 }
 void launch_tile_ranges(int64_t R, const uint32_t* keys, uint2* ranges, hipStream_t s) {
     if (R > 0) hipLaunchKernelGGL(tile_ranges_kernel, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, s, R, keys, ranges);
