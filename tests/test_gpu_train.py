@@ -836,3 +836,79 @@ def test_view_parallel_step_rehearsed_on_rccl_with_early_gather():
             assert torch.equal(a, b)
     finally:
         dist.destroy_process_group()
+
+
+def test_whole_training_iterations_match_the_oracle_chain():
+    """Three complete training iterations (train.py:54-138) of the HIP trainer against the same iterations composed from the CPU
+    oracles, every stage in fp64: oracle rasterizer forward -> L1 + SSIM and allmap post-processing + regularisers
+    (oracle/train_oracle.py, pinned to the reference's own Python) -> oracle rasterizer backward -> the reference's Adam set-up
+    on the reference's activations (AdamOracle) with the position-lr schedule.  Iteration k's loss terms depend on every update
+    before it, so matching scalars over the three iterations checks the glue between the individually tested stages (gradient
+    routing, lambda scaling, activations, learning rates).  Parameters: Adam's first steps move every element by ~lr * sign(g), so
+    an element whose gradient sits in fp32 noise may land 2 lr away — a fraction-close bar, as for the gradients."""
+    import torch
+    import surfel_model
+    import surfel_trainer as TR
+    from oracle import train_oracle as T
+    from oracle.surfel_oracle import Oracle
+    d = dev()
+    W, H, P = 80, 64, 600
+    cams = TR.orbit_cameras(1, W, H, device=d)
+    bg = torch.zeros(3, device=d)
+    gt_model = TR.synthetic_object(P, d, seed=4, px_scale=0.08)
+    TR.capture_views(gt_model, cams, bg)
+    cam = cams[0]
+    m = TR.synthetic_object(P, d, seed=5, px_scale=0.07)
+    m.spatial_lr_scale = 2.0
+    raw0 = {k: m._pv[k].detach().cpu().numpy().astype(np.float64).copy() for k in ("xyz", "opacity", "scaling", "rotation")}
+    sh0 = m._pv["sh"].detach().cpu().numpy().astype(np.float64).reshape(P, 16, 3).copy()
+    opt = TR.optimization_params(lambda_dist=100.0, lambda_normal=0.05, dist_from_iter=0, normal_from_iter=0, densify_from_iter=10 ** 9,
+                                 opacity_reset_interval=10 ** 9)
+    ratio = 0.3
+    os.environ["SURFEL_SH_FUSED"] = "1"
+    tr = TR.Trainer(m, cams, opt, TR.pipeline_params(depth_ratio=ratio))
+    hip_scalars = []
+    for _ in range(3):
+        tr.step()
+        hip_scalars.append(tr.last["scalars"].detach().cpu().numpy().astype(np.float64))
+    torch.cuda.synchronize()
+
+    # ---- the same three iterations on the CPU, fp64
+    O = Oracle("f64")
+    A = T.AdamOracle(raw0["xyz"], sh0[:, :1], sh0[:, 1:], raw0["opacity"], raw0["scaling"], raw0["rotation"])
+    gt = cam.original_image.cpu().numpy().astype(np.float64)
+    wvt = cam.world_view_transform.cpu().numpy(); fpt = cam.full_proj_transform.cpu().numpy(); campos = cam.camera_center.cpu().numpy()
+    tanx, tany = math.tan(cam.FoVx * 0.5), math.tan(cam.FoVy * 0.5)
+    p = {k: v.detach().numpy() for k, v in A.p.items()}
+    ora_scalars = []
+    for it in (1, 2, 3):
+        o, s, r = T.activate(p["opacity"], p["scaling"], p["rotation"])
+        feats = np.concatenate([p["f_dc"], p["f_rest"]], axis=1)
+        R, col, oth, radii, st = O.rasterize_forward(np.zeros(3), p["xyz"], None, o, s, r, 1.0, None, wvt, fpt, tanx, tany, H, W, feats, 3, campos)
+        ph = T.photometric(col, gt, opt.lambda_dssim)
+        rp = T.render_post_np(oth, wvt, fpt, W, H, ratio, lambda_normal=opt.lambda_normal, lambda_dist=opt.lambda_dist)
+        total = ph["loss"] + opt.lambda_normal * rp["normal_err_mean"] + opt.lambda_dist * rp["dist_mean"]
+        ora_scalars.append(np.array([ph["l1"], ph["ssim"], rp["normal_err_mean"], rp["dist_mean"], ph["loss"], total]))
+        g = O.rasterize_backward(st, ph["g_loss"], np.nan_to_num(rp["g_reg"], nan=0.0))
+        lr_xyz = T.expon_lr(it, opt.position_lr_init * 2.0, opt.position_lr_final * 2.0, lr_delay_mult=opt.position_lr_delay_mult,
+                            max_steps=opt.position_lr_max_steps)
+        lrs = [lr_xyz, opt.feature_lr, opt.feature_lr / 20.0, opt.opacity_lr, opt.scaling_lr, opt.rotation_lr]
+        p = A.step(lrs, g.dL_dmeans3D, g.dL_dsh, g.dL_dopacity, g.dL_dscales, g.dL_drots)
+    for k in range(3):
+        rel = np.abs(hip_scalars[k] - ora_scalars[k]) / np.maximum(np.abs(ora_scalars[k]), 1e-6)
+        print("iteration %d: max relative deviation of the six loss scalars %.2e" % (k + 1, rel.max()))
+        assert (rel < 1e-4).all(), (k, hip_scalars[k], ora_scalars[k])        # measured 6e-6 .. 3e-5
+    # parameters after three steps (synthetic_object starts at SH degree 3: all 16 coefficients are live)
+    hip = {k: m._pv[k].detach().cpu().numpy().astype(np.float64) for k in ("xyz", "opacity", "scaling", "rotation")}
+    hip_sh = m._pv["sh"].detach().cpu().numpy().astype(np.float64).reshape(P, 16, 3)
+    lr_of = dict(xyz=opt.position_lr_init * 2.0, opacity=opt.opacity_lr, scaling=opt.scaling_lr, rotation=opt.rotation_lr)
+    for k in hip:
+        moved = np.abs(p[k] - raw0[k]).max()
+        assert moved > 0.5 * lr_of[k], k                                   # the parameters did move
+        frac = (np.abs(hip[k] - p[k]) <= 0.05 * lr_of[k] + 1e-6 * np.abs(p[k])).mean()
+        print("%s: %.4f of the elements within 5 %% of a learning rate after three steps" % (k, frac))
+        assert frac >= 0.995, (k, frac)        # measured 1.0000
+    frac_dc = (np.abs(hip_sh[:, 0] - p["f_dc"][:, 0]) <= 0.05 * opt.feature_lr).mean()
+    frac_rest = (np.abs(hip_sh[:, 1:] - p["f_rest"]) <= 0.05 * opt.feature_lr / 20.0).mean()
+    assert frac_dc >= 0.995 and frac_rest >= 0.995, (frac_dc, frac_rest)
+    assert np.abs(p["f_rest"] - sh0[:, 1:]).max() > 0.5 * opt.feature_lr / 20.0
