@@ -838,7 +838,8 @@ def test_view_parallel_step_rehearsed_on_rccl_with_early_gather():
         dist.destroy_process_group()
 
 
-def test_whole_training_iterations_match_the_oracle_chain():
+@pytest.mark.parametrize("ratio,white", [(0.3, False), (1.0, True)])
+def test_whole_training_iterations_match_the_oracle_chain(ratio, white):
     """Three complete training iterations (train.py:54-138) of the HIP trainer against the same iterations composed from the CPU
     oracles, every stage in fp64: oracle rasterizer forward -> L1 + SSIM and allmap post-processing + regularisers
     (oracle/train_oracle.py, pinned to the reference's own Python) -> oracle rasterizer backward -> the reference's Adam set-up
@@ -854,7 +855,7 @@ def test_whole_training_iterations_match_the_oracle_chain():
     d = dev()
     W, H, P = 80, 64, 600
     cams = TR.orbit_cameras(1, W, H, device=d)
-    bg = torch.zeros(3, device=d)
+    bg = torch.ones(3, device=d) if white else torch.zeros(3, device=d)
     gt_model = TR.synthetic_object(P, d, seed=4, px_scale=0.08)
     TR.capture_views(gt_model, cams, bg)
     cam = cams[0]
@@ -864,9 +865,7 @@ def test_whole_training_iterations_match_the_oracle_chain():
     sh0 = m._pv["sh"].detach().cpu().numpy().astype(np.float64).reshape(P, 16, 3).copy()
     opt = TR.optimization_params(lambda_dist=100.0, lambda_normal=0.05, dist_from_iter=0, normal_from_iter=0, densify_from_iter=10 ** 9,
                                  opacity_reset_interval=10 ** 9)
-    ratio = 0.3
-    os.environ["SURFEL_SH_FUSED"] = "1"
-    tr = TR.Trainer(m, cams, opt, TR.pipeline_params(depth_ratio=ratio))
+    tr = TR.Trainer(m, cams, opt, TR.pipeline_params(depth_ratio=ratio), white_background=white)
     hip_scalars = []
     for _ in range(3):
         tr.step()
@@ -884,7 +883,7 @@ def test_whole_training_iterations_match_the_oracle_chain():
     for it in (1, 2, 3):
         o, s, r = T.activate(p["opacity"], p["scaling"], p["rotation"])
         feats = np.concatenate([p["f_dc"], p["f_rest"]], axis=1)
-        R, col, oth, radii, st = O.rasterize_forward(np.zeros(3), p["xyz"], None, o, s, r, 1.0, None, wvt, fpt, tanx, tany, H, W, feats, 3, campos)
+        R, col, oth, radii, st = O.rasterize_forward(np.ones(3) if white else np.zeros(3), p["xyz"], None, o, s, r, 1.0, None, wvt, fpt, tanx, tany, H, W, feats, 3, campos)
         ph = T.photometric(col, gt, opt.lambda_dssim)
         rp = T.render_post_np(oth, wvt, fpt, W, H, ratio, lambda_normal=opt.lambda_normal, lambda_dist=opt.lambda_dist)
         total = ph["loss"] + opt.lambda_normal * rp["normal_err_mean"] + opt.lambda_dist * rp["dist_mean"]
