@@ -911,3 +911,66 @@ def test_whole_training_iterations_match_the_oracle_chain(ratio, white):
     frac_rest = (np.abs(hip_sh[:, 1:] - p["f_rest"]) <= 0.05 * opt.feature_lr / 20.0).mean()
     assert frac_dc >= 0.995 and frac_rest >= 0.995, (frac_dc, frac_rest)
     assert np.abs(p["f_rest"] - sh0[:, 1:]).max() > 0.5 * opt.feature_lr / 20.0
+
+
+def test_view_parallel_semantics_match_the_oracle_chain():
+    """The optimisation semantics of N view-parallel ranks (one Adam step on the AVERAGE of the views' gradients, SH gradients
+    rebuilt from the N colour gradients and view directions — Trainer.views_per_step, the single-process form of the N-rank
+    step) against the fp64 oracle chain: both views' gradients from the oracle rasterizer / losses, averaged, one reference Adam
+    step; three iterations, two views."""
+    import torch
+    import surfel_trainer as TR
+    from oracle import train_oracle as T
+    from oracle.surfel_oracle import Oracle
+    d = dev()
+    W, H, P = 72, 56, 500
+    cams = TR.orbit_cameras(2, W, H, device=d)
+    bg = torch.zeros(3, device=d)
+    TR.capture_views(TR.synthetic_object(P, d, seed=14, px_scale=0.08), cams, bg)
+    m = TR.synthetic_object(P, d, seed=15, px_scale=0.07)
+    m.spatial_lr_scale = 1.5
+    raw0 = {k: m._pv[k].detach().cpu().numpy().astype(np.float64).copy() for k in ("xyz", "opacity", "scaling", "rotation")}
+    sh0 = m._pv["sh"].detach().cpu().numpy().astype(np.float64).reshape(P, 16, 3).copy()
+    opt = TR.optimization_params(lambda_dist=100.0, lambda_normal=0.05, dist_from_iter=0, normal_from_iter=0, densify_from_iter=10 ** 9,
+                                 opacity_reset_interval=10 ** 9)
+    tr = TR.Trainer(m, cams, opt, TR.pipeline_params(depth_ratio=1.0))
+    tr.views_per_step = 2
+    last = []
+    for _ in range(3):
+        tr.step()
+        last.append(tr.last["scalars"].detach().cpu().numpy().astype(np.float64))
+    torch.cuda.synchronize()
+
+    O = Oracle("f64")
+    A = T.AdamOracle(raw0["xyz"], sh0[:, :1], sh0[:, 1:], raw0["opacity"], raw0["scaling"], raw0["rotation"])
+    p = {k: v.detach().numpy() for k, v in A.p.items()}
+    for it in (1, 2, 3):
+        o, s, r = T.activate(p["opacity"], p["scaling"], p["rotation"])
+        feats = np.concatenate([p["f_dc"], p["f_rest"]], axis=1)
+        acc, totals = None, []
+        for cam in cams:
+            wvt = cam.world_view_transform.cpu().numpy(); fpt = cam.full_proj_transform.cpu().numpy()
+            R, col, oth, radii, st = O.rasterize_forward(np.zeros(3), p["xyz"], None, o, s, r, 1.0, None, wvt, fpt, math.tan(cam.FoVx * 0.5),
+                                                         math.tan(cam.FoVy * 0.5), H, W, feats, 3, cam.camera_center.cpu().numpy())
+            ph = T.photometric(col, cam.original_image.cpu().numpy().astype(np.float64), opt.lambda_dssim)
+            rp = T.render_post_np(oth, wvt, fpt, W, H, 1.0, lambda_normal=opt.lambda_normal, lambda_dist=opt.lambda_dist)
+            totals.append(ph["loss"] + opt.lambda_normal * rp["normal_err_mean"] + opt.lambda_dist * rp["dist_mean"])
+            g = O.rasterize_backward(st, ph["g_loss"], np.nan_to_num(rp["g_reg"], nan=0.0))
+            gs = [g.dL_dmeans3D, g.dL_dsh, g.dL_dopacity, g.dL_dscales, g.dL_drots]
+            acc = gs if acc is None else [a + b for a, b in zip(acc, gs)]
+        # the trainer reports the scalars of the step's last view: one of the two
+        assert min(abs(last[it - 1][5] - t) / t for t in totals) < 1e-4, (last[it - 1][5], totals)
+        lr_xyz = T.expon_lr(it, opt.position_lr_init * 1.5, opt.position_lr_final * 1.5, lr_delay_mult=opt.position_lr_delay_mult,
+                            max_steps=opt.position_lr_max_steps)
+        p = A.step([lr_xyz, opt.feature_lr, opt.feature_lr / 20.0, opt.opacity_lr, opt.scaling_lr, opt.rotation_lr], *[0.5 * a for a in acc])
+    hip = {k: m._pv[k].detach().cpu().numpy().astype(np.float64) for k in ("xyz", "opacity", "scaling", "rotation")}
+    hip_sh = m._pv["sh"].detach().cpu().numpy().astype(np.float64).reshape(P, 16, 3)
+    lr_of = dict(xyz=opt.position_lr_init * 1.5, opacity=opt.opacity_lr, scaling=opt.scaling_lr, rotation=opt.rotation_lr)
+    for k in hip:
+        frac = (np.abs(hip[k] - p[k]) <= 0.05 * lr_of[k] + 1e-6 * np.abs(p[k])).mean()
+        print("%s: %.4f of the elements within 5 %% of a learning rate" % (k, frac))
+        assert frac >= 0.995, (k, frac)
+    frac_dc = (np.abs(hip_sh[:, 0] - p["f_dc"][:, 0]) <= 0.05 * opt.feature_lr).mean()
+    frac_rest = (np.abs(hip_sh[:, 1:] - p["f_rest"]) <= 0.05 * opt.feature_lr / 20.0).mean()
+    print("sh: dc %.4f rest %.4f" % (frac_dc, frac_rest))
+    assert frac_dc >= 0.995 and frac_rest >= 0.995, (frac_dc, frac_rest)
