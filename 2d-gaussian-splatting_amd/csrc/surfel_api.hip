@@ -21,7 +21,7 @@ namespace {
 thread_local std::string g_err;
 int g_opt_cull = 1;        // surfel_set_option("cull", .)
 int g_opt_tile_sort = 1;   // surfel_set_option("tile_depth_sort", .): 0 never, 1 auto (by last frame's R / tiles), 2 always
-int g_opt_bwd_variant = 2; // surfel_set_option("bwd_variant", .): 0 per-row walk, 1 per-quad walk, 2 auto (bit-identical)
+int g_opt_bwd_variant = 2; // surfel_set_option("bwd_variant", .): 0 per-row walk, 1 per-quad walk, 2 auto (0 / 1 / 2 bit-identical), 3 scan walk
 surfel_hook_fn g_colour_hook = nullptr;   // surfel_set_backward_hook
 void* g_colour_hook_user = nullptr;
 int g_opt_bwd_tune = 1;    // surfel_set_option("bwd_tune", .): auto = timed probes (1) or the device-side rule alone (0)
@@ -314,7 +314,7 @@ int surfel_set_option(const char* name, int value) {
     if (name && std::strcmp(name, "cull") == 0) { g_opt_cull = value ? 1 : 0; return 0; }
     if (name && std::strcmp(name, "tile_depth_sort") == 0) { g_opt_tile_sort = value < 0 ? 0 : (value > 2 ? 2 : value); return 0; }
     if (name && std::strcmp(name, "large_sort") == 0) { set_large_sort_impl(value); return 0; }
-    if (name && std::strcmp(name, "bwd_variant") == 0) { g_opt_bwd_variant = value < 0 ? 0 : (value > 2 ? 2 : value); return 0; }
+    if (name && std::strcmp(name, "bwd_variant") == 0) { g_opt_bwd_variant = value < 0 ? 0 : (value > 3 ? 3 : value); return 0; }
     if (name && std::strcmp(name, "bwd_tune") == 0) { g_opt_bwd_tune = value != 0; return 0; }
     return fail(SURFEL_E_INVALID, "unknown option");
 }
@@ -494,6 +494,7 @@ int64_t surfel_rasterize_forward(surfel_alloc_fn geom_alloc, void* geom_user, su
     ba.W = width; ba.H = height; ba.gx = gx; ba.gy = gy;
     ba.ranges = img.ranges; ba.point_list = bin.point_list; ba.rec = geom.rec; ba.bg = background;
     ba.out_color = out_color; ba.out_others = out_others; ba.final_T = img.final_T; ba.n_contrib = img.n_contrib;
+    ba.stats = g_blend_stats;
     tm.begin();
     launch_blend_fwd(ba, s);
     STAGE_END(tm, ST_BLEND);
@@ -514,7 +515,7 @@ int surfel_rasterize_backward(surfel_alloc_fn scratch_alloc, void* scratch_user,
     (void)tan_fovx; (void)tan_fovy; (void)colors_precomp;
     g_stage_n = 0;
     const int debug_in = debug;
-    const int opt_variant = (debug & SURFEL_OPT_BWD_QUAD) ? 1 : ((debug & SURFEL_OPT_BWD_ROWS) ? 0 : g_opt_bwd_variant);   // 2 = auto
+    const int opt_variant = (debug & SURFEL_OPT_BWD_SCAN) ? 3 : ((debug & SURFEL_OPT_BWD_QUAD) ? 1 : ((debug & SURFEL_OPT_BWD_ROWS) ? 0 : g_opt_bwd_variant));   // 2 = auto
     debug &= 0xff;
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (P == 0) return 0;
@@ -529,17 +530,19 @@ int surfel_rasterize_backward(surfel_alloc_fn scratch_alloc, void* scratch_user,
     BinState bin = BinState::carve(const_cast<void*>(binning_buffer), (size_t)R, 0, nullptr);
     ImgState img = ImgState::carve(const_cast<void*>(image_buffer), width, height, nullptr);
 
-    // per-instance gradient records: every record is written exactly once by blend_bwd (no memset, no atomics)
-    const size_t grec_bytes = (size_t)(R > 0 ? R : 1) * GREC_F * sizeof(float);
-    float* grec = static_cast<float*>(scratch_alloc(scratch_user, grec_bytes));
+    // per-instance gradient records: blend_bwd writes the record of every instance up to its tile's cut exactly once (no memset, no
+    // atomics); the cuts (8 B per tile) sit behind the records
+    const size_t grec_bytes = align_up((size_t)(R > 0 ? R : 1) * GREC_F * sizeof(float));
+    float* grec = static_cast<float*>(scratch_alloc(scratch_user, grec_bytes + (size_t)gx * gy * sizeof(uint2)));
     if (!grec) return fail(SURFEL_E_ALLOC, "gradient record allocation failed");
+    uint2* cut = reinterpret_cast<uint2*>(reinterpret_cast<char*>(grec) + grec_bytes);
     StageTimer tm(debug, s);
 
     BlendBwdArgs bb{};
     bb.W = width; bb.H = height; bb.gx = gx; bb.gy = gy;
     bb.ranges = img.ranges; bb.point_list = bin.point_list; bb.rec = geom.rec; bb.bg = background;
     bb.final_T = img.final_T; bb.n_contrib = img.n_contrib; bb.dL_dpix = dL_dout_color; bb.dL_dothers = dL_dout_others;
-    bb.grec = grec; bb.variant = opt_variant; bb.stats = g_blend_stats; bb.totals = img.total;
+    bb.grec = grec; bb.cut = cut; bb.depths = geom.depths; bb.variant = opt_variant; bb.stats = g_blend_stats; bb.totals = img.total;
     if (R > 0) {
         WalkTuner* tuner = nullptr;
         int probe = -1;
@@ -565,7 +568,7 @@ int surfel_rasterize_backward(surfel_alloc_fn scratch_alloc, void* scratch_user,
     pb.coop = (debug_in & SURFEL_OPT_PBWD_COOP) ? 1 : ((debug_in & SURFEL_OPT_PBWD_THREAD) ? 0 : ((R >= (int64_t)6 * P && R >= ((int64_t)32 << 20)) ? 1 : 0));
     pb.means3D = means3D; pb.radii = radii; pb.shs = shs; pb.clamped = geom.clamped; pb.scales = scales; pb.rotations = rotations;
     pb.transMat_precomp = transMat_precomp; pb.viewmatrix = viewmatrix; pb.projmatrix = projmatrix; pb.campos = cam_pos;
-    pb.rec = geom.rec; pb.tiles_touched = geom.tiles_touched; pb.grec = grec;
+    pb.rec = geom.rec; pb.tiles_touched = geom.tiles_touched; pb.grec = grec; pb.cut = cut; pb.depths = geom.depths; pb.gx = gx;
     pb.dL_dtransMat = dL_dtransMat; pb.dL_dnormal = dL_dnormal; pb.dL_dopacity = dL_dopacity; pb.dL_dcolors = dL_dcolors;
     pb.dL_dsh = dL_dsh; pb.dL_dmeans2D = dL_dmeans2D; pb.dL_dmeans3D = dL_dmeans3D; pb.dL_dscales = dL_dscales; pb.dL_drots = dL_drots;
     tm.begin();

@@ -14,8 +14,7 @@
 //                   (38 DPP adds + 5 permlane swaps), per-wave LDS partials.  Round 1's kernel; the faster walk on wide footprints.
 // Which of the two runs is decided by the caller (surfel_api.hip: timed probes, `bwd_tune`) or, for variant 2, on the device.
 // Semantics: oracle/surfel_oracle.c stages 4-5 (restating the absent diff-surfel-rasterization).
-#include "surfel_common.h"
-#include "surfel_kernels.h"
+#include "surfel_blend_bwd.h"
 
 namespace surfel {
 
@@ -143,70 +142,6 @@ __device__ __forceinline__ void wave_reduce20(const float (&v)[NVP], float& u0, 
     u1 = fold32(t2, t2);
 }
 
-// ---------------------------------------------------------------------------------------------
-// per-pixel state and the per-(pixel, surfel) arithmetic shared by both variants
-// ---------------------------------------------------------------------------------------------
-struct Pixel {
-    float pxf, pyf;
-    float gC0, gC1, gC2, g_depth, g_alpha, gN0, gN1, gN2, g_med, g_dist;     // upstream gradients
-    float fM1, fM2, final_A;
-    int last, medc;
-    float T, X;      // running transmittance and the suffix sum (see pair_gradients)
-};
-
-__device__ __forceinline__ Pixel load_pixel(const BlendBwdArgs& a, int pxi, int pyi) {
-    Pixel p;
-    p.pxf = (float)pxi; p.pyf = (float)pyi;
-    const bool inside = pxi < a.W && pyi < a.H;
-    const size_t HW = (size_t)a.H * a.W;
-    const size_t pix = (size_t)pyi * a.W + pxi;
-    float T_final = 0.f;
-    p.fM1 = 0.f; p.fM2 = 0.f; p.last = 0; p.medc = 0;
-    p.gC0 = p.gC1 = p.gC2 = p.g_depth = p.g_alpha = p.gN0 = p.gN1 = p.gN2 = p.g_med = p.g_dist = 0.f;
-    if (inside) {
-        T_final = a.final_T[pix]; p.fM1 = a.final_T[HW + pix]; p.fM2 = a.final_T[2 * HW + pix];
-        p.last = (int)a.n_contrib[pix]; p.medc = (int)a.n_contrib[HW + pix];
-        p.gC0 = a.dL_dpix[pix]; p.gC1 = a.dL_dpix[HW + pix]; p.gC2 = a.dL_dpix[2 * HW + pix];
-        p.g_depth = a.dL_dothers[pix]; p.g_alpha = a.dL_dothers[HW + pix];
-        p.gN0 = a.dL_dothers[2 * HW + pix]; p.gN1 = a.dL_dothers[3 * HW + pix]; p.gN2 = a.dL_dothers[4 * HW + pix];
-        p.g_med = a.dL_dothers[5 * HW + pix]; p.g_dist = a.dL_dothers[6 * HW + pix];
-    }
-    p.final_A = 1.f - T_final;
-    p.T = T_final;
-    p.X = T_final * __builtin_fmaf(a.bg[2], p.gC2, __builtin_fmaf(a.bg[1], p.gC1, a.bg[0] * p.gC0));     // suffix sum, seeded with the background term
-    return p;
-}
-
-struct Hit {     // ray-splat intersection of one (pixel, surfel) pair
-    float kx, ky, kz, lx, ly, lz, sx, sy, ip, dx, dy, depth, G, alpha, Twx, Twy, opa;
-    bool use3d;
-};
-
-// This file is compiled with -ffp-contract=off and every fused multiply-add below is spelled out, so the two kernel variants
-// (and any future one) execute the SAME rounding sequence per (pixel, surfel) pair — that is what makes them bit-identical.
-#define FMA(a, b, c) __builtin_fmaf((a), (b), (c))
-
-// branch-free intersection; returns whether the pair was composited by the forward (pos <= last and the forward's tests)
-__device__ __forceinline__ bool pair_hit(const Pixel& p, const float4 q0, const float4 q1, const float4 q2, int pos, Hit& h) {
-    const float Tux = q0.x, Tuy = q0.y, Tuz = q0.z, Tvx = q0.w, Tvy = q1.x, Tvz = q1.y;
-    const float Twx = q1.z, Twy = q1.w, Twz = q2.x;
-    h.Twx = Twx; h.Twy = Twy; h.opa = q2.w;
-    h.kx = FMA(p.pxf, Twx, -Tux); h.ky = FMA(p.pxf, Twy, -Tuy); h.kz = FMA(p.pxf, Twz, -Tuz);
-    h.lx = FMA(p.pyf, Twx, -Tvx); h.ly = FMA(p.pyf, Twy, -Tvy); h.lz = FMA(p.pyf, Twz, -Tvz);
-    const float p0 = FMA(h.ky, h.lz, -(h.kz * h.ly)), p1 = FMA(h.kz, h.lx, -(h.kx * h.lz)), p2 = FMA(h.kx, h.ly, -(h.ky * h.lx));
-    h.ip = SURFEL_RCP(p2);
-    h.sx = p0 * h.ip; h.sy = p1 * h.ip;
-    const float rho3d = FMA(h.sx, h.sx, h.sy * h.sy);
-    h.dx = q2.y - p.pxf; h.dy = q2.z - p.pyf;
-    const float rho2d = FILTER_INV_SQUARE * FMA(h.dx, h.dx, h.dy * h.dy);
-    h.use3d = rho3d <= rho2d;
-    const float rho = fminf(rho3d, rho2d);
-    h.depth = h.use3d ? FMA(h.sx, Twx, h.sy * Twy) + Twz : Twz;
-    h.G = SURFEL_EXP(-0.5f * rho);
-    h.alpha = fminf(ALPHA_MAX, h.opa * h.G);
-    return (pos <= p.last) & (p2 != 0.f) & (h.depth >= NEAR_N) & (h.alpha >= ALPHA_MIN);
-}
-
 // Sequential per-pixel state + the 18 per-pair gradient values.  Every upstream gradient enters dL/dalpha only through its
 // dot product with this surfel's attributes, so the back-to-front recurrences (colour, depth, alpha, normal, distortion,
 // background) collapse into ONE scalar suffix sum
@@ -253,49 +188,6 @@ __device__ __forceinline__ void pair_gradients(Pixel& p, const Hit& h, const flo
     gv[8] = dL_dz - FMA(p.pxf, nk2, p.pyf * nl2);
     gv[9] = g2 * h.dx; gv[10] = g2 * h.dy;
 }
-
-// gradient-record slot of the (tile, surfel) instance whose staged record holds q4
-__device__ __forceinline__ size_t grec_slot(const float4 q4, int tx, int ty) {
-    const uint32_t basei = __float_as_uint(q4.z), rectbits = __float_as_uint(q4.w);
-    const int x0 = rectbits & 1023, y0 = (rectbits >> 10) & 1023, rw = rectbits >> 20;
-    return (size_t)basei + (size_t)((ty - y0) * rw + (tx - x0));
-}
-
-// variant == 2: both kernels are launched and each decides on the device, from the frame's totals, whether it is the one to run.
-// Small footprints (few tile instances per emitting surfel) favour the per-row walk — it wastes fewer lanes; on wide footprints
-// the per-quad walk's cheaper visit wins (profiles/r02_blend_bwd_variants.md).  Every workgroup reaches the same verdict.
-constexpr int AUTO_ROWS_MAX_INST_PER_SURFEL = 4;
-__device__ __forceinline__ bool auto_picks_rows(const BlendBwdArgs& a) {
-    const int lane = threadIdx.x & 63;
-    uint32_t r = a.totals[lane], v = a.totals[R_SLOTS + lane];
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { r += __shfl_xor(r, o); v += __shfl_xor(v, o); }
-    return (unsigned long long)r <= (unsigned long long)AUTO_ROWS_MAX_INST_PER_SURFEL * v;
-}
-
-__device__ __forceinline__ int block_max(int v, int* s_max) {
-    if (threadIdx.x == 0) *s_max = 0;
-    __syncthreads();
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o));
-    if ((threadIdx.x & 63) == 0) atomicMax(s_max, v);
-    __syncthreads();
-    return *s_max;
-}
-
-// instances behind every pixel's last contributor are never staged: their records are zero
-__device__ __forceinline__ void zero_tail(const BlendBwdArgs& a, const uint2 range, int maxc, int tx, int ty) {
-    for (int pos = maxc + 1 + (int)threadIdx.x; pos <= (int)(range.y - range.x); pos += BLOCK) {
-        const uint32_t id = a.point_list[range.x + pos - 1];
-        const float4 q4 = reinterpret_cast<const float4*>(a.rec + (size_t)id * REC_F)[4];
-        float4* __restrict__ dst = reinterpret_cast<float4*>(a.grec + grec_slot(q4, tx, ty) * GREC_F);
-        const float4 zz = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-        for (int q = 0; q < 5; q++) dst[q] = zz;
-    }
-}
-
-__device__ __forceinline__ float4 add4(const float4 a, const float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
 
 // ---------------------------------------------------------------------------------------------
 // blend_bwd, rows variant
@@ -486,7 +378,7 @@ __global__ void __launch_bounds__(BLOCK, ROWS_WAVES) blend_bwd_rows_kernel(Blend
         atomicAdd(&a.stats[7], (unsigned long long)tm_bar);
     }
 #endif
-    zero_tail(a, range, maxc, tx, ty);
+    write_cut(a, range, maxc, tile);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -600,11 +492,12 @@ __global__ void __launch_bounds__(BLOCK) blend_bwd_quad_kernel(BlendBwdArgs a) {
             __syncthreads();                  // s_acc / s_mask reusable
         }
     }
-    zero_tail(a, range, maxc, tx, ty);
+    write_cut(a, range, maxc, tile);
 }
 
 void launch_blend_bwd(const BlendBwdArgs& a, hipStream_t s) {
     const dim3 grid(a.gx * a.gy), block(BLOCK);
+    if (a.variant == 3) { launch_blend_bwd_scan(a, s); return; }
     if (a.variant != 1) {
         if (a.stats) hipLaunchKernelGGL(blend_bwd_rows_kernel<true>, grid, block, 0, s, a);
         else hipLaunchKernelGGL(blend_bwd_rows_kernel<false>, grid, block, 0, s, a);

@@ -1,0 +1,292 @@
+// surfel_backward_scan.hip — blend_bwd, "scan" walk: LANES ARE INSTANCES, pixels are the steps (gfx950).
+//
+// The rows / quad walks (surfel_backward.hip) keep a pixel per lane and pay a 38-DPP cross-lane reduction plus an LDS slot per
+// (instance, sub-tile) visit to turn 16 per-pixel contributions into one per-instance total — 20-25 % of a visit's issue slots,
+// on kernels that are bound by VALU issue.  Here the roles are swapped:
+//   * every DPP row of 16 lanes still owns one 4x4-pixel sub-tile and ITS OWN list of the staged instances whose alpha >= 1/255
+//     footprint reaches it — but a lane now holds one INSTANCE of that list (16 consecutive ones = a chunk), with the instance's
+//     record and its 18 gradient accumulators in registers, and the row steps through the sub-tile's 16 pixels;
+//   * the per-pixel back-to-front recurrences (T_k = T_{k+1} / (1 - alpha_k), X_k = X_{k+1} + w_k u_k; see pair_gradients in
+//     surfel_backward.hip for the two-scalar formulation) become two 16-lane DPP SCANS per step (4 v_mul_f32_dpp + 5 v_add_f32_dpp),
+//     the pixel's state (T, X) lives in LDS next to its upstream gradients and is advanced by the row's last lane;
+//   * gradients accumulate in the owning lane's registers as fused multiply-adds — no reduction tree, no per-visit slot.
+// After a chunk (16 pixel steps) a lane parks its partial record in an LDS slot; the slots of a round (chunk c of all 16 lists)
+// are added into the instance's totals by a fixed thread in a fixed order ((round, sub-tile) ascending), and every staged instance's
+// 80-B gradient record is written once per batch — no atomics, bit-reproducible run to run.  The summation order differs from the
+// rows / quad walks, so this walk is NOT bit-identical to them; it is held to the same oracle bars instead
+// (tests/test_gpu_parity.py::test_scan_walk_*).
+// Semantics: oracle/surfel_oracle.c stages 4-5 (restating the absent diff-surfel-rasterization).
+#include "surfel_blend_bwd.h"
+
+namespace surfel {
+
+namespace {
+
+constexpr int SB = 128;      // instances staged per batch (one 112-B gather per thread of waves 0-1)
+constexpr int CH = 16;       // instances per chunk = lanes of a DPP row
+
+// inclusive product / exclusive sum over the 16 lanes of every DPP row, lane 0 first
+__device__ __forceinline__ float row_scan_mul(float x) {
+    // v_mul_f32_dpp without bound_ctrl: lanes whose source lies outside the row keep their value.  2 wait states between the
+    // VALU write of a register and its use as a DPP source (the compiler cannot see into the asm).
+    asm volatile("s_nop 2\n\t"
+                 "v_mul_f32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\t"
+                 "v_mul_f32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\t"
+                 "v_mul_f32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\t"
+                 "v_mul_f32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf"
+                 : "+v"(x));
+    return x;
+}
+template <int N>
+__device__ __forceinline__ float row_shr_add(float x) {      // x + (x shifted right by N lanes inside each row, zero fill): one v_add_f32_dpp
+    return x + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x110 + N, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float row_scan_add_excl(float x) {
+    float e = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x111, 0xf, 0xf, true));      // row_shr:1, zero fill
+    e = row_shr_add<1>(e); e = row_shr_add<2>(e); e = row_shr_add<4>(e); e = row_shr_add<8>(e);
+    return e;
+}
+
+}  // namespace
+
+// LDS records of a pixel, indexed by the pixel's owner thread (tid = 16 * sub-tile row + pixel of the sub-tile):
+//   s_pix  (read-only in the walk, 3 x float4): [0] gC0 gC1 gC2 g_depth   [1] gN0 gN1 gN2 g_med   [2] a2 a1 a0 last
+//   s_state (float4): T X medc -      (T, X) advanced once per chunk by the row's last lane
+// with the distortion / alpha terms of u pre-multiplied:  u = mm (mm a2 + a1) + a0 + c.gC + depth g_depth + n.gN,
+//   a2 = final_A g_dist,  a1 = -2 M1 g_dist,  a0 = M2 g_dist + g_alpha.
+// The walk of a chunk is ONE basic block: any branch inside it (a predicated state write, a conditional slot write) lets LLVM sink
+// the gradient half of all sixteen steps behind the last step and spill their intermediates.  So the state write is issued by
+// every lane — the last lane of a row writes the pixel's state, the others a scratch area behind it — and idle lanes park a
+// (never read) slot as well.
+constexpr int STATE_SCRATCH = 49;      // float4s: 16 steps x 16 B + 64 lanes x 8 B
+template <bool STATS>
+__global__ void __launch_bounds__(BLOCK, 3) blend_bwd_scan_kernel(BlendBwdArgs a) {
+    __shared__ float4 s_rec[SB * 5];                          // 10 KB: q0-q4 of the staged instances
+    __shared__ float4 s_slot[BLOCK * 5];                      // 20 KB: the round's partial records, one per walking lane
+    __shared__ float4 s_pix[BLOCK * 3];                       // 12 KB
+    __shared__ float4 s_state[BLOCK + STATE_SCRATCH];         // 4.8 KB
+    __shared__ unsigned long long s_bal[16][SB / 64];         // per sub-tile: the staged instances on its list
+    __shared__ uint8_t s_list[16][SB];                        // per sub-tile: its list (staged indices, back to front)
+    __shared__ uint4 s_rank[SB];                              // per staged instance: its rank on each of the 16 lists (0xff: not on it)
+    __shared__ uint32_t s_cmm[SB];                            // per staged instance: first | last << 8 round it takes part in
+    __shared__ int s_rowlast[16];
+    __shared__ int s_max;
+    const int tid = threadIdx.x;
+    const int tile = xcd_tile(blockIdx.x, a.gx * a.gy);
+    const int tx = tile % a.gx, ty = tile / a.gx;
+    int lx, ly, sub;
+    thread_pixel(tid, lx, ly, sub);
+    (void)sub;
+    const int wave = tid >> 6, lane = tid & 63, i16 = tid & 15;
+    const int srow = tid >> 4;                                // this lane's DPP row among the tile's 16 = its sub-tile's bit
+    const uint2 range = a.ranges[tile];
+    {
+        const Pixel px = load_pixel(a, tx * TILE + lx, ty * TILE + ly);
+        int m = px.last;
+        m = max(m, __shfl_xor(m, 1)); m = max(m, __shfl_xor(m, 2)); m = max(m, __shfl_xor(m, 4)); m = max(m, __shfl_xor(m, 8));
+        if (i16 == 0) s_rowlast[srow] = m;
+        s_pix[tid * 3 + 0] = make_float4(px.gC0, px.gC1, px.gC2, px.g_depth);
+        s_pix[tid * 3 + 1] = make_float4(px.gN0, px.gN1, px.gN2, px.g_med);
+        s_pix[tid * 3 + 2] = make_float4(px.final_A * px.g_dist, -2.f * px.fM1 * px.g_dist, FMA(px.fM2, px.g_dist, px.g_alpha), __int_as_float(px.last));
+        s_state[tid] = make_float4(px.T, px.X, __int_as_float(px.medc), 0.f);
+        const int maxc0 = block_max(px.last, &s_max);         // (its barriers also publish s_rowlast and s_pix)
+        (void)maxc0;
+    }
+    const int maxc = s_max;
+    const float sx0 = (float)(tx * TILE + (lx & ~3)), sy0 = (float)(ty * TILE + (ly & ~3));      // the sub-tile's first pixel
+    const float4* const prow = s_pix + (srow * 16) * 3;       // the sub-tile's 16 pixel records
+    const float4* const srd = s_state + srow * 16;            // ... and states
+    // where this lane's state writes go: the row's last lane advances the pixel's (T, X), every other lane hits scratch
+    float2* const swr = i16 == 15 ? reinterpret_cast<float2*>(s_state + srow * 16) : reinterpret_cast<float2*>(s_state + BLOCK) + lane;
+
+    // flush ownership: thread (t, half) adds up values [0, 12) or [12, 20) of staged instance t
+    const int ft = tid & (SB - 1), fh = tid >> 7;
+    float4 f0 = make_float4(0.f, 0.f, 0.f, 0.f), f1 = f0, f2 = f0;
+
+    for (int hi = maxc; hi > 0; hi -= SB) {
+        const int mb = min(SB, hi);
+        __syncthreads();                      // previous batch written out: s_rec / s_list / s_rank reusable
+        unsigned ovr = 0;
+        if (wave < SB / 64) {
+            if (tid < mb) {
+                const int pos = hi - tid;
+                const uint32_t id = a.point_list[range.x + pos - 1];
+                const float4* __restrict__ src = reinterpret_cast<const float4*>(a.rec + (size_t)id * REC_F);
+                const float4 v0 = src[0], v1 = src[1], v2 = src[2], v3 = src[3], v4 = src[4], v5 = src[5], v6 = src[6];
+                s_rec[tid * 5 + 0] = v0; s_rec[tid * 5 + 1] = v1; s_rec[tid * 5 + 2] = v2;
+                s_rec[tid * 5 + 3] = v3; s_rec[tid * 5 + 4] = v4;
+                ovr = subtile_overlap_rows(make_foot(v2, v5, v6), tx * TILE, ty * TILE);
+                unsigned live = 0;            // a sub-tile never meets an instance behind the last contributor of all its pixels
+#pragma unroll
+                for (int s = 0; s < 16; s++) live |= (pos <= s_rowlast[s]) ? (1u << s) : 0u;
+                ovr &= live;
+            }
+#pragma unroll
+            for (int s = 0; s < 16; s++) {
+                const unsigned long long b = __ballot((ovr >> s) & 1u);
+                if (lane == 0) s_bal[s][wave] = b;
+            }
+        }
+        __syncthreads();
+        if (tid < SB) {
+            // rank of this instance on every list it is on = instances ahead of it (staged order = back to front) on that list
+            uint32_t rk[4] = {~0u, ~0u, ~0u, ~0u};
+            uint32_t cmin = 255u, cmax = 0u;
+            const unsigned long long lt = (1ull << (tid & 63)) - 1ull;
+#pragma unroll
+            for (int s = 0; s < 16; s++) {
+                const unsigned long long m0 = s_bal[s][0], m1 = s_bal[s][1];
+                const uint32_t r = tid < 64 ? (uint32_t)__popcll(m0 & lt) : (uint32_t)(__popcll(m0) + __popcll(m1 & lt));
+                if ((ovr >> s) & 1u) {
+                    s_list[s][r] = (uint8_t)tid;
+                    rk[s >> 2] = (rk[s >> 2] & ~(0xffu << (8 * (s & 3)))) | (r << (8 * (s & 3)));
+                    cmin = min(cmin, r >> 4); cmax = max(cmax, r >> 4);
+                }
+            }
+            s_rank[tid] = make_uint4(rk[0], rk[1], rk[2], rk[3]);
+            s_cmm[tid] = cmin | (cmax << 8);      // an instance on no list: 255 | 0 -> takes part in no round
+        }
+        // list length of this row's sub-tile, and the number of rounds = chunks of the longest list (the same in every thread)
+        const int n_row = __popcll(s_bal[srow][0]) + __popcll(s_bal[srow][1]);
+        int nmax = __popcll(s_bal[i16][0]) + __popcll(s_bal[i16][1]);
+        nmax = max(nmax, __shfl_xor(nmax, 1)); nmax = max(nmax, __shfl_xor(nmax, 2)); nmax = max(nmax, __shfl_xor(nmax, 4)); nmax = max(nmax, __shfl_xor(nmax, 8));
+        const int nrounds = (nmax + CH - 1) / CH;
+        __syncthreads();
+        const uint32_t fcm = s_cmm[ft];
+        const int fcmin = (int)(fcm & 255u), fcmax = (int)(fcm >> 8);
+
+        for (int c = 0; c < nrounds; c++) {
+            const int idx = c * CH + i16;
+            const bool valid = idx < n_row;
+            if (__any(valid)) {
+                // ---- chunk c of this row's list: lane = instance
+                const int t = valid ? (int)s_list[srow][idx] : 0;
+                const float4 q0 = s_rec[t * 5 + 0], q1 = s_rec[t * 5 + 1], q2 = s_rec[t * 5 + 2], q3 = s_rec[t * 5 + 3], q4 = s_rec[t * 5 + 4];
+                const int pos = valid ? hi - t : 0x7fffffff;      // 1-based position in the tile's list; an idle lane composites nothing
+                const float Twx = q1.z, Twy = q1.w, Twz = q2.x, opa = q2.w;
+                // planes of the sub-tile's 4 pixel columns (the forward's k = px Tw - Tu, same rounding); the rows' planes
+                // (l = py Tw - Tv) are set up once per pixel row below — 16 registers instead of 40 for all eight
+                float K[4][3], DX[4];
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    Hit hh;
+                    pair_planes(sx0 + (float)e, sy0, q0, q1, q2, hh);
+                    K[e][0] = hh.kx; K[e][1] = hh.ky; K[e][2] = hh.kz; DX[e] = hh.dx;
+                }
+                float g[18];
+#pragma unroll
+                for (int v = 0; v < 18; v++) g[v] = 0.f;
+                float4 Sn = srd[0];
+                constexpr float MC1 = FAR_N / (FAR_N - NEAR_N), MC2 = (FAR_N * NEAR_N) / (FAR_N - NEAR_N);
+#pragma unroll
+                for (int cb = 0; cb < 4; cb++) {
+                Hit hr;
+                const float pyf = sy0 + (float)cb;
+                pair_planes(sx0, pyf, q0, q1, q2, hr);        // l and dy of this pixel row
+#pragma unroll
+                for (int ca = 0; ca < 4; ca++) {
+                    const int p = 4 * cb + ca;
+                    const float pxf = sx0 + (float)ca;
+                    const float4 A = prow[p * 3 + 0], B = prow[p * 3 + 1], Cq = prow[p * 3 + 2];
+                    const float4 S = Sn;
+                    Sn = srd[(p + 1) & 15];                   // next pixel's state: read ahead of this step's write (the compiler cannot tell them apart)
+                    Hit h;
+                    h.kx = K[ca][0]; h.ky = K[ca][1]; h.kz = K[ca][2]; h.lx = hr.lx; h.ly = hr.ly; h.lz = hr.lz;
+                    h.dx = DX[ca]; h.dy = hr.dy;
+                    const bool hit = pair_intersect(Twx, Twy, Twz, opa, h);
+                    const bool ok = hit && (pos <= __float_as_int(Cq.w));
+                    // a pair that was not composited runs the same instructions with alpha = 0 and depth = 1: T x 1, X + 0
+                    const float alpha = ok ? h.alpha : 0.f, depth = ok ? h.depth : 1.f;
+                    const float i1a = SURFEL_RCP(1.f - alpha);
+                    const float T = S.x * row_scan_mul(i1a);                  // transmittance in front of this lane's instance
+                    const float w = alpha * T;
+                    const float inv_d = SURFEL_RCP(depth);
+                    const float mm = FMA(-(MC1 * NEAR_N), inv_d, MC1);
+                    float u = FMA(mm, FMA(mm, Cq.x, Cq.y), Cq.z);
+                    u = FMA(q3.w, A.x, u); u = FMA(q4.x, A.y, u); u = FMA(q4.y, A.z, u);
+                    u = FMA(depth, A.w, u);
+                    u = FMA(q3.x, B.x, u); u = FMA(q3.y, B.y, u); u = FMA(q3.z, B.z, u);
+                    const float wu = w * u;
+                    const float Xb = S.y + row_scan_add_excl(wu);             // suffix sum behind this lane's instance
+                    const float dL_dalpha = ok ? FMA(T, u, -(Xb * i1a)) : 0.f;
+                    swr[p * 2] = make_float2(T, Xb + wu);
+                    if (STATS) {
+                        const unsigned long long okb = __ballot(ok), vb = __ballot(valid);
+                        if (lane == 0) {
+                            atomicAdd(&a.stats[0], 64ull); atomicAdd(&a.stats[1], (unsigned long long)__popcll(okb));
+                            atomicAdd(&a.stats[2], 1ull);
+                            if (p == 0) atomicAdd(&a.stats[3], (unsigned long long)__popcll(vb));
+                        }
+                    }
+                    float dL_dz = w * FMA(FMA(mm + mm, Cq.x, Cq.y), (MC2 * inv_d) * inv_d, A.w);
+                    dL_dz += (ok & (pos == __float_as_int(S.z))) ? B.w : 0.f;
+                    g[15] = FMA(w, A.x, g[15]); g[16] = FMA(w, A.y, g[16]); g[17] = FMA(w, A.z, g[17]);
+                    g[11] = FMA(w, B.x, g[11]); g[12] = FMA(w, B.y, g[12]); g[13] = FMA(w, B.z, g[13]);
+                    g[14] = FMA(h.G, dL_dalpha, g[14]);
+                    const float nGG = -h.G * (opa * dL_dalpha);               // dL/dG * dG/drho * 2; the 0.99 clamp is pass-through
+                    // low-pass branch: no gradient reaches the intersection; the selects zero (s, 1/p2) themselves (they may be inf)
+                    const float sxg = h.use3d ? h.sx : 0.f, syg = h.use3d ? h.sy : 0.f, ipg = h.use3d ? h.ip : 0.f;
+                    const float g2 = h.use3d ? 0.f : nGG * FILTER_INV_SQUARE;
+                    const float ax = FMA(nGG, sxg, dL_dz * Twx) * ipg, ay = FMA(nGG, syg, dL_dz * Twy) * ipg;
+                    const float dp2 = -FMA(ax, sxg, ay * syg);
+                    // -dk = dp x l ,  -dl = k x dp
+                    const float nk0 = FMA(ay, h.lz, -(dp2 * h.ly)), nk1 = FMA(dp2, h.lx, -(ax * h.lz)), nk2 = FMA(ax, h.ly, -(ay * h.lx));
+                    const float nl0 = FMA(h.ky, dp2, -(h.kz * ay)), nl1 = FMA(h.kz, ax, -(h.kx * dp2)), nl2 = FMA(h.kx, ay, -(h.ky * ax));
+                    g[0] += nk0; g[1] += nk1; g[2] += nk2; g[3] += nl0; g[4] += nl1; g[5] += nl2;
+                    g[6] = FMA(dL_dz, sxg, g[6]); g[6] = FMA(-pxf, nk0, g[6]); g[6] = FMA(-pyf, nl0, g[6]);
+                    g[7] = FMA(dL_dz, syg, g[7]); g[7] = FMA(-pxf, nk1, g[7]); g[7] = FMA(-pyf, nl1, g[7]);
+                    g[8] += dL_dz; g[8] = FMA(-pxf, nk2, g[8]); g[8] = FMA(-pyf, nl2, g[8]);
+                    g[9] = FMA(g2, h.dx, g[9]); g[10] = FMA(g2, h.dy, g[10]);
+                    // one pixel step at a time: left alone, the scheduler starts the next steps' intersections before this step's
+                    // gradient half and spills every intermediate (sx, sy, 1/p2, G ...) of several steps
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                }
+                s_slot[tid * 5 + 0] = make_float4(g[0], g[1], g[2], g[3]);
+                s_slot[tid * 5 + 1] = make_float4(g[4], g[5], g[6], g[7]);
+                s_slot[tid * 5 + 2] = make_float4(g[8], g[9], g[10], g[11]);
+                s_slot[tid * 5 + 3] = make_float4(g[12], g[13], g[14], g[15]);
+                s_slot[tid * 5 + 4] = make_float4(g[16], g[17], 0.f, 0.f);
+            }
+            __syncthreads();
+            // ---- flush round c: the slot of (sub-tile s, lane r & 15) belongs to the instance of rank r = 16 c + lane on list s.
+            // Fixed order: rounds ascending, sub-tiles ascending inside a round.
+            if (ft < mb && c >= fcmin && c <= fcmax) {
+                // (the ranks are re-read every round: kept in registers, the compiler hoists sixteen slot addresses per thread out
+                // of the round loop and spills them across the walk)
+                const uint4 frk = s_rank[ft];
+                const uint32_t rkw[4] = {frk.x, frk.y, frk.z, frk.w};
+#pragma unroll
+                for (int s = 0; s < 16; s++) {
+                    const int li = (int)((rkw[s >> 2] >> (8 * (s & 3))) & 0xffu) - CH * c;      // lane of the slot, if this is the rank's round
+                    if ((unsigned)li < (unsigned)CH) {      // (rank 0xff = not on the list: 255 - 16 c >= 143)
+                        const float4* sp = s_slot + (s * 16 + li) * 5;
+                        if (fh == 0) { f0 = add4(f0, sp[0]); f1 = add4(f1, sp[1]); f2 = add4(f2, sp[2]); }
+                        else { f0 = add4(f0, sp[3]); f1 = add4(f1, sp[4]); }
+                    }
+                }
+            }
+            __syncthreads();                  // slots reusable
+        }
+        // ---- the batch's gradient records: every staged instance gets one (zeros if no pixel took it)
+        if (ft < mb) {
+            const float4 r4 = s_rec[ft * 5 + 4];
+            float4* __restrict__ dst = reinterpret_cast<float4*>(a.grec + grec_slot(r4, tx, ty) * GREC_F);
+            if (fh == 0) { dst[0] = f0; dst[1] = f1; dst[2] = f2; }
+            else { dst[3] = f0; dst[4] = f1; }
+        }
+        f0 = make_float4(0.f, 0.f, 0.f, 0.f); f1 = f0; f2 = f0;
+    }
+    write_cut(a, range, maxc, tile);
+}
+
+void launch_blend_bwd_scan(const BlendBwdArgs& a, hipStream_t s) {
+    const dim3 grid(a.gx * a.gy), block(BLOCK);
+    if (a.stats) hipLaunchKernelGGL(blend_bwd_scan_kernel<true>, grid, block, 0, s, a);
+    else hipLaunchKernelGGL(blend_bwd_scan_kernel<false>, grid, block, 0, s, a);
+}
+
+}  // namespace surfel

@@ -1,0 +1,96 @@
+// surfel_blend_bwd.h — pieces shared by the blend-backward walks (surfel_backward.hip: rows / quad; surfel_backward_scan.hip: scan).
+#pragma once
+#include "surfel_common.h"
+#include "surfel_kernels.h"
+
+namespace surfel {
+
+struct Pixel {
+    float pxf, pyf;
+    float gC0, gC1, gC2, g_depth, g_alpha, gN0, gN1, gN2, g_med, g_dist;     // upstream gradients
+    float fM1, fM2, final_A;
+    int last, medc;
+    float T, X;      // running transmittance and the suffix sum (see pair_gradients)
+};
+
+__device__ __forceinline__ Pixel load_pixel(const BlendBwdArgs& a, int pxi, int pyi) {
+    Pixel p;
+    p.pxf = (float)pxi; p.pyf = (float)pyi;
+    const bool inside = pxi < a.W && pyi < a.H;
+    const size_t HW = (size_t)a.H * a.W;
+    const size_t pix = (size_t)pyi * a.W + pxi;
+    float T_final = 0.f;
+    p.fM1 = 0.f; p.fM2 = 0.f; p.last = 0; p.medc = 0;
+    p.gC0 = p.gC1 = p.gC2 = p.g_depth = p.g_alpha = p.gN0 = p.gN1 = p.gN2 = p.g_med = p.g_dist = 0.f;
+    if (inside) {
+        T_final = a.final_T[pix]; p.fM1 = a.final_T[HW + pix]; p.fM2 = a.final_T[2 * HW + pix];
+        p.last = (int)a.n_contrib[pix]; p.medc = (int)a.n_contrib[HW + pix];
+        p.gC0 = a.dL_dpix[pix]; p.gC1 = a.dL_dpix[HW + pix]; p.gC2 = a.dL_dpix[2 * HW + pix];
+        p.g_depth = a.dL_dothers[pix]; p.g_alpha = a.dL_dothers[HW + pix];
+        p.gN0 = a.dL_dothers[2 * HW + pix]; p.gN1 = a.dL_dothers[3 * HW + pix]; p.gN2 = a.dL_dothers[4 * HW + pix];
+        p.g_med = a.dL_dothers[5 * HW + pix]; p.g_dist = a.dL_dothers[6 * HW + pix];
+    }
+    p.final_A = 1.f - T_final;
+    p.T = T_final;
+    p.X = T_final * __builtin_fmaf(a.bg[2], p.gC2, __builtin_fmaf(a.bg[1], p.gC1, a.bg[0] * p.gC0));     // suffix sum, seeded with the background term
+    return p;
+}
+
+// This header's users are compiled with -ffp-contract=off and spell every fused multiply-add out, so the walk variants that share
+// pair_gradients execute the SAME rounding sequence per (pixel, surfel) pair — that is what makes rows / quad bit-identical.
+#define FMA(a, b, c) __builtin_fmaf((a), (b), (c))
+
+// did the forward composite this pair?  (pos <= last and the forward's own tests, surfel_common.h)
+__device__ __forceinline__ bool pair_hit(const Pixel& p, const float4 q0, const float4 q1, const float4 q2, int pos, Hit& h) {
+    return pair_hit(p.pxf, p.pyf, q0, q1, q2, h) & (pos <= p.last);
+}
+
+// gradient-record slot of the (tile, surfel) instance whose staged record holds q4
+__device__ __forceinline__ size_t grec_slot(const float4 q4, int tx, int ty) {
+    const uint32_t basei = __float_as_uint(q4.z), rectbits = __float_as_uint(q4.w);
+    const int x0 = rectbits & 1023, y0 = (rectbits >> 10) & 1023, rw = rectbits >> 20;
+    return (size_t)basei + (size_t)((ty - y0) * rw + (tx - x0));
+}
+
+// variant == 2: both kernels are launched and each decides on the device, from the frame's totals, whether it is the one to run.
+// Small footprints (few tile instances per emitting surfel) favour the per-row walk — it wastes fewer lanes; on wide footprints
+// the per-quad walk's cheaper visit wins (profiles/r02_blend_bwd_variants.md).  Every workgroup reaches the same verdict.
+constexpr int AUTO_ROWS_MAX_INST_PER_SURFEL = 4;
+__device__ __forceinline__ bool auto_picks_rows(const BlendBwdArgs& a) {
+    const int lane = threadIdx.x & 63;
+    uint32_t r = a.totals[lane], v = a.totals[R_SLOTS + lane];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { r += __shfl_xor(r, o); v += __shfl_xor(v, o); }
+    return (unsigned long long)r <= (unsigned long long)AUTO_ROWS_MAX_INST_PER_SURFEL * v;
+}
+
+__device__ __forceinline__ int block_max(int v, int* s_max) {
+    if (threadIdx.x == 0) *s_max = 0;
+    __syncthreads();
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o));
+    if ((threadIdx.x & 63) == 0) atomicMax(s_max, v);
+    __syncthreads();
+    return *s_max;
+}
+
+// Instances behind every pixel's last contributor (list positions > maxc) are never staged and get NO gradient record: a tile's
+// list is ordered by (depth bits, surfel index), so "position <= maxc" is decidable from the surfel's own key against the key of
+// the instance at position maxc — the tile's CUT, 8 B per tile, which preprocess_bwd checks before it fetches an 80-B record
+// (round 2 wrote, and read back, a zero record for every such instance: half of the record traffic of crowded frames).
+//   cut = (depth bits, surfel index + 1) of the last staged instance; (0, 0) when nothing was staged.
+__device__ __forceinline__ void write_cut(const BlendBwdArgs& a, const uint2 range, int maxc, int tile) {
+    if (threadIdx.x == 0) {
+        uint2 c = make_uint2(0u, 0u);
+        if (maxc > 0) {
+            const uint32_t id = a.point_list[range.x + maxc - 1];
+            c = make_uint2(__float_as_uint(a.depths[id]), id + 1u);
+        }
+        a.cut[tile] = c;
+    }
+}
+
+__device__ __forceinline__ float4 add4(const float4 a, const float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+
+
+}  // namespace surfel

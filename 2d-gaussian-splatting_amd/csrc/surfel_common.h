@@ -49,6 +49,45 @@ constexpr int GREC_F = 20;
 #define SURFEL_EXP(x) __expf(x)
 #endif
 
+// ---- ray-splat intersection of one (pixel, surfel) pair --------------------------------------------
+// ONE definition for blend_fwd and every blend_bwd walk: the backward re-decides, pair by pair, what the forward composited
+// (alpha >= 1/255, depth >= near, p2 != 0), so both sides must round identically.  Every fused multiply-add is spelled out and
+// contraction is switched off inside these functions, whatever -ffp-contract the including file is compiled with
+// (tests/test_gpu_parity.py::test_forward_and_backward_composite_the_same_pairs counts both sides).
+#define SURFEL_FMA(a, b, c) __builtin_fmaf((a), (b), (c))
+struct Hit {
+    float kx, ky, kz, lx, ly, lz, sx, sy, ip, dx, dy, depth, G, alpha, Twx, Twy, opa;
+    bool use3d;
+};
+// k = px*Tw - Tu, l = py*Tw - Tv and the offsets to the projected centre (the low-pass branch)
+__device__ __forceinline__ void pair_planes(float pxf, float pyf, const float4 q0, const float4 q1, const float4 q2, Hit& h) {
+#pragma clang fp contract(off)
+    const float Twx = q1.z, Twy = q1.w, Twz = q2.x;
+    h.kx = SURFEL_FMA(pxf, Twx, -q0.x); h.ky = SURFEL_FMA(pxf, Twy, -q0.y); h.kz = SURFEL_FMA(pxf, Twz, -q0.z);
+    h.lx = SURFEL_FMA(pyf, Twx, -q0.w); h.ly = SURFEL_FMA(pyf, Twy, -q1.x); h.lz = SURFEL_FMA(pyf, Twz, -q1.y);
+    h.dx = q2.y - pxf; h.dy = q2.z - pyf;
+}
+// from the planes: intersection (s), depth, alpha; returns the forward's compositing tests (p2 != 0, depth >= near, alpha >= 1/255)
+__device__ __forceinline__ bool pair_intersect(const float Twx, const float Twy, const float Twz, const float opa, Hit& h) {
+#pragma clang fp contract(off)
+    h.Twx = Twx; h.Twy = Twy; h.opa = opa;
+    const float p0 = SURFEL_FMA(h.ky, h.lz, -(h.kz * h.ly)), p1 = SURFEL_FMA(h.kz, h.lx, -(h.kx * h.lz)), p2 = SURFEL_FMA(h.kx, h.ly, -(h.ky * h.lx));
+    h.ip = SURFEL_RCP(p2);
+    h.sx = p0 * h.ip; h.sy = p1 * h.ip;
+    const float rho3d = SURFEL_FMA(h.sx, h.sx, h.sy * h.sy);
+    const float rho2d = FILTER_INV_SQUARE * SURFEL_FMA(h.dx, h.dx, h.dy * h.dy);
+    h.use3d = rho3d <= rho2d;
+    const float rho = fminf(rho3d, rho2d);
+    h.depth = h.use3d ? SURFEL_FMA(h.sx, Twx, h.sy * Twy) + Twz : Twz;
+    h.G = SURFEL_EXP(-0.5f * rho);
+    h.alpha = fminf(ALPHA_MAX, opa * h.G);
+    return (p2 != 0.f) & (h.depth >= NEAR_N) & (h.alpha >= ALPHA_MIN);
+}
+__device__ __forceinline__ bool pair_hit(float pxf, float pyf, const float4 q0, const float4 q1, const float4 q2, Hit& h) {
+    pair_planes(pxf, pyf, q0, q1, q2, h);
+    return pair_intersect(q1.z, q1.w, q2.x, q2.w, h);
+}
+
 struct Rect { int x0, y0, x1, y1; };
 
 __device__ __forceinline__ Rect tile_rect(float px, float py, int r, int gx, int gy) {

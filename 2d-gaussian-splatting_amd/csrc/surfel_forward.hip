@@ -16,6 +16,7 @@ namespace surfel {
 constexpr int MW = 8;             // 32-bit mask words per staged batch of 256
 constexpr int MSTRIDE = MW + 2;   // + zero sentinel word, padded so each sub-tile's words start 8-B aligned
 
+template <bool STATS>
 __global__ void __launch_bounds__(BLOCK) blend_fwd_kernel(BlendFwdArgs a) {
     __shared__ float4 s_rec[BLOCK * 5];
     __shared__ __attribute__((aligned(8))) uint32_t s_mask[16 * MSTRIDE];    // [sub-tile][word]
@@ -35,6 +36,7 @@ __global__ void __launch_bounds__(BLOCK) blend_fwd_kernel(BlendFwdArgs a) {
     float T = 1.f, C0 = 0.f, C1 = 0.f, C2 = 0.f, N0 = 0.f, N1 = 0.f, N2 = 0.f;
     float D = 0.f, M1 = 0.f, M2 = 0.f, dist = 0.f, med = 0.f;
     uint32_t last = 0, medc = 0;
+    unsigned npairs = 0;      // STATS: (pixel, surfel) pairs this thread composited
     constexpr float MC1 = FAR_N / (FAR_N - NEAR_N);
     if (threadIdx.x < 16) s_mask[threadIdx.x * MSTRIDE + MW] = 0u;     // sentinel
 
@@ -71,24 +73,17 @@ __global__ void __launch_bounds__(BLOCK) blend_fwd_kernel(BlendFwdArgs a) {
             const int j = (widx << 5) + __builtin_ctz(cur | 0x80000000u);
             cur &= cur - 1u;
             const float4 q0 = s_rec[j * 5 + 0], q1 = s_rec[j * 5 + 1], q2 = s_rec[j * 5 + 2];
-            // ray-splat intersection, branch-free
-            const float Twx = q1.z, Twy = q1.w, Twz = q2.x;
-            const float kx = pxf * Twx - q0.x, ky = pxf * Twy - q0.y, kz = pxf * Twz - q0.z;
-            const float lx_ = pyf * Twx - q0.w, ly_ = pyf * Twy - q1.x, lz_ = pyf * Twz - q1.y;
-            const float p0 = ky * lz_ - kz * ly_, p1 = kz * lx_ - kx * lz_, p2 = kx * ly_ - ky * lx_;
-            const float ip = SURFEL_RCP(p2);
-            const float sx = p0 * ip, sy = p1 * ip;
-            const float rho3d = sx * sx + sy * sy;
-            const float dx = q2.y - pxf, dy = q2.z - pyf;
-            const float rho2d = FILTER_INV_SQUARE * (dx * dx + dy * dy);
-            const float depth = (rho3d <= rho2d) ? (sx * Twx + sy * Twy) + Twz : Twz;
-            const float alpha = fminf(ALPHA_MAX, q2.w * SURFEL_EXP(-0.5f * fminf(rho3d, rho2d)));
-            const bool ok = act & (!done) & (p2 != 0.f) & (depth >= NEAR_N) & (alpha >= ALPHA_MIN);
+            // ray-splat intersection, branch-free: the one definition the backward walks re-decide with (surfel_common.h)
+            Hit h;
+            const bool hit = pair_hit(pxf, pyf, q0, q1, q2, h);
+            const float depth = h.depth, alpha = h.alpha;
+            const bool ok = act & (!done) & hit;
             if (__any(ok)) {
                 if (ok) {
                     const float testT = T * (1.f - alpha);
                     if (testT < T_EPS) done = true;       // the terminating surfel is not composited
                     else {
+                        if (STATS) npairs++;
                         const uint32_t contributor = base + j + 1;
                         const float4 q3 = s_rec[j * 5 + 3], q4 = s_rec[j * 5 + 4];
                         const float w = alpha * T;
@@ -109,6 +104,11 @@ __global__ void __launch_bounds__(BLOCK) blend_fwd_kernel(BlendFwdArgs a) {
             if (cur == 0u && widx < nw - 1) { widx++; cur = next; next = mrow[widx + 1]; }
         }
     }
+    if (STATS) {      // stats[6] += composited pairs (the backward's stats[1] must count the same set)
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) npairs += __shfl_xor(npairs, o);
+        if (lane == 0) atomicAdd(&a.stats[6], (unsigned long long)npairs);
+    }
     if (inside) {
         const size_t HW = (size_t)a.H * a.W;
         const size_t pix = (size_t)pyi * a.W + pxi;
@@ -126,7 +126,8 @@ __global__ void __launch_bounds__(BLOCK) blend_fwd_kernel(BlendFwdArgs a) {
 }
 
 void launch_blend_fwd(const BlendFwdArgs& a, hipStream_t s) {
-    hipLaunchKernelGGL(blend_fwd_kernel, dim3(a.gx * a.gy), dim3(BLOCK), 0, s, a);
+    if (a.stats) hipLaunchKernelGGL(blend_fwd_kernel<true>, dim3(a.gx * a.gy), dim3(BLOCK), 0, s, a);
+    else hipLaunchKernelGGL(blend_fwd_kernel<false>, dim3(a.gx * a.gy), dim3(BLOCK), 0, s, a);
 }
 
 }  // namespace surfel

@@ -23,6 +23,7 @@ struct BlendFwdArgs {
     int W, H, gx, gy;
     const uint2* ranges; const uint32_t* point_list; const float* rec; const float* bg;
     float* out_color; float* out_others; float* final_T; uint32_t* n_contrib;
+    unsigned long long* stats;   // optional [8]: [6] += (pixel, surfel) pairs composited (surfel_debug_set_blend_stats)
 };
 
 struct BlendBwdArgs {
@@ -30,8 +31,10 @@ struct BlendBwdArgs {
     const uint2* ranges; const uint32_t* point_list; const float* rec; const float* bg;
     const float* final_T; const uint32_t* n_contrib;
     const float* dL_dpix; const float* dL_dothers;
-    float* grec;      // [R][GREC_F] per-instance gradient records (every record written exactly once)
-    int variant;      // 0: per-DPP-row walk, 1: per-wave (8x8 quad) walk, 2: both launched, the device picks from the frame's totals; bit-identical results
+    float* grec;      // [R][GREC_F] per-instance gradient records: the records of a tile's list positions <= its cut are written exactly once, the rest never
+    uint2* cut;       // [tiles] (depth bits, surfel index + 1) of the last instance of every tile that has a record (surfel_blend_bwd.h: write_cut)
+    const float* depths;   // [P] view depths (the sort key's source)
+    int variant;      // 0: per-DPP-row walk, 1: per-wave (8x8 quad) walk, 2: both launched, the device picks from the frame's totals (0 / 1 / 2 bit-identical); 3: scan walk
     const uint32_t* totals;      // [2 * R_SLOTS] partial sums written by preprocess: tile instances | visible surfels
     unsigned long long* stats;   // optional [4]: lane slots issued, useful (pixel, surfel) lanes, wave visits, row / quad visits
 };
@@ -45,6 +48,7 @@ struct PreprocessBwdArgs {
     const float* scales; const float* rotations; const float* transMat_precomp;
     const float* viewmatrix; const float* projmatrix; const float* campos;
     const float* rec; const uint32_t* tiles_touched; const float* grec;
+    const uint2* cut; const float* depths; int gx;      // which of a surfel's instance records exist (BlendBwdArgs::cut)
     float* dL_dtransMat; float* dL_dnormal; float* dL_dopacity; float* dL_dcolors; float* dL_dsh;
     float* dL_dmeans2D; float* dL_dmeans3D; float* dL_dscales; float* dL_drots;
 };
@@ -56,6 +60,7 @@ void launch_tile_ranges(int64_t R, const uint32_t* keys, uint2* ranges, hipStrea
 void launch_blend_fwd(const BlendFwdArgs& a, hipStream_t s);
 void launch_mark_visible(int P, const float* means3D, const float* vm, uint8_t* present, hipStream_t s);
 void launch_blend_bwd(const BlendBwdArgs& a, hipStream_t s);
+void launch_blend_bwd_scan(const BlendBwdArgs& a, hipStream_t s);      // variant 3 (surfel_backward_scan.hip)
 void launch_preprocess_bwd(const PreprocessBwdArgs& a, hipStream_t s);
 // dL/dcolour alone (the sum of three floats of every gradient record, same order as preprocess_bwd -> the same bits), so that a
 // caller can put it on the wire while preprocess_bwd still runs the geometry chain rule (surfel_set_backward_hook)

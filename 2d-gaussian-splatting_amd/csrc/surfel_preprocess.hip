@@ -383,6 +383,24 @@ __device__ __constant__ float BSH_C3[7] = {-0.5900435899266435f, 2.8906114426405
 
 constexpr int NV = 18;    // gradient values per instance record
 
+// Does instance k (0-based) of a surfel's emitted tile rect have a gradient record?  blend_bwd writes records only for the list
+// positions of a tile up to its cut (the last instance any pixel of the tile reached); lists are ordered by (depth bits, surfel
+// index), so the surfel's own key decides — 8 B from a per-tile array instead of an 80-B record of zeros.
+struct RecWalk {
+    uint32_t key, idp, x0, rw, gx;
+    uint32_t tile, col;      // tile of the current record, its column inside the rect
+    __device__ __forceinline__ void init(uint32_t depth_bits, uint32_t i, uint32_t rectbits, int gx_) {
+        key = depth_bits; idp = i; gx = (uint32_t)gx_;
+        x0 = rectbits & 1023u; rw = rectbits >> 20;
+        tile = ((rectbits >> 10) & 1023u) * gx + x0; col = 0u;
+    }
+    __device__ __forceinline__ bool has_record(const uint2* __restrict__ cut) const {
+        const uint2 c = cut[tile];
+        return key < c.x || (key == c.x && idp < c.y);
+    }
+    __device__ __forceinline__ void next() { col++; tile++; if (col == rw) { col = 0u; tile += gx - rw; } }
+};
+
 // ---------------------------------------------------------------------------------------------
 // preprocess_bwd: one thread per surfel.
 // ---------------------------------------------------------------------------------------------
@@ -401,10 +419,12 @@ __global__ void __launch_bounds__(256) preprocess_bwd_kernel(PreprocessBwdArgs a
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (COOP) {
         const int lane = threadIdx.x & 63, wbase = threadIdx.x & ~63;
-        uint32_t beg = 0, cnt = 0;
+        uint32_t beg = 0, cnt = 0, dbits = 0, rbits = 0;
         if (i < a.P && a.radii[i] > 0) {
             beg = __float_as_uint(a.rec[(size_t)i * REC_F + 18]);          // q4.z: inst_base patched by emit_instances
+            rbits = __float_as_uint(a.rec[(size_t)i * REC_F + 19]);        // q4.w: emitted tile rect
             cnt = a.tiles_touched[i];
+            dbits = __float_as_uint(a.depths[i]);
         }
         const int grp = lane / 5, q = lane - 5 * grp;                       // lanes 60-63 idle
         const bool worker = grp < 12;
@@ -412,6 +432,8 @@ __global__ void __launch_bounds__(256) preprocess_bwd_kernel(PreprocessBwdArgs a
         int owner = worker ? grp : 64;                                      // wave lane whose surfel this group is summing
         int next = 12;                                                      // next unassigned surfel (wave-uniform)
         uint32_t b = __shfl(beg, owner & 63), c = __shfl(cnt, owner & 63), r = 0;
+        RecWalk rw;
+        rw.init(__shfl(dbits, owner & 63), (uint32_t)(blockIdx.x * blockDim.x + wbase + (owner & 63)), __shfl(rbits, owner & 63), a.gx);
         if (!worker) c = 0;
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
         const float4* __restrict__ g4 = reinterpret_cast<const float4*>(a.grec);
@@ -429,13 +451,17 @@ __global__ void __launch_bounds__(256) preprocess_bwd_kernel(PreprocessBwdArgs a
                     acc = make_float4(0.f, 0.f, 0.f, 0.f); r = 0;
                 }
                 const uint32_t nb = __shfl(beg, owner & 63), nc = __shfl(cnt, owner & 63);
-                if (done) { b = nb; c = owner < 64 ? nc : 0u; }
+                const uint32_t nd = __shfl(dbits, owner & 63), nr = __shfl(rbits, owner & 63);
+                if (done) { b = nb; c = owner < 64 ? nc : 0u; rw.init(nd, (uint32_t)(blockIdx.x * blockDim.x + wbase + (owner & 63)), nr, a.gx); }
             }
             const bool live = worker && owner < 64 && r < c;
             if (!__any(worker && owner < 64)) break;
             if (live) {
-                const float4 v = g4[(size_t)(b + r) * 5 + q];
-                acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+                if (rw.has_record(a.cut)) {      // (a record that does not exist is a record of zeros: skipping the addition keeps the bits)
+                    const float4 v = g4[(size_t)(b + r) * 5 + q];
+                    acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+                }
+                rw.next();
                 r++;
             }
         }
@@ -493,15 +519,23 @@ __global__ void __launch_bounds__(256) preprocess_bwd_kernel(PreprocessBwdArgs a
         g[8] = v2.x; g[9] = v2.y; g[10] = v2.z; g[11] = v2.w; g[12] = v3.x; g[13] = v3.y; g[14] = v3.z; g[15] = v3.w;
         g[16] = v4.x; g[17] = v4.y;
     } else {
+    RecWalk rw;
+    rw.init(__float_as_uint(a.depths[i]), (uint32_t)i, __float_as_uint(r4.w), a.gx);
     uint32_t k = beg;
     for (; k + 1 < end; k += 2) {
+        const bool h0 = rw.has_record(a.cut);
+        rw.next();
+        const bool h1 = rw.has_record(a.cut);
+        rw.next();
         const float4* __restrict__ src = reinterpret_cast<const float4*>(a.grec + (size_t)k * GREC_F);
-        const float4 v0 = src[0], v1 = src[1], v2 = src[2], v3 = src[3], v4 = src[4];
-        const float4 w0 = src[5], w1 = src[6], w2 = src[7], w3 = src[8], w4 = src[9];
-        add_rec(v0, v1, v2, v3, v4);
-        add_rec(w0, w1, w2, w3, w4);
+        const float4 zz = make_float4(0.f, 0.f, 0.f, 0.f);
+        float4 v0 = zz, v1 = zz, v2 = zz, v3 = zz, v4 = zz, w0 = zz, w1 = zz, w2 = zz, w3 = zz, w4 = zz;
+        if (h0) { v0 = src[0]; v1 = src[1]; v2 = src[2]; v3 = src[3]; v4 = src[4]; }
+        if (h1) { w0 = src[5]; w1 = src[6]; w2 = src[7]; w3 = src[8]; w4 = src[9]; }
+        if (h0) add_rec(v0, v1, v2, v3, v4);
+        if (h1) add_rec(w0, w1, w2, w3, w4);
     }
-    if (k < end) {
+    if (k < end && rw.has_record(a.cut)) {
         const float4* __restrict__ src = reinterpret_cast<const float4*>(a.grec + (size_t)k * GREC_F);
         const float4 v0 = src[0], v1 = src[1], v2 = src[2], v3 = src[3], v4 = src[4];
         add_rec(v0, v1, v2, v3, v4);
@@ -693,7 +727,10 @@ __global__ void __launch_bounds__(256) colour_gradients_kernel(PreprocessBwdArgs
     if (a.radii[i] > 0) {
         const uint32_t beg = __float_as_uint(a.rec[(size_t)i * REC_F + 18]);
         const uint32_t end = beg + a.tiles_touched[i];
-        for (uint32_t k = beg; k < end; k++) {
+        RecWalk rw;
+        rw.init(__float_as_uint(a.depths[i]), (uint32_t)i, __float_as_uint(a.rec[(size_t)i * REC_F + 19]), a.gx);
+        for (uint32_t k = beg; k < end; k++, rw.next()) {
+            if (!rw.has_record(a.cut)) continue;
             const float* __restrict__ src = a.grec + (size_t)k * GREC_F;
             const float v0 = src[15];
             const float2 v1 = *reinterpret_cast<const float2*>(src + 16);

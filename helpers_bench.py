@@ -133,7 +133,7 @@ def time_trainer(tr, steps, warmup, prime=15):
     # both blend_bwd walks on this very state (the library default picks one per frame on the device): data for that choice
     ab = {}
     lib = surfel_native.load()
-    for name, v in (("rows", 0), ("quad", 1)):
+    for name, v in (("rows", 0), ("quad", 1), ("scan", 3)):
         lib.surfel_set_option(b"bwd_variant", v)
         tr.pipe.debug = 2
         for _ in range(6):

@@ -34,7 +34,7 @@ def main():
         tiles = ((W + 15) // 16) * ((H + 15) // 16)
         row = {"workload": spec, "P": P, "R": run.R, "inst_per_tile": round(run.R / tiles, 1)}
         ref = None
-        for vname, flag in (("rows", n.OPT_BWD_ROWS), ("quad", n.OPT_BWD_QUAD)):
+        for vname, flag in (("rows", n.OPT_BWD_ROWS), ("quad", n.OPT_BWD_QUAD), ("scan", n.OPT_BWD_SCAN)):
             run.debug = flag | 2
             for _ in range(3):
                 g = run.backward(gC, gO)
@@ -55,8 +55,11 @@ def main():
             row[vname + "_units_with_hits"] = int(s[4]); row[vname + "_s5"] = int(s[5]); row[vname + "_raw"] = [int(x) for x in s]
             if ref is None:
                 ref = g
-            else:
+            elif vname == "quad":
                 row["bit_identical"] = all(np.array_equal(ref[k], g[k]) for k in ref)
+            else:      # the scan walk sums in another order: agreement to summation noise
+                row["scan_min_cosine_vs_rows"] = round(min(float(np.dot(ref[k].ravel().astype(np.float64), g[k].ravel().astype(np.float64)) /
+                                                              max(1e-300, np.linalg.norm(ref[k].astype(np.float64)) * np.linalg.norm(g[k].astype(np.float64)))) for k in ref), 9)
         run.debug = 2          # library default: variant chosen on the device
         for _ in range(3):
             run.backward(gC, gO)
@@ -75,6 +78,7 @@ def main():
             t = n.collect_stage_times()
             row[nm] = round(1e3 * t["preprocess_bwd"][0] / t["preprocess_bwd"][1], 1)
         row["speedup"] = round(row["quad_us"] / row["rows_us"], 3)
+        row["scan_vs_best_other"] = round(row["scan_us"] / min(row["rows_us"], row["quad_us"]), 3)
         print(json.dumps(row), flush=True)
         out.append(row)
         del run

@@ -161,19 +161,26 @@ def test_config_sizes(name):
     gC = rng.normal(size=col.shape).astype(np.float32); gO = rng.normal(size=oth.shape).astype(np.float32)
     g = run.backward(gC, gO)
     og, og32 = o64.rasterize_backward(st, gC, gO), o32.rasterize_backward(st32, gC, gO)
-    for k, ref, r32 in [("means3D", og.dL_dmeans3D, og32.dL_dmeans3D), ("scales", og.dL_dscales, og32.dL_dscales),
-                        ("rots", og.dL_drots, og32.dL_drots), ("opacity", og.dL_dopacity, og32.dL_dopacity),
-                        ("sh", og.dL_dsh, og32.dL_dsh), ("means2D", og.dL_dmean2D, og32.dL_dmean2D)]:
-        x = g[k].reshape(ref.shape)
-        assert np.isfinite(x).all(), k
-        scale = np.abs(ref).mean()
-        f, f32 = frac_close(x, ref, 1e-4 * scale, G_RTOL), frac_close(r32, ref, 1e-4 * scale, G_RTOL)
-        cs, cs32 = cosine(x, ref), cosine(r32, ref)
-        assert f >= 0.985 and f >= f32 - 0.002, "%s: hip %.5f, cpu-fp32 %.5f" % (k, f, f32)
-        # the cosine of the ill-conditioned tensors (the means2D statistic above all) is dominated by a handful of edge-on
-        # surfels whose fp32 value swings with the last bit of T; like `f`, it is judged against the fp32 CPU run as well
-        assert cs >= 0.999 or cs >= cs32 - 1e-3, "%s cosine hip %.7f, cpu-fp32 %.7f" % (k, cs, cs32)
-        print("%s %s: frac hip %.5f cpu-fp32 %.5f | cosine hip %.7f cpu-fp32 %.7f" % (name, k, f, f32, cs, cs32))
+
+    def check(g, walk):
+        for k, ref, r32 in [("means3D", og.dL_dmeans3D, og32.dL_dmeans3D), ("scales", og.dL_dscales, og32.dL_dscales),
+                            ("rots", og.dL_drots, og32.dL_drots), ("opacity", og.dL_dopacity, og32.dL_dopacity),
+                            ("sh", og.dL_dsh, og32.dL_dsh), ("means2D", og.dL_dmean2D, og32.dL_dmean2D)]:
+            x = g[k].reshape(ref.shape)
+            assert np.isfinite(x).all(), k
+            scale = np.abs(ref).mean()
+            f, f32 = frac_close(x, ref, 1e-4 * scale, G_RTOL), frac_close(r32, ref, 1e-4 * scale, G_RTOL)
+            cs, cs32 = cosine(x, ref), cosine(r32, ref)
+            assert f >= 0.985 and f >= f32 - 0.002, "%s %s: hip %.5f, cpu-fp32 %.5f" % (walk, k, f, f32)
+            # the cosine of the ill-conditioned tensors (the means2D statistic above all) is dominated by a handful of edge-on
+            # surfels whose fp32 value swings with the last bit of T; like `f`, it is judged against the fp32 CPU run as well
+            assert cs >= 0.999 or cs >= cs32 - 1e-3, "%s %s cosine hip %.7f, cpu-fp32 %.7f" % (walk, k, cs, cs32)
+            print("%s %s %s: frac hip %.5f cpu-fp32 %.5f | cosine hip %.7f cpu-fp32 %.7f" % (name, walk, k, f, f32, cs, cs32))
+
+    check(g, "auto")
+    run.debug = n.OPT_BWD_SCAN          # the scan walk is held to the same bars
+    check(run.backward(gC, gO), "scan")
+    run.debug = 0
     if name in ("C3", "C4"):
         base = (run.R, c, o, run.radii.cpu().numpy(), g)
         for mode in (0, 2):      # depth-presorted emission | per-tile depth sort
@@ -372,6 +379,106 @@ def test_backward_variants_are_identical(kind):
         d = np.abs(res[0][k].astype(np.float64) - res[1][k])
         assert np.array_equal(res[0][k], res[1][k]), "%s: dL/d%s differs between the variants (max |d| %.3e, %d elements)" % (
             kind, k, d.max(), int((d > 0).sum()))
+
+
+def _walk_scene(kind, seed=31):
+    import synthetic
+    if kind == "C1":
+        return _scene("C1", seed=2)
+    if kind == "crowded":
+        sc = synthetic.make_scene(9000, 96, 64, seed=6, px_radius=30.0, z_near=2.0, z_far=8.0)
+        sc["opacities"] = np.full_like(sc["opacities"], 0.02)
+        return sc
+    if kind == "saturating":      # opaque, deep: most lists are cut short by saturation (tile cuts, dead sub-tiles)
+        sc = synthetic.make_scene(20000, 128, 96, seed=9, px_radius=9.0, z_near=1.0, z_far=9.0)
+        sc["opacities"] = np.full_like(sc["opacities"], 0.95)
+        return sc
+    return _stress_scene(kind, seed)
+
+
+@pytest.mark.parametrize("kind", ["plain", "needles", "huge", "tiny", "grazing", "opaque_faint", "crowded", "saturating", "C1"])
+def test_scan_walk_matches_the_oracle_and_the_other_walks(kind):
+    """blend_bwd scan walk (lanes = instances, DPP row scans for T and the suffix sum, gradients accumulated in registers;
+    surfel_backward_scan.hip).  Its summation order differs from the rows / quad walks, so it cannot share their bits; it must
+    (a) be bit-reproducible run to run, (b) meet the oracle bars of the element test wherever the rows walk meets them,
+    (c) agree with the rows walk to fp32 summation noise: cosine >= 0.999999 and >= 99.9 % of elements within
+    1e-5 mean|ref| + 1e-3 |ref|."""
+    import surfel_native as n
+    from oracle.surfel_oracle import Oracle
+    a = scene_args(_walk_scene(kind))
+    rng = np.random.default_rng(8)
+    gC = rng.normal(size=(3, a["H"], a["W"])).astype(np.float32); gO = rng.normal(size=(7, a["H"], a["W"])).astype(np.float32)
+    run = HipRun(a).forward()
+    res = {}
+    for name, flag in (("rows", n.OPT_BWD_ROWS), ("scan", n.OPT_BWD_SCAN), ("scan2", n.OPT_BWD_SCAN)):
+        run.debug = flag
+        res[name] = run.backward(gC, gO)
+    o = Oracle("f64")
+    R, col, oth, radii, st = oracle_forward(o, a, depth_key=run.depths())
+    og = o.rasterize_backward(st, gC, gO)
+    refs = dict(means3D=og.dL_dmeans3D, opacity=og.dL_dopacity, sh=og.dL_dsh, means2D=og.dL_dmean2D, scales=og.dL_dscales, rots=og.dL_drots)
+    for k in res["rows"]:
+        x, y = res["scan"][k], res["rows"][k]
+        assert np.isfinite(x).all(), k
+        assert np.array_equal(x, res["scan2"][k]), "scan walk not reproducible: %s" % k
+        scale = np.abs(y).mean() + 1e-30
+        f = frac_close(x, y, 1e-5 * scale, 1e-3)
+        cs = cosine(x, y)
+        assert f >= 0.999 and cs >= 0.999999, "%s: dL/d%s scan vs rows: %.5f of elements, cosine %.8f" % (kind, k, f, cs)
+        if k in refs:
+            ref = refs[k]
+            sc_ = np.abs(ref).mean() + 1e-30
+            fs = frac_close(x.reshape(ref.shape), ref, 1e-4 * sc_ + 1e-12, G_RTOL)
+            fr = frac_close(y.reshape(ref.shape), ref, 1e-4 * sc_ + 1e-12, G_RTOL)
+            assert fs >= fr - 5e-4, "%s: dL/d%s vs oracle: scan %.5f, rows %.5f" % (kind, k, fs, fr)
+
+
+@pytest.mark.parametrize("kind", ["plain", "needles", "huge", "tiny", "opaque_faint", "huge_faint"])
+def test_scan_walk_culling_is_exact(kind):
+    """The scan walk with culling on / off: the cull only removes (pixel, surfel) pairs that contribute nothing, but it changes
+    which instances share a chunk, i.e. the association of the T product and of the suffix sums — so the comparison is to
+    summation noise, not bits: cosine >= 0.999999, >= 99.9 % of elements within 1e-5 mean + 1e-3 |ref|."""
+    import surfel_native as n
+    a = scene_args(_stress_scene(kind, 11))
+    rng = np.random.default_rng(11)
+    gC = rng.normal(size=(3, a["H"], a["W"])).astype(np.float32); gO = rng.normal(size=(7, a["H"], a["W"])).astype(np.float32)
+    res = []
+    for cull in (1, 0):
+        run = HipRun(a, debug=0 if cull else n.OPT_NO_CULL).forward()
+        run.debug = n.OPT_BWD_SCAN | (0 if cull else n.OPT_NO_CULL)
+        res.append(run.backward(gC, gO))
+    for k in res[0]:
+        x, y = res[0][k], res[1][k]
+        assert np.isfinite(x).all() and np.isfinite(y).all(), k
+        scale = np.abs(y).mean() + 1e-30
+        assert frac_close(x, y, 1e-5 * scale, 1e-3) >= 0.999 and cosine(x, y) >= 0.999999, (kind, k)
+
+
+@pytest.mark.parametrize("kind", ["plain", "needles", "huge", "tiny", "grazing", "opaque_faint", "crowded", "saturating", "C1"])
+def test_forward_and_backward_composite_the_same_pairs(kind):
+    """The backward re-decides, pair by pair, what the forward composited (alpha >= 1/255, depth >= near, p2 != 0, position <= last).
+    Both sides evaluate ONE definition of the intersection (surfel_common.h: pair_hit, contraction off) — so the number of pairs the
+    instrumented forward composited must equal the number of lanes every backward walk treats as composited."""
+    import torch
+    import surfel_native as n
+    lib = n.load()
+    a = scene_args(_walk_scene(kind))
+    rng = np.random.default_rng(1)
+    gC = rng.normal(size=(3, a["H"], a["W"])).astype(np.float32); gO = rng.normal(size=(7, a["H"], a["W"])).astype(np.float32)
+    st = torch.zeros(8, dtype=torch.int64, device="cuda:0")
+    try:
+        assert lib.surfel_debug_set_blend_stats(n.ptr(st)) == 0
+        run = HipRun(a).forward()
+        fwd_pairs = int(st.cpu().numpy()[6])
+        assert fwd_pairs > 0
+        for name, flag in (("rows", n.OPT_BWD_ROWS), ("quad", n.OPT_BWD_QUAD), ("scan", n.OPT_BWD_SCAN)):
+            st.zero_()
+            run.debug = flag
+            run.backward(gC, gO)
+            got = int(st.cpu().numpy()[1])
+            assert got == fwd_pairs, "%s / %s: forward composited %d pairs, the backward %d" % (kind, name, fwd_pairs, got)
+    finally:
+        lib.surfel_debug_set_blend_stats(None)
 
 
 @pytest.mark.parametrize("kind", ["plain", "huge", "crowded", "C1"])
