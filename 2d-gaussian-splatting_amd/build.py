@@ -28,6 +28,25 @@ def _stale(out, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+def build_variant(tag, defines, verbose=False):
+    """Diagnostic twin lib/libsurfel_hip_<tag>.so with extra -D flags (e.g. -DSCAN_TIMING); loaded only through SURFEL_LIB."""
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    bdir = os.path.join(HERE, "build_" + tag)
+    os.makedirs(bdir, exist_ok=True)
+    os.makedirs(os.path.join(HERE, "lib"), exist_ok=True)
+    lib = os.path.join(HERE, "lib", "libsurfel_hip_%s.so" % tag)
+    objs = []
+    for src in SOURCES:
+        obj = os.path.join(bdir, src + ".o")
+        objs.append(obj)
+        cmd = [hipcc] + FLAGS + list(defines) + EXTRA.get(src, []) + ["-c", os.path.join(CSRC, src), "-o", obj]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs)
+    return lib
+
+
 def build(force=False, verbose=False, ieee=False):
     """ieee=True: the diagnostic twin lib/libsurfel_hip_ieee.so (-DSURFEL_IEEE_MATH: IEEE division and libm expf in the blend kernels);
     never loaded by the product (surfel_native loads it only when SURFEL_LIB points at it)."""
@@ -56,4 +75,8 @@ def build(force=False, verbose=False, ieee=False):
 
 
 if __name__ == "__main__":
+    if "--variant" in sys.argv:      # python build.py --variant TAG -DFOO -DBAR=1
+        k = sys.argv.index("--variant")
+        print(build_variant(sys.argv[k + 1], sys.argv[k + 2:], verbose=False))
+        sys.exit(0)
     print(build(force="--force" in sys.argv, verbose=True, ieee="--ieee" in sys.argv))

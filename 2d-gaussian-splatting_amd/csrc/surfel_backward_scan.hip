@@ -29,7 +29,8 @@ constexpr int CH = 16;       // instances per chunk = lanes of a DPP row
 __device__ __forceinline__ float row_scan_mul(float x) {
     // v_mul_f32_dpp without bound_ctrl: lanes whose source lies outside the row keep their value.  2 wait states between the
     // VALU write of a register and its use as a DPP source (the compiler cannot see into the asm).
-    asm volatile("s_nop 2\n\t"
+    asm(
+                 "s_nop 2\n\t"
                  "v_mul_f32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
                  "s_nop 1\n\t"
                  "v_mul_f32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
@@ -62,8 +63,21 @@ __device__ __forceinline__ float row_scan_add_excl(float x) {
 // every lane — the last lane of a row writes the pixel's state, the others a scratch area behind it — and idle lanes park a
 // (never read) slot as well.
 constexpr int STATE_SCRATCH = 49;      // float4s: 16 steps x 16 B + 64 lanes x 8 B
+// -DSCAN_TIMING (diagnostic build): the instrumented kernel accumulates shader-clock ticks per phase of every wave instead of the lane
+// counters — stats[0] staging + lists, [1] walk, [2] wait at the barrier behind the walk, [3] flush, [4] wait behind the flush,
+// [5] record write, [6] whole kernel, [7] waves (scripts/bwd_ab.py prints them as scan_raw).
+#ifdef SCAN_TIMING
+#define TM(acc) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); const long long t_ = __builtin_readcyclecounter(); acc += t_ - tm_t; tm_t = t_; }
+#define LANE_STATS false
+#else
+#define TM(acc)
+#define LANE_STATS STATS
+#endif
+#ifndef SCAN_MIN_WG
+#define SCAN_MIN_WG 3
+#endif
 template <bool STATS>
-__global__ void __launch_bounds__(BLOCK, 3) blend_bwd_scan_kernel(BlendBwdArgs a) {
+__global__ void __launch_bounds__(BLOCK, SCAN_MIN_WG) blend_bwd_scan_kernel(BlendBwdArgs a) {
     __shared__ float4 s_rec[SB * 5];                          // 10 KB: q0-q4 of the staged instances
     __shared__ float4 s_slot[BLOCK * 5];                      // 20 KB: the round's partial records, one per walking lane
     __shared__ float4 s_pix[BLOCK * 3];                       // 12 KB
@@ -74,6 +88,14 @@ __global__ void __launch_bounds__(BLOCK, 3) blend_bwd_scan_kernel(BlendBwdArgs a
     __shared__ uint32_t s_cmm[SB];                            // per staged instance: first | last << 8 round it takes part in
     __shared__ int s_rowlast[16];
     __shared__ int s_max;
+#ifdef SCAN_PAD_LDS      // occupancy experiment: SCAN_PAD_LDS bytes of unused LDS
+    __shared__ char s_pad[SCAN_PAD_LDS];
+    if (a.W < 0) s_pad[threadIdx.x] = 1;
+#endif
+#ifdef SCAN_TIMING
+    const long long tm_start = __builtin_readcyclecounter();
+    long long tm_stage = 0, tm_walk = 0, tm_bar1 = 0, tm_flush = 0, tm_bar2 = 0, tm_rec = 0, tm_t = tm_start;
+#endif
     const int tid = threadIdx.x;
     const int tile = xcd_tile(blockIdx.x, a.gx * a.gy);
     const int tx = tile % a.gx, ty = tile / a.gx;
@@ -106,48 +128,79 @@ __global__ void __launch_bounds__(BLOCK, 3) blend_bwd_scan_kernel(BlendBwdArgs a
     const int ft = tid & (SB - 1), fh = tid >> 7;
     float4 f0 = make_float4(0.f, 0.f, 0.f, 0.f), f1 = f0, f2 = f0;
 
+    // Software-pipelined staging: the records of batch b+1 are loaded into registers while batch b is walked (every thread holds
+    // half a record: (instance li, half hf) — hf 0: q0 q1 q3 q4, hf 1: q2 q5 q6 and the footprint test), the surfel ids one batch
+    // further ahead; the gradient records of batch b are stored at the top of batch b+1, BEHIND the consumption of the prefetched
+    // registers (gfx9 counts loads and stores in one vmcnt: a wait for the loads would otherwise wait for the stores as well).
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 pa = zero4, pb = zero4, pc = zero4, pd = zero4;
+    uint32_t nid = 0;
+    {
+        const float4* __restrict__ recq = reinterpret_cast<const float4*>(a.rec);
+        if (ft < min(SB, maxc)) {
+            const uint32_t id = a.point_list[range.x + (maxc - ft) - 1];
+            const float4* __restrict__ src = recq + (size_t)id * REC_Q;
+            if (fh == 0) { pa = src[0]; pb = src[1]; pc = src[3]; pd = src[4]; } else { pa = src[2]; pb = src[5]; pc = src[6]; }
+        }
+        if (maxc - SB > 0 && ft < min(SB, maxc - SB)) nid = a.point_list[range.x + (maxc - SB - ft) - 1];
+    }
+    bool pend = false;
+    size_t pend_slot = 0;
     for (int hi = maxc; hi > 0; hi -= SB) {
         const int mb = min(SB, hi);
         __syncthreads();                      // previous batch written out: s_rec / s_list / s_rank reusable
         unsigned ovr = 0;
-        if (wave < SB / 64) {
-            if (tid < mb) {
-                const int pos = hi - tid;
-                const uint32_t id = a.point_list[range.x + pos - 1];
-                const float4* __restrict__ src = reinterpret_cast<const float4*>(a.rec + (size_t)id * REC_F);
-                const float4 v0 = src[0], v1 = src[1], v2 = src[2], v3 = src[3], v4 = src[4], v5 = src[5], v6 = src[6];
-                s_rec[tid * 5 + 0] = v0; s_rec[tid * 5 + 1] = v1; s_rec[tid * 5 + 2] = v2;
-                s_rec[tid * 5 + 3] = v3; s_rec[tid * 5 + 4] = v4;
-                ovr = subtile_overlap_rows(make_foot(v2, v5, v6), tx * TILE, ty * TILE);
+        if (ft < mb) {
+            if (fh == 0) { s_rec[ft * 5 + 0] = pa; s_rec[ft * 5 + 1] = pb; s_rec[ft * 5 + 3] = pc; s_rec[ft * 5 + 4] = pd; }
+            else {
+                s_rec[ft * 5 + 2] = pa;
+                ovr = subtile_overlap_rows(make_foot(pa, pb, pc), tx * TILE, ty * TILE);
+                const int pos = hi - ft;
                 unsigned live = 0;            // a sub-tile never meets an instance behind the last contributor of all its pixels
 #pragma unroll
                 for (int s = 0; s < 16; s++) live |= (pos <= s_rowlast[s]) ? (1u << s) : 0u;
                 ovr &= live;
             }
+        }
+        if (pend) {                           // the previous batch's gradient records
+            float4* __restrict__ dst = reinterpret_cast<float4*>(a.grec + pend_slot * GREC_F);
+            if (fh == 0) { dst[0] = f0; dst[1] = f1; dst[2] = f2; }
+            else { dst[3] = f0; dst[4] = f1; }
+        }
+        f0 = zero4; f1 = zero4; f2 = zero4;
+        if (hi - SB > 0) {                    // next batch's records, and the ids of the one behind it
+            const float4* __restrict__ recq = reinterpret_cast<const float4*>(a.rec);
+            if (ft < min(SB, hi - SB)) {
+                const float4* __restrict__ src = recq + (size_t)nid * REC_Q;
+                if (fh == 0) { pa = src[0]; pb = src[1]; pc = src[3]; pd = src[4]; } else { pa = src[2]; pb = src[5]; pc = src[6]; }
+            }
+            if (hi - 2 * SB > 0 && ft < min(SB, hi - 2 * SB)) nid = a.point_list[range.x + (hi - 2 * SB - ft) - 1];
+        }
+        if (fh == 1) {
 #pragma unroll
             for (int s = 0; s < 16; s++) {
                 const unsigned long long b = __ballot((ovr >> s) & 1u);
-                if (lane == 0) s_bal[s][wave] = b;
+                if (lane == 0) s_bal[s][wave - 2] = b;
             }
         }
         __syncthreads();
-        if (tid < SB) {
+        if (fh == 1) {                        // (the threads that hold the footprints)
             // rank of this instance on every list it is on = instances ahead of it (staged order = back to front) on that list
             uint32_t rk[4] = {~0u, ~0u, ~0u, ~0u};
             uint32_t cmin = 255u, cmax = 0u;
-            const unsigned long long lt = (1ull << (tid & 63)) - 1ull;
+            const unsigned long long lt = (1ull << (ft & 63)) - 1ull;
 #pragma unroll
             for (int s = 0; s < 16; s++) {
                 const unsigned long long m0 = s_bal[s][0], m1 = s_bal[s][1];
-                const uint32_t r = tid < 64 ? (uint32_t)__popcll(m0 & lt) : (uint32_t)(__popcll(m0) + __popcll(m1 & lt));
+                const uint32_t r = ft < 64 ? (uint32_t)__popcll(m0 & lt) : (uint32_t)(__popcll(m0) + __popcll(m1 & lt));
                 if ((ovr >> s) & 1u) {
-                    s_list[s][r] = (uint8_t)tid;
+                    s_list[s][r] = (uint8_t)ft;
                     rk[s >> 2] = (rk[s >> 2] & ~(0xffu << (8 * (s & 3)))) | (r << (8 * (s & 3)));
                     cmin = min(cmin, r >> 4); cmax = max(cmax, r >> 4);
                 }
             }
-            s_rank[tid] = make_uint4(rk[0], rk[1], rk[2], rk[3]);
-            s_cmm[tid] = cmin | (cmax << 8);      // an instance on no list: 255 | 0 -> takes part in no round
+            s_rank[ft] = make_uint4(rk[0], rk[1], rk[2], rk[3]);
+            s_cmm[ft] = cmin | (cmax << 8);      // an instance on no list: 255 | 0 -> takes part in no round
         }
         // list length of this row's sub-tile, and the number of rounds = chunks of the longest list (the same in every thread)
         const int n_row = __popcll(s_bal[srow][0]) + __popcll(s_bal[srow][1]);
@@ -158,6 +211,7 @@ __global__ void __launch_bounds__(BLOCK, 3) blend_bwd_scan_kernel(BlendBwdArgs a
         const uint32_t fcm = s_cmm[ft];
         const int fcmin = (int)(fcm & 255u), fcmax = (int)(fcm >> 8);
 
+        TM(tm_stage)
         for (int c = 0; c < nrounds; c++) {
             const int idx = c * CH + i16;
             const bool valid = idx < n_row;
@@ -213,7 +267,7 @@ __global__ void __launch_bounds__(BLOCK, 3) blend_bwd_scan_kernel(BlendBwdArgs a
                     const float Xb = S.y + row_scan_add_excl(wu);             // suffix sum behind this lane's instance
                     const float dL_dalpha = ok ? FMA(T, u, -(Xb * i1a)) : 0.f;
                     swr[p * 2] = make_float2(T, Xb + wu);
-                    if (STATS) {
+                    if (LANE_STATS) {
                         const unsigned long long okb = __ballot(ok), vb = __ballot(valid);
                         if (lane == 0) {
                             atomicAdd(&a.stats[0], 64ull); atomicAdd(&a.stats[1], (unsigned long long)__popcll(okb));
@@ -240,9 +294,6 @@ __global__ void __launch_bounds__(BLOCK, 3) blend_bwd_scan_kernel(BlendBwdArgs a
                     g[7] = FMA(dL_dz, syg, g[7]); g[7] = FMA(-pxf, nk1, g[7]); g[7] = FMA(-pyf, nl1, g[7]);
                     g[8] += dL_dz; g[8] = FMA(-pxf, nk2, g[8]); g[8] = FMA(-pyf, nl2, g[8]);
                     g[9] = FMA(g2, h.dx, g[9]); g[10] = FMA(g2, h.dy, g[10]);
-                    // one pixel step at a time: left alone, the scheduler starts the next steps' intersections before this step's
-                    // gradient half and spills every intermediate (sx, sy, 1/p2, G ...) of several steps
-                    __builtin_amdgcn_sched_barrier(0);
                 }
                 }
                 s_slot[tid * 5 + 0] = make_float4(g[0], g[1], g[2], g[3]);
@@ -251,7 +302,9 @@ __global__ void __launch_bounds__(BLOCK, 3) blend_bwd_scan_kernel(BlendBwdArgs a
                 s_slot[tid * 5 + 3] = make_float4(g[12], g[13], g[14], g[15]);
                 s_slot[tid * 5 + 4] = make_float4(g[16], g[17], 0.f, 0.f);
             }
+            TM(tm_walk)
             __syncthreads();
+            TM(tm_bar1)
             // ---- flush round c: the slot of (sub-tile s, lane r & 15) belongs to the instance of rank r = 16 c + lane on list s.
             // Fixed order: rounds ascending, sub-tiles ascending inside a round.
             if (ft < mb && c >= fcmin && c <= fcmax) {
@@ -269,17 +322,28 @@ __global__ void __launch_bounds__(BLOCK, 3) blend_bwd_scan_kernel(BlendBwdArgs a
                     }
                 }
             }
+            TM(tm_flush)
             __syncthreads();                  // slots reusable
+            TM(tm_bar2)
         }
         // ---- the batch's gradient records: every staged instance gets one (zeros if no pixel took it)
-        if (ft < mb) {
-            const float4 r4 = s_rec[ft * 5 + 4];
-            float4* __restrict__ dst = reinterpret_cast<float4*>(a.grec + grec_slot(r4, tx, ty) * GREC_F);
-            if (fh == 0) { dst[0] = f0; dst[1] = f1; dst[2] = f2; }
-            else { dst[3] = f0; dst[4] = f1; }
-        }
-        f0 = make_float4(0.f, 0.f, 0.f, 0.f); f1 = f0; f2 = f0;
+        pend = ft < mb;
+        if (pend) pend_slot = grec_slot(s_rec[ft * 5 + 4], tx, ty);
+        TM(tm_rec)
     }
+    if (pend) {
+        float4* __restrict__ dst = reinterpret_cast<float4*>(a.grec + pend_slot * GREC_F);
+        if (fh == 0) { dst[0] = f0; dst[1] = f1; dst[2] = f2; }
+        else { dst[3] = f0; dst[4] = f1; }
+    }
+#ifdef SCAN_TIMING
+    if (STATS && lane == 0) {
+        atomicAdd(&a.stats[0], (unsigned long long)tm_stage); atomicAdd(&a.stats[1], (unsigned long long)tm_walk);
+        atomicAdd(&a.stats[2], (unsigned long long)tm_bar1); atomicAdd(&a.stats[3], (unsigned long long)tm_flush);
+        atomicAdd(&a.stats[4], (unsigned long long)tm_bar2); atomicAdd(&a.stats[5], (unsigned long long)tm_rec);
+        atomicAdd(&a.stats[6], (unsigned long long)(__builtin_readcyclecounter() - tm_start)); atomicAdd(&a.stats[7], 1ull);
+    }
+#endif
     write_cut(a, range, maxc, tile);
 }
 

@@ -521,6 +521,10 @@ __global__ void __launch_bounds__(256) preprocess_bwd_kernel(PreprocessBwdArgs a
     } else {
     RecWalk rw;
     rw.init(__float_as_uint(a.depths[i]), (uint32_t)i, __float_as_uint(r4.w), a.gx);
+    // A surfel with few instances fetches its records WITHOUT waiting for the cuts (the record loads are then not serialised behind
+    // the cut loads: one round trip instead of two — small frames hold 1-2 records per surfel and are latency-bound here) and masks
+    // what it fetched; a surfel with many instances saves the traffic of the records that do not exist instead.
+    const bool few = end - beg <= 4u;
     uint32_t k = beg;
     for (; k + 1 < end; k += 2) {
         const bool h0 = rw.has_record(a.cut);
@@ -530,15 +534,18 @@ __global__ void __launch_bounds__(256) preprocess_bwd_kernel(PreprocessBwdArgs a
         const float4* __restrict__ src = reinterpret_cast<const float4*>(a.grec + (size_t)k * GREC_F);
         const float4 zz = make_float4(0.f, 0.f, 0.f, 0.f);
         float4 v0 = zz, v1 = zz, v2 = zz, v3 = zz, v4 = zz, w0 = zz, w1 = zz, w2 = zz, w3 = zz, w4 = zz;
-        if (h0) { v0 = src[0]; v1 = src[1]; v2 = src[2]; v3 = src[3]; v4 = src[4]; }
-        if (h1) { w0 = src[5]; w1 = src[6]; w2 = src[7]; w3 = src[8]; w4 = src[9]; }
+        if (few || h0) { v0 = src[0]; v1 = src[1]; v2 = src[2]; v3 = src[3]; v4 = src[4]; }
+        if (few || h1) { w0 = src[5]; w1 = src[6]; w2 = src[7]; w3 = src[8]; w4 = src[9]; }
         if (h0) add_rec(v0, v1, v2, v3, v4);
         if (h1) add_rec(w0, w1, w2, w3, w4);
     }
-    if (k < end && rw.has_record(a.cut)) {
-        const float4* __restrict__ src = reinterpret_cast<const float4*>(a.grec + (size_t)k * GREC_F);
-        const float4 v0 = src[0], v1 = src[1], v2 = src[2], v3 = src[3], v4 = src[4];
-        add_rec(v0, v1, v2, v3, v4);
+    if (k < end) {
+        const bool h0 = rw.has_record(a.cut);
+        if (few || h0) {
+            const float4* __restrict__ src = reinterpret_cast<const float4*>(a.grec + (size_t)k * GREC_F);
+            const float4 v0 = src[0], v1 = src[1], v2 = src[2], v3 = src[3], v4 = src[4];
+            if (h0) add_rec(v0, v1, v2, v3, v4);
+        }
     }
     }
     a.dL_dopacity[i] = g[14];
