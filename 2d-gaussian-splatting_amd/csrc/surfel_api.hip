@@ -28,6 +28,19 @@ int g_opt_bwd_tune = 1;    // surfel_set_option("bwd_tune", .): auto = timed pro
 unsigned long long* g_blend_stats = nullptr;   // surfel_debug_set_blend_stats
 thread_local int64_t g_last_R = -1; thread_local int g_last_W = 0, g_last_H = 0;   // auto heuristic (speed only; results identical; a stale
                                                                                     // value from another device / stream only costs one slower frame)
+// capacity binning: the largest instance count recent frames of a size produced (per host thread; speed only)
+struct CapEntry { int W = 0, H = 0; int64_t maxR = -1; };
+thread_local CapEntry g_caps[4];
+thread_local unsigned g_cap_next = 0;
+int g_opt_capacity = 1;    // surfel_set_option("capacity_binning", .)
+thread_local int g_last_binning = 0;      // 0 exact-size path, 1 capacity path, 2 capacity path overflowed and the frame was redone (surfel_debug_last_binning)
+CapEntry* cap_entry(int W, int H, bool create) {
+    for (auto& c : g_caps) if (c.W == W && c.H == H) return &c;
+    if (!create) return nullptr;
+    CapEntry* c = &g_caps[g_cap_next++ % 4];
+    c->W = W; c->H = H; c->maxR = -1;
+    return c;
+}
 thread_local float g_stage_ms[16];
 thread_local int g_stage_n = 0;
 thread_local int g_stage_id[16];
@@ -106,7 +119,7 @@ struct ImgState {    // per-pixel / per-tile state ("imgBuffer")
     static ImgState carve(void* base, int W, int H, size_t* total) {
         Carver c(base); ImgState im;
         const size_t tiles = (size_t)((W + TILE - 1) / TILE) * ((H + TILE - 1) / TILE);
-        im.ranges = c.take<uint2>(tiles + R_SLOTS);           // [tiles] ranges + R_SLOTS partial instance totals + R_SLOTS partial visible-surfel counts (zeroed together)
+        im.ranges = c.take<uint2>(tiles + R_SLOTS + 1);       // [tiles] ranges + R_SLOTS partial instance totals + R_SLOTS partial visible-surfel counts + the instance total of the capacity path (zeroed together)
         im.total = reinterpret_cast<uint32_t*>(im.ranges + tiles);
         im.final_T = c.take<float>((size_t)3 * W * H);
         im.n_contrib = c.take<uint32_t>((size_t)2 * W * H);
@@ -316,6 +329,7 @@ int surfel_set_option(const char* name, int value) {
     if (name && std::strcmp(name, "large_sort") == 0) { set_large_sort_impl(value); return 0; }
     if (name && std::strcmp(name, "bwd_variant") == 0) { g_opt_bwd_variant = value < 0 ? 0 : (value > 3 ? 3 : value); return 0; }
     if (name && std::strcmp(name, "bwd_tune") == 0) { g_opt_bwd_tune = value != 0; return 0; }
+    if (name && std::strcmp(name, "capacity_binning") == 0) { g_opt_capacity = value != 0; return 0; }
     return fail(SURFEL_E_INVALID, "unknown option");
 }
 
@@ -333,6 +347,7 @@ int surfel_debug_walk_choice(int width, int height) {
     for (auto& c : g_tuners) if (c.dev == dev && c.W == width && c.H == height && c.calls >= best) { best = c.calls; choice = c.choice; }
     return choice;
 }
+int surfel_debug_last_binning(void) { return g_last_binning; }
 int surfel_debug_set_blend_stats(void* dev_u64x8) { g_blend_stats = static_cast<unsigned long long*>(dev_u64x8); return 0; }
 
 int surfel_collect_stage_ms(float* sum_ms, int* count, int cap) {
@@ -361,7 +376,9 @@ int64_t surfel_rasterize_forward(surfel_alloc_fn geom_alloc, void* geom_user, su
     // per-call option overrides ride in the upper bits of `debug` (include/surfel_hip.h); the low byte is the debug mode
     const int opt_cull = (debug & SURFEL_OPT_NO_CULL) ? 0 : g_opt_cull;
     const int opt_tile_sort = ((debug >> 9) & 3) ? ((debug >> 9) & 3) - 1 : g_opt_tile_sort;
+    const int opt_capacity = (debug & SURFEL_OPT_EXACT_BINNING) ? 0 : g_opt_capacity;
     debug &= 0xff;
+    g_last_binning = 0;
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (!geom_alloc || !binning_alloc || !image_alloc) return fail(SURFEL_E_INVALID, "allocator callback is NULL");
     if (P < 0 || width <= 0 || height <= 0) return fail(SURFEL_E_INVALID, "bad sizes");
@@ -383,7 +400,7 @@ int64_t surfel_rasterize_forward(surfel_alloc_fn geom_alloc, void* geom_user, su
     void* img_base = image_alloc(image_user, img_bytes);
     if (!img_base) return fail(SURFEL_E_ALLOC, "image buffer allocation failed");
     ImgState img = ImgState::carve(img_base, width, height, nullptr);
-    HIP_TRY(hipMemsetAsync(img.ranges, 0, sizeof(uint2) * ((size_t)gx * gy + R_SLOTS), s));
+    HIP_TRY(hipMemsetAsync(img.ranges, 0, sizeof(uint2) * ((size_t)gx * gy + R_SLOTS + 1), s));
 
     StageTimer tm(debug, s);
     int64_t R = 0;
@@ -410,79 +427,143 @@ int64_t surfel_rasterize_forward(surfel_alloc_fn geom_alloc, void* geom_user, su
         uint32_t* scan_state = reinterpret_cast<uint32_t*>(geom.temp + psort_bytes);
         pa.zero_a = reinterpret_cast<uint32_t*>(geom.temp); pa.zero_a_words = (uint32_t)radix_sort_head_words((size_t)P);
         pa.zero_b = scan_state; pa.zero_b_words = (uint32_t)scan_scratch_words((size_t)P);
+
+        // Binning plan, from history only (nothing of this frame is known on the host yet).
+        //  * path: per-tile depth sort (small / medium frames: emit in surfel-index order, order every tile's run by depth afterwards
+        //    in LDS — no P-sized radix sort) or depth-presorted emission (large frames: the original two-level scheme).  Both give the
+        //    same per-tile order (depth bits, then surfel index); the choice is a speed heuristic on the previous frame's instances
+        //    per tile (unknown on the first call: decided once R has arrived).
+        //  * sizes: CAPACITY binning (per-tile path, <= 2^20 instances) sizes the binning buffers from the largest count recent frames
+        //    of this size produced and never waits for this frame's count in the middle of the forward (surfel_sort.hip); otherwise
+        //    the buffers are sized exactly, after a host wait for R.
+        const int64_t ntiles_all = (int64_t)gx * gy;
+        constexpr int64_t kTileSortMaxAvg = 640;      // bitonic work grows as n log^2 n: at ~1100 instances per tile it costs 0.25 ms vs 0.15 ms for the P-sized radix sort (C4)
+        const int end_bit = higher_msb((uint32_t)(gx * gy));
+        int per_tile = opt_tile_sort == 2 ? 1 : (opt_tile_sort == 0 ? 0 : -1);
+        if (per_tile < 0 && g_last_R >= 0 && g_last_W == width && g_last_H == height) per_tile = g_last_R <= kTileSortMaxAvg * ntiles_all ? 1 : 0;
+        CapEntry* ce = cap_entry(width, height, true);
+        int64_t cap = 0;
+        if (opt_capacity && per_tile == 1 && ce->maxR >= 0 && debug != 1) {
+            cap = ce->maxR + ce->maxR / 8 + 4096;
+            cap = (cap + 16383) / 16384 * 16384;      // stable sizes for the caller's caching allocator
+            if (cap > ((int64_t)1 << 20) || !capacity_binning_ok((size_t)cap, end_bit)) cap = 0;
+        }
+        if (cap > 0) {      // the binning buffers exist before preprocess runs: it clears the tile sort's head on the way
+            const size_t sort_bytes = radix_sort_scratch_bytes((size_t)cap);
+            size_t bin_bytes = 0;
+            BinState::carve(nullptr, (size_t)cap, sort_bytes, &bin_bytes);
+            void* bin_base = binning_alloc(binning_user, bin_bytes);
+            if (!bin_base) return fail(SURFEL_E_ALLOC, "binning buffer allocation failed");
+            bin = BinState::carve(bin_base, (size_t)cap, sort_bytes, nullptr);
+            pa.zero_c = reinterpret_cast<uint32_t*>(bin.sort_temp); pa.zero_c_words = (uint32_t)radix_sort_head_words((size_t)cap);
+        }
         tm.begin();
         launch_preprocess_fwd(pa, s);
         STAGE_END(tm, ST_PRE);
-        // The instance count sizes the binning buffers, so it has to reach the host (one 4-byte D2H).  It is copied
-        // right behind preprocess and waited for only after the depth sort + scan have been enqueued: the host then
-        // allocates and enqueues the rest of the forward while the device is still sorting.
+        // The instance count is copied to the host right behind preprocess.  Exact path: waited for after the depth sort + scan have
+        // been enqueued.  Capacity path: looked at when the whole forward is enqueued (validation only).
         uint32_t* hR = pinned_u32();
         hipEvent_t evR = r_event();
         if (!hR || !evR) return fail(SURFEL_E_HIP, "pinned buffer / event creation failed");
         HIP_TRY(hipMemcpyAsync(hR, img.total, sizeof(uint32_t) * R_SLOTS, hipMemcpyDeviceToHost, s));
         HIP_TRY(hipEventRecord(evR, s));
 
-        // Binning path.  Per-tile depth sort (small / medium frames): emit in surfel-index order, order every tile's run by depth
-        // afterwards in LDS — no P-sized radix sort.  Depth-presorted emission (large frames): the original two-level scheme.
-        // Both give the same per-tile order (depth bits, then surfel index); the choice is a speed heuristic on the previous
-        // frame's instances per tile (unknown on the first call: decided once R has arrived).
-        const int64_t ntiles_all = (int64_t)gx * gy;
-        constexpr int64_t kTileSortMaxAvg = 640;      // bitonic work grows as n log^2 n: at ~1100 instances per tile it costs 0.25 ms vs 0.15 ms for the P-sized radix sort (C4)
-        int per_tile = opt_tile_sort == 2 ? 1 : (opt_tile_sort == 0 ? 0 : -1);
-        if (per_tile < 0 && g_last_R >= 0 && g_last_W == width && g_last_H == height) per_tile = g_last_R <= kTileSortMaxAvg * ntiles_all ? 1 : 0;
-        if (per_tile < 0) {         // first frame of this size: wait for R now (loses the host/device overlap once)
-            HIP_TRY(hipEventSynchronize(evR));
-            int64_t r0 = 0;
-            for (int k = 0; k < R_SLOTS; k++) r0 += (int64_t)hR[k];
-            per_tile = r0 <= kTileSortMaxAvg * ntiles_all ? 1 : 0;
-        }
-        tm.begin();
-        const uint32_t* order = geom.ord_a;      // identity (written by preprocess)
-        if (!per_tile) {
-            // (1) surfel order by view depth (stable; culled surfels carry key 0xffffffff and sort last)
-            const int which = radix_sort_pairs_u32(geom.dkey_a, geom.ord_a, geom.dkey_b, geom.ord_b, (size_t)P, 0, 32, geom.temp, s, true);
-            if (which < 0) return fail(SURFEL_E_LIMIT, "too many surfels for the depth sort");
-            order = which ? geom.ord_b : geom.ord_a;
-        }
-        // (2) instance offsets in emission order: inclusive scan of tiles_touched[order[k]]
-        launch_scan_gather(geom.tiles_touched, order, geom.offsets, (size_t)P, scan_state, s);
-        STAGE_END(tm, ST_SCAN);
-        HIP_TRY(hipEventSynchronize(evR));
-        for (int k = 0; k < R_SLOTS; k++) R += (int64_t)hR[k];
-        g_last_R = R; g_last_W = width; g_last_H = height;
-
-        const int end_bit = higher_msb((uint32_t)(gx * gy));
-        const size_t sort_bytes = radix_sort_scratch_bytes((size_t)R);
-        size_t bin_bytes = 0;
-        BinState::carve(nullptr, (size_t)R, sort_bytes, &bin_bytes);
-        void* bin_base = binning_alloc(binning_user, bin_bytes > 0 ? bin_bytes : 256);
-        if (!bin_base) return fail(SURFEL_E_ALLOC, "binning buffer allocation failed");
-        bin = BinState::carve(bin_base, (size_t)R, sort_bytes, nullptr);
-        if (R > 0) {
-            // (3) stable sort on the tile-id bits only: depth order inside every tile is preserved.  The value buffers
-            // are assigned so that the ping-pong ends in bin.point_list.
-            const bool odd = radix_sort_result_buffer((size_t)R, 0, end_bit) == 1;      // result lands in the b buffers
+        bool blended = false;
+        if (cap > 0) {
+            const uint32_t* n_dev = img.total + 2 * R_SLOTS;      // written by bin_emit_kernel
+            const bool odd = radix_sort_result_buffer((size_t)cap, 0, end_bit) == 1;
             uint32_t* va = odd ? bin.vals_alt : bin.point_list;
             uint32_t* vb = odd ? bin.point_list : bin.vals_alt;
             tm.begin();
-            launch_emit_instances(P, geom.rec, geom.rects, order, geom.offsets, bin.keys_a, va, gx, reinterpret_cast<uint32_t*>(bin.sort_temp),
-                                  (uint32_t)radix_sort_head_words((size_t)R), s);
+            launch_bin_emit(P, geom.tiles_touched, geom.rects, geom.rec, bin.keys_a, va, gx, (size_t)cap, scan_state, bin.sort_temp, end_bit,
+                            img.total + 2 * R_SLOTS, s);
             STAGE_END(tm, ST_EMIT);
             tm.begin();
-            const int wk = radix_sort_pairs_u32(bin.keys_a, va, bin.keys_b, vb, (size_t)R, 0, end_bit, bin.sort_temp, s, true);
-            if (wk < 0) return fail(SURFEL_E_LIMIT, "too many tile instances for the tile sort");
-            const uint32_t* sorted_keys = wk ? bin.keys_b : bin.keys_a;
+            const int wk = radix_sort_pairs_u32_devn(bin.keys_a, va, bin.keys_b, vb, (size_t)cap, end_bit, n_dev, bin.sort_temp, s);
             STAGE_END(tm, ST_SORT);
             tm.begin();
-            launch_tile_ranges(R, sorted_keys, img.ranges, s);
+            launch_tile_ranges_devn((size_t)cap, n_dev, wk ? bin.keys_b : bin.keys_a, img.ranges, s);
             STAGE_END(tm, ST_RANGES);
-            if (per_tile) {
-                // (4) every tile orders its run by (depth bits, surfel index); the ping-pong buffers of the tile sort are free now
-                tm.begin();
-                launch_tile_depth_sort(gx * gy, R, img.ranges, bin.point_list, geom.dkey_a, bin.vals_alt, bin.keys_a, bin.keys_b, s);
-                STAGE_END(tm, ST_TSORT);
+            tm.begin();
+            launch_tile_depth_sort(gx * gy, ce->maxR, img.ranges, bin.point_list, geom.dkey_a, bin.vals_alt, bin.keys_a, bin.keys_b, s);
+            STAGE_END(tm, ST_TSORT);
+            BlendFwdArgs ba{};
+            ba.W = width; ba.H = height; ba.gx = gx; ba.gy = gy;
+            ba.ranges = img.ranges; ba.point_list = bin.point_list; ba.rec = geom.rec; ba.bg = background;
+            ba.out_color = out_color; ba.out_others = out_others; ba.final_T = img.final_T; ba.n_contrib = img.n_contrib;
+            ba.stats = g_blend_stats;
+            tm.begin();
+            launch_blend_fwd(ba, s);
+            STAGE_END(tm, ST_BLEND);
+            HIP_TRY(hipEventSynchronize(evR));      // preprocess finished long ago; the device still holds the rest of the forward
+            for (int k = 0; k < R_SLOTS; k++) R += (int64_t)hR[k];
+            g_last_binning = 1;
+            blended = R <= cap;
+            if (!blended) {      // overflow: the frame is redone with exact sizes below (same results as if it had taken that path at once)
+                g_last_binning = 2;
+                HIP_TRY(hipMemsetAsync(img.ranges, 0, sizeof(uint2) * (size_t)gx * gy, s));
             }
         }
+        if (!blended) {
+            const bool r_known = cap > 0;
+            if (per_tile < 0 && !r_known) {         // first frame of this size: wait for R now (loses the host/device overlap once)
+                HIP_TRY(hipEventSynchronize(evR));
+                int64_t r0 = 0;
+                for (int k = 0; k < R_SLOTS; k++) r0 += (int64_t)hR[k];
+                per_tile = r0 <= kTileSortMaxAvg * ntiles_all ? 1 : 0;
+            }
+            tm.begin();
+            const uint32_t* order = geom.ord_a;      // identity (written by preprocess)
+            if (!per_tile) {
+                // (1) surfel order by view depth (stable; culled surfels carry key 0xffffffff and sort last)
+                const int which = radix_sort_pairs_u32(geom.dkey_a, geom.ord_a, geom.dkey_b, geom.ord_b, (size_t)P, 0, 32, geom.temp, s, true);
+                if (which < 0) return fail(SURFEL_E_LIMIT, "too many surfels for the depth sort");
+                order = which ? geom.ord_b : geom.ord_a;
+            }
+            // (2) instance offsets in emission order: inclusive scan of tiles_touched[order[k]]
+            if (r_known) HIP_TRY(hipMemsetAsync(scan_state, 0, sizeof(uint32_t) * scan_scratch_words((size_t)P), s));      // (used by the capacity attempt)
+            launch_scan_gather(geom.tiles_touched, order, geom.offsets, (size_t)P, scan_state, s);
+            STAGE_END(tm, ST_SCAN);
+            if (!r_known) {
+                HIP_TRY(hipEventSynchronize(evR));
+                for (int k = 0; k < R_SLOTS; k++) R += (int64_t)hR[k];
+            }
+
+            const size_t sort_bytes = radix_sort_scratch_bytes((size_t)R);
+            size_t bin_bytes = 0;
+            BinState::carve(nullptr, (size_t)R, sort_bytes, &bin_bytes);
+            void* bin_base = binning_alloc(binning_user, bin_bytes > 0 ? bin_bytes : 256);
+            if (!bin_base) return fail(SURFEL_E_ALLOC, "binning buffer allocation failed");
+            bin = BinState::carve(bin_base, (size_t)R, sort_bytes, nullptr);
+            if (R > 0) {
+                // (3) stable sort on the tile-id bits only: depth order inside every tile is preserved.  The value buffers
+                // are assigned so that the ping-pong ends in bin.point_list.
+                const bool odd = radix_sort_result_buffer((size_t)R, 0, end_bit) == 1;      // result lands in the b buffers
+                uint32_t* va = odd ? bin.vals_alt : bin.point_list;
+                uint32_t* vb = odd ? bin.point_list : bin.vals_alt;
+                tm.begin();
+                launch_emit_instances(P, geom.rec, geom.rects, order, geom.offsets, bin.keys_a, va, gx, reinterpret_cast<uint32_t*>(bin.sort_temp),
+                                      (uint32_t)radix_sort_head_words((size_t)R), s);
+                STAGE_END(tm, ST_EMIT);
+                tm.begin();
+                const int wk = radix_sort_pairs_u32(bin.keys_a, va, bin.keys_b, vb, (size_t)R, 0, end_bit, bin.sort_temp, s, true);
+                if (wk < 0) return fail(SURFEL_E_LIMIT, "too many tile instances for the tile sort");
+                const uint32_t* sorted_keys = wk ? bin.keys_b : bin.keys_a;
+                STAGE_END(tm, ST_SORT);
+                tm.begin();
+                launch_tile_ranges(R, sorted_keys, img.ranges, s);
+                STAGE_END(tm, ST_RANGES);
+                if (per_tile) {
+                    // (4) every tile orders its run by (depth bits, surfel index); the ping-pong buffers of the tile sort are free now
+                    tm.begin();
+                    launch_tile_depth_sort(gx * gy, R, img.ranges, bin.point_list, geom.dkey_a, bin.vals_alt, bin.keys_a, bin.keys_b, s);
+                    STAGE_END(tm, ST_TSORT);
+                }
+            }
+        }
+        g_last_R = R; g_last_W = width; g_last_H = height;
+        ce->maxR = R > ce->maxR - ce->maxR / 64 ? R : ce->maxR - ce->maxR / 64;      // the largest recent count, slowly forgotten
+        if (blended) { HIP_TRY(hipGetLastError()); return R; }
     } else {
         (void)geom_alloc(geom_user, 256);
         void* bin_base = binning_alloc(binning_user, 256);

@@ -17,6 +17,7 @@ struct PreprocessArgs {
     uint32_t* total_instances;     // [2 * R_SLOTS], zeroed by the caller: partial sums of tiles_touched | of (tiles_touched > 0)
     uint32_t* zero_a; uint32_t zero_a_words;   // scratch words this kernel clears for the launches that follow
     uint32_t* zero_b; uint32_t zero_b_words;   // (sort head, scan state) — saves two memset launches
+    uint32_t* zero_c; uint32_t zero_c_words;   // capacity binning: head of the tile sort's scratch
 };
 
 struct BlendFwdArgs {
@@ -78,5 +79,13 @@ size_t scan_scratch_words(size_t n);          // zeroed scratch of launch_scan_g
 void launch_tile_depth_sort(int ntiles, int64_t R, const uint2* ranges, uint32_t* point_list, const uint32_t* depth_keys, uint32_t* tmp_ids,
                             uint32_t* tmp_keys, uint32_t* tmp_rank, hipStream_t s);
 void launch_scan_gather(const uint32_t* vals, const uint32_t* order, uint32_t* out, size_t n, void* zeroed_scratch, hipStream_t s);
+// capacity binning (surfel_sort.hip): scan + emission + tile-sort histograms in one launch, sort passes / ranges with the count on the device
+bool capacity_binning_ok(size_t cap, int end_bit);
+size_t bin_emit_scratch_words(size_t P);      // zeroed scan state of launch_bin_emit
+void launch_bin_emit(int P, const uint32_t* tiles_touched, const uint32_t* rects, float* rec, uint32_t* keys, uint32_t* vals, int gx, size_t cap,
+                     void* zeroed_scan_state, void* sort_scratch /* head zeroed */, int end_bit, uint32_t* n_out, hipStream_t s);
+int radix_sort_pairs_u32_devn(uint32_t* keys_a, uint32_t* vals_a, uint32_t* keys_b, uint32_t* vals_b, size_t cap, int end_bit, const uint32_t* n_dev,
+                              void* scratch, hipStream_t s);
+void launch_tile_ranges_devn(size_t cap, const uint32_t* n_dev, const uint32_t* keys, uint2* ranges, hipStream_t s);
 
 }  // namespace surfel

@@ -266,6 +266,7 @@ __global__ void __launch_bounds__(256) preprocess_fwd_kernel(PreprocessArgs a) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     for (uint32_t w = (uint32_t)i; w < a.zero_a_words; w += gridDim.x * blockDim.x) a.zero_a[w] = 0u;
     for (uint32_t w = (uint32_t)i; w < a.zero_b_words; w += gridDim.x * blockDim.x) a.zero_b[w] = 0u;
+    for (uint32_t w = (uint32_t)i; w < a.zero_c_words; w += gridDim.x * blockDim.x) a.zero_c[w] = 0u;
     uint32_t tiles = i < a.P ? preprocess_one(a, i) : 0u;
     const uint32_t vis = (uint32_t)__popcll(__ballot(tiles != 0u));     // surfels that emit at least one instance
 #pragma unroll
@@ -717,6 +718,23 @@ void launch_emit_instances(int P, float* rec, const uint32_t* rects, const uint3
                            uint32_t* vals, int gx, uint32_t* zero_ptr, uint32_t zero_words, hipStream_t s) {
     if (P > 0) hipLaunchKernelGGL(emit_instances_kernel, dim3((P + 255) / 256), dim3(256), 0, s, P, rec, rects, order, offsets_sorted, keys, vals,
                                   gx, zero_ptr, zero_words);
+}
+// capacity binning: the count is on the device, the grid covers the capacity
+__global__ void __launch_bounds__(256) tile_ranges_devn_kernel(const uint32_t* __restrict__ n_dev, uint32_t cap, const uint32_t* __restrict__ keys,
+                                                               uint2* __restrict__ ranges) {
+    const uint32_t R = min(*n_dev, cap);
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= R) return;
+    const uint32_t tile = keys[k];
+    if (k == 0) ranges[tile].x = 0;
+    else {
+        const uint32_t prev = keys[k - 1];
+        if (prev != tile) { ranges[prev].y = k; ranges[tile].x = k; }
+    }
+    if (k == R - 1) ranges[tile].y = R;
+}
+void launch_tile_ranges_devn(size_t cap, const uint32_t* n_dev, const uint32_t* keys, uint2* ranges, hipStream_t s) {
+    if (cap > 0) hipLaunchKernelGGL(tile_ranges_devn_kernel, dim3((unsigned)((cap + 255) / 256)), dim3(256), 0, s, n_dev, (uint32_t)cap, keys, ranges);
 }
 void launch_tile_ranges(int64_t R, const uint32_t* keys, uint2* ranges, hipStream_t s) {
     if (R > 0) hipLaunchKernelGGL(tile_ranges_kernel, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, s, R, keys, ranges);

@@ -31,6 +31,7 @@ OPT_BWD_QUAD = 1 << 11
 OPT_BWD_ROWS = 1 << 12
 OPT_PBWD_COOP = 1 << 13
 OPT_PBWD_THREAD = 1 << 14
+OPT_EXACT_BINNING = 1 << 16    # forward: size the binning buffers exactly (host wait for the instance count) for this call
 OPT_BWD_SCAN = 1 << 15         # scan walk (lanes = instances); deterministic, not bit-identical to rows / quad
 
 

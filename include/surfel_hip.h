@@ -44,6 +44,7 @@ extern "C" {
 #define SURFEL_OPT_BWD_ROWS       (1 << 12)            /* backward: per-row walk ("bwd_variant" = 0) for this call */
 #define SURFEL_OPT_PBWD_COOP      (1 << 13)            /* backward: wave-cooperative gather of the gradient records (default: R >= 6 P and R >= 2^25) */
 #define SURFEL_OPT_PBWD_THREAD    (1 << 14)            /* backward: per-thread gather of the gradient records */
+#define SURFEL_OPT_EXACT_BINNING  (1 << 16)            /* forward: "capacity_binning" = 0 for this call (binning buffers sized after a host wait for the instance count) */
 #define SURFEL_OPT_BWD_SCAN       (1 << 15)            /* backward: scan walk ("bwd_variant" = 3) for this call; deterministic, NOT bit-identical to rows / quad */
 
 /* Allocator callback: return a device pointer to `bytes` bytes, 256-byte aligned, valid until the
@@ -160,6 +161,13 @@ int surfel_debug_sort_pairs(surfel_alloc_fn scratch_alloc, void* scratch_user, u
  *          the faster walk per tile instance is launched alone in between; 0: both kernels are launched every call and the device decides from the frame's
  *          totals (rows iff tile instances <= 4 x emitting surfels) — also what happens before both walks have been timed and
  *          while the stream is being captured into a graph.
+ *   "capacity_binning" (default 1): frames on the per-tile-depth-sort path with <= 2^20 tile instances size their binning buffers
+ *          from the largest instance count recent frames of the same size produced (+ 1/8 head room) instead of waiting for this
+ *          frame's count in the middle of the forward: scan, emission and the tile sort's histograms run as ONE kernel right behind
+ *          preprocess, the sort passes and the tile ranges read the count from the device, and the host looks at the count only once
+ *          the whole forward is enqueued.  A frame that overflows its capacity is redone with exact sizes (surfel_debug_last_binning
+ *          reports 2).  Results are bit-identical either way (tests/test_gpu_parity.py::test_capacity_binning_is_identical); the
+ *          returned instance count is always the exact one.
  * Threading: the library keeps one pinned read-back buffer and one event per (host thread, device); calls are not re-entrant
  * per thread, and the intended layout is one process per GPU (torch.distributed.run).  Stage-timing events recorded with
  * debug >= 2 are kept until surfel_collect_stage_ms() (at most 8192 pairs; older ones are dropped). */
@@ -179,6 +187,10 @@ int surfel_set_backward_hook(surfel_hook_fn colour_ready, void* user);
  * [3] (sub-tile | quad, instance) visits, [4] of those, the ones with at least one composited pair, [5] quad variant: 4x4 sub-tiles
  * with a composited pair — or NULL to switch the instrumented kernels off again. */
 int surfel_debug_set_blend_stats(void* dev_u64x8);
+
+/* Debug: how the last forward of this thread sized its binning buffers — 0 exact (host wait for the count), 1 capacity,
+ * 2 capacity overflowed and the frame was redone with exact sizes. */
+int surfel_debug_last_binning(void);
 
 /* Debug: the walk the "bwd_tune" probes currently favour for frames of this size on the current device (the most used entry of
  * that size) — 0 per-row, 1 per-quad, -1 not decided yet (fewer than two timed calls have completed). */

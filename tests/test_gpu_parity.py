@@ -381,6 +381,57 @@ def test_backward_variants_are_identical(kind):
             kind, k, d.max(), int((d > 0).sum()))
 
 
+def test_capacity_binning_is_identical():
+    """Capacity binning (binning buffers sized from the previous frames' instance counts, fused scan + emission + histogram kernel,
+    sort passes / tile ranges with the count on the device, no host wait in the middle of the forward) against the exact-size path:
+    instance count, radii, images and gradients BIT-IDENTICAL — on the steady-state frame, and on a frame that overflows its
+    capacity and is redone (frame sizes no other test uses, so the history of this thread's capacity table is this test's own)."""
+    import surfel_native as n
+    import synthetic
+    lib = n.load()
+
+    def run(sc, flags):
+        a = scene_args(sc)
+        r = HipRun(a, debug=flags | n.opt_tile_sort(2)).forward()      # (per-tile depth sort forced: the capacity path's precondition)
+        kind = lib.surfel_debug_last_binning()
+        gC = np.random.default_rng(1).normal(size=(3, a["H"], a["W"])).astype(np.float32)
+        gO = np.random.default_rng(2).normal(size=(7, a["H"], a["W"])).astype(np.float32)
+        g = r.backward(gC, gO)
+        return kind, (r.R, r.color.cpu().numpy(), r.others.cpu().numpy(), r.radii.cpu().numpy(), g)
+
+    def same(x, y, what):
+        assert x[0] == y[0], (what, x[0], y[0])
+        assert np.array_equal(x[3], y[3]), what
+        assert np.array_equal(x[1], y[1]) and np.array_equal(x[2], y[2]), "%s: images differ" % what
+        for k in x[4]:
+            assert np.array_equal(x[4][k], y[4][k]), "%s: dL/d%s differs" % (what, k)
+
+    W, H = 304, 176
+    sc = synthetic.make_scene(20000, W, H, seed=3, px_radius=4.0)
+    k0, exact = run(sc, n.OPT_EXACT_BINNING)
+    assert k0 == 0
+    k1, first = run(sc, 0)            # the exact frame above left a count behind: capacity path at once
+    k2, steady = run(sc, 0)
+    assert k1 == 1 and k2 == 1, (k1, k2)
+    same(first, exact, "first capacity frame"); same(steady, exact, "steady capacity frame")
+    # overflow: four times the surfels at the same frame size
+    sc2 = synthetic.make_scene(80000, W, H, seed=5, px_radius=4.0)
+    k3, over = run(sc2, 0)
+    assert k3 == 2, k3
+    k4, exact2 = run(sc2, n.OPT_EXACT_BINNING)
+    assert k4 == 0 and over[0] > 1.5 * exact[0]
+    same(over, exact2, "overflowing frame")
+    k5, after = run(sc2, 0)           # the capacity has grown
+    assert k5 == 1
+    same(after, exact2, "frame after the overflow")
+    # an empty view (every surfel behind the camera) on the capacity path
+    sc3 = dict(sc); sc3["means3D"] = (sc["means3D"] - 1e3 * (sc["means3D"] - sc["campos"][None])).astype(np.float32)
+    k6, empty = run(sc3, 0)
+    k7, empty_exact = run(sc3, n.OPT_EXACT_BINNING)
+    assert k6 == 1 and empty[0] == 0
+    same(empty, empty_exact, "empty frame")
+
+
 def _walk_scene(kind, seed=31):
     import synthetic
     if kind == "C1":
