@@ -378,7 +378,7 @@ __global__ void __launch_bounds__(BLOCK, ROWS_WAVES) blend_bwd_rows_kernel(Blend
         atomicAdd(&a.stats[7], (unsigned long long)tm_bar);
     }
 #endif
-    write_cut(a, range, maxc, tile);
+    finish_tail(a, range, maxc, tile, tx, ty);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -492,7 +492,7 @@ __global__ void __launch_bounds__(BLOCK) blend_bwd_quad_kernel(BlendBwdArgs a) {
             __syncthreads();                  // s_acc / s_mask reusable
         }
     }
-    write_cut(a, range, maxc, tile);
+    finish_tail(a, range, maxc, tile, tx, ty);
 }
 
 void launch_blend_bwd(const BlendBwdArgs& a, hipStream_t s) {

@@ -344,7 +344,7 @@ __global__ void __launch_bounds__(BLOCK, SCAN_MIN_WG) blend_bwd_scan_kernel(Blen
         atomicAdd(&a.stats[6], (unsigned long long)(__builtin_readcyclecounter() - tm_start)); atomicAdd(&a.stats[7], 1ull);
     }
 #endif
-    write_cut(a, range, maxc, tile);
+    finish_tail(a, range, maxc, tile, tx, ty);
 }
 
 void launch_blend_bwd_scan(const BlendBwdArgs& a, hipStream_t s) {

@@ -74,19 +74,32 @@ __device__ __forceinline__ int block_max(int v, int* s_max) {
     return *s_max;
 }
 
-// Instances behind every pixel's last contributor (list positions > maxc) are never staged and get NO gradient record: a tile's
-// list is ordered by (depth bits, surfel index), so "position <= maxc" is decidable from the surfel's own key against the key of
-// the instance at position maxc — the tile's CUT, 8 B per tile, which preprocess_bwd checks before it fetches an 80-B record
-// (round 2 wrote, and read back, a zero record for every such instance: half of the record traffic of crowded frames).
-//   cut = (depth bits, surfel index + 1) of the last staged instance; (0, 0) when nothing was staged.
-__device__ __forceinline__ void write_cut(const BlendBwdArgs& a, const uint2 range, int maxc, int tile) {
-    if (threadIdx.x == 0) {
-        uint2 c = make_uint2(0u, 0u);
-        if (maxc > 0) {
-            const uint32_t id = a.point_list[range.x + maxc - 1];
-            c = make_uint2(__float_as_uint(a.depths[id]), id + 1u);
+// Instances behind every pixel's last contributor (list positions > maxc) are never staged.  What becomes of their gradient records:
+//   * frames with few instances (a.cut == NULL): a record of zeros each, so that preprocess_bwd can sum a surfel's records blindly
+//     (1-2 records per surfel: any test in front of the fetch costs more than the zeros it saves);
+//   * large frames (a.cut given): NO record.  A tile's list is ordered by (depth bits, surfel index), so "position <= maxc" is
+//     decidable from the surfel's own key against the key of the instance at position maxc — the tile's CUT, 8 B per tile, which
+//     preprocess_bwd checks before it fetches an 80-B record (crowded frames saturate early: half of their records were zeros,
+//     written here and read back there).   cut = (depth bits, surfel index + 1) of the last staged instance; (0, 0): none.
+__device__ __forceinline__ void finish_tail(const BlendBwdArgs& a, const uint2 range, int maxc, int tile, int tx, int ty) {
+    if (a.cut) {
+        if (threadIdx.x == 0) {
+            uint2 c = make_uint2(0u, 0u);
+            if (maxc > 0) {
+                const uint32_t id = a.point_list[range.x + maxc - 1];
+                c = make_uint2(__float_as_uint(a.depths[id]), id + 1u);
+            }
+            a.cut[tile] = c;
         }
-        a.cut[tile] = c;
+        return;
+    }
+    for (int pos = maxc + 1 + (int)threadIdx.x; pos <= (int)(range.y - range.x); pos += BLOCK) {
+        const uint32_t id = a.point_list[range.x + pos - 1];
+        const float4 q4 = reinterpret_cast<const float4*>(a.rec + (size_t)id * REC_F)[4];
+        float4* __restrict__ dst = reinterpret_cast<float4*>(a.grec + grec_slot(q4, tx, ty) * GREC_F);
+        const float4 zz = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int q = 0; q < 5; q++) dst[q] = zz;
     }
 }
 

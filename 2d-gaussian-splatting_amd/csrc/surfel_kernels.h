@@ -15,6 +15,7 @@ struct PreprocessArgs {
     float* rec; float* depths; uint32_t* depth_keys; uint32_t* ident; int* radii; uint32_t* tiles_touched; uint8_t* clamped;
     uint32_t* rects;          // packed emission rect per surfel (x0 | y0 << 10 | width << 20), a compact copy of record word 19
     uint32_t* total_instances;     // [2 * R_SLOTS], zeroed by the caller: partial sums of tiles_touched | of (tiles_touched > 0)
+    uint32_t* block_totals;        // [workgroups] instances emitted by every workgroup's 256 surfels (bin_emit_kernel's scan), or NULL
     uint32_t* zero_a; uint32_t zero_a_words;   // scratch words this kernel clears for the launches that follow
     uint32_t* zero_b; uint32_t zero_b_words;   // (sort head, scan state) — saves two memset launches
     uint32_t* zero_c; uint32_t zero_c_words;   // capacity binning: head of the tile sort's scratch
@@ -33,7 +34,7 @@ struct BlendBwdArgs {
     const float* final_T; const uint32_t* n_contrib;
     const float* dL_dpix; const float* dL_dothers;
     float* grec;      // [R][GREC_F] per-instance gradient records: the records of a tile's list positions <= its cut are written exactly once, the rest never
-    uint2* cut;       // [tiles] (depth bits, surfel index + 1) of the last instance of every tile that has a record (surfel_blend_bwd.h: write_cut)
+    uint2* cut;       // [tiles] (depth bits, surfel index + 1) of the last instance of every tile that has a record, or NULL: every instance gets a record (surfel_blend_bwd.h: finish_tail)
     const float* depths;   // [P] view depths (the sort key's source)
     int variant;      // 0: per-DPP-row walk, 1: per-wave (8x8 quad) walk, 2: both launched, the device picks from the frame's totals (0 / 1 / 2 bit-identical); 3: scan walk
     const uint32_t* totals;      // [2 * R_SLOTS] partial sums written by preprocess: tile instances | visible surfels
@@ -49,7 +50,7 @@ struct PreprocessBwdArgs {
     const float* scales; const float* rotations; const float* transMat_precomp;
     const float* viewmatrix; const float* projmatrix; const float* campos;
     const float* rec; const uint32_t* tiles_touched; const float* grec;
-    const uint2* cut; const float* depths; int gx;      // which of a surfel's instance records exist (BlendBwdArgs::cut)
+    const uint2* cut; const float* depths; int gx;      // which of a surfel's instance records exist (BlendBwdArgs::cut); cut == NULL: all of them
     float* dL_dtransMat; float* dL_dnormal; float* dL_dopacity; float* dL_dcolors; float* dL_dsh;
     float* dL_dmeans2D; float* dL_dmeans3D; float* dL_dscales; float* dL_drots;
 };
@@ -81,9 +82,10 @@ void launch_tile_depth_sort(int ntiles, int64_t R, const uint2* ranges, uint32_t
 void launch_scan_gather(const uint32_t* vals, const uint32_t* order, uint32_t* out, size_t n, void* zeroed_scratch, hipStream_t s);
 // capacity binning (surfel_sort.hip): scan + emission + tile-sort histograms in one launch, sort passes / ranges with the count on the device
 bool capacity_binning_ok(size_t cap, int end_bit);
-size_t bin_emit_scratch_words(size_t P);      // zeroed scan state of launch_bin_emit
-void launch_bin_emit(int P, const uint32_t* tiles_touched, const uint32_t* rects, float* rec, uint32_t* keys, uint32_t* vals, int gx, size_t cap,
-                     void* zeroed_scan_state, void* sort_scratch /* head zeroed */, int end_bit, uint32_t* n_out, hipStream_t s);
+size_t capacity_sort_scratch_bytes(size_t cap, int end_bit);
+size_t bin_emit_head_words();                 // words at the start of the capacity path's sort scratch that must be zero
+void launch_bin_emit(int P, const uint32_t* tiles_touched, const uint32_t* rects, const uint32_t* block_totals, float* rec, uint32_t* keys, uint32_t* vals,
+                     int gx, size_t cap, void* sort_scratch /* head zeroed */, int end_bit, uint32_t* n_out, hipStream_t s);
 int radix_sort_pairs_u32_devn(uint32_t* keys_a, uint32_t* vals_a, uint32_t* keys_b, uint32_t* vals_b, size_t cap, int end_bit, const uint32_t* n_dev,
                               void* scratch, hipStream_t s);
 void launch_tile_ranges_devn(size_t cap, const uint32_t* n_dev, const uint32_t* keys, uint2* ranges, hipStream_t s);

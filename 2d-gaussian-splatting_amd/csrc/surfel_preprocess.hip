@@ -275,6 +275,7 @@ __global__ void __launch_bounds__(256) preprocess_fwd_kernel(PreprocessArgs a) {
     __syncthreads();
     if (threadIdx.x == 0) {
         const uint32_t t = s_tot[0] + s_tot[1] + s_tot[2] + s_tot[3];
+        if (a.block_totals) a.block_totals[blockIdx.x] = t;
         if (t) {
             atomicAdd(a.total_instances + (blockIdx.x % R_SLOTS), t);
             // the blend-backward picks its walk variant from instances per emitting surfel (surfel_backward.hip)
@@ -414,7 +415,7 @@ __device__ __forceinline__ void store3(float* p, size_t i, float x, float y, flo
 // bounce through L2: 3 TB/s at C5); here groups of 5 lanes read one record's five float4 as one contiguous 80 B, twelve groups
 // per wave work on twelve surfels at a time and fetch the next unassigned surfel of the wave when theirs is done.  Every value is
 // still added over the records in emission order, so the sums are bit-identical to the per-thread walk.
-template <bool COOP>
+template <bool COOP, bool CUT>
 __global__ void __launch_bounds__(256) preprocess_bwd_kernel(PreprocessBwdArgs a) {
     __shared__ float4 s_sum[COOP ? 256 * 5 : 1];
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -458,7 +459,7 @@ __global__ void __launch_bounds__(256) preprocess_bwd_kernel(PreprocessBwdArgs a
             const bool live = worker && owner < 64 && r < c;
             if (!__any(worker && owner < 64)) break;
             if (live) {
-                if (rw.has_record(a.cut)) {      // (a record that does not exist is a record of zeros: skipping the addition keeps the bits)
+                if (!CUT || rw.has_record(a.cut)) {      // (a record that does not exist is a record of zeros: skipping the addition keeps the bits)
                     const float4 v = g4[(size_t)(b + r) * 5 + q];
                     acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
                 }
@@ -520,32 +521,41 @@ __global__ void __launch_bounds__(256) preprocess_bwd_kernel(PreprocessBwdArgs a
         g[8] = v2.x; g[9] = v2.y; g[10] = v2.z; g[11] = v2.w; g[12] = v3.x; g[13] = v3.y; g[14] = v3.z; g[15] = v3.w;
         g[16] = v4.x; g[17] = v4.y;
     } else {
-    RecWalk rw;
-    rw.init(__float_as_uint(a.depths[i]), (uint32_t)i, __float_as_uint(r4.w), a.gx);
-    // A surfel with few instances fetches its records WITHOUT waiting for the cuts (the record loads are then not serialised behind
-    // the cut loads: one round trip instead of two — small frames hold 1-2 records per surfel and are latency-bound here) and masks
-    // what it fetched; a surfel with many instances saves the traffic of the records that do not exist instead.
-    const bool few = end - beg <= 4u;
-    uint32_t k = beg;
-    for (; k + 1 < end; k += 2) {
-        const bool h0 = rw.has_record(a.cut);
-        rw.next();
-        const bool h1 = rw.has_record(a.cut);
-        rw.next();
-        const float4* __restrict__ src = reinterpret_cast<const float4*>(a.grec + (size_t)k * GREC_F);
-        const float4 zz = make_float4(0.f, 0.f, 0.f, 0.f);
-        float4 v0 = zz, v1 = zz, v2 = zz, v3 = zz, v4 = zz, w0 = zz, w1 = zz, w2 = zz, w3 = zz, w4 = zz;
-        if (few || h0) { v0 = src[0]; v1 = src[1]; v2 = src[2]; v3 = src[3]; v4 = src[4]; }
-        if (few || h1) { w0 = src[5]; w1 = src[6]; w2 = src[7]; w3 = src[8]; w4 = src[9]; }
-        if (h0) add_rec(v0, v1, v2, v3, v4);
-        if (h1) add_rec(w0, w1, w2, w3, w4);
-    }
-    if (k < end) {
-        const bool h0 = rw.has_record(a.cut);
-        if (few || h0) {
+    if (CUT) {
+        RecWalk rw;
+        rw.init(__float_as_uint(a.depths[i]), (uint32_t)i, __float_as_uint(r4.w), a.gx);
+        uint32_t k = beg;
+        for (; k + 1 < end; k += 2) {
+            const bool h0 = rw.has_record(a.cut);
+            rw.next();
+            const bool h1 = rw.has_record(a.cut);
+            rw.next();
+            const float4* __restrict__ src = reinterpret_cast<const float4*>(a.grec + (size_t)k * GREC_F);
+            const float4 zz = make_float4(0.f, 0.f, 0.f, 0.f);
+            float4 v0 = zz, v1 = zz, v2 = zz, v3 = zz, v4 = zz, w0 = zz, w1 = zz, w2 = zz, w3 = zz, w4 = zz;
+            if (h0) { v0 = src[0]; v1 = src[1]; v2 = src[2]; v3 = src[3]; v4 = src[4]; }
+            if (h1) { w0 = src[5]; w1 = src[6]; w2 = src[7]; w3 = src[8]; w4 = src[9]; }
+            if (h0) add_rec(v0, v1, v2, v3, v4);
+            if (h1) add_rec(w0, w1, w2, w3, w4);
+        }
+        if (k < end && rw.has_record(a.cut)) {
             const float4* __restrict__ src = reinterpret_cast<const float4*>(a.grec + (size_t)k * GREC_F);
             const float4 v0 = src[0], v1 = src[1], v2 = src[2], v3 = src[3], v4 = src[4];
-            if (h0) add_rec(v0, v1, v2, v3, v4);
+            add_rec(v0, v1, v2, v3, v4);
+        }
+    } else {
+        uint32_t k = beg;
+        for (; k + 1 < end; k += 2) {
+            const float4* __restrict__ src = reinterpret_cast<const float4*>(a.grec + (size_t)k * GREC_F);
+            const float4 v0 = src[0], v1 = src[1], v2 = src[2], v3 = src[3], v4 = src[4];
+            const float4 w0 = src[5], w1 = src[6], w2 = src[7], w3 = src[8], w4 = src[9];
+            add_rec(v0, v1, v2, v3, v4);
+            add_rec(w0, w1, w2, w3, w4);
+        }
+        if (k < end) {
+            const float4* __restrict__ src = reinterpret_cast<const float4*>(a.grec + (size_t)k * GREC_F);
+            const float4 v0 = src[0], v1 = src[1], v2 = src[2], v3 = src[3], v4 = src[4];
+            add_rec(v0, v1, v2, v3, v4);
         }
     }
     }
@@ -755,7 +765,7 @@ __global__ void __launch_bounds__(256) colour_gradients_kernel(PreprocessBwdArgs
         RecWalk rw;
         rw.init(__float_as_uint(a.depths[i]), (uint32_t)i, __float_as_uint(a.rec[(size_t)i * REC_F + 19]), a.gx);
         for (uint32_t k = beg; k < end; k++, rw.next()) {
-            if (!rw.has_record(a.cut)) continue;
+            if (a.cut && !rw.has_record(a.cut)) continue;
             const float* __restrict__ src = a.grec + (size_t)k * GREC_F;
             const float v0 = src[15];
             const float2 v1 = *reinterpret_cast<const float2*>(src + 16);
@@ -775,8 +785,14 @@ void launch_colour_gradients(const PreprocessBwdArgs& a, hipStream_t s) {
 
 void launch_preprocess_bwd(const PreprocessBwdArgs& a, hipStream_t s) {
     if (a.P <= 0) return;
-    if (a.coop) hipLaunchKernelGGL(preprocess_bwd_kernel<true>, dim3((a.P + 255) / 256), dim3(256), 0, s, a);
-    else hipLaunchKernelGGL(preprocess_bwd_kernel<false>, dim3((a.P + 255) / 256), dim3(256), 0, s, a);
+    const dim3 grid((a.P + 255) / 256), block(256);
+    if (a.coop) {
+        if (a.cut) hipLaunchKernelGGL((preprocess_bwd_kernel<true, true>), grid, block, 0, s, a);
+        else hipLaunchKernelGGL((preprocess_bwd_kernel<true, false>), grid, block, 0, s, a);
+    } else {
+        if (a.cut) hipLaunchKernelGGL((preprocess_bwd_kernel<false, true>), grid, block, 0, s, a);
+        else hipLaunchKernelGGL((preprocess_bwd_kernel<false, false>), grid, block, 0, s, a);
+    }
 }
 
 }  // namespace surfel

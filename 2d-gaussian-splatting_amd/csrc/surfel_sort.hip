@@ -174,7 +174,7 @@ __global__ void __launch_bounds__(RS_THREADS) os_pass_kernel(const uint32_t* __r
                                                              uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out, uint32_t n,
                                                              int shift, uint32_t mask, const uint32_t* __restrict__ ghist,
                                                              uint32_t* __restrict__ status, uint32_t* __restrict__ ticket, uint32_t nblocks,
-                                                             const uint32_t* __restrict__ n_dev) {
+                                                             const uint32_t* __restrict__ n_dev, int hstride) {
     __shared__ uint32_t s_cnt[4][RS_RADIX];      // per-wave digit counts -> then per-wave output offsets
     __shared__ uint32_t s_w[4];
     __shared__ uint32_t s_tile;
@@ -256,7 +256,7 @@ __global__ void __launch_bounds__(RS_THREADS) os_pass_kernel(const uint32_t* __r
     }
     // global base of every digit = exclusive scan of the digit totals + everything earlier tiles hold of this digit
     {
-        const uint32_t tot = ghist[d_t];
+        const uint32_t tot = ghist[(size_t)d_t * hstride];
         uint32_t x = tot;
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) { const uint32_t y = __shfl_up(x, o); if (lane >= o) x += y; }
@@ -498,7 +498,7 @@ int radix_sort_pairs_u32(uint32_t* keys_a, uint32_t* vals_a, uint32_t* keys_b, u
             hipLaunchKernelGGL(rs_hist_kernel, dim3(nblocks), dim3(RS_THREADS), 0, s, kin, (uint32_t)n, bit, mask, hist, nblocks);
             hipLaunchKernelGGL(rs_scan_kernel, dim3(RS_RADIX), dim3(RS_THREADS), 0, s, hist, nblocks, total);
             hipLaunchKernelGGL(os_pass_kernel<false>, dim3(nblocks), dim3(RS_THREADS), 0, s, kin, vin, kout, vout, (uint32_t)n, bit, mask, total, hist,
-                               (uint32_t*)nullptr, nblocks, (const uint32_t*)nullptr);
+                               (uint32_t*)nullptr, nblocks, (const uint32_t*)nullptr, 1);
             cur ^= 1;
         }
         return cur;
@@ -515,7 +515,7 @@ int radix_sort_pairs_u32(uint32_t* keys_a, uint32_t* vals_a, uint32_t* keys_b, u
         const uint32_t* kin = cur ? keys_b : keys_a; const uint32_t* vin = cur ? vals_b : vals_a;
         uint32_t* kout = cur ? keys_a : keys_b; uint32_t* vout = cur ? vals_a : vals_b;
         hipLaunchKernelGGL(os_pass_kernel<true>, dim3(nblocks), dim3(RS_THREADS), 0, s, kin, vin, kout, vout, (uint32_t)n, bit, mask,
-                           ghist + p * RS_RADIX, status + (size_t)p * nblocks * RS_RADIX, ticket + p, nblocks, (const uint32_t*)nullptr);
+                           ghist + p * RS_RADIX, status + (size_t)p * nblocks * RS_RADIX, ticket + p, nblocks, (const uint32_t*)nullptr, 1);
         cur ^= 1;
     }
     return cur;
@@ -529,109 +529,72 @@ int radix_sort_pairs_u32(uint32_t* keys_a, uint32_t* vals_a, uint32_t* keys_b, u
 // frame that overflows).  With the buffers in place before the scan, three launches collapse into one:
 //   bin_emit_kernel = inclusive scan of tiles_touched (surfel-index order, decoupled look-back) + emission of the (tile id,
 //   surfel) pairs + the digit histograms of the tile sort + clearing of its look-back state.
-constexpr int BE_IPT = 8, BE_TILE = RS_THREADS * BE_IPT;
-size_t bin_emit_scratch_words(size_t P) { return 64 + (P + BE_TILE - 1) / BE_TILE; }      // ticket (+pad) | status[tiles]; must be zero
+// bin_emit_kernel — one thread per surfel (surfel-index order, workgroups of 256 like preprocess_fwd):
+//   first instance slot = sum of the totals of the preprocess workgroups ahead (written there, 4 B per workgroup: no look-back
+//   chain, no ticket) + an in-block scan;  emission of the (tile id, surfel) pairs;  digit histograms of the tile sort in LDS,
+//   flushed with one atomic per (workgroup, non-empty bin) into bins padded to a cache line each (same-line atomics serialise:
+//   1172 workgroups x 272 bins on 17 lines would cost ~20 us, on 272 lines ~1 us);  clearing of the sort's look-back state.
+constexpr int BE_HSTRIDE = 32;      // words between histogram bins of the capacity path (128 B)
+size_t bin_emit_head_words() { return (size_t)RS_MAX_PASSES * RS_RADIX * BE_HSTRIDE + 64; }      // padded ghist | tickets: must be zero
 
 __global__ void __launch_bounds__(RS_THREADS) bin_emit_kernel(int P, const uint32_t* __restrict__ tiles_touched, const uint32_t* __restrict__ rects,
-                                                              float* __restrict__ rec, uint32_t* __restrict__ keys, uint32_t* __restrict__ vals,
-                                                              int gx, uint32_t cap, uint32_t* __restrict__ scan_state, uint32_t* __restrict__ ghist,
-                                                              uint32_t* __restrict__ sort_status, uint32_t sort_status_words, int passes, int end_bit,
-                                                              uint32_t* __restrict__ n_out) {
-    __shared__ uint32_t s_w[4];
-    __shared__ uint32_t s_tile, s_excl;
-    __shared__ uint32_t s_h[RS_MAX_PASSES][RS_RADIX];
-    uint32_t* ticket = scan_state;
-    uint32_t* status = scan_state + 64;
+                                                              const uint32_t* __restrict__ block_totals, float* __restrict__ rec,
+                                                              uint32_t* __restrict__ keys, uint32_t* __restrict__ vals, int gx, uint32_t cap,
+                                                              uint32_t* __restrict__ ghist, uint32_t* __restrict__ sort_status,
+                                                              uint32_t sort_status_words, int passes, int end_bit, uint32_t* __restrict__ n_out) {
+    __shared__ uint32_t s_w[4], s_p[4];
+    __shared__ uint32_t s_h[2][RS_RADIX];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (threadIdx.x == 0) s_tile = atomicAdd(ticket, 1u);
-    for (int p = 0; p < passes; p++) s_h[p][threadIdx.x] = 0u;
-    // look-back state of the tile sort that follows (its head — histograms and tickets — was cleared by preprocess_fwd)
-    for (uint32_t w = blockIdx.x * RS_THREADS + threadIdx.x; w < sort_status_words; w += gridDim.x * RS_THREADS) sort_status[w] = 0u;
-    __syncthreads();
-    const uint32_t tile = s_tile;
-    const uint32_t base = tile * BE_TILE + threadIdx.x * BE_IPT;
-    uint32_t v[BE_IPT], sum = 0;
-#pragma unroll
-    for (int i = 0; i < BE_IPT; i++) {
-        const uint32_t e = base + i;
-        v[i] = e < (uint32_t)P ? tiles_touched[e] : 0u;
-        sum += v[i];
-    }
-    uint32_t x = sum;                              // inclusive scan of the per-thread sums over the workgroup
+    const uint32_t k = blockIdx.x * RS_THREADS + threadIdx.x;
+    s_h[0][threadIdx.x] = 0u; s_h[1][threadIdx.x] = 0u;
+    for (uint32_t w = k; w < sort_status_words; w += gridDim.x * RS_THREADS) sort_status[w] = 0u;
+    uint32_t pre = 0;                              // instances of the workgroups ahead of this one
+    for (uint32_t j = threadIdx.x; j < blockIdx.x; j += RS_THREADS) pre += block_totals[j];
+    const uint32_t n = k < (uint32_t)P ? tiles_touched[k] : 0u;
+    uint32_t x = n;                                // inclusive scan over the workgroup
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) { const uint32_t y = __shfl_up(x, o); if (lane >= o) x += y; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) pre += __shfl_xor(pre, o);
     if (lane == 63) s_w[wave] = x;
+    if (lane == 0) s_p[wave] = pre;
     __syncthreads();
-    uint32_t woff = 0;
-    for (int w = 0; w < wave; w++) woff += s_w[w];
-    const uint32_t agg = s_w[0] + s_w[1] + s_w[2] + s_w[3];
-    if (wave == 0) {
-        uint32_t excl = 0;
-        if (tile == 0) {
-            if (lane == 0) st_agent(status, agg | ST_PREFIX);
-        } else {
-            if (lane == 0) st_agent(status + tile, agg | ST_AGG);
-            int p = (int)tile - 1;
-            for (;;) {
-                const int idx = p - lane;
-                const uint32_t sw = idx >= 0 ? ld_agent(status + idx) : ST_PREFIX;
-                const unsigned long long ready = __ballot((sw >> 30) != 0u);
-                const unsigned long long pref = __ballot((sw & ST_PREFIX) != 0u);
-                const int nready = ready == ~0ull ? 64 : __builtin_ctzll(~ready);
-                const int firstp = pref ? __builtin_ctzll(pref) : 64;
-                const int take = min(nready, firstp + 1);
-                uint32_t c = lane < take ? (sw & ST_VALUE) : 0u;
-#pragma unroll
-                for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
-                excl += c;
-                if (firstp < nready) break;
-                p -= take;
-                if (take == 0) __builtin_amdgcn_s_sleep(1);
+    uint32_t off = s_p[0] + s_p[1] + s_p[2] + s_p[3] + x - n;
+    for (int w = 0; w < wave; w++) off += s_w[w];
+    if (k == (uint32_t)P - 1u) n_out[0] = off + n;      // the instance total, for the kernels that follow
+    const uint32_t mask0 = (1u << min(RS_BITS, end_bit)) - 1u;
+    const uint32_t mask1 = passes > 1 ? (1u << min(RS_BITS, end_bit - RS_BITS)) - 1u : 0u;
+    if (n) {
+        const uint32_t rectbits = rects[k];
+        rec[(size_t)k * REC_F + 18] = __uint_as_float(off);      // the record's first-instance slot
+        const int x0 = rectbits & 1023, y0 = (rectbits >> 10) & 1023, w = rectbits >> 20;
+        int xx = 0, yy = 0;
+        for (uint32_t t = 0; t < n; t++) {
+            const uint32_t key = (uint32_t)((y0 + yy) * gx + (x0 + xx));
+            if (off + t < cap) {      // (an overflowing frame is redone by the caller; what is sorted here stays consistent and in bounds)
+                keys[off + t] = key; vals[off + t] = k;
+                atomicAdd(&s_h[0][key & mask0], 1u);
+                if (passes > 1) atomicAdd(&s_h[1][(key >> RS_BITS) & mask1], 1u);
             }
-            if (lane == 0) st_agent(status + tile, (excl + agg) | ST_PREFIX);
+            if (++xx == w) { xx = 0; ++yy; }
         }
-        if (lane == 0) s_excl = excl;
-    }
-    __syncthreads();
-    uint32_t run = s_excl + woff + x - sum;        // first instance slot of this thread's first surfel
-    const uint32_t mask_lo = (1u << min(RS_BITS, end_bit)) - 1u;
-#pragma unroll
-    for (int i = 0; i < BE_IPT; i++) {
-        const uint32_t e = base + i;
-        const uint32_t n = v[i];
-        if (n) {
-            const uint32_t rectbits = rects[e];
-            rec[(size_t)e * REC_F + 18] = __uint_as_float(run);      // the record's first-instance slot
-            const int x0 = rectbits & 1023, y0 = (rectbits >> 10) & 1023, w = rectbits >> 20;
-            int xx = 0, yy = 0;
-            for (uint32_t t = 0; t < n; t++) {
-                const uint32_t key = (uint32_t)((y0 + yy) * gx + (x0 + xx));
-                if (run + t < cap) {      // (an overflowing frame is redone by the caller; what is sorted here stays consistent and in bounds)
-                    keys[run + t] = key; vals[run + t] = e;
-                    atomicAdd(&s_h[0][key & mask_lo], 1u);
-                    if (passes > 1) atomicAdd(&s_h[1][(key >> RS_BITS) & ((1u << min(RS_BITS, end_bit - RS_BITS)) - 1u)], 1u);
-                }
-                if (++xx == w) { xx = 0; ++yy; }
-            }
-        }
-        run += n;
-        if (e == (uint32_t)P - 1u) n_out[0] = run;      // the instance total, for the kernels that follow (and the overflow check)
     }
     __syncthreads();
     for (int p = 0; p < passes; p++) {
         const uint32_t c = s_h[p][threadIdx.x];
-        if (c) atomicAdd(&ghist[p * RS_RADIX + threadIdx.x], c);
+        if (c) atomicAdd(&ghist[(size_t)(p * RS_RADIX + threadIdx.x) * BE_HSTRIDE], c);
     }
 }
 
 // tile sort of the capacity path: the look-back passes alone (histograms and state come from bin_emit_kernel); at most two passes
 int radix_sort_pairs_u32_devn(uint32_t* keys_a, uint32_t* vals_a, uint32_t* keys_b, uint32_t* vals_b, size_t cap, int end_bit, const uint32_t* n_dev,
                               void* scratch, hipStream_t s) {
+    // scratch layout of the capacity path (u32 words): ghist[RS_MAX_PASSES][256] padded to BE_HSTRIDE | ticket (+pad to 64) | status
     const uint32_t nblocks = rs_nblocks(cap);
     const int passes = radix_sort_passes(cap, 0, end_bit);
     uint32_t* ghist = static_cast<uint32_t*>(scratch);
-    uint32_t* ticket = ghist + RS_MAX_PASSES * RS_RADIX;
-    uint32_t* status = ghist + RS_HEAD_WORDS;
+    uint32_t* ticket = ghist + (size_t)RS_MAX_PASSES * RS_RADIX * BE_HSTRIDE;
+    uint32_t* status = ghist + bin_emit_head_words();
     int cur = 0;
     for (int p = 0; p < passes; p++) {
         const int bit = p * RS_BITS;
@@ -640,20 +603,21 @@ int radix_sort_pairs_u32_devn(uint32_t* keys_a, uint32_t* vals_a, uint32_t* keys
         const uint32_t* kin = cur ? keys_b : keys_a; const uint32_t* vin = cur ? vals_b : vals_a;
         uint32_t* kout = cur ? keys_a : keys_b; uint32_t* vout = cur ? vals_a : vals_b;
         hipLaunchKernelGGL(os_pass_kernel<true>, dim3(nblocks), dim3(RS_THREADS), 0, s, kin, vin, kout, vout, (uint32_t)cap, bit, mask,
-                           ghist + p * RS_RADIX, status + (size_t)p * nblocks * RS_RADIX, ticket + p, nblocks, n_dev);
+                           ghist + (size_t)p * RS_RADIX * BE_HSTRIDE, status + (size_t)p * nblocks * RS_RADIX, ticket + p, nblocks, n_dev, BE_HSTRIDE);
         cur ^= 1;
     }
     return cur;
 }
 bool capacity_binning_ok(size_t cap, int end_bit) { return rs_onesweep(cap) && radix_sort_passes(cap, 0, end_bit) <= 2 && g_large_sort_impl != 3; }
 size_t bin_emit_sort_status_words(size_t cap, int end_bit) { return (size_t)radix_sort_passes(cap, 0, end_bit) * rs_nblocks(cap) * RS_RADIX; }
+size_t capacity_sort_scratch_bytes(size_t cap, int end_bit) { return (bin_emit_head_words() + bin_emit_sort_status_words(cap, end_bit)) * sizeof(uint32_t) + 256; }
 
-void launch_bin_emit(int P, const uint32_t* tiles_touched, const uint32_t* rects, float* rec, uint32_t* keys, uint32_t* vals, int gx, size_t cap,
-                     void* zeroed_scan_state, void* sort_scratch, int end_bit, uint32_t* n_out, hipStream_t s) {
+void launch_bin_emit(int P, const uint32_t* tiles_touched, const uint32_t* rects, const uint32_t* block_totals, float* rec, uint32_t* keys, uint32_t* vals,
+                     int gx, size_t cap, void* sort_scratch, int end_bit, uint32_t* n_out, hipStream_t s) {
     uint32_t* ghist = static_cast<uint32_t*>(sort_scratch);
-    hipLaunchKernelGGL(bin_emit_kernel, dim3((unsigned)((P + BE_TILE - 1) / BE_TILE)), dim3(RS_THREADS), 0, s, P, tiles_touched, rects, rec, keys, vals, gx,
-                       (uint32_t)cap, static_cast<uint32_t*>(zeroed_scan_state), ghist, ghist + RS_HEAD_WORDS,
-                       (uint32_t)bin_emit_sort_status_words(cap, end_bit), radix_sort_passes(cap, 0, end_bit), end_bit, n_out);
+    hipLaunchKernelGGL(bin_emit_kernel, dim3((unsigned)((P + RS_THREADS - 1) / RS_THREADS)), dim3(RS_THREADS), 0, s, P, tiles_touched, rects, block_totals,
+                       rec, keys, vals, gx, (uint32_t)cap, ghist, ghist + bin_emit_head_words(), (uint32_t)bin_emit_sort_status_words(cap, end_bit),
+                       radix_sort_passes(cap, 0, end_bit), end_bit, n_out);
 }
 
 }  // namespace surfel

@@ -45,6 +45,8 @@ extern "C" {
 #define SURFEL_OPT_PBWD_COOP      (1 << 13)            /* backward: wave-cooperative gather of the gradient records (default: R >= 6 P and R >= 2^25) */
 #define SURFEL_OPT_PBWD_THREAD    (1 << 14)            /* backward: per-thread gather of the gradient records */
 #define SURFEL_OPT_EXACT_BINNING  (1 << 16)            /* forward: "capacity_binning" = 0 for this call (binning buffers sized after a host wait for the instance count) */
+#define SURFEL_OPT_TILE_CUTS      (1 << 17)            /* backward: no gradient records behind a tile's saturation point, preprocess_bwd tests the tile cuts (default: R >= 2^21) */
+#define SURFEL_OPT_ZERO_RECORDS   (1 << 18)            /* backward: zero records behind a tile's saturation point (default: R < 2^21); bit-identical to the cuts */
 #define SURFEL_OPT_BWD_SCAN       (1 << 15)            /* backward: scan walk ("bwd_variant" = 3) for this call; deterministic, NOT bit-identical to rows / quad */
 
 /* Allocator callback: return a device pointer to `bytes` bytes, 256-byte aligned, valid until the

@@ -381,6 +381,27 @@ def test_backward_variants_are_identical(kind):
             kind, k, d.max(), int((d > 0).sum()))
 
 
+@pytest.mark.parametrize("kind", ["plain", "huge", "crowded", "saturating", "C1"])
+def test_tile_cuts_equal_zero_records(kind):
+    """Behind a tile's saturation point blend_bwd either writes zero gradient records (small frames) or writes NOTHING and leaves
+    the tile's cut — the (depth bits, surfel index) key of its last staged instance — for preprocess_bwd to test before every
+    record fetch (frames with >= 2^21 instances).  Both forms, every walk, both record gathers: BIT-IDENTICAL gradients."""
+    import surfel_native as n
+    a = scene_args(_walk_scene(kind))
+    rng = np.random.default_rng(3)
+    gC = rng.normal(size=(3, a["H"], a["W"])).astype(np.float32); gO = rng.normal(size=(7, a["H"], a["W"])).astype(np.float32)
+    run = HipRun(a).forward()
+    for walk in (n.OPT_BWD_ROWS, n.OPT_BWD_QUAD, n.OPT_BWD_SCAN):
+        for gather in (n.OPT_PBWD_THREAD, n.OPT_PBWD_COOP):
+            res = []
+            for tail in (n.OPT_ZERO_RECORDS, n.OPT_TILE_CUTS):
+                run.debug = walk | gather | tail
+                res.append(run.backward(gC, gO))
+            for k in res[0]:
+                assert np.isfinite(res[1][k]).all(), k
+                assert np.array_equal(res[0][k], res[1][k]), "%s: dL/d%s differs between zero records and tile cuts (walk %x, gather %x)" % (kind, k, walk, gather)
+
+
 def test_capacity_binning_is_identical():
     """Capacity binning (binning buffers sized from the previous frames' instance counts, fused scan + emission + histogram kernel,
     sort passes / tile ranges with the count on the device, no host wait in the middle of the forward) against the exact-size path:
