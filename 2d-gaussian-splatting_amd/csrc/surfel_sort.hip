@@ -537,19 +537,22 @@ int radix_sort_pairs_u32(uint32_t* keys_a, uint32_t* vals_a, uint32_t* keys_b, u
 constexpr int BE_HSTRIDE = 32;      // words between histogram bins of the capacity path (128 B)
 size_t bin_emit_head_words() { return (size_t)RS_MAX_PASSES * RS_RADIX * BE_HSTRIDE + 64; }      // padded ghist | tickets: must be zero
 
-__global__ void __launch_bounds__(RS_THREADS) bin_emit_kernel(int P, const uint32_t* __restrict__ tiles_touched, const uint32_t* __restrict__ rects,
-                                                              const uint32_t* __restrict__ block_totals, float* __restrict__ rec,
+constexpr int BE_THREADS = 1024;      // 16 waves per workgroup: a quarter of the (workgroup, bin) histogram atomics of 256-thread workgroups
+__global__ void __launch_bounds__(BE_THREADS) bin_emit_kernel(int P, const uint32_t* __restrict__ tiles_touched, const uint32_t* __restrict__ rects,
+                                                              const uint32_t* __restrict__ block_totals, uint32_t nblock_totals, float* __restrict__ rec,
                                                               uint32_t* __restrict__ keys, uint32_t* __restrict__ vals, int gx, uint32_t cap,
                                                               uint32_t* __restrict__ ghist, uint32_t* __restrict__ sort_status,
                                                               uint32_t sort_status_words, int passes, int end_bit, uint32_t* __restrict__ n_out) {
-    __shared__ uint32_t s_w[4], s_p[4];
+    constexpr int NW = BE_THREADS / 64;
+    __shared__ uint32_t s_w[NW], s_p[NW];
     __shared__ uint32_t s_h[2][RS_RADIX];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const uint32_t k = blockIdx.x * RS_THREADS + threadIdx.x;
-    s_h[0][threadIdx.x] = 0u; s_h[1][threadIdx.x] = 0u;
-    for (uint32_t w = k; w < sort_status_words; w += gridDim.x * RS_THREADS) sort_status[w] = 0u;
-    uint32_t pre = 0;                              // instances of the workgroups ahead of this one
-    for (uint32_t j = threadIdx.x; j < blockIdx.x; j += RS_THREADS) pre += block_totals[j];
+    const uint32_t k = blockIdx.x * BE_THREADS + threadIdx.x;
+    if (threadIdx.x < 2 * RS_RADIX) s_h[threadIdx.x >> 8][threadIdx.x & (RS_RADIX - 1)] = 0u;
+    for (uint32_t w = k; w < sort_status_words; w += gridDim.x * BE_THREADS) sort_status[w] = 0u;
+    uint32_t pre = 0;                              // instances of the surfels ahead of this workgroup (preprocess workgroups of 256)
+    const uint32_t ahead = min(nblock_totals, blockIdx.x * (uint32_t)(BE_THREADS / 256));
+    for (uint32_t j = threadIdx.x; j < ahead; j += BE_THREADS) pre += block_totals[j];
     const uint32_t n = k < (uint32_t)P ? tiles_touched[k] : 0u;
     uint32_t x = n;                                // inclusive scan over the workgroup
 #pragma unroll
@@ -559,8 +562,9 @@ __global__ void __launch_bounds__(RS_THREADS) bin_emit_kernel(int P, const uint3
     if (lane == 63) s_w[wave] = x;
     if (lane == 0) s_p[wave] = pre;
     __syncthreads();
-    uint32_t off = s_p[0] + s_p[1] + s_p[2] + s_p[3] + x - n;
-    for (int w = 0; w < wave; w++) off += s_w[w];
+    uint32_t off = x - n;
+#pragma unroll
+    for (int w = 0; w < NW; w++) off += s_p[w] + (w < wave ? s_w[w] : 0u);
     if (k == (uint32_t)P - 1u) n_out[0] = off + n;      // the instance total, for the kernels that follow
     const uint32_t mask0 = (1u << min(RS_BITS, end_bit)) - 1u;
     const uint32_t mask1 = passes > 1 ? (1u << min(RS_BITS, end_bit - RS_BITS)) - 1u : 0u;
@@ -580,9 +584,9 @@ __global__ void __launch_bounds__(RS_THREADS) bin_emit_kernel(int P, const uint3
         }
     }
     __syncthreads();
-    for (int p = 0; p < passes; p++) {
-        const uint32_t c = s_h[p][threadIdx.x];
-        if (c) atomicAdd(&ghist[(size_t)(p * RS_RADIX + threadIdx.x) * BE_HSTRIDE], c);
+    if ((int)threadIdx.x < passes * RS_RADIX) {
+        const uint32_t c = s_h[threadIdx.x >> 8][threadIdx.x & (RS_RADIX - 1)];
+        if (c) atomicAdd(&ghist[(size_t)threadIdx.x * BE_HSTRIDE], c);
     }
 }
 
@@ -615,8 +619,8 @@ size_t capacity_sort_scratch_bytes(size_t cap, int end_bit) { return (bin_emit_h
 void launch_bin_emit(int P, const uint32_t* tiles_touched, const uint32_t* rects, const uint32_t* block_totals, float* rec, uint32_t* keys, uint32_t* vals,
                      int gx, size_t cap, void* sort_scratch, int end_bit, uint32_t* n_out, hipStream_t s) {
     uint32_t* ghist = static_cast<uint32_t*>(sort_scratch);
-    hipLaunchKernelGGL(bin_emit_kernel, dim3((unsigned)((P + RS_THREADS - 1) / RS_THREADS)), dim3(RS_THREADS), 0, s, P, tiles_touched, rects, block_totals,
-                       rec, keys, vals, gx, (uint32_t)cap, ghist, ghist + bin_emit_head_words(), (uint32_t)bin_emit_sort_status_words(cap, end_bit),
+    hipLaunchKernelGGL(bin_emit_kernel, dim3((unsigned)((P + BE_THREADS - 1) / BE_THREADS)), dim3(BE_THREADS), 0, s, P, tiles_touched, rects, block_totals,
+                       (uint32_t)((P + 255) / 256), rec, keys, vals, gx, (uint32_t)cap, ghist, ghist + bin_emit_head_words(), (uint32_t)bin_emit_sort_status_words(cap, end_bit),
                        radix_sort_passes(cap, 0, end_bit), end_bit, n_out);
 }
 

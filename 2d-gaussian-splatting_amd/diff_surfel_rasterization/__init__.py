@@ -28,6 +28,22 @@ def tile_row_instances():
     r = buf[:gx * gy * 8].view(torch.int32).view(gy, gx, 2).to(torch.int64)
     return (r[..., 1] - r[..., 0]).sum(1)
 
+
+def staged_instances(width, height):
+    """Σ over tiles of the deepest list position any pixel of the tile composited (max n_contrib) of the most recent forward: the
+    instances a blend pass has to read — the rest of a tile's list lies behind its saturation point.  White-box read of the image
+    buffer (csrc/surfel_api.hip: ImgState = ranges + 2 x 64 partial counters + 1 | final_T 3HW | n_contrib 2HW, 256-B aligned)."""
+    if _last_image is None:
+        return None
+    buf, gx, gy = _last_image
+    al = lambda v: (v + 255) // 256 * 256
+    off = al(al((gx * gy + 64 + 1) * 8) + 12 * width * height)
+    last = buf[off:off + 4 * width * height].view(torch.int32).view(height, width)
+    pad = torch.zeros((gy * 16, gx * 16), dtype=torch.int32, device=buf.device)
+    pad[:height, :width] = last
+    return int(pad.view(gy, 16, gx, 16).amax(dim=(1, 3)).sum().item())
+
+
 _grad_arena = None
 
 

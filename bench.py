@@ -25,20 +25,75 @@ sys.path.insert(0, REPO)
 HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/s achievable)
 
 
-def algorithmic_bytes(stage, P, V, R, W, H, n_pass):
-    """SURVEY.md §8d per-launch ALGORITHMIC bytes of each stage (76-B record figure, not our 80-B layout)."""
+def algorithmic_bytes(stage, P, V, R, W, H, n_pass, Rs=None):
+    """SURVEY.md §8d per-launch ALGORITHMIC bytes of each stage (76-B record figure, not our 80-B layout).  Rs = STAGED instances
+    (Σ over tiles of the deepest list position any pixel composited): what a blend pass has to read and the backward has to write —
+    the instances behind a tile's saturation point are touched by neither, so charging all R of them to the blend stages made
+    crowded frames (C5) print more than the HBM peak.  Binning stages move all R."""
     HW = W * H
+    Rs = R if Rs is None else min(R, Rs)
     return {
         "preprocess_fwd": P * (232 + 87),
         "scan": P * 8,
         "emit_instances": R * 12,
         "radix_sort": R * 24 * n_pass,
         "tile_ranges": R * 8,
-        "blend_fwd": R * (4 + 76) + HW * 60,
+        "blend_fwd": Rs * (4 + 76) + HW * 60,
         "zero_grec": 0,
-        "blend_bwd": R * (4 + 76) + HW * (60 + 40) + V * 18 * 4 * 2,
+        "blend_bwd": Rs * (4 + 76) + HW * (60 + 40) + V * 18 * 4 * 2,
         "preprocess_bwd": P * (87 + 232 + 72) + P * (232 + 12),
     }.get(stage, 0)
+
+
+def roofline_object(per_kernel, workload, P, V, R, Rs, W, H, n_pass):
+    """The `roofline` object of one bench leg: dominant rasterizer kernel, its algorithmic bytes / its measured mean duration against
+    the HBM peak, the committed PMC traffic of that kernel on that workload (if profiles/ holds one), the VALU-issue yardstick."""
+    if not per_kernel:
+        return None
+    dom = max(per_kernel, key=per_kernel.get)
+    B = algorithmic_bytes(dom, P, V, R, W, H, n_pass, Rs)
+    ach = B / (per_kernel[dom] * 1e-3) / 1e9
+    # HBM traffic of the dominant kernel: PMC counters cannot be read from inside the process, so this is the figure of the
+    # committed rocprofv3 pass over this same command (scripts/profile_gpu.sh), labelled as such
+    traffic, traffic_src, walk = None, None, None
+    tf = os.path.join(REPO, "profiles", "pmc_traffic.json")
+    if os.path.exists(tf):
+        try:
+            tj = json.load(open(tf))
+            ent = tj.get(workload, {})
+            traffic = ent.get(dom)
+            walk = ent.get("_blend_bwd_walk")
+            if traffic is not None:
+                traffic_src = ("profiles/pmc_traffic.json (%s): separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over `python bench.py --workload %s`%s, "
+                               "not read in this run" % (ent.get("_tag", tj.get("_tag", "committed")), workload,
+                                                         (", blend_bwd walk forced to '%s'" % walk) if walk else ""))
+        except Exception:
+            traffic = None
+    # second yardstick for the VALU-bound blend kernels: issued VALU wave-instructions per launch (SQ_INSTS_VALU from the
+    # committed PMC pass) against the chip's fp32 vector issue peak: 157.3 TFLOP/s / 128 flop per wave-FMA (MI355X_MICROARCH.md)
+    valu = None
+    try:
+        import glob
+        pm = sorted(glob.glob(os.path.join(REPO, "profiles", "r*_%s_pmc.json" % workload)))[-1]
+        pj = json.load(open(pm))
+        n_inst = max([v.get("SQ_INSTS_VALU", 0.0) for k, v in pj.items() if k.startswith(dom)] or [0.0]) or None
+        if n_inst:
+            rate = n_inst / (per_kernel[dom] * 1e-3) / 1e9
+            # measured_ceiling: what independent v_fma_f32 streams reach on this chip with 8 waves / SIMD — 1.44 ns per
+            # wave-instruction per SIMD (scripts/ubench/valu_rate.hip, profiles/r02_valu_rate_ubench.txt) = 711 G/s over
+            # 1024 SIMDs; DPP adds / compares / selects run at 0.75x of that, v_exp / v_rcp at 0.35x
+            valu = {"wave_insts_per_launch": int(n_inst), "achieved_Ginst_per_s": round(rate, 1), "peak_Ginst_per_s": 1228.9,
+                    "frac": round(rate / 1228.9, 4), "measured_ceiling_Ginst_per_s": 711.0,
+                    "frac_of_measured_ceiling": round(rate / 711.0, 4), "source": os.path.basename(pm)}
+    except Exception:
+        valu = None
+    return {"bound": "hbm", "kernel": dom, "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_src, "algorithmic_bytes": int(B),
+            "instances_R": int(R), "instances_staged": None if Rs is None else int(Rs),
+            "kernel_ms": round(per_kernel[dom], 4), "valu_issue": valu,
+            "all_kernels_ms": {k: round(v, 4) for k, v in per_kernel.items()},
+            "all_kernels_GBps": {k: round(algorithmic_bytes(k, P, V, R, W, H, n_pass, Rs) / (v * 1e-3) / 1e9, 1)
+                                 for k, v in per_kernel.items() if v > 0}}
 
 
 def _respawn(n):
@@ -82,7 +137,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--workload", default="C2", help="synthetic config name (synthetic.CONFIGS); C2 = BASELINE configs[1] shape")
+    ap.add_argument("--workload", default="C2", help="synthetic config name (synthetic.CONFIGS; C2 = BASELINE configs[1] shape, the headline), or a "
+                                                     "trained state: 'trained' (54 k surfels, 800x800) / 'garden' (>= 1 M surfels, 1600x1060: BASELINE configs[3]'s per-GPU shape)")
+    ap.add_argument("--state", default=None, help="trained workloads: .ply cache of the trained model (loaded if present, written otherwise)")
+    ap.add_argument("--legs", default="C4,C2H,trained,garden", help="comma-separated side legs at N = 1 (any of C4, C2H, C3, trained, garden)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-1080p", action="store_true")
     ap.add_argument("--no-raster-only", action="store_true")
@@ -132,10 +190,16 @@ def main():
         else:
             dist.init_process_group(backend)
 
-    from helpers_bench import make_trainer
-    P, W, H, zf = synthetic.CONFIGS[args.workload]
+    from helpers_bench import TRAINED_PRESETS, make_trainer, trained_trainer
     n_views = max(8, world)
-    tr = make_trainer(dev, args.workload, n_views=n_views, sharding=args.sharding)      # Trainer picks up the process group
+    trained_info = None
+    if args.workload in TRAINED_PRESETS:
+        tr, trained_info = trained_trainer(dev, args.workload, args.state)
+        P, (W, H) = int(tr.model.P), TRAINED_PRESETS[args.workload]["res"]
+        n_views = len(tr.cams)
+    else:
+        P, W, H, zf = synthetic.CONFIGS[args.workload]
+        tr = make_trainer(dev, args.workload, n_views=n_views, sharding=args.sharding)      # Trainer picks up the process group
     PRIME = 15      # set-up iterations before the contract's W warm-up steps: allocator high-water marks, binning-path heuristic, clocks
     for _ in range(PRIME):
         tr.step()
@@ -182,6 +246,7 @@ def main():
     V = int((tr.last["radii"] > 0).sum().item())
     import diff_surfel_rasterization
     R = int(diff_surfel_rasterization.last_num_rendered)
+    Rs = diff_surfel_rasterization.staged_instances(W, H)
     tiles = ((W + 15) // 16) * ((H + 15) // 16)
     n_pass = -(-(32 + max(1, (tiles - 1).bit_length())) // 8)
 
@@ -191,57 +256,17 @@ def main():
         bands = world > 1 and args.sharding == "bands"
         iters_per_s = (1 if bands else world) * args.steps / dt
         per_kernel = {k: v[0] / v[1] for k, v in stages.items()}
-        dom = max(per_kernel, key=per_kernel.get) if per_kernel else None
-        roof = None
-        if dom:
-            B = algorithmic_bytes(dom, P, V, R, W, H, n_pass)
-            ach = B / (per_kernel[dom] * 1e-3) / 1e9
-            # HBM traffic of the dominant kernel: PMC counters cannot be read from inside the process, so this is the figure of the
-            # committed rocprofv3 pass over this same command (scripts/profile_gpu.sh), labelled as such
-            traffic, traffic_src = None, None
-            tf = os.path.join(REPO, "profiles", "pmc_traffic.json")
-            if os.path.exists(tf):
-                try:
-                    tj = json.load(open(tf))
-                    traffic = tj.get(args.workload, {}).get(dom)
-                    traffic_src = "profiles/pmc_traffic.json (%s): separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over `python bench.py`, not read in this run" % tj.get("_tag", "committed")
-                except Exception:
-                    traffic = None
-            # second yardstick for the VALU-bound blend kernels: issued VALU wave-instructions per launch (SQ_INSTS_VALU from the
-            # committed PMC pass) against the chip's fp32 vector issue peak: 157.3 TFLOP/s / 128 flop per wave-FMA (MI355X_MICROARCH.md)
-            valu = None
-            try:
-                import glob
-                pm = sorted(glob.glob(os.path.join(REPO, "profiles", "r*_%s_pmc.json" % args.workload)))[-1]
-                pj = json.load(open(pm))
-                # blend_bwd = blend_bwd_rows_kernel | blend_bwd_quad_kernel: the walk that ran (the other one is launched for the
-                # tuner's probes only, its per-launch mean mixes probes and idle launches)
-                n_inst = max([v.get("SQ_INSTS_VALU", 0.0) for k, v in pj.items() if k.startswith(dom)] or [0.0]) or None
-                if n_inst:
-                    rate = n_inst / (per_kernel[dom] * 1e-3) / 1e9
-                    # measured_ceiling: what independent v_fma_f32 streams reach on this chip with 8 waves / SIMD — 1.44 ns per
-                    # wave-instruction per SIMD (scripts/ubench/valu_rate.hip, profiles/r02_valu_rate_ubench.txt) = 711 G/s over
-                    # 1024 SIMDs; DPP adds / compares / selects run at 0.75x of that, v_exp / v_rcp at 0.35x
-                    valu = {"wave_insts_per_launch": int(n_inst), "achieved_Ginst_per_s": round(rate, 1), "peak_Ginst_per_s": 1228.9,
-                            "frac": round(rate / 1228.9, 4), "measured_ceiling_Ginst_per_s": 711.0,
-                            "frac_of_measured_ceiling": round(rate / 711.0, 4), "source": os.path.basename(pm)}
-            except Exception:
-                valu = None
-            roof = {"bound": "hbm", "kernel": dom, "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_src, "algorithmic_bytes": int(B),
-                    "kernel_ms": round(per_kernel[dom], 4), "valu_issue": valu,
-                    "all_kernels_ms": {k: round(v, 4) for k, v in per_kernel.items()},
-                    "all_kernels_GBps": {k: round(algorithmic_bytes(k, P, V, R, W, H, n_pass) / (v * 1e-3) / 1e9, 1)
-                                         for k, v in per_kernel.items() if v > 0}}
+        roof = roofline_object(per_kernel, args.workload, P, V, R, Rs, W, H, n_pass)
         out = {"metric": "train iters/sec (full iteration: rasterizer fwd+bwd, L1+SSIM, normal+dist regularisers, Adam) + fwd Msplats/s @1080p",
                "value": round(iters_per_s, 3), "unit": "train-iters/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "strong" if bands else "weak", "vs_baseline": None,
                "dtype": "f32", "data": "synthetic",
-               "config": {"workload": "%s-synthetic: %d random surfels, %dx%d, sh_degree 3, %d target views rendered from the unperturbed "
+               "config": {"workload": (trained_info["workload"] + "; steady-state iteration, every loss term on") if trained_info else
+                                      "%s-synthetic: %d random surfels, %dx%d, sh_degree 3, %d target views rendered from the unperturbed "
                                       "surfels, %s, lambda_dssim 0.2, lambda_normal 0.05, lambda_dist 1000, depth_ratio 1, "
                                       "Adam on 58 floats/surfel; %d set-up iterations before the warm-up" % (args.workload, P, W, H, n_views,
                                       "1 view/iteration split into row bands" if bands else "1 view/GPU/iteration", PRIME),
-                          "P": P, "visible": V, "instances_R": R, "n_pass": n_pass, "tiles": tiles,
+                          "P": P, "visible": V, "instances_R": R, "instances_staged": Rs, "n_pass": n_pass, "tiles": tiles,
                           "parallelism": ("tile-band sharding of one view over %d GPUs (image bands all-gathered, same gradient exchange)" % world) if bands
                           else ("view-parallel dp%d; per iteration 1 all-reduce of 40 B/surfel (geometry gradients) + 1 all-gather of "
                                 "12 B/surfel/rank (colour gradients -> SH gradients rebuilt locally)" % world)},
@@ -274,8 +299,12 @@ def main():
     if rank == 0 and world == 1 and not args.no_legs:
         from helpers_bench import config_leg, copy_bandwidth, trained_leg
         out["hbm_copy_probe"] = copy_bandwidth(dev)
-        out["legs"] = {"C4": config_leg(dev, "C4", steps=20, warmup=5), "C2H": config_leg(dev, "C2H", steps=30, warmup=5),
-                       "trained": trained_leg(dev)}
+        out["legs"] = {}
+        for leg in [x for x in args.legs.split(",") if x]:
+            if leg in TRAINED_PRESETS:
+                out["legs"][leg] = trained_leg(dev, leg, steps=30 if leg == "trained" else 20, warmup=5)
+            else:
+                out["legs"][leg] = config_leg(dev, leg, steps=30 if leg == "C2H" else 20, warmup=5)
 
     # ---- CPU baselines, rank 0 / N=1 only: the oracle's fp32 OpenMP port of the rasterizer on the headline workload shape, and
     # BASELINE configs[0]: the dense pure-PyTorch rasterizer at C1

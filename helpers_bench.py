@@ -110,7 +110,7 @@ def _frozen_schedule(TR, regularizers=True):
                                   normal_from_iter=0 if regularizers else far, lambda_dist=1000.0, lambda_normal=0.05)
 
 
-def time_trainer(tr, steps, warmup, prime=15):
+def time_trainer(tr, steps, warmup, prime=15, workload=None):
     """ms per full training iteration of an existing Trainer + the rasterizer's per-stage kernel times (second, untimed pass)."""
     import torch
     import surfel_native
@@ -144,9 +144,15 @@ def time_trainer(tr, steps, warmup, prime=15):
     lib.surfel_set_option(b"bwd_variant", 2)
     tr.pipe.debug = 0
     cam = tr.cams[0]
-    tiles = ((int(cam.image_width) + 15) // 16) * ((int(cam.image_height) + 15) // 16)
+    W, H = int(cam.image_width), int(cam.image_height)
+    tiles = ((W + 15) // 16) * ((H + 15) // 16)
     R = int(dsr.last_num_rendered)
-    return {"ms_per_step": round(dt / steps * 1e3, 4), "iters_per_s": round(steps / dt, 2), "steps": steps, "P": int(tr.model.P),
+    Rs = dsr.staged_instances(W, H)
+    V = int((tr.last["radii"] > 0).sum().item())
+    from bench import roofline_object
+    n_pass = -(-(32 + max(1, (tiles - 1).bit_length())) // 8)
+    roof = roofline_object({k: v[0] / v[1] for k, v in st.items()}, workload or "?", int(tr.model.P), V, R, Rs, W, H, n_pass)
+    return {"roofline": roof, "instances_staged": Rs, "ms_per_step": round(dt / steps * 1e3, 4), "iters_per_s": round(steps / dt, 2), "steps": steps, "P": int(tr.model.P),
             "visible": int((tr.last["radii"] > 0).sum().item()), "instances_R": R, "inst_per_tile": round(R / tiles, 1),
             "inst_per_surfel": round(R / max(1, int(tr.model.P)), 2), "loss": round(float(tr.last["loss"]), 5),
             "kernels_ms": {k: round(v[0] / v[1], 4) for k, v in st.items()}, "blend_bwd_ms_by_walk": ab}
@@ -160,7 +166,7 @@ def config_leg(dev, workload, steps=20, warmup=5):
     import diff_surfel_rasterization as dsr
     P, W, H, zf = synthetic.CONFIGS[workload]
     tr = make_trainer(dev, workload, n_views=8)
-    out = time_trainer(tr, steps, warmup)
+    out = time_trainer(tr, steps, warmup, workload=workload)
     out["workload"] = ("%s-synthetic: %d random surfels, %dx%d, median 1-sigma radius %.1f px, full iteration as the headline leg"
                        % (workload, P, W, H, synthetic.PX_RADIUS.get(workload) or max(4.0 * W / 1920.0, 1.5)))
     del tr
@@ -169,45 +175,83 @@ def config_leg(dev, workload, steps=20, warmup=5):
     return out
 
 
-def trained_leg(dev, train_iters=6000, n_gt=200_000, n_views=48, res=800, steps=30, warmup=5):
-    """A TRAINED state instead of random surfels: run the reference's default schedule (random-point initialisation, densification
-    500 -> every 100, opacity resets, lambda_dist after 3000) on a synthetic capture for `train_iters` iterations — untimed —
-    then time the steady-state iteration on the resulting model (post-densification scale / opacity statistics, every loss on)."""
+TRAINED_PRESETS = {
+    # name: ground-truth surfels, initial random points, views, (W, H), iterations of the reference schedule (untimed), gt disc scale
+    "trained": dict(n_gt=200_000, n_init=200_000, n_views=48, res=(800, 800), train_iters=6000, px_scale=0.035),
+    # BASELINE configs[3]'s per-GPU shape (Mip-NeRF360 garden: ~2 M surfels, 1600x1060) on post-densification statistics: the capture
+    # is dense enough for the densification to settle above a million surfels
+    "garden": dict(n_gt=2_500_000, n_init=1_500_000, n_views=24, res=(1600, 1060), train_iters=3000, px_scale=0.012),
+}
+
+
+def trained_state(dev, preset="trained", state=None):
+    """(model, train cameras, held-out cameras, extent, info) of a TRAINED state: the reference's default schedule (random-point
+    initialisation, densification 500 -> every 100, opacity resets, lambda_dist after 3000) run — untimed — on a synthetic capture.
+    `state`: a .ply path — loaded if it exists (the capture is regenerated, it is deterministic), written otherwise, so that several
+    processes (the rocprofv3 passes of scripts/profile_gpu.sh) time the same model without training it again."""
     import torch
     import surfel_model
     import surfel_trainer as TR
-    import diff_surfel_rasterization as dsr
+    c = TRAINED_PRESETS[preset]
+    W, H = c["res"]
     torch.manual_seed(0)
     bg = torch.zeros(3, device=dev)
-    gt = TR.synthetic_object(n_gt, dev, seed=0, px_scale=0.035)
-    cams = TR.capture_views(gt, TR.orbit_cameras(n_views + 8, res, res, device=dev), bg)
+    gt = TR.synthetic_object(c["n_gt"], dev, seed=0, px_scale=c["px_scale"])
+    cams = TR.capture_views(gt, TR.orbit_cameras(c["n_views"] + 8, W, H, device=dev), bg)
     del gt
-    train_cams, test_cams = cams[:n_views], cams[n_views:]
+    train_cams, test_cams = cams[:c["n_views"]], cams[c["n_views"]:]
     extent = TR.cameras_extent(train_cams)
-    rng = np.random.default_rng(0)
-    pcd = type("PCD", (), {})()
-    pcd.points = (rng.random((n_gt, 3)) * 2.6 - 1.3).astype(np.float32)
-    pcd.colors = rng.random((n_gt, 3)).astype(np.float32)
     model = surfel_model.GaussianModel(3, device=dev)
-    model.create_from_pcd(pcd, spatial_lr_scale=extent)
-    opt = TR.optimization_params(iterations=train_iters, lambda_dist=100.0, position_lr_max_steps=train_iters)
-    tr = TR.Trainer(model, train_cams, opt, TR.pipeline_params(depth_ratio=1.0), extent=extent)
-    p0 = tr.evaluate(train_cams[:8])[0]
-    torch.cuda.synchronize(); t0 = time.perf_counter()
-    for _ in range(train_iters - 1):       # the schedule's last iteration takes no optimiser step (train.py:136)
-        tr.step()
-    torch.cuda.synchronize(); t_train = time.perf_counter() - t0
-    psnr_train, psnr_test = tr.evaluate(train_cams[:8])[0], tr.evaluate(test_cams)[0]
+    info = {"preset": preset}
+    if state and os.path.exists(state):
+        model.load_ply(state)
+        model.active_sh_degree = 3
+        model.spatial_lr_scale = extent
+        info["loaded_from"] = os.path.basename(state)
+    else:
+        rng = np.random.default_rng(0)
+        pcd = type("PCD", (), {})()
+        pcd.points = (rng.random((c["n_init"], 3)) * 2.6 - 1.3).astype(np.float32)
+        pcd.colors = rng.random((c["n_init"], 3)).astype(np.float32)
+        model.create_from_pcd(pcd, spatial_lr_scale=extent)
+        opt = TR.optimization_params(iterations=c["train_iters"], lambda_dist=100.0, position_lr_max_steps=c["train_iters"])
+        tr = TR.Trainer(model, train_cams, opt, TR.pipeline_params(depth_ratio=1.0), extent=extent)
+        p0 = tr.evaluate(train_cams[:8])[0]
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for _ in range(c["train_iters"] - 1):       # the schedule's last iteration takes no optimiser step (train.py:136)
+            tr.step()
+        torch.cuda.synchronize(); t_train = time.perf_counter() - t0
+        info.update({"train_wall_s": round(t_train, 2), "train_iters_per_s": round((c["train_iters"] - 1) / t_train, 1), "psnr_init": round(p0, 2),
+                     "psnr_train": round(tr.evaluate(train_cams[:8])[0], 2), "psnr_heldout": round(tr.evaluate(test_cams)[0], 2)})
+        del tr
+        if state:
+            model.save_ply(state)
     sc = model._av["scaling"]; op = model._av["opacity"]
-    stats = {"median_scale": round(float(sc.median()), 5), "median_opacity": round(float(op.median()), 4), "frac_opacity_gt_0.5": round(float((op > 0.5).float().mean()), 4)}
-    tr2 = TR.Trainer(model, train_cams, _frozen_schedule(TR), TR.pipeline_params(depth_ratio=1.0), extent=extent)
-    tr2.iteration = train_iters
-    out = time_trainer(tr2, steps, warmup, prime=5)
-    out.update({"workload": "trained synthetic capture: %d random points -> %d surfels after %d iterations of the reference schedule, %d views of %dx%d"
-                            % (n_gt, int(model.P), train_iters, n_views, res, res),
-                "train_wall_s": round(t_train, 2), "train_iters_per_s": round((train_iters - 1) / t_train, 1), "psnr_init": round(p0, 2),
-                "psnr_train": round(psnr_train, 2), "psnr_heldout": round(psnr_test, 2), "model_stats": stats})
-    del tr, tr2, model
+    info["model_stats"] = {"median_scale": round(float(sc.median()), 5), "median_opacity": round(float(op.median()), 4),
+                           "frac_opacity_gt_0.5": round(float((op > 0.5).float().mean()), 4)}
+    info["workload"] = ("%s: trained synthetic capture, %d random points -> %d surfels after %d iterations of the reference schedule, %d views of %dx%d"
+                        % (preset, c["n_init"], int(model.P), c["train_iters"], c["n_views"], W, H))
+    return model, train_cams, test_cams, extent, info
+
+
+def trained_trainer(dev, preset="trained", state=None):
+    """A Trainer on the steady-state iteration (every loss term on, no densification inside the timed window) of a trained state."""
+    import surfel_trainer as TR
+    model, train_cams, test_cams, extent, info = trained_state(dev, preset, state)
+    tr = TR.Trainer(model, train_cams, _frozen_schedule(TR), TR.pipeline_params(depth_ratio=1.0), extent=extent)
+    tr.iteration = TRAINED_PRESETS[preset]["train_iters"]
+    return tr, info
+
+
+def trained_leg(dev, preset="trained", steps=30, warmup=5, state=None):
+    """A TRAINED state instead of random surfels (post-densification scale / opacity statistics): the steady-state iteration on it."""
+    import torch
+    import diff_surfel_rasterization as dsr
+    tr, info = trained_trainer(dev, preset, state)
+    out = time_trainer(tr, steps, warmup, prime=5, workload=preset)
+    out.update(info)
+    model = tr.model
+    del tr, model
     dsr.set_grad_arena(None)
     torch.cuda.empty_cache()
     return out
