@@ -21,7 +21,7 @@ namespace {
 thread_local std::string g_err;
 int g_opt_cull = 1;        // surfel_set_option("cull", .)
 int g_opt_tile_sort = 1;   // surfel_set_option("tile_depth_sort", .): 0 never, 1 auto (by last frame's R / tiles), 2 always
-int g_opt_bwd_variant = 2; // surfel_set_option("bwd_variant", .): 0 per-row walk, 1 per-quad walk, 2 auto (0 / 1 / 2 bit-identical), 3 scan walk
+int g_opt_bwd_variant = 2; // surfel_set_option("bwd_variant", .): 0 per-row walk, 1 per-quad walk, 2 auto (0 / 1 / 2 bit-identical), 3 scan walk, 4 auto over all three
 surfel_hook_fn g_colour_hook = nullptr;   // surfel_set_backward_hook
 void* g_colour_hook_user = nullptr;
 int g_opt_bwd_tune = 1;    // surfel_set_option("bwd_tune", .): auto = timed probes (1) or the device-side rule alone (0)
@@ -187,28 +187,30 @@ struct StageTimer {
 // alone until the next probe.  Until both walks have been timed, and while the stream is being
 // captured into a graph, both kernels are launched and the device-side rule (R <= 4 V) picks.
 struct WalkTuner {
-    int dev = -1, W = 0, H = 0, octave = 0;
+    int dev = -1, W = 0, H = 0, octave = 0, nwalks = 2;
     unsigned calls = 0;
     int choice = -1;
-    float ns_per_inst[2] = {0.f, 0.f};
-    bool have[2] = {false, false}, pending[2] = {false, false};
-    int64_t pend_R[2] = {0, 0};
-    hipEvent_t e0[2] = {nullptr, nullptr}, e1[2] = {nullptr, nullptr};
+    float ns_per_inst[3] = {0.f, 0.f, 0.f};
+    bool have[3] = {false, false, false}, pending[3] = {false, false, false};
+    int64_t pend_R[3] = {0, 0, 0};
+    hipEvent_t e0[3] = {nullptr, nullptr, nullptr}, e1[3] = {nullptr, nullptr, nullptr};
 };
 constexpr int kTuners = 8;
 constexpr unsigned kTunePeriod = 32;
 constexpr unsigned kTuneFirst = 2;      // phase of the first probe
+constexpr int kWalkVariant[3] = {0, 1, 3};      // probe slot -> BlendBwdArgs::variant (rows, quad, scan)
 WalkTuner g_tuners[kTuners];
 unsigned g_tuner_next = 0;
 std::mutex g_tuner_mu;
 
-// returns the variant to launch (0 rows, 1 quad, 2 both + device rule); *probe = the walk being timed by this call, or -1
+// returns the variant to launch (0 rows, 1 quad, 3 scan, 2 rows + quad with the device rule); *probe = the slot being timed by this
+// call, or -1.  nwalks = 2: rows / quad (bit-identical, "bwd_variant" 2); 3: the scan walk competes as well ("bwd_variant" 4).
 int walk_octave(int P, int64_t R) {
     int o = 0;
     for (int64_t x = R / (P > 0 ? P : 1); x > 1 && o < 15; x >>= 1) o++;
     return o;
 }
-int walk_tuner_pick(int P, int W, int H, int64_t R, hipStream_t s, WalkTuner** out, int* probe) {
+int walk_tuner_pick(int P, int W, int H, int64_t R, hipStream_t s, int nwalks, WalkTuner** out, int* probe) {
     *out = nullptr; *probe = -1;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return 2;
@@ -216,16 +218,18 @@ int walk_tuner_pick(int P, int W, int H, int64_t R, hipStream_t s, WalkTuner** o
     if (hipStreamIsCapturing(s, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) return 2;
     WalkTuner* t = nullptr;
     const int octave = walk_octave(P, R);
-    for (auto& c : g_tuners) if (c.dev == dev && c.W == W && c.H == H && c.octave == octave) { t = &c; break; }
+    for (auto& c : g_tuners) if (c.dev == dev && c.W == W && c.H == H && c.octave == octave && c.nwalks == nwalks) { t = &c; break; }
     if (!t) {
         t = &g_tuners[g_tuner_next++ % kTuners];
-        for (int v = 0; v < 2; v++) {
+        for (int v = 0; v < 3; v++) {
             if (t->pending[v]) (void)hipEventSynchronize(t->e1[v]);        // an evicted entry: its events are about to be reused
+            // events belong to the device they were created on: an entry that moves to another device gets fresh ones
+            if (t->dev != dev && t->e0[v]) { (void)hipEventDestroy(t->e0[v]); (void)hipEventDestroy(t->e1[v]); t->e0[v] = t->e1[v] = nullptr; }
             t->pending[v] = false; t->have[v] = false; t->ns_per_inst[v] = 0.f;
         }
-        t->dev = dev; t->W = W; t->H = H; t->octave = octave; t->calls = 0; t->choice = -1;
+        t->dev = dev; t->W = W; t->H = H; t->octave = octave; t->nwalks = nwalks; t->calls = 0; t->choice = -1;
     }
-    for (int v = 0; v < 2; v++) {
+    for (int v = 0; v < nwalks; v++) {
         if (!t->pending[v] || hipEventQuery(t->e1[v]) != hipSuccess) continue;
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, t->e0[v], t->e1[v]) == hipSuccess && t->pend_R[v] > 0) {
@@ -235,13 +239,19 @@ int walk_tuner_pick(int P, int W, int H, int64_t R, hipStream_t s, WalkTuner** o
         }
         t->pending[v] = false;
     }
-    if (t->have[0] && t->have[1]) t->choice = t->ns_per_inst[1] < t->ns_per_inst[0] ? 1 : 0;
+    bool all = true;
+    for (int v = 0; v < nwalks; v++) all = all && t->have[v];
+    if (all) {
+        int best = 0;
+        for (int v = 1; v < nwalks; v++) if (t->ns_per_inst[v] < t->ns_per_inst[best]) best = v;
+        t->choice = kWalkVariant[best];
+    }
     const unsigned phase = t->calls++ % kTunePeriod;
-    if (phase >= kTuneFirst && phase < kTuneFirst + 2 && !t->pending[phase - kTuneFirst]) {
+    if (phase >= kTuneFirst && phase < kTuneFirst + (unsigned)nwalks && !t->pending[phase - kTuneFirst]) {
         const int v = (int)(phase - kTuneFirst);
         if (!t->e0[v] && (hipEventCreate(&t->e0[v]) != hipSuccess || hipEventCreate(&t->e1[v]) != hipSuccess)) { t->e0[v] = nullptr; return t->choice >= 0 ? t->choice : 2; }
         *out = t; *probe = v;
-        return v;
+        return kWalkVariant[v];
     }
     return t->choice >= 0 ? t->choice : 2;
 }
@@ -327,7 +337,7 @@ int surfel_set_option(const char* name, int value) {
     if (name && std::strcmp(name, "cull") == 0) { g_opt_cull = value ? 1 : 0; return 0; }
     if (name && std::strcmp(name, "tile_depth_sort") == 0) { g_opt_tile_sort = value < 0 ? 0 : (value > 2 ? 2 : value); return 0; }
     if (name && std::strcmp(name, "large_sort") == 0) { set_large_sort_impl(value); return 0; }
-    if (name && std::strcmp(name, "bwd_variant") == 0) { g_opt_bwd_variant = value < 0 ? 0 : (value > 3 ? 3 : value); return 0; }
+    if (name && std::strcmp(name, "bwd_variant") == 0) { g_opt_bwd_variant = value < 0 ? 0 : (value > 4 ? 4 : value); return 0; }
     if (name && std::strcmp(name, "bwd_tune") == 0) { g_opt_bwd_tune = value != 0; return 0; }
     if (name && std::strcmp(name, "capacity_binning") == 0) { g_opt_capacity = value != 0; return 0; }
     return fail(SURFEL_E_INVALID, "unknown option");
@@ -631,9 +641,10 @@ int surfel_rasterize_backward(surfel_alloc_fn scratch_alloc, void* scratch_user,
         WalkTuner* tuner = nullptr;
         int probe = -1;
         std::unique_lock<std::mutex> tl(g_tuner_mu, std::defer_lock);
-        if (opt_variant == 2 && !g_blend_stats && g_opt_bwd_tune) {
+        if (opt_variant == 4) bb.variant = 2;      // (no verdict yet, stats mode, tuning off: rows + quad with the device rule)
+        if ((opt_variant == 2 || opt_variant == 4) && !g_blend_stats && g_opt_bwd_tune) {
             tl.lock();
-            bb.variant = walk_tuner_pick(P, width, height, R, s, &tuner, &probe);
+            bb.variant = walk_tuner_pick(P, width, height, R, s, opt_variant == 4 ? 3 : 2, &tuner, &probe);
             if (probe >= 0) (void)hipEventRecord(tuner->e0[probe], s);
         }
         tm.begin(ST_BBWD);

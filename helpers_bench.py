@@ -177,10 +177,11 @@ def config_leg(dev, workload, steps=20, warmup=5):
 
 TRAINED_PRESETS = {
     # name: ground-truth surfels, initial random points, views, (W, H), iterations of the reference schedule (untimed), gt disc scale
-    "trained": dict(n_gt=200_000, n_init=200_000, n_views=48, res=(800, 800), train_iters=6000, px_scale=0.035),
+    "trained": dict(n_gt=200_000, n_init=200_000, n_views=48, res=(800, 800), train_iters=6000, px_scale=0.035, init="cube"),
     # BASELINE configs[3]'s per-GPU shape (Mip-NeRF360 garden: ~2 M surfels, 1600x1060) on post-densification statistics: the capture
     # is dense enough for the densification to settle above a million surfels
-    "garden": dict(n_gt=2_500_000, n_init=1_500_000, n_views=24, res=(1600, 1060), train_iters=3000, px_scale=0.012),
+    # is dense enough, and the initial points lie near its surface (as SfM points do), for the densification to settle above a million
+    "garden": dict(n_gt=1_500_000, n_init=1_600_000, n_views=24, res=(1600, 1060), train_iters=2500, px_scale=0.012, init="surface"),
 }
 
 
@@ -198,6 +199,7 @@ def trained_state(dev, preset="trained", state=None):
     bg = torch.zeros(3, device=dev)
     gt = TR.synthetic_object(c["n_gt"], dev, seed=0, px_scale=c["px_scale"])
     cams = TR.capture_views(gt, TR.orbit_cameras(c["n_views"] + 8, W, H, device=dev), bg)
+    gt_xyz = gt._xyz.detach().cpu().numpy() if c["init"] == "surface" else None
     del gt
     train_cams, test_cams = cams[:c["n_views"]], cams[c["n_views"]:]
     extent = TR.cameras_extent(train_cams)
@@ -211,7 +213,11 @@ def trained_state(dev, preset="trained", state=None):
     else:
         rng = np.random.default_rng(0)
         pcd = type("PCD", (), {})()
-        pcd.points = (rng.random((c["n_init"], 3)) * 2.6 - 1.3).astype(np.float32)
+        if gt_xyz is not None:      # points near the captured surface, 2 % of the object's radius off
+            pick = rng.integers(0, gt_xyz.shape[0], c["n_init"])
+            pcd.points = (gt_xyz[pick] + 0.024 * rng.standard_normal((c["n_init"], 3))).astype(np.float32)
+        else:
+            pcd.points = (rng.random((c["n_init"], 3)) * 2.6 - 1.3).astype(np.float32)
         pcd.colors = rng.random((c["n_init"], 3)).astype(np.float32)
         model.create_from_pcd(pcd, spatial_lr_scale=extent)
         opt = TR.optimization_params(iterations=c["train_iters"], lambda_dist=100.0, position_lr_max_steps=c["train_iters"])
@@ -229,7 +235,7 @@ def trained_state(dev, preset="trained", state=None):
     sc = model._av["scaling"]; op = model._av["opacity"]
     info["model_stats"] = {"median_scale": round(float(sc.median()), 5), "median_opacity": round(float(op.median()), 4),
                            "frac_opacity_gt_0.5": round(float((op > 0.5).float().mean()), 4)}
-    info["workload"] = ("%s: trained synthetic capture, %d random points -> %d surfels after %d iterations of the reference schedule, %d views of %dx%d"
+    info["workload"] = ("%s: trained synthetic capture, %d initial points -> %d surfels after %d iterations of the reference schedule, %d views of %dx%d"
                         % (preset, c["n_init"], int(model.P), c["train_iters"], c["n_views"], W, H))
     return model, train_cams, test_cams, extent, info
 

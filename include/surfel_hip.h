@@ -158,6 +158,11 @@ int surfel_debug_sort_pairs(surfel_alloc_fn scratch_alloc, void* scratch_user, u
  *          instance list, row totals gathered through private LDS slots; 1: every wave (8x8 pixels) walks one list (round 1's
  *          kernel).  Same per-pair arithmetic and the same summation tree: gradients are bit-identical
  *          (tests/test_gpu_parity.py::test_backward_variants_are_identical), so auto only ever changes speed.
+ *          3: the scan walk (surfel_backward_scan.hip: lanes are instances, DPP row scans carry the per-pixel recurrences, gradients
+ *          accumulate in registers) — deterministic, but a different summation order: agrees with rows / quad to fp32 summation noise,
+ *          not bit for bit; 5-13 % faster than both on wide-footprint / trained frames, 13 % slower on small random footprints
+ *          (profiles/r03_blend_bwd_scan.md).  4: auto over all three walks by the same timed probes — fastest, but which bits a frame
+ *          gets then depends on the probes' verdict.
  *   "bwd_tune" (default 1): how auto chooses.  1: per (device, width, height, octave of tile instances per surfel), two backward
  *          calls in every 32 are timed with HIP events on the launch stream (one per walk; polled later, never synchronised) and
  *          the faster walk per tile instance is launched alone in between; 0: both kernels are launched every call and the device decides from the frame's

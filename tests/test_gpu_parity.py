@@ -402,6 +402,41 @@ def test_tile_cuts_equal_zero_records(kind):
                 assert np.array_equal(res[0][k], res[1][k]), "%s: dL/d%s differs between zero records and tile cuts (walk %x, gather %x)" % (kind, k, walk, gather)
 
 
+def test_heavy_surfels_are_gathered_by_the_wave():
+    """Surfels with more than 128 instance records (background-sized discs covering hundreds of tiles) have their records summed by
+    the whole wave in preprocess_bwd (lane-strided partial sums + butterfly) instead of by one thread walking them: gradients against
+    the fp64 oracle, the two record gathers and the two tail forms (zero records / tile cuts) bit-identical to each other, and
+    reproducible."""
+    import surfel_native as n
+    import synthetic
+    from oracle.surfel_oracle import Oracle
+    sc = synthetic.make_scene(1200, 512, 384, seed=13, px_radius=6.0, z_near=1.0, z_far=8.0)
+    rng = np.random.default_rng(13)
+    P = sc["means3D"].shape[0]
+    big = rng.random(P) < 0.03                                   # a few dozen discs of 100-300 px radius, faint enough to see through
+    sc["scales"][big] *= rng.choice([20.0, 40.0], size=(int(big.sum()), 1)).astype(np.float32)
+    sc["opacities"][big] = 0.05
+    a = scene_args(sc)
+    gC = rng.normal(size=(3, a["H"], a["W"])).astype(np.float32); gO = rng.normal(size=(7, a["H"], a["W"])).astype(np.float32)
+    run = HipRun(a).forward()
+    touched = run.ga.last()                                       # white box: tiles_touched sits behind rec | depths in the geometry buffer
+    off = ((P * 112 + 255) // 256 * 256) + ((4 * P + 255) // 256 * 256)
+    tt = touched[off:off + 4 * P].view(run.torch.int32).cpu().numpy()
+    assert (tt > 128).sum() >= 5, "scene has no heavy surfels (max %d instances)" % tt.max()
+    res = []
+    for flags in (n.OPT_PBWD_THREAD | n.OPT_ZERO_RECORDS, n.OPT_PBWD_COOP | n.OPT_ZERO_RECORDS, n.OPT_PBWD_THREAD | n.OPT_TILE_CUTS,
+                  n.OPT_PBWD_COOP | n.OPT_TILE_CUTS, n.OPT_PBWD_THREAD | n.OPT_ZERO_RECORDS):
+        run.debug = flags
+        res.append(run.backward(gC, gO))
+    for r in res[1:]:
+        for k in res[0]:
+            assert np.array_equal(res[0][k], r[k]), "dL/d%s differs between the gather / tail variants" % k
+    o = Oracle("f64")
+    R, col, oth, radii, st = oracle_forward(o, a, depth_key=run.depths())
+    _check_images(run, col, oth, st)
+    _check_grads(res[0], o.rasterize_backward(st, gC, gO))
+
+
 def test_capacity_binning_is_identical():
     """Capacity binning (binning buffers sized from the previous frames' instance counts, fused scan + emission + histogram kernel,
     sort passes / tile ranges with the count on the device, no host wait in the middle of the forward) against the exact-size path:
