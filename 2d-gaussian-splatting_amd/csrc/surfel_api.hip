@@ -313,7 +313,7 @@ int surfel_last_stage_ids(int* ids, int cap) {
 
 int surfel_debug_sort_pairs(surfel_alloc_fn scratch_alloc, void* scratch_user, uint32_t* keys, uint32_t* vals, int64_t n,
                             int begin_bit, int end_bit, void* stream) {
-    if (!scratch_alloc || n < 0 || (n > 0 && (!keys || !vals)) || begin_bit < 0 || end_bit > 32 || begin_bit >= end_bit)
+    if (!scratch_alloc || n < 0 || (n > 0 && (!keys || !vals)) || begin_bit < 0 || end_bit > 32 || begin_bit > end_bit)
         return fail(SURFEL_E_INVALID, "bad arguments");
     if (n == 0) return 0;
     hipStream_t s = static_cast<hipStream_t>(stream);

@@ -46,9 +46,14 @@ static inline bool use_rocprim(size_t n, int begin_bit, int end_bit) {
     return (end_bit - begin_bit) <= 16 || n >= ((size_t)4 << 20);
 }
 static size_t rocprim_sort_temp_bytes(size_t n) {
+    // (queried for the full 32-bit key: an upper bound for every [begin_bit, end_bit) the library sorts on; the host-side query is
+    // cached per item count — frames repeat their sizes, and this sits on the forward's launch path)
+    thread_local size_t last_n = 0, last_bytes = 0;
+    if (n == last_n && last_bytes) return last_bytes;
     size_t bytes = 0;
     uint32_t* nul = nullptr;
     (void)rocprim::radix_sort_pairs(nullptr, bytes, nul, nul, nul, nul, n, 0u, 32u, (hipStream_t)0);
+    last_n = n; last_bytes = bytes;
     return bytes;
 }
 
@@ -86,7 +91,7 @@ int radix_sort_passes(size_t, int begin_bit, int end_bit) { return (end_bit - be
 // which buffer pair radix_sort_pairs_u32 will leave the result in (0: a, 1: b) — callers that need it in a particular buffer
 // assign a / b accordingly BEFORE the call
 int radix_sort_result_buffer(size_t n, int begin_bit, int end_bit) {
-    if (n == 0) return 0;
+    if (n == 0 || end_bit <= begin_bit) return 0;
     if (use_rocprim(n, begin_bit, end_bit)) return 1;
     return radix_sort_passes(n, begin_bit, end_bit) & 1;
 }
@@ -475,7 +480,7 @@ void launch_tile_depth_sort(int ntiles, int64_t R, const uint2* ranges, uint32_t
 // 1 if in (keys_b, vals_b); -1 if n is too large for the 30-bit look-back counters.
 int radix_sort_pairs_u32(uint32_t* keys_a, uint32_t* vals_a, uint32_t* keys_b, uint32_t* vals_b, size_t n, int begin_bit, int end_bit,
                          void* scratch, hipStream_t s, bool head_zeroed) {
-    if (n == 0) return 0;
+    if (n == 0 || end_bit <= begin_bit) return 0;      // an empty key field: the input order is the sorted order
     if (n >= ST_VALUE) return -1;
     const uint32_t nblocks = rs_nblocks(n);
     const int passes = radix_sort_passes(n, begin_bit, end_bit);

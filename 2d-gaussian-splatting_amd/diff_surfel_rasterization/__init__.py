@@ -55,7 +55,8 @@ def set_grad_arena(arena):
     The kernels write every element, so the tensors need no zeroing.  An explicit `sh=None` entry makes the backward skip the
     SH-coefficient gradients altogether (their autograd gradient is then None).  An optional `_owner` tensor scopes the arena to
     one model: it is used only by backwards whose means3D shares that tensor's storage (GaussianModel.bind passes its parameter
-    store), every other caller — and any tensor that does not match in shape — gets fresh gradient tensors.  None restores the default."""
+    store), every other caller gets fresh gradient tensors.  An arena tensor that is used but does not fit the backward (shape, dtype,
+    device, contiguity) raises: a stale binding must not silently drop gradients.  None restores the default."""
     global _grad_arena
     _grad_arena = arena
 
@@ -150,8 +151,14 @@ class _RasterizeGaussians(torch.autograd.Function):
 
         def out(name, *shape):
             t = arena.get(name)
-            if t is None or tuple(t.shape) != shape or t.dtype != torch.float32 or t.device != dev or not t.is_contiguous():
-                return z(*shape)          # no (matching) arena tensor: the default behaviour
+            if t is None:
+                return z(*shape)          # no arena tensor for this output: the default behaviour
+            if tuple(t.shape) != shape or t.dtype != torch.float32 or t.device != dev or not t.is_contiguous():
+                # the arena belongs to THIS model (the owner check above passed) but does not fit: a stale binding (the model was
+                # re-sized without bind()) — a fresh tensor here would be dropped by the parameter gate and training would silently
+                # receive no gradient
+                raise RuntimeError("diff_surfel_rasterization: grad arena tensor %r is %s %s on %s, the backward needs contiguous float32 %s on %s "
+                                   "(re-bind the arena after resizing the model)" % (name, tuple(t.shape), t.dtype, t.device, shape, dev))
             return t
         g_means2D, g_normal, g_colors = out("means2D", P, 3), None, out("colors", P, 3)      # dL/dnormal: internal, not requested
         g_opac = out("opacities", P, 1)

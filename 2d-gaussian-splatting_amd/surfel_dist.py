@@ -126,8 +126,12 @@ def band_bounds(H: int, world: int, weights: Optional[Sequence[float]] = None, m
     rows16 = (H + 15) // 16
     w16 = [1.0] * rows16 if weights is None else [float(x) + 1e-6 for x in weights]
     assert len(w16) == rows16
-    rows = (rows16 + k - 1) // k                       # band granules of `multiple` rows
-    w = [sum(w16[i * k:(i + 1) * k]) for i in range(rows)]
+    # band granules of `multiple` rows; a trailing partial granule (H not a multiple of `multiple`) is folded into the one before it,
+    # so that no band is ever shorter than `multiple` rows (the halo exchange needs bands of at least HALO = 32 rows: H = 1080 with
+    # bottom-heavy weights used to end in a 24-row band)
+    rows = max(1, H // multiple)
+    edges = [i * multiple for i in range(rows)] + [H]
+    w = [sum(w16[i * k:((i + 1) * k if i + 1 < rows else rows16)]) for i in range(rows)]
     total = sum(w)
     cuts, acc, r = [0], 0.0, 0
     for b in range(1, world):
@@ -138,7 +142,7 @@ def band_bounds(H: int, world: int, weights: Optional[Sequence[float]] = None, m
         if cuts[-1] > r:
             acc += sum(w[r:cuts[-1]]); r = cuts[-1]
     cuts.append(rows)
-    return [(min(cuts[i] * multiple, H), min(cuts[i + 1] * multiple, H)) for i in range(world)]
+    return [(edges[cuts[i]], edges[cuts[i + 1]]) for i in range(world)]
 
 
 def band_settings(raster_settings, y0: int, y1: int):

@@ -169,7 +169,8 @@ class Trainer:
         self._one = torch.ones((), dtype=torch.float32, device=model.device)
         self.views_per_step = 1         # single process: > 1 = accumulate that many views per optimiser step (_step_accumulate)
         self.rebalance_every = 8        # bands: iterations between re-balancing the band edges (one small all-gather + D2H)
-        self._row_weights = None        # bands: running mean of tile instances per 16-row tile row (host list)
+        self._row_weights = None        # bands: running mean of tile instances per 16-row tile row (host list) of frames of ...
+        self._row_weights_hw = None     # ... this (height, width): cameras of another resolution start a fresh mean
         self.wire = {"total": 0}        # bytes on the wire per GPU of the most recent step, by collective (surfel_dist.wire_bytes_per_step)
         self.time_exchange = False      # bench: bracket the stream waits on the exchange with events -> self.exchange_events
         self.exchange_events = []
@@ -253,6 +254,8 @@ class Trainer:
         stats_live = it < opt.densify_until_iter
         if bands:
             H, W = int(cam.image_height), int(cam.image_width)
+            if self._row_weights_hw != (H, W):      # real capture sets mix resolutions: the running weights belong to one of them
+                self._row_weights, self._row_weights_hw = None, (H, W)
             bounds = surfel_dist.band_bounds(H, self.world, self._row_weights, multiple=surfel_dist.HALO)
             y0, y1 = bounds[self.rank]
             # the densification statistic of the view = norm of the SUM over bands: it rides in the same all-reduce, right

@@ -73,6 +73,23 @@ def test_gloo_world2_collectives():
     assert res == [(0, True), (1, True)]
 
 
+def test_band_bounds_never_shorter_than_the_halo():
+    """H = 1080 (67.5 tile rows) with bottom-heavy weights used to end in a (1056, 1080) band of 24 rows — shorter than the
+    32-row halo the band-sharded loss exchanges, so the step after a re-balance raised.  A trailing partial granule now belongs to
+    the granule before it."""
+    import surfel_dist as sd
+    for H in (1080, 1060, 2160, 600, 97):
+        rows16 = (H + 15) // 16
+        for world in (1, 2, 3, 4, 8):
+            for w in (None, [1.0] * (rows16 - 1) + [1e6], [1e6] + [1.0] * (rows16 - 1), [float(i * i) for i in range(rows16)]):
+                b = sd.band_bounds(H, world, w, multiple=sd.HALO)
+                assert b[0][0] == 0 and b[-1][1] == H and all(b[i][1] == b[i + 1][0] for i in range(world - 1)), (H, world, b)
+                live = [y1 - y0 for y0, y1 in b if y1 > y0]
+                if H // sd.HALO >= world:
+                    assert len(live) == world and min(live) >= sd.HALO, (H, world, w is None, b)
+                assert all(y0 % sd.HALO == 0 for y0, _ in b if y0 < H), b
+
+
 def test_band_bounds():
     import surfel_dist as sd
     b = sd.band_bounds(2160, 8)

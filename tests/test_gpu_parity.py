@@ -725,16 +725,18 @@ def test_blend_stats_counters():
 
 
 @pytest.mark.parametrize("n,bits", [(1, (0, 32)), (63, (0, 32)), (2047, (0, 12)), (2048, (0, 32)), (2049, (3, 17)), (300_000, (0, 32)),
-                                    (611_573, (0, 12)), (3_000_001, (0, 32)), (5_000_000, (0, 15))])
+                                    (611_573, (0, 12)), (3_000_001, (0, 32)), (5_000_000, (0, 15)), (2_000_003, (7, 8)), (2_000_003, (5, 5)),
+                                    (4097, (31, 32)), (4097, (0, 0))])
 def test_radix_sort_is_stable_and_exact(n, bits):
-    """The one-launch-per-pass radix sort (decoupled look-back) against numpy's stable argsort, incl. heavy duplicates."""
+    """The one-launch-per-pass radix sort (decoupled look-back) against numpy's stable argsort, incl. heavy duplicates; 1-bit and
+    empty key fields (the order is then the input order); large inputs also through rocprim::radix_sort_pairs."""
     import torch
     import surfel_native as nat
     lib = nat.load()
     dev = torch.device("cuda:0")
     rng = np.random.default_rng(n)
     lo, hi = bits
-    impls = (0, 1) if n > (1 << 20) else (0,)          # large inputs: the library's own passes and rocprim::radix_sort_pairs
+    impls = (0, 1) if n > (1 << 20) else (0, 3)        # large inputs: the library's own passes and rocprim::radix_sort_pairs (3: rocPRIM at every size)
     for trial in [(t, i) for i in impls for t in range(3)]:
         trial, impl = trial
         assert lib.surfel_set_option(b"large_sort", impl) == 0
@@ -750,7 +752,7 @@ def test_radix_sort_is_stable_and_exact(n, bits):
         rc = lib.surfel_debug_sort_pairs(alloc.cb, None, nat.ptr(k), nat.ptr(v), n, lo, hi, nat.current_stream_ptr(dev))
         assert rc == 0, nat.last_error()
         torch.cuda.synchronize()
-        field = (keys >> np.uint32(lo)) & np.uint32((1 << (hi - lo)) - 1 if hi - lo < 32 else 0xffffffff)
+        field = (keys >> np.uint32(min(lo, 31))) & np.uint32((1 << (hi - lo)) - 1 if hi - lo < 32 else 0xffffffff)
         order = np.argsort(field, kind="stable")
         assert np.array_equal(v.cpu().numpy().view(np.uint32), vals[order]), "trial %d impl %d: order differs" % (trial, impl)
         assert np.array_equal(k.cpu().numpy().view(np.uint32), keys[order])
