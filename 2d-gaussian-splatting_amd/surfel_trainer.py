@@ -182,7 +182,12 @@ class Trainer:
         # finalises them is on the stream (surfel_set_backward_hook), and overlaps the per-surfel geometry chain rule.  The split
         # costs a second pass over the gradient records (measured +15 us at C2, +208 us at C4: scripts/hook_cost.py) and buys up to
         # min(gather time, chain-rule time): worth it once the gather is long, i.e. from 4 ranks on (12 B/surfel/rank received)
-        self.early_gather = self.world >= 4 or bool(rehearse_exchange)
+        # ... or not: RCCL's launch latency, the link count and the frame size decide, so with more than one rank it is MEASURED at
+        # start-up ("auto": four iterations with the early gather, four without, device time by events on the compute stream, the
+        # slower rank decides for all: _probe_early_gather) — results are bit-identical either way.
+        self.early_gather = True if rehearse_exchange else ("auto" if (self.world > 1 and self._async_exchange and sharding == "views") else False)
+        self.early_gather_probe = None      # {"early_ms": .., "late_ms": .., "choice": ..} once decided
+        self._eg_events, self._eg_first = [], None
         self._early, self._early_err = None, None
         # fused SH path (default): the rasterizer's backward skips the 192 B/surfel SH gradients, the optimiser kernel rebuilds them
         # from the 12 B/surfel colour gradients.  Always on under view-parallel training (that is how the gradients are exchanged).
@@ -280,7 +285,7 @@ class Trainer:
                                        self.pipe.depth_ratio, opt.lambda_dssim, lam_n, lam_d)
             halo_b = 0
         self.wire = surfel_dist.wire_bytes_per_step(m.P, self.world, self.sharding, stats_live, halo_b)
-        early = self.early_gather and self._async_exchange and not bands and it < opt.iterations
+        early = self._probe_early_gather() and self._async_exchange and not bands and it < opt.iterations
         if early:
             self._early, self._early_err = None, None
             _n.set_backward_hook(self._on_colour_ready)
@@ -341,6 +346,41 @@ class Trainer:
             if self._early is not None:      # an iteration without an optimiser step (parameters re-created): retire the gather
                 self._early[1].wait()
                 self._early = None
+
+    EG_WARM, EG_LEN = 2, 4      # start-up probe: iterations skipped, iterations per setting
+
+    @staticmethod
+    def decide_early_gather(early_ms, late_ms):
+        """The early gather pays a second pass over the gradient records: keep it only when it wins by more than measurement noise."""
+        return early_ms < 0.98 * late_ms
+
+    def _probe_early_gather(self):
+        """early_gather == "auto": whether THIS iteration takes the early gather; after 2 x EG_LEN probe iterations the faster setting
+        (max over ranks of the device time) is fixed for the rest of the run."""
+        if self.early_gather != "auto":
+            return bool(self.early_gather)
+        if self._eg_first is None:
+            self._eg_first = self.iteration + self.EG_WARM
+        ph = self.iteration - self._eg_first
+        if ph < 0:
+            return False
+        if ph in (0, self.EG_LEN, 2 * self.EG_LEN):
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record()
+            self._eg_events.append(ev)
+        if ph < self.EG_LEN:
+            return True
+        if ph < 2 * self.EG_LEN:
+            return False
+        e0, e1, e2 = self._eg_events
+        e2.synchronize()
+        t = torch.tensor([e0.elapsed_time(e1), e1.elapsed_time(e2)], dtype=torch.float32, device=self.model.device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        early_ms, late_ms = (float(x) / self.EG_LEN for x in t.tolist())
+        self.early_gather = self.decide_early_gather(early_ms, late_ms)
+        self.early_gather_probe = {"early_ms_per_step": round(early_ms, 4), "late_ms_per_step": round(late_ms, 4), "choice": "early" if self.early_gather else "late"}
+        self._eg_events = []
+        return self.early_gather
 
     def _on_colour_ready(self):
         """Called by the C library inside the rasterizer's backward (autograd's thread, the forward's stream) once dL/dcolour is

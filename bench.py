@@ -145,6 +145,7 @@ def main():
     ap.add_argument("--no-1080p", action="store_true")
     ap.add_argument("--no-raster-only", action="store_true")
     ap.add_argument("--no-train-iter", action="store_true", help="(kept for older scripts; the timed step IS the training iteration)")
+    ap.add_argument("--no-scale-leg", action="store_true", help="N > 1: skip the second weak-scaling line (C4 per GPU)")
     ap.add_argument("--no-legs", action="store_true", help="skip the extra N = 1 workload legs (C4-synthetic, heavy-footprint C2H, trained state)")
     ap.add_argument("--quick", action="store_true", help="headline leg only (= --no-legs --no-cpu-baseline --no-1080p --no-raster-only)")
     ap.add_argument("--sharding", choices=("views", "bands"), default="views",
@@ -227,6 +228,28 @@ def main():
     exposed_ms = (sum(e0.elapsed_time(e1) for e0, e1 in tr.exchange_events) / args.steps) if tr.exchange_events else None
     tr.time_exchange = False
     wire = dict(tr.wire)
+    coll_us = None
+    if world > 1 and args.sharding == "views" and backend == "nccl":
+        # the two collectives of the step on their real buffers, back to back and alone on the device: what the exchange costs when
+        # NOTHING hides it (exposed_ms_per_step above is what was not hidden in the timed region)
+        from surfel_trainer import GEOM_FLOATS
+        m = tr.model
+        geo = m.grad[:GEOM_FLOATS * m.P].clone()
+        gall = torch.empty((world, m.P, 3), dtype=torch.float32, device=dev)
+        coll_us = {}
+        for name, fn in (("all_reduce_geometry_40B_per_surfel", lambda: dist.all_reduce(geo, op=dist.ReduceOp.SUM)),
+                         ("all_gather_colour_12B_per_surfel_per_rank", lambda: dist.all_gather_into_tensor(gall, m.gcol))):
+            for _ in range(3):
+                fn()
+            fence()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(10):
+                fn()
+            e1.record()
+            fence()
+            coll_us[name] = round(e0.elapsed_time(e1) * 100.0, 1)
+        del geo, gall
     loss_last = float(tr.last["loss"])
     # per-stage breakdown of the rasterizer: a second, untimed pass with every stage bracketed by events
     # (bracketing all ~9 stages costs ~10 us each, which would perturb the timed region by ~9 % at this size)
@@ -272,6 +295,8 @@ def main():
                                 "12 B/surfel/rank (colour gradients -> SH gradients rebuilt locally)" % world)},
                "world_size_seen": world, "backend": backend if world > 1 else None,
                "exchange": None if world == 1 else {"wire_bytes_per_step_per_gpu": wire, "exposed_ms_per_step": None if exposed_ms is None else round(exposed_ms, 4),
+                                                     "exposed_frac_of_step": None if exposed_ms is None else round(exposed_ms / ms_per_step, 4),
+                                                     "collective_us_standalone": coll_us, "early_gather_probe": getattr(tr, "early_gather_probe", None),
                                                      "note": "wire bytes = ring-algorithm bytes per GPU per step by collective; exposed = mean time the "
                                                              "compute stream spent waiting on the collectives (events around the stream waits)"},
                "loss_first": round(loss_first, 5), "loss_last": round(loss_last, 5),
@@ -283,6 +308,35 @@ def main():
     import diff_surfel_rasterization as _d
     _d.set_grad_arena(None)
     torch.cuda.empty_cache()
+
+    # ---- N > 1: a second weak-scaling line on BASELINE configs[3]'s per-GPU shape (C4: 2 M surfels, 1600x1060) — the headline C2 step
+    # is 0.6 ms, where RCCL's launch latency alone is a visible fraction; same barrier / max-over-ranks timing
+    if world > 1 and args.workload == "C2" and args.sharding == "views" and not args.no_scale_leg:
+        tr = make_trainer(dev, "C4", n_views=max(8, world), sharding=args.sharding)
+        for _ in range(8 + args.warmup):
+            tr.step()
+        fence()
+        tr.time_exchange = True
+        tr.exchange_events = []
+        k4 = max(10, args.steps // 2)
+        t0 = time.perf_counter()
+        for _ in range(k4):
+            tr.step()
+        fence()
+        dt4 = time.perf_counter() - t0
+        ex4 = (sum(e0.elapsed_time(e1) for e0, e1 in tr.exchange_events) / k4) if tr.exchange_events else None
+        tt = torch.tensor([dt4], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt4 = float(tt.item())
+        if rank == 0:
+            out["scale_leg_C4"] = {"workload": "C4-synthetic: 2 000 000 random surfels, 1600x1060, full iteration, 1 view/GPU/iteration (weak scaling)",
+                                   "value": round(world * k4 / dt4, 3), "unit": "train-iters/s", "ms_per_step": round(dt4 / k4 * 1e3, 4), "steps": k4,
+                                   "exposed_ms_per_step": None if ex4 is None else round(ex4, 4), "wire_bytes_per_step_per_gpu": dict(tr.wire),
+                                   "early_gather_probe": getattr(tr, "early_gather_probe", None)}
+        dist.barrier()
+        del tr
+        _d.set_grad_arena(None)
+        torch.cuda.empty_cache()
 
     # ---- rasterizer alone (the north-star hot path without loss / optimiser), N=1 leg only
     if rank == 0 and world == 1 and not args.no_raster_only:

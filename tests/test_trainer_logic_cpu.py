@@ -101,3 +101,16 @@ def test_white_background_resets_opacity_at_densify_start(monkeypatch):
     assert len(resets) == 1                                                             # at iteration == densify_from_iter (train.py:134)
     # that iteration still takes its optimiser step, with the opacity gradient dropped (the reference re-creates only that parameter)
     assert m.log[resets[0] + 1][0] == "adam" and float(m._gv["opacity"].abs().sum()) == 0.0
+
+
+def test_early_gather_is_a_measured_choice(trainer):
+    """N > 1 start-up probe (VERDICT r2 #8b): "auto" runs EG_LEN iterations with the early colour gather, EG_LEN without, and keeps
+    the early form only if it wins by more than noise; a single process never probes."""
+    import surfel_trainer as TR
+    tr, m, calls, opt = trainer
+    assert tr.early_gather is False and tr._probe_early_gather() is False          # world 1: nothing to gather
+    assert TR.Trainer.decide_early_gather(0.95, 1.00) and not TR.Trainer.decide_early_gather(0.99, 1.00)
+    assert not TR.Trainer.decide_early_gather(1.10, 1.00)
+    # the probe's schedule (events and the collective are device-side: checked on the GPU box by the RCCL rehearsal)
+    tr.early_gather, tr.iteration, tr._eg_first = "auto", 10, 12
+    assert tr._probe_early_gather() is False                                       # still warming up
