@@ -372,9 +372,12 @@ class Trainer:
             return True
         if ph < 2 * self.EG_LEN:
             return False
-        e0, e1, e2 = self._eg_events
-        e2.synchronize()
-        t = torch.tensor([e0.elapsed_time(e1), e1.elapsed_time(e2)], dtype=torch.float32, device=self.model.device)
+        try:
+            e0, e1, e2 = self._eg_events
+            e2.synchronize()
+            t = torch.tensor([e0.elapsed_time(e1), e1.elapsed_time(e2)], dtype=torch.float32, device=self.model.device)
+        except Exception:      # noqa: BLE001 — no timing, no early gather; every rank still joins the collective below
+            t = torch.tensor([1.0, 0.0], dtype=torch.float32, device=self.model.device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         early_ms, late_ms = (float(x) / self.EG_LEN for x in t.tolist())
         self.early_gather = self.decide_early_gather(early_ms, late_ms)

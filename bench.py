@@ -232,24 +232,27 @@ def main():
     if world > 1 and args.sharding == "views" and backend == "nccl":
         # the two collectives of the step on their real buffers, back to back and alone on the device: what the exchange costs when
         # NOTHING hides it (exposed_ms_per_step above is what was not hidden in the timed region)
-        from surfel_trainer import GEOM_FLOATS
-        m = tr.model
-        geo = m.grad[:GEOM_FLOATS * m.P].clone()
-        gall = torch.empty((world, m.P, 3), dtype=torch.float32, device=dev)
-        coll_us = {}
-        for name, fn in (("all_reduce_geometry_40B_per_surfel", lambda: dist.all_reduce(geo, op=dist.ReduceOp.SUM)),
-                         ("all_gather_colour_12B_per_surfel_per_rank", lambda: dist.all_gather_into_tensor(gall, m.gcol))):
-            for _ in range(3):
-                fn()
-            fence()
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            for _ in range(10):
-                fn()
-            e1.record()
-            fence()
-            coll_us[name] = round(e0.elapsed_time(e1) * 100.0, 1)
-        del geo, gall
+        try:      # (an extra: must never cost the run its headline)
+            from surfel_trainer import GEOM_FLOATS
+            m = tr.model
+            geo = m.grad[:GEOM_FLOATS * m.P].clone()
+            gall = torch.empty((world, m.P, 3), dtype=torch.float32, device=dev)
+            coll_us = {}
+            for name, fn in (("all_reduce_geometry_40B_per_surfel", lambda: dist.all_reduce(geo, op=dist.ReduceOp.SUM)),
+                             ("all_gather_colour_12B_per_surfel_per_rank", lambda: dist.all_gather_into_tensor(gall, m.gcol))):
+                for _ in range(3):
+                    fn()
+                fence()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(10):
+                    fn()
+                e1.record()
+                fence()
+                coll_us[name] = round(e0.elapsed_time(e1) * 100.0, 1)
+            del geo, gall
+        except Exception as e:      # noqa: BLE001
+            coll_us = {"error": repr(e)}
     loss_last = float(tr.last["loss"])
     # per-stage breakdown of the rasterizer: a second, untimed pass with every stage bracketed by events
     # (bracketing all ~9 stages costs ~10 us each, which would perturb the timed region by ~9 % at this size)
@@ -312,29 +315,33 @@ def main():
     # ---- N > 1: a second weak-scaling line on BASELINE configs[3]'s per-GPU shape (C4: 2 M surfels, 1600x1060) — the headline C2 step
     # is 0.6 ms, where RCCL's launch latency alone is a visible fraction; same barrier / max-over-ranks timing
     if world > 1 and args.workload == "C2" and args.sharding == "views" and not args.no_scale_leg:
-        tr = make_trainer(dev, "C4", n_views=max(8, world), sharding=args.sharding)
-        for _ in range(8 + args.warmup):
-            tr.step()
-        fence()
-        tr.time_exchange = True
-        tr.exchange_events = []
-        k4 = max(10, args.steps // 2)
-        t0 = time.perf_counter()
-        for _ in range(k4):
-            tr.step()
-        fence()
-        dt4 = time.perf_counter() - t0
-        ex4 = (sum(e0.elapsed_time(e1) for e0, e1 in tr.exchange_events) / k4) if tr.exchange_events else None
-        tt = torch.tensor([dt4], device=dev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt4 = float(tt.item())
-        if rank == 0:
-            out["scale_leg_C4"] = {"workload": "C4-synthetic: 2 000 000 random surfels, 1600x1060, full iteration, 1 view/GPU/iteration (weak scaling)",
-                                   "value": round(world * k4 / dt4, 3), "unit": "train-iters/s", "ms_per_step": round(dt4 / k4 * 1e3, 4), "steps": k4,
-                                   "exposed_ms_per_step": None if ex4 is None else round(ex4, 4), "wire_bytes_per_step_per_gpu": dict(tr.wire),
-                                   "early_gather_probe": getattr(tr, "early_gather_probe", None)}
+        try:      # (an extra: a failure here is reported, the headline line above stands; every rank takes the same path)
+            tr = make_trainer(dev, "C4", n_views=max(8, world), sharding=args.sharding)
+            for _ in range(8 + args.warmup):
+                tr.step()
+            fence()
+            tr.time_exchange = True
+            tr.exchange_events = []
+            k4 = max(10, args.steps // 2)
+            t0 = time.perf_counter()
+            for _ in range(k4):
+                tr.step()
+            fence()
+            dt4 = time.perf_counter() - t0
+            ex4 = (sum(e0.elapsed_time(e1) for e0, e1 in tr.exchange_events) / k4) if tr.exchange_events else None
+            tt = torch.tensor([dt4], device=dev, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt4 = float(tt.item())
+            if rank == 0:
+                out["scale_leg_C4"] = {"workload": "C4-synthetic: 2 000 000 random surfels, 1600x1060, full iteration, 1 view/GPU/iteration (weak scaling)",
+                                       "value": round(world * k4 / dt4, 3), "unit": "train-iters/s", "ms_per_step": round(dt4 / k4 * 1e3, 4), "steps": k4,
+                                       "exposed_ms_per_step": None if ex4 is None else round(ex4, 4), "wire_bytes_per_step_per_gpu": dict(tr.wire),
+                                       "early_gather_probe": getattr(tr, "early_gather_probe", None)}
+        except Exception as e:      # noqa: BLE001
+            if rank == 0:
+                out["scale_leg_C4"] = {"error": repr(e)}
         dist.barrier()
-        del tr
+        tr = None
         _d.set_grad_arena(None)
         torch.cuda.empty_cache()
 

@@ -834,6 +834,22 @@ def test_view_parallel_step_rehearsed_on_rccl_with_early_gather():
             thetas.append((m.theta.clone(), m.m.clone(), m.v.clone()))
         for a, b in zip(*thetas):
             assert torch.equal(a, b)
+        # early_gather = "auto" (the default with more than one rank): the start-up probe runs EG_LEN iterations with the early
+        # gather, EG_LEN without, reduces the two device times over the ranks and fixes the choice — same bits whatever it picks
+        m = TR.synthetic_object(4000, d, seed=2, px_scale=0.05)
+        m.spatial_lr_scale = 1.0
+        tr = TR.Trainer(m, cams, TR.optimization_params(dist_from_iter=0, normal_from_iter=0, lambda_dist=10.0, densify_from_iter=10 ** 9),
+                        TR.pipeline_params(depth_ratio=1.0), rehearse_exchange=True)
+        tr.early_gather = "auto"
+        for _ in range(TR.Trainer.EG_WARM + 2 * TR.Trainer.EG_LEN + 2):
+            tr.step()
+            if tr.iteration == 4:
+                ref4 = (m.theta.clone(), m.m.clone(), m.v.clone())
+        torch.cuda.synchronize()
+        assert tr.early_gather in (True, False) and tr.early_gather_probe["choice"] in ("early", "late"), tr.early_gather_probe
+        assert tr.early_gather_probe["early_ms_per_step"] > 0 and tr.early_gather_probe["late_ms_per_step"] > 0
+        for a, b in zip(ref4, thetas[0]):
+            assert torch.equal(a, b)
     finally:
         dist.destroy_process_group()
 
