@@ -10,13 +10,13 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "lib", "libsurfel_hip.so")
 SOURCES = ["surfel_preprocess.hip", "surfel_forward.hip", "surfel_backward.hip", "surfel_backward_scan.hip", "surfel_sort.hip", "surfel_api.hip", "knn.hip",
-           "train_loss.hip", "train_post.hip", "train_optim.hip", "train_api.hip"]
+           "train_loss.hip", "train_post.hip", "train_fused.hip", "train_optim.hip", "train_api.hip"]
 # blend kernels: packed-f32 VALU (SLP) costs ~1.6x a scalar op on gfx950 plus the v_movs that pair the operands
 # surfel_backward.hip spells every fused multiply-add out (FMA macro) and is compiled with contraction off, so its kernel variants
 # round identically per (pixel, surfel) pair
 EXTRA = {"surfel_forward.hip": ["-fno-slp-vectorize"], "surfel_backward.hip": ["-fno-slp-vectorize", "-ffp-contract=off"],
          "surfel_backward_scan.hip": ["-fno-slp-vectorize", "-ffp-contract=off"]}
-HEADERS = ["surfel_common.h", "surfel_kernels.h", "surfel_blend_bwd.h", "train_kernels.h", os.path.join("..", "..", "include", "surfel_hip.h"),
+HEADERS = ["surfel_common.h", "surfel_kernels.h", "surfel_blend_bwd.h", "train_kernels.h", "train_loss_body.h", "train_post_body.h", os.path.join("..", "..", "include", "surfel_hip.h"),
            os.path.join("..", "..", "include", "surfel_train.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast", "-Wall", "-Wno-unused-result"]
 

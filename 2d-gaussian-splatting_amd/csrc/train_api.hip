@@ -60,6 +60,24 @@ int surfel_render_post_backward(int H, int W, const float* allmap, const float* 
     return launched("post_bwd_kernel");
 }
 
+int surfel_train_loss_forward(int H, int W, const float* img, const float* gt, float* dmaps, float* ssim_partials, const float* allmap,
+                              const float* cam, float depth_ratio, float* post_partials, void* stream) {
+    if (H <= 0 || W <= 0 || !img || !gt || !dmaps || !ssim_partials || !allmap || !cam || !post_partials) return api_fail(SURFEL_E_INVALID, "bad arguments");
+    launch_train_loss_fwd(H, W, img, gt, dmaps, ssim_partials, allmap, cam, depth_ratio, post_partials, static_cast<hipStream_t>(stream));
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : api_fail(SURFEL_E_HIP, "train_loss_fwd", e);
+}
+
+int surfel_train_loss_backward(int H, int W, const float* img, const float* gt, const float* dmaps, float c_l1, float c_ssim, const float* allmap,
+                               const float* cam, float depth_ratio, float c_normal, float c_dist, const float* g_dev, float* grad_img,
+                               float* grad_allmap, void* stream) {
+    if (H <= 0 || W <= 0 || !img || !gt || !dmaps || !allmap || !cam || !grad_img || !grad_allmap) return api_fail(SURFEL_E_INVALID, "bad arguments");
+    launch_train_loss_bwd(H, W, img, gt, dmaps, c_l1, c_ssim, g_dev, grad_img, allmap, cam, depth_ratio, c_normal, c_dist, grad_allmap,
+                          static_cast<hipStream_t>(stream));
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : api_fail(SURFEL_E_HIP, "train_loss_bwd", e);
+}
+
 int surfel_reduce_partials(const float* partials, int groups, int n, int stride, float scale, float* out, void* stream) {
     if (!partials || !out || groups <= 0 || n <= 0 || stride <= 0 || stride > 65535 || groups > 65535)
         return api_fail(SURFEL_E_INVALID, "reduce_partials: bad arguments");

@@ -21,6 +21,13 @@ void launch_post_fwd(int H, int W, const float* allmap, const float* cam, float 
 void launch_post_bwd(int H, int W, const float* allmap, const float* cam, float ratio, const float* gmaps, float c_normal, float c_dist,
                      const float* gscale_dev, float* gall, hipStream_t s);
 
+// horizontally fused training loss (train_fused.hip): [3,H,W] image vs target (window 11) + allmap regularisers, one launch per direction
+void launch_train_loss_fwd(int H, int W, const float* img, const float* gt, float* dmaps, float* partials, const float* allmap, const float* cam,
+                           float ratio, float* post_partials, hipStream_t s);
+void launch_train_loss_bwd(int H, int W, const float* img, const float* gt, const float* dmaps, float c_l1, float c_ssim, const float* g_dev,
+                           float* grad_img, const float* allmap, const float* cam, float ratio, float c_normal, float c_dist, float* gall,
+                           hipStream_t s);
+
 void launch_activate(int P, const float* theta, float* act, hipStream_t s);
 void launch_adam(int P, float* theta, const float* grad, float* m, float* v, float* act, const float* lr, float beta1, float beta2, float eps,
                  float bc1, float bc2_sqrt, float grad_scale, int D, int N, const float* campos_all, const float* gcol_all, int parts,

@@ -1,0 +1,245 @@
+// train_loss_body.h — the L1 + SSIM kernels' bodies as device functions over a caller-provided LDS workspace, so that they can run
+// as ordinary kernels (train_loss.hip) and as one half of the horizontally fused training-loss launches (train_fused.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "surfel_common.h"
+
+namespace surfel {
+namespace lossk {
+
+constexpr int ST = 32;             // output tile edge
+// per window radius SR: SHALO = staged tile edge (42 for SR = 5), NSTAGE = staged elements per thread (7), NE = consecutive
+// elements a thread slides its (2 SR + 1)-tap window over to produce 4 outputs (14), XP = float2 pitch of the staged tile
+// (even: 16-B aligned b128 reads at even columns)
+#define SSIM_GEOMETRY(SR)                                                                                           \
+    constexpr int SHALO = ST + 2 * (SR), NSTAGE = (SHALO * SHALO + 255) / 256, NE = 4 + 2 * (SR), NW = 2 * (SR) + 1, \
+                  XP = SHALO + 4
+struct SsimWin { float w[15]; };     // the normalised 1-D Gaussian window, passed by value
+constexpr float SSIM_C1 = 0.01f * 0.01f;
+constexpr float SSIM_C2 = 0.03f * 0.03f;
+
+// gaussian(11, 1.5) of loss_utils.py:29-31 evaluated in fp32 exactly as torch does (exp in double, stored fp32, fp32 sum)
+constexpr float kG11[11] = {1.028380124e-03f, 7.598758209e-03f, 3.600077331e-02f, 1.093606874e-01f,
+                            2.130055279e-01f, 2.660117149e-01f, 2.130055279e-01f, 1.093606874e-01f,
+                            3.600077331e-02f, 7.598758209e-03f, 1.028380124e-03f};
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// LDS layout (42 KB at window 11 -> 3 workgroups / CU): the staged tile as float2 (x,y) with pitch XP, the horizontal moments as
+// float4 (E[x], E[y], E[x^2], E[y^2]) with pitch HZP + float (E[xy]).  Each thread slides the window over NE consecutive
+// elements held in registers (window 11: 4 outputs per 14 LDS reads instead of 44), horizontally then vertically.
+constexpr int HZP = ST + 1;       // float4 pitch of the horizontal-pass result
+
+template <int SR>
+__device__ __forceinline__ void ssim_fwd_body(char* smem, int vblock, int vgrid, int H, int W, const float* __restrict__ img, const float* __restrict__ gt,
+                                                       float* __restrict__ dmaps, size_t map_stride, float* __restrict__ partials, SsimWin win) {
+    SSIM_GEOMETRY(SR);
+    // LDS carve-up (the caller provides ssim_fwd_lds<SR>() bytes, 16-B aligned): hz4 | sxy | hz1 | red
+    float4* const hz4 = reinterpret_cast<float4*>(smem);
+    float2* const sxy = reinterpret_cast<float2*>(smem + sizeof(float4) * SHALO * HZP);
+    float* const hz1 = reinterpret_cast<float*>(smem + sizeof(float4) * SHALO * HZP + sizeof(float2) * SHALO * XP);
+    float* const red = hz1 + SHALO * ST;
+    const int tid = threadIdx.x;
+    // workgroup b runs on XCD b % 8: every XCD gets a contiguous run of (plane, tile) so that neighbouring tiles' halos hit in
+    // one L2 instead of being fetched from HBM once per XCD
+    const int gxt = (W + ST - 1) / ST, ntile = gxt * ((H + ST - 1) / ST);
+    const int lin = xcd_tile(vblock, vgrid);
+    const int plane = lin / ntile, tile = lin - plane * ntile;
+    const int x0 = (tile % gxt) * ST, y0 = (tile / gxt) * ST;
+    const size_t poff = (size_t)plane * H * W;
+    const float* X = img + poff;
+    const float* Y = gt + poff;
+    {   // stage the tile (42x42 at window 11): ALL of a thread's 7 x 2 loads are issued before the first one is consumed (as a rolled loop this
+        // was seven dependent global round trips per workgroup — most of the kernel's time)
+        float2 v[NSTAGE];
+#pragma unroll
+        for (int k = 0; k < NSTAGE; k++) {
+            const int i = tid + 256 * k;
+            const int r = i / SHALO, c = i - r * SHALO;
+            const int gy = y0 + r - SR, gx = x0 + c - SR;
+            const bool in = i < SHALO * SHALO && gy >= 0 && gy < H && gx >= 0 && gx < W;
+            v[k] = in ? make_float2(X[(size_t)gy * W + gx], Y[(size_t)gy * W + gx]) : make_float2(0.f, 0.f);
+        }
+#pragma unroll
+        for (int k = 0; k < NSTAGE; k++) {
+            const int i = tid + 256 * k;
+            const int r = i / SHALO, c = i - r * SHALO;
+            if (i < SHALO * SHALO) sxy[r * XP + c] = v[k];
+        }
+    }
+    __syncthreads();
+    // horizontal pass: item = (row r of 42, group of 4 output columns)
+    for (int it = tid; it < SHALO * (ST / 4); it += 256) {
+        const int r = it >> 3, c0 = (it & 7) << 2;
+        float xv[NE], yv[NE];
+        const float4* src = reinterpret_cast<const float4*>(&sxy[r * XP + c0]);
+#pragma unroll
+        for (int k = 0; k < NE / 2; k++) { const float4 t = src[k]; xv[2 * k] = t.x; yv[2 * k] = t.y; xv[2 * k + 1] = t.z; yv[2 * k + 1] = t.w; }
+        float a[4] = {0.f, 0.f, 0.f, 0.f}, b[4] = {0.f, 0.f, 0.f, 0.f}, aa[4] = {0.f, 0.f, 0.f, 0.f}, bb[4] = {0.f, 0.f, 0.f, 0.f},
+              ab[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int e = 0; e < NE; e++) {
+            const float x = xv[e], y = yv[e], xx = x * x, yy = y * y, xy = x * y;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int k = e - j;
+                if (k >= 0 && k < NW) {
+                    const float w = win.w[k];
+                    a[j] += w * x; b[j] += w * y; aa[j] += w * xx; bb[j] += w * yy; ab[j] += w * xy;
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            hz4[r * HZP + c0 + j] = make_float4(a[j], b[j], aa[j], bb[j]);
+            hz1[r * ST + c0 + j] = ab[j];
+        }
+    }
+    __syncthreads();
+    // vertical pass: thread -> column c, output rows 4g .. 4g+3
+    const int c = tid & 31, g = tid >> 5;
+    float mu1[4] = {0.f, 0.f, 0.f, 0.f}, mu2[4] = {0.f, 0.f, 0.f, 0.f}, e11[4] = {0.f, 0.f, 0.f, 0.f}, e22[4] = {0.f, 0.f, 0.f, 0.f},
+          e12[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int e = 0; e < NE; e++) {
+        const float4 h = hz4[(4 * g + e) * HZP + c];
+        const float h1 = hz1[(4 * g + e) * ST + c];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int k = e - j;
+            if (k >= 0 && k < NW) {
+                const float w = win.w[k];
+                mu1[j] += w * h.x; mu2[j] += w * h.y; e11[j] += w * h.z; e22[j] += w * h.w; e12[j] += w * h1;
+            }
+        }
+    }
+    float l1 = 0.f, ss = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int r = 4 * g + j;
+        const int gy = y0 + r, gx = x0 + c;
+        if (gy < H && gx < W) {
+            const float mu1_sq = mu1[j] * mu1[j], mu2_sq = mu2[j] * mu2[j], mu12 = mu1[j] * mu2[j];
+            const float s1 = e11[j] - mu1_sq, s2 = e22[j] - mu2_sq, s12 = e12[j] - mu12;
+            const float A = 2.f * mu12 + SSIM_C1, B = 2.f * s12 + SSIM_C2;
+            const float C = mu1_sq + mu2_sq + SSIM_C1, D = s1 + s2 + SSIM_C2;
+            const float iCD = 1.f / (C * D);
+            const float S = A * B * iCD;
+            const float2 v = sxy[(r + SR) * XP + c + SR];
+            l1 += fabsf(v.x - v.y);
+            ss += S;
+            if (dmaps) {
+                const size_t o = poff + (size_t)gy * W + gx;
+                dmaps[o] = 2.f * mu2[j] * (B - A) * iCD + 2.f * mu1[j] * S * (1.f / D - 1.f / C);   // dS/dmu1 (mu1, E[x^2], E[xy] independent)
+                dmaps[map_stride + o] = -S / D;                                                   // dS/dE[x^2]
+                dmaps[2 * map_stride + o] = 2.f * A * iCD;                                        // dS/dE[xy]
+            }
+        }
+    }
+    l1 = wave_sum(l1); ss = wave_sum(ss);
+    if ((tid & 63) == 0) { red[2 * (tid >> 6)] = l1; red[2 * (tid >> 6) + 1] = ss; }
+    __syncthreads();
+    if (tid == 0) {
+        const size_t blk = (size_t)lin;
+        partials[2 * blk] = (red[0] + red[2]) + (red[4] + red[6]);
+        partials[2 * blk + 1] = (red[1] + red[3]) + (red[5] + red[7]);
+    }
+}
+
+
+template <int SR>
+__device__ __forceinline__ void ssim_bwd_body(char* smem, int vblock, int vgrid, int H, int W, const float* __restrict__ img, const float* __restrict__ gt,
+                                                       const float* __restrict__ dmaps, size_t map_stride, float c_l1, float c_ssim,
+                                                       const float* __restrict__ g_l1_dev, const float* __restrict__ g_ssim_dev,
+                                                       float* __restrict__ grad_img, SsimWin win) {
+    SSIM_GEOMETRY(SR);
+    // LDS carve-up (ssim_bwd_lds<SR>() bytes): hz (horizontal pass of (M1, M2, M3, -)) | s12 (M1, M2) | s3 (M3)
+    float4* const hz = reinterpret_cast<float4*>(smem);
+    float2* const s12 = reinterpret_cast<float2*>(smem + sizeof(float4) * SHALO * HZP);
+    float* const s3 = reinterpret_cast<float*>(smem + sizeof(float4) * SHALO * HZP + sizeof(float2) * SHALO * XP);
+    const int tid = threadIdx.x;
+    // workgroup b runs on XCD b % 8: every XCD gets a contiguous run of (plane, tile) so that neighbouring tiles' halos hit in
+    // one L2 instead of being fetched from HBM once per XCD
+    const int gxt = (W + ST - 1) / ST, ntile = gxt * ((H + ST - 1) / ST);
+    const int lin = xcd_tile(vblock, vgrid);
+    const int plane = lin / ntile, tile = lin - plane * ntile;
+    const int x0 = (tile % gxt) * ST, y0 = (tile / gxt) * ST;
+    const size_t poff = (size_t)plane * H * W;
+    {   // all 7 x 3 loads of a thread in flight before the first LDS store (see ssim_fwd_kernel)
+        float2 v12[NSTAGE];
+        float v3[NSTAGE];
+#pragma unroll
+        for (int k = 0; k < NSTAGE; k++) {
+            const int i = tid + 256 * k;
+            const int r = i / SHALO, c = i - r * SHALO;
+            const int gy = y0 + r - SR, gx = x0 + c - SR;
+            const bool in = i < SHALO * SHALO && gy >= 0 && gy < H && gx >= 0 && gx < W;
+            const size_t o = poff + (size_t)gy * W + gx;
+            v12[k] = in ? make_float2(dmaps[o], dmaps[map_stride + o]) : make_float2(0.f, 0.f);
+            v3[k] = in ? dmaps[2 * map_stride + o] : 0.f;
+        }
+#pragma unroll
+        for (int k = 0; k < NSTAGE; k++) {
+            const int i = tid + 256 * k;
+            const int r = i / SHALO, c = i - r * SHALO;
+            if (i < SHALO * SHALO) { s12[r * XP + c] = v12[k]; s3[r * XP + c] = v3[k]; }
+        }
+    }
+    __syncthreads();
+    for (int it = tid; it < SHALO * (ST / 4); it += 256) {
+        const int r = it >> 3, c0 = (it & 7) << 2;
+        float m1[NE], m2[NE], m3[NE];
+        const float4* src = reinterpret_cast<const float4*>(&s12[r * XP + c0]);
+#pragma unroll
+        for (int k = 0; k < NE / 2; k++) { const float4 t = src[k]; m1[2 * k] = t.x; m2[2 * k] = t.y; m1[2 * k + 1] = t.z; m2[2 * k + 1] = t.w; }
+        const float2* src3 = reinterpret_cast<const float2*>(&s3[r * XP + c0]);
+#pragma unroll
+        for (int k = 0; k < NE / 2; k++) { const float2 t = src3[k]; m3[2 * k] = t.x; m3[2 * k + 1] = t.y; }
+        float a[4] = {0.f, 0.f, 0.f, 0.f}, b[4] = {0.f, 0.f, 0.f, 0.f}, d[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int e = 0; e < NE; e++) {
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int k = e - j;
+                if (k >= 0 && k < NW) { const float w = win.w[k]; a[j] += w * m1[e]; b[j] += w * m2[e]; d[j] += w * m3[e]; }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++) hz[r * HZP + c0 + j] = make_float4(a[j], b[j], d[j], 0.f);
+    }
+    __syncthreads();
+    const float k_l1 = c_l1 * (g_l1_dev ? g_l1_dev[0] : 1.f), k_ss = c_ssim * (g_ssim_dev ? g_ssim_dev[0] : 1.f);
+    const int c = tid & 31, g = tid >> 5;
+    float a[4] = {0.f, 0.f, 0.f, 0.f}, b[4] = {0.f, 0.f, 0.f, 0.f}, d[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int e = 0; e < NE; e++) {
+        const float4 h = hz[(4 * g + e) * HZP + c];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int k = e - j;
+            if (k >= 0 && k < NW) { const float w = win.w[k]; a[j] += w * h.x; b[j] += w * h.y; d[j] += w * h.z; }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int gy = y0 + 4 * g + j, gx = x0 + c;
+        if (gy >= H || gx >= W) continue;
+        const size_t o = poff + (size_t)gy * W + gx;
+        const float xv = img[o], yv = gt[o];
+        const float df = xv - yv;
+        const float sgn = df > 0.f ? 1.f : (df < 0.f ? -1.f : 0.f);
+        grad_img[o] = k_l1 * sgn + k_ss * (a[j] + 2.f * xv * b[j] + yv * d[j]);
+    }
+}
+
+
+template <int SR> constexpr size_t ssim_fwd_lds() { return sizeof(float4) * (ST + 2 * SR) * HZP + sizeof(float2) * (ST + 2 * SR) * (ST + 2 * SR + 4) + sizeof(float) * (ST + 2 * SR) * ST + 32; }
+template <int SR> constexpr size_t ssim_bwd_lds() { return sizeof(float4) * (ST + 2 * SR) * HZP + (sizeof(float2) + sizeof(float)) * (ST + 2 * SR) * (ST + 2 * SR + 4); }
+
+}  // namespace lossk
+}  // namespace surfel

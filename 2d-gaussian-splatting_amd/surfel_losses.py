@@ -5,6 +5,8 @@ Same names, argument meaning and return shapes; the work is done by two LDS-tile
 (include/surfel_train.h) instead of five grouped conv2d calls + ~40 elementwise kernels per iteration.
 No CPU / PyTorch fallback: CPU tensors raise.
 """
+import os
+
 import torch
 
 import surfel_native as _n
@@ -177,6 +179,11 @@ def photometric_loss(image, gt_image, lambda_dssim=0.2):
     return _PhotometricLoss.apply(image, gt_image, lambda_dssim)
 
 
+# the two halves of the training loss (L1 + SSIM | allmap regularisers) in one launch per direction (csrc/train_fused.hip); 0: separate
+# launches — same kernels' bodies, same bits (tests/test_gpu_train.py::test_fused_loss_launches_keep_the_bits)
+FUSED_LOSS = os.environ.get("SURFEL_FUSED_LOSS", "1") != "0"
+
+
 class _TrainLoss(torch.autograd.Function):
     """The whole loss of a training iteration (train.py:72-88) as one autograd node:
     (1-l)*L1 + l*(1-SSIM) + lambda_normal*mean(1 - rend_normal.surf_normal) + lambda_dist*mean(rend_dist)
@@ -199,14 +206,22 @@ class _TrainLoss(torch.autograd.Function):
         am = pb = None
         npost = 0
         with torch.cuda.device(dev):
-            _check(lib.surfel_l1_ssim_forward(planes, H, W, _n.ptr(x), _n.ptr(y), _n.ptr(dmaps), _n.ptr(partials), s), "surfel_l1_ssim_forward")
-            if reg:
+            if reg and planes == 3 and FUSED_LOSS:
+                # both halves in one launch (csrc/train_fused.hip): they share no data, their workgroups run side by side
                 am = allmap.detach().contiguous().float()
                 npost = ((W + 15) // 16) * ((H + 15) // 16)
                 pb = torch.empty((npost, 2), dtype=torch.float32, device=dev)
-                # maps = NULL: only the two regulariser sums are needed (the backward recomputes from allmap)
-                _check(lib.surfel_render_post_forward(H, W, _n.ptr(am), _n.ptr(cam), float(depth_ratio), None, _n.ptr(pb), s),
-                       "surfel_render_post_forward")
+                _check(lib.surfel_train_loss_forward(H, W, _n.ptr(x), _n.ptr(y), _n.ptr(dmaps), _n.ptr(partials), _n.ptr(am), _n.ptr(cam),
+                                                     float(depth_ratio), _n.ptr(pb), s), "surfel_train_loss_forward")
+            else:
+                _check(lib.surfel_l1_ssim_forward(planes, H, W, _n.ptr(x), _n.ptr(y), _n.ptr(dmaps), _n.ptr(partials), s), "surfel_l1_ssim_forward")
+                if reg:
+                    am = allmap.detach().contiguous().float()
+                    npost = ((W + 15) // 16) * ((H + 15) // 16)
+                    pb = torch.empty((npost, 2), dtype=torch.float32, device=dev)
+                    # maps = NULL: only the two regulariser sums are needed (the backward recomputes from allmap)
+                    _check(lib.surfel_render_post_forward(H, W, _n.ptr(am), _n.ptr(cam), float(depth_ratio), None, _n.ptr(pb), s),
+                           "surfel_render_post_forward")
             _check(lib.surfel_loss_finalize(_n.ptr(partials), planes * nblk, planes * H * W, _n.ptr(pb), npost, H * W, float(lambda_dssim),
                                             float(lambda_normal) if reg else 0.0, float(lambda_dist) if reg else 0.0, _n.ptr(out), _n.ptr(total), s),
                    "surfel_loss_finalize")
@@ -231,12 +246,18 @@ class _TrainLoss(torch.autograd.Function):
         grad_am = None
         s = _n.current_stream_ptr(dev)
         with torch.cuda.device(dev):
-            _check(lib.surfel_l1_ssim_backward(planes, H, W, _n.ptr(x), _n.ptr(y), _n.ptr(dmaps), (1.0 - lam) / N, -lam / N, _n.ptr(g), _n.ptr(g),
-                                               _n.ptr(grad_img), s), "surfel_l1_ssim_backward")
-            if reg:
+            if reg and planes == 3 and FUSED_LOSS:
                 grad_am = torch.empty_like(am)
-                _check(lib.surfel_render_post_backward(H, W, _n.ptr(am), _n.ptr(cam), ratio, None, ln / (H * W), ld / (H * W), _n.ptr(g),
-                                                       _n.ptr(grad_am), s), "surfel_render_post_backward")
+                _check(lib.surfel_train_loss_backward(H, W, _n.ptr(x), _n.ptr(y), _n.ptr(dmaps), (1.0 - lam) / N, -lam / N, _n.ptr(am), _n.ptr(cam),
+                                                      ratio, ln / (H * W), ld / (H * W), _n.ptr(g), _n.ptr(grad_img), _n.ptr(grad_am), s),
+                       "surfel_train_loss_backward")
+            else:
+                _check(lib.surfel_l1_ssim_backward(planes, H, W, _n.ptr(x), _n.ptr(y), _n.ptr(dmaps), (1.0 - lam) / N, -lam / N, _n.ptr(g), _n.ptr(g),
+                                                   _n.ptr(grad_img), s), "surfel_l1_ssim_backward")
+                if reg:
+                    grad_am = torch.empty_like(am)
+                    _check(lib.surfel_render_post_backward(H, W, _n.ptr(am), _n.ptr(cam), ratio, None, ln / (H * W), ld / (H * W), _n.ptr(g),
+                                                           _n.ptr(grad_am), s), "surfel_render_post_backward")
         return grad_img.view(ctx.shapes[0]), grad_am, None, None, None, None, None, None
 
 
@@ -280,12 +301,18 @@ class _TrainLossBand(torch.autograd.Function):
         s = _n.current_stream_ptr(dev)
         am = pb = None
         with torch.cuda.device(dev):
-            _check(lib.surfel_l1_ssim_forward(planes, He, W, _n.ptr(x), _n.ptr(y), _n.ptr(dmaps), _n.ptr(partials), s), "surfel_l1_ssim_forward")
-            if reg:
+            if reg and planes == 3 and FUSED_LOSS:
                 am = allmap.detach().contiguous().float()
                 pb = torch.empty((((W + 15) // 16) * ((He + 15) // 16), 2), dtype=torch.float32, device=dev)
-                _check(lib.surfel_render_post_forward(He, W, _n.ptr(am), _n.ptr(cam), float(depth_ratio), None, _n.ptr(pb), s),
-                       "surfel_render_post_forward")
+                _check(lib.surfel_train_loss_forward(He, W, _n.ptr(x), _n.ptr(y), _n.ptr(dmaps), _n.ptr(partials), _n.ptr(am), _n.ptr(cam),
+                                                     float(depth_ratio), _n.ptr(pb), s), "surfel_train_loss_forward")
+            else:
+                _check(lib.surfel_l1_ssim_forward(planes, He, W, _n.ptr(x), _n.ptr(y), _n.ptr(dmaps), _n.ptr(partials), s), "surfel_l1_ssim_forward")
+                if reg:
+                    am = allmap.detach().contiguous().float()
+                    pb = torch.empty((((W + 15) // 16) * ((He + 15) // 16), 2), dtype=torch.float32, device=dev)
+                    _check(lib.surfel_render_post_forward(He, W, _n.ptr(am), _n.ptr(cam), float(depth_ratio), None, _n.ptr(pb), s),
+                           "surfel_render_post_forward")
         sums = torch.zeros((4,), dtype=torch.float32, device=dev)
         sums[0:2] = partials.view(planes, nby, nbx, 2)[:, a // 32:(b + 31) // 32].sum((0, 1, 2))
         if reg:
@@ -312,12 +339,18 @@ class _TrainLossBand(torch.autograd.Function):
         grad_am = None
         s = _n.current_stream_ptr(dev)
         with torch.cuda.device(dev):
-            _check(lib.surfel_l1_ssim_backward(planes, He, W, _n.ptr(x), _n.ptr(y), _n.ptr(dmaps), (1.0 - lam) / N3, -lam / N3, _n.ptr(g), _n.ptr(g),
-                                               _n.ptr(grad_img), s), "surfel_l1_ssim_backward")
-            if reg:
+            if reg and planes == 3 and FUSED_LOSS:
                 grad_am = torch.empty_like(am)
-                _check(lib.surfel_render_post_backward(He, W, _n.ptr(am), _n.ptr(cam), ratio, None, ln / N1, ld / N1, _n.ptr(g),
-                                                       _n.ptr(grad_am), s), "surfel_render_post_backward")
+                _check(lib.surfel_train_loss_backward(He, W, _n.ptr(x), _n.ptr(y), _n.ptr(dmaps), (1.0 - lam) / N3, -lam / N3, _n.ptr(am), _n.ptr(cam),
+                                                      ratio, ln / N1, ld / N1, _n.ptr(g), _n.ptr(grad_img), _n.ptr(grad_am), s),
+                       "surfel_train_loss_backward")
+            else:
+                _check(lib.surfel_l1_ssim_backward(planes, He, W, _n.ptr(x), _n.ptr(y), _n.ptr(dmaps), (1.0 - lam) / N3, -lam / N3, _n.ptr(g), _n.ptr(g),
+                                                   _n.ptr(grad_img), s), "surfel_l1_ssim_backward")
+                if reg:
+                    grad_am = torch.empty_like(am)
+                    _check(lib.surfel_render_post_backward(He, W, _n.ptr(am), _n.ptr(cam), ratio, None, ln / N1, ld / N1, _n.ptr(g),
+                                                           _n.ptr(grad_am), s), "surfel_render_post_backward")
         return (grad_img.view(ctx.shapes[0]), grad_am) + (None,) * 8
 
 

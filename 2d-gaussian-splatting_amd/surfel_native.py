@@ -22,7 +22,7 @@ EXPORTS = ["surfel_abi_version", "surfel_last_error", "surfel_rasterize_forward"
            "surfel_mark_visible", "surfel_knn_dist2", "surfel_last_stage_ms", "surfel_last_stage_ids", "surfel_stage_name",
            "surfel_collect_stage_ms", "surfel_set_option", "surfel_debug_sort_pairs", "surfel_debug_set_blend_stats", "surfel_debug_walk_choice", "surfel_debug_last_binning", "surfel_set_backward_hook",
            # include/surfel_train.h
-           "surfel_l1_ssim_forward", "surfel_l1_ssim_backward", "surfel_l1_ssim_forward_w", "surfel_l1_ssim_backward_w", "surfel_render_post_forward", "surfel_render_post_backward",
+           "surfel_l1_ssim_forward", "surfel_l1_ssim_backward", "surfel_l1_ssim_forward_w", "surfel_l1_ssim_backward_w", "surfel_render_post_forward", "surfel_render_post_backward", "surfel_train_loss_forward", "surfel_train_loss_backward",
            "surfel_reduce_partials", "surfel_loss_finalize", "surfel_activate", "surfel_adam_step", "surfel_sh_grad_gather", "surfel_densify_stats"]
 
 # per-call option overrides carried in the upper bits of the `debug` argument (include/surfel_hip.h)
@@ -96,6 +96,8 @@ def load():
                            ("surfel_l1_ssim_backward_w", [i, i, i, i, vp, vp, vp, f, f, vp, vp, vp, vp]),
                            ("surfel_render_post_forward", [i, i, vp, vp, f, vp, vp, vp]),
                            ("surfel_render_post_backward", [i, i, vp, vp, f, vp, f, f, vp, vp, vp]),
+                           ("surfel_train_loss_forward", [i, i, vp, vp, vp, vp, vp, vp, f, vp, vp]),
+                           ("surfel_train_loss_backward", [i, i, vp, vp, vp, f, f, vp, vp, f, f, f, vp, vp, vp, vp]),
                            ("surfel_reduce_partials", [vp, i, i, i, f, vp, vp]),
                            ("surfel_loss_finalize", [vp, i, i, vp, i, i, f, f, f, vp, vp, vp]),
                            ("surfel_activate", [i, vp, vp, vp]),

@@ -88,6 +88,21 @@ int surfel_render_post_backward(int H, int W, const float* allmap, const float* 
                                 const float* grad_maps, float c_normal, float c_dist, const float* gscale_dev,
                                 float* grad_allmap, void* stream);
 
+/*
+ * The training loss of one iteration (train.py:72-88) with both halves in ONE launch per direction: L1 + SSIM of the [3,H,W] image
+ * against the target (window_size 11) and the allmap post-processing with the normal / distortion regulariser sums — the same
+ * kernels as surfel_l1_ssim_* and surfel_render_post_* (maps = NULL, grad_maps = NULL), fused horizontally: the two halves share
+ * no data, so their workgroups run side by side instead of as two dependent launches.  Same bits as the separate calls.
+ *   forward : dmaps[3][3][H][W], ssim_partials[3 * ceil(W/32)*ceil(H/32)][2], post_partials[ceil(W/16)*ceil(H/16)][2]
+ *             -> surfel_loss_finalize
+ *   backward: g_dev = device scalar multiplying every constant (the upstream gradient of the total), may be NULL (= 1)
+ */
+int surfel_train_loss_forward(int H, int W, const float* img, const float* gt, float* dmaps, float* ssim_partials,
+                              const float* allmap, const float* cam, float depth_ratio, float* post_partials, void* stream);
+int surfel_train_loss_backward(int H, int W, const float* img, const float* gt, const float* dmaps, float c_l1, float c_ssim,
+                               const float* allmap, const float* cam, float depth_ratio, float c_normal, float c_dist,
+                               const float* g_dev, float* grad_img, float* grad_allmap, void* stream);
+
 /* out[g*stride + k] = scale * sum_i partials[(g*n + i)*stride + k], fixed summation order. groups*stride <= 65535. */
 int surfel_reduce_partials(const float* partials, int groups, int n, int stride, float scale, float* out, void* stream);
 

@@ -411,6 +411,39 @@ def test_single_node_train_loss_matches_reference_sum(gt, ratio):
     grad_ok(x2.grad.cpu().numpy(), o["g_loss"])
 
 
+@pytest.mark.parametrize("hw", [(64, 80), (101, 77), (800, 800)])
+def test_fused_loss_launches_keep_the_bits(hw):
+    """The training loss's two halves in one launch per direction (csrc/train_fused.hip: SSIM workgroups and post-processing
+    workgroups of one grid, the same kernel bodies over one LDS workspace) against the four separate launches: loss scalars and both
+    gradients BIT-IDENTICAL, also on frame sizes that are no multiple of either tile."""
+    import torch
+    import surfel_losses as L
+    import surfel_render as R
+    import surfel_trainer as TR
+    H, W = hw
+    d = dev()
+    cams = TR.orbit_cameras(1, W, H, device=d)
+    cam = cams[0]
+    g = torch.Generator().manual_seed(H * 1000 + W)
+    tgt = torch.rand((3, H, W), generator=g).to(d)
+    img = (tgt + 0.1 * torch.randn((3, H, W), generator=g).to(d)).clamp(0, 1)
+    allmap = torch.randn((7, H, W), generator=g).to(d)
+    allmap[0] = allmap[0].abs() * 3 + 0.5; allmap[1] = torch.rand((H, W), generator=g).to(d) * 0.9 + 0.05; allmap[5] = allmap[5].abs() * 3 + 0.5
+    consts = cam.post_consts()
+    res = []
+    try:
+        for fused in (False, True):
+            L.FUSED_LOSS = fused
+            x = img.clone().requires_grad_(True); am = allmap.clone().requires_grad_(True)
+            total, sc = L.train_loss(x, am, tgt, consts, 0.7, 0.2, 0.05, 100.0)
+            (1.5 * total).backward()
+            res.append((total.detach().clone(), sc.clone(), x.grad.clone(), am.grad.clone()))
+    finally:
+        L.FUSED_LOSS = True
+    for a, b in zip(*res):
+        assert torch.isfinite(a).all() and torch.equal(a, b)
+
+
 def test_render_python_covariance_and_override_color_paths():
     """render()'s compute_cov3D_python branch (gaussian_renderer/__init__.py:59-75 with scene/gaussian_model.py:27-33) and
     override_color produce the same image as the native scale/rotation + SH path."""
