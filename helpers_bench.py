@@ -131,7 +131,7 @@ def time_trainer(tr, steps, warmup, prime=15, workload=None):
     st = surfel_native.collect_stage_times()
     tr.pipe.debug = 0
     # both blend_bwd walks on this very state (the library default picks one per frame on the device): data for that choice
-    ab = {}
+    ab, lanes = {}, {}
     lib = surfel_native.load()
     for name, v in (("rows", 0), ("quad", 1), ("scan", 3)):
         lib.surfel_set_option(b"bwd_variant", v)
@@ -141,6 +141,17 @@ def time_trainer(tr, steps, warmup, prime=15, workload=None):
         torch.cuda.synchronize()
         t = surfel_native.collect_stage_times()
         ab[name] = round(t["blend_bwd"][0] / t["blend_bwd"][1], 4)
+        # instrumented twin of the walk: lane slots issued vs lanes that held a composited (pixel, surfel) pair (one step)
+        bs = torch.zeros(8, dtype=torch.int64, device=tr.model.device)
+        lib.surfel_debug_set_blend_stats(surfel_native.ptr(bs))
+        tr.pipe.debug = 0
+        try:
+            tr.step()
+            torch.cuda.synchronize()
+        finally:
+            lib.surfel_debug_set_blend_stats(None)
+        sv = bs.cpu().numpy()
+        lanes[name] = {"useful_lane_frac": round(float(sv[1]) / max(1.0, float(sv[0])), 4), "wave_visits": int(sv[2]), "useful_pairs": int(sv[1])}
     lib.surfel_set_option(b"bwd_variant", 2)
     tr.pipe.debug = 0
     cam = tr.cams[0]
@@ -155,7 +166,7 @@ def time_trainer(tr, steps, warmup, prime=15, workload=None):
     return {"roofline": roof, "instances_staged": Rs, "ms_per_step": round(dt / steps * 1e3, 4), "iters_per_s": round(steps / dt, 2), "steps": steps, "P": int(tr.model.P),
             "visible": int((tr.last["radii"] > 0).sum().item()), "instances_R": R, "inst_per_tile": round(R / tiles, 1),
             "inst_per_surfel": round(R / max(1, int(tr.model.P)), 2), "loss": round(float(tr.last["loss"]), 5),
-            "kernels_ms": {k: round(v[0] / v[1], 4) for k, v in st.items()}, "blend_bwd_ms_by_walk": ab}
+            "kernels_ms": {k: round(v[0] / v[1], 4) for k, v in st.items()}, "blend_bwd_ms_by_walk": ab, "blend_bwd_lanes_by_walk": lanes}
 
 
 def config_leg(dev, workload, steps=20, warmup=5):

@@ -21,9 +21,11 @@ import re
 import sys
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-STAGE_OF = {"preprocess_fwd_kernel": "preprocess_fwd", "emit_instances_kernel": "emit_instances", "tile_ranges_kernel": "tile_ranges",
+STAGE_OF = {"preprocess_fwd_kernel": "preprocess_fwd", "emit_instances_kernel": "emit_instances", "bin_emit_kernel": "emit_instances",
+            "tile_ranges_kernel": "tile_ranges", "tile_ranges_devn_kernel": "tile_ranges",
             "blend_fwd_kernel": "blend_fwd", "blend_bwd_kernel": "blend_bwd", "blend_bwd_rows_kernel": "blend_bwd", "blend_bwd_quad_kernel": "blend_bwd",
-            "preprocess_bwd_kernel": "preprocess_bwd"}
+            "blend_bwd_scan_kernel": "blend_bwd", "preprocess_bwd_kernel": "preprocess_bwd"}
+WALK_NAME = {"0": "rows", "1": "quad", "3": "scan"}
 
 
 def short(name):
@@ -50,7 +52,12 @@ def pmc_means(d):
 def main():
     tag = sys.argv[1]
     wl = sys.argv[2] if len(sys.argv) > 2 else "C2"
-    src = os.path.join(REPO, "gpurun_out", "prof_" + tag)
+    src = os.path.join(REPO, "gpurun_out", "prof_%s_%s" % (tag, wl))
+    if not os.path.isdir(src):
+        src = os.path.join(REPO, "gpurun_out", "prof_" + tag)
+    walk = None
+    if os.path.exists(os.path.join(src, "walk.txt")):
+        walk = WALK_NAME.get(open(os.path.join(src, "walk.txt")).read().strip())
     dst = os.path.join(REPO, "profiles")
     os.makedirs(dst, exist_ok=True)
     # 1. kernel stats
@@ -72,7 +79,7 @@ def main():
     for sub in ("fetch", "write", "sq", "sq2"):
         for k, cs in pmc_means(os.path.join(src, sub)).items():
             merged[k].update(cs)
-    ours = ("rs_", "os_", "scan_", "tile_", "ssim_", "post_", "adam_", "loss_", "densify_", "activate_", "reduce_")
+    ours = ("rs_", "os_", "scan_", "tile_", "ssim_", "post_", "adam_", "loss_", "densify_", "activate_", "reduce_", "bin_", "train_loss_")
     merged = {k: v for k, v in merged.items() if k in STAGE_OF or k.startswith(ours) or "knn" in k}
     traffic = {}
     bwd_launches = -1
@@ -81,7 +88,7 @@ def main():
             cs["VALUUtilization_exec_lanes"] = round(cs["SQ_THREAD_CYCLES_VALU"] / (64.0 * cs["SQ_ACTIVE_INST_VALU"]), 4)
         if "FETCH_SIZE" in cs and "WRITE_SIZE" in cs:
             cs["HBM_bytes_per_launch"] = int(2 * cs["FETCH_SIZE"] * 1024 + cs["WRITE_SIZE"] * 1024)
-            if k in STAGE_OF or k.startswith(("ssim_", "post_", "adam_")):
+            if k in STAGE_OF or k.startswith(("ssim_", "post_", "adam_", "train_loss_")):
                 st = STAGE_OF.get(k, k.replace("_kernel", ""))
                 # blend_bwd = the walk that ran most (rows | quad): the other kernel is launched for the tuner's probes and the
                 # pre-verdict calls, so its per-launch mean is a mix of full and idle launches — not a summand
@@ -94,6 +101,9 @@ def main():
     json.dump(merged, open(os.path.join(dst, "%s_%s_pmc.json" % (tag, wl)), "w"), indent=1, sort_keys=True)
     tf = os.path.join(dst, "pmc_traffic.json")
     allt = json.load(open(tf)) if os.path.exists(tf) else {}
+    traffic["_tag"] = tag
+    if walk:
+        traffic["_blend_bwd_walk"] = walk      # the walk the passes were forced to (scripts/profile_gpu.sh)
     allt[wl] = traffic
     allt["_tag"] = tag
     allt.setdefault("_note", "HBM bytes per launch = (2*FETCH_SIZE + WRITE_SIZE) KiB, separate --pmc passes, gfx950 FETCH_SIZE x2 "
