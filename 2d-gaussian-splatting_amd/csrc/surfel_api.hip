@@ -33,6 +33,7 @@ struct CapEntry { int W = 0, H = 0; int64_t maxR = -1; };
 thread_local CapEntry g_caps[4];
 thread_local unsigned g_cap_next = 0;
 int g_opt_capacity = 1;    // surfel_set_option("capacity_binning", .)
+int g_opt_tile_order = 0;  // surfel_set_option("tile_order", .): 0 decided per frame on the device, 1 XCD-contiguous runs, 2 longest lists first
 thread_local int g_last_binning = 0;      // 0 exact-size path, 1 capacity path, 2 capacity path overflowed and the frame was redone (surfel_debug_last_binning)
 CapEntry* cap_entry(int W, int H, bool create) {
     for (auto& c : g_caps) if (c.W == W && c.H == H) return &c;
@@ -115,7 +116,7 @@ struct BinState {    // per-instance state ("binningBuffer"); point_list is alwa
 };
 
 struct ImgState {    // per-pixel / per-tile state ("imgBuffer")
-    uint2* ranges; uint32_t* total; float* final_T; uint32_t* n_contrib;
+    uint2* ranges; uint32_t* total; float* final_T; uint32_t* n_contrib; int* tile_map;
     static ImgState carve(void* base, int W, int H, size_t* total) {
         Carver c(base); ImgState im;
         const size_t tiles = (size_t)((W + TILE - 1) / TILE) * ((H + TILE - 1) / TILE);
@@ -123,6 +124,7 @@ struct ImgState {    // per-pixel / per-tile state ("imgBuffer")
         im.total = reinterpret_cast<uint32_t*>(im.ranges + tiles);
         im.final_T = c.take<float>((size_t)3 * W * H);
         im.n_contrib = c.take<uint32_t>((size_t)2 * W * H);
+        im.tile_map = c.take<int>((size_t)tile_map_len((W + TILE - 1) / TILE, (H + TILE - 1) / TILE));      // blend workgroup -> tile (tile_order_kernel)
         if (total) *total = c.size();
         return im;
     }
@@ -340,6 +342,7 @@ int surfel_set_option(const char* name, int value) {
     if (name && std::strcmp(name, "bwd_variant") == 0) { g_opt_bwd_variant = value < 0 ? 0 : (value > 4 ? 4 : value); return 0; }
     if (name && std::strcmp(name, "bwd_tune") == 0) { g_opt_bwd_tune = value != 0; return 0; }
     if (name && std::strcmp(name, "capacity_binning") == 0) { g_opt_capacity = value != 0; return 0; }
+    if (name && std::strcmp(name, "tile_order") == 0) { g_opt_tile_order = value < 0 ? 0 : (value > 2 ? 2 : value); return 0; }
     return fail(SURFEL_E_INVALID, "unknown option");
 }
 
@@ -387,6 +390,8 @@ int64_t surfel_rasterize_forward(surfel_alloc_fn geom_alloc, void* geom_user, su
     const int opt_cull = (debug & SURFEL_OPT_NO_CULL) ? 0 : g_opt_cull;
     const int opt_tile_sort = ((debug >> 9) & 3) ? ((debug >> 9) & 3) - 1 : g_opt_tile_sort;
     const int opt_capacity = (debug & SURFEL_OPT_EXACT_BINNING) ? 0 : g_opt_capacity;
+    const int opt_tile_order = ((debug >> 19) & 3) ? ((debug >> 19) & 3) - 1 : g_opt_tile_order;
+    const int map_len = tile_map_len((width + TILE - 1) / TILE, (height + TILE - 1) / TILE);
     debug &= 0xff;
     g_last_binning = 0;
     hipStream_t s = static_cast<hipStream_t>(stream);
@@ -498,10 +503,12 @@ int64_t surfel_rasterize_forward(surfel_alloc_fn geom_alloc, void* geom_user, su
             tm.begin();
             launch_tile_depth_sort(gx * gy, ce->maxR, img.ranges, bin.point_list, geom.dkey_a, bin.vals_alt, bin.keys_a, bin.keys_b, s);
             STAGE_END(tm, ST_TSORT);
+            launch_tile_order(img.ranges, gx, gy, img.tile_map, opt_tile_order, s);
             BlendFwdArgs ba{};
             ba.W = width; ba.H = height; ba.gx = gx; ba.gy = gy;
             ba.ranges = img.ranges; ba.point_list = bin.point_list; ba.rec = geom.rec; ba.bg = background;
             ba.out_color = out_color; ba.out_others = out_others; ba.final_T = img.final_T; ba.n_contrib = img.n_contrib;
+            ba.tile_map = img.tile_map; ba.map_len = map_len;
             ba.stats = g_blend_stats;
             tm.begin();
             launch_blend_fwd(ba, s);
@@ -581,10 +588,12 @@ int64_t surfel_rasterize_forward(surfel_alloc_fn geom_alloc, void* geom_user, su
         bin = BinState::carve(bin_base, 0, 0, nullptr);
     }
 
+    launch_tile_order(img.ranges, gx, gy, img.tile_map, opt_tile_order, s);
     BlendFwdArgs ba{};
     ba.W = width; ba.H = height; ba.gx = gx; ba.gy = gy;
     ba.ranges = img.ranges; ba.point_list = bin.point_list; ba.rec = geom.rec; ba.bg = background;
     ba.out_color = out_color; ba.out_others = out_others; ba.final_T = img.final_T; ba.n_contrib = img.n_contrib;
+    ba.tile_map = img.tile_map; ba.map_len = map_len;
     ba.stats = g_blend_stats;
     tm.begin();
     launch_blend_fwd(ba, s);
@@ -636,6 +645,7 @@ int surfel_rasterize_backward(surfel_alloc_fn scratch_alloc, void* scratch_user,
     bb.W = width; bb.H = height; bb.gx = gx; bb.gy = gy;
     bb.ranges = img.ranges; bb.point_list = bin.point_list; bb.rec = geom.rec; bb.bg = background;
     bb.final_T = img.final_T; bb.n_contrib = img.n_contrib; bb.dL_dpix = dL_dout_color; bb.dL_dothers = dL_dout_others;
+    bb.tile_map = img.tile_map; bb.map_len = tile_map_len(gx, gy);      // the forward's tile order (its lists are the backward's lists)
     bb.grec = grec; bb.cut = cut; bb.depths = geom.depths; bb.variant = opt_variant; bb.stats = g_blend_stats; bb.totals = img.total;
     if (R > 0) {
         WalkTuner* tuner = nullptr;

@@ -205,7 +205,8 @@ __global__ void __launch_bounds__(BLOCK, ROWS_WAVES) blend_bwd_rows_kernel(Blend
 #ifdef ROWS_TIMING
     const long long tm_start = __builtin_readcyclecounter();
 #endif
-    const int tile = xcd_tile(blockIdx.x, a.gx * a.gy);
+    const int tile = a.tile_map[blockIdx.x];
+    if (tile < 0) return;
     const int tx = tile % a.gx, ty = tile / a.gx;
     int lx, ly, sub;
     thread_pixel(threadIdx.x, lx, ly, sub);
@@ -393,7 +394,8 @@ __global__ void __launch_bounds__(BLOCK) blend_bwd_quad_kernel(BlendBwdArgs a) {
     __shared__ int s_quadlast[4];                    // per quad (= wave): the largest `last` of its 64 pixels
     __shared__ int s_max;
     if (a.variant == 2 && auto_picks_rows(a)) return;
-    const int tile = xcd_tile(blockIdx.x, a.gx * a.gy);
+    const int tile = a.tile_map[blockIdx.x];
+    if (tile < 0) return;
     const int tx = tile % a.gx, ty = tile / a.gx;
     int lx, ly, sub;
     thread_pixel(threadIdx.x, lx, ly, sub);
@@ -496,7 +498,7 @@ __global__ void __launch_bounds__(BLOCK) blend_bwd_quad_kernel(BlendBwdArgs a) {
 }
 
 void launch_blend_bwd(const BlendBwdArgs& a, hipStream_t s) {
-    const dim3 grid(a.gx * a.gy), block(BLOCK);
+    const dim3 grid(a.map_len), block(BLOCK);
     if (a.variant == 3) { launch_blend_bwd_scan(a, s); return; }
     if (a.variant != 1) {
         if (a.stats) hipLaunchKernelGGL(blend_bwd_rows_kernel<true>, grid, block, 0, s, a);

@@ -97,7 +97,8 @@ __global__ void __launch_bounds__(BLOCK, SCAN_MIN_WG) blend_bwd_scan_kernel(Blen
     long long tm_stage = 0, tm_walk = 0, tm_bar1 = 0, tm_flush = 0, tm_bar2 = 0, tm_rec = 0, tm_t = tm_start;
 #endif
     const int tid = threadIdx.x;
-    const int tile = xcd_tile(blockIdx.x, a.gx * a.gy);
+    const int tile = a.tile_map[blockIdx.x];
+    if (tile < 0) return;
     const int tx = tile % a.gx, ty = tile / a.gx;
     int lx, ly, sub;
     thread_pixel(tid, lx, ly, sub);
@@ -348,7 +349,7 @@ __global__ void __launch_bounds__(BLOCK, SCAN_MIN_WG) blend_bwd_scan_kernel(Blen
 }
 
 void launch_blend_bwd_scan(const BlendBwdArgs& a, hipStream_t s) {
-    const dim3 grid(a.gx * a.gy), block(BLOCK);
+    const dim3 grid(a.map_len), block(BLOCK);
     if (a.stats) hipLaunchKernelGGL(blend_bwd_scan_kernel<true>, grid, block, 0, s, a);
     else hipLaunchKernelGGL(blend_bwd_scan_kernel<false>, grid, block, 0, s, a);
 }

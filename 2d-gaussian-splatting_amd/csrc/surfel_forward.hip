@@ -20,7 +20,8 @@ template <bool STATS>
 __global__ void __launch_bounds__(BLOCK) blend_fwd_kernel(BlendFwdArgs a) {
     __shared__ float4 s_rec[BLOCK * 5];
     __shared__ __attribute__((aligned(8))) uint32_t s_mask[16 * MSTRIDE];    // [sub-tile][word]
-    const int tile = xcd_tile(blockIdx.x, a.gx * a.gy);
+    const int tile = a.tile_map[blockIdx.x];      // (tile_order_kernel: XCD-contiguous runs on uniform frames, longest lists first otherwise)
+    if (tile < 0) return;
     const int tx = tile % a.gx, ty = tile / a.gx;
     int lx, ly, sub;
     thread_pixel(threadIdx.x, lx, ly, sub);
@@ -126,8 +127,8 @@ __global__ void __launch_bounds__(BLOCK) blend_fwd_kernel(BlendFwdArgs a) {
 }
 
 void launch_blend_fwd(const BlendFwdArgs& a, hipStream_t s) {
-    if (a.stats) hipLaunchKernelGGL(blend_fwd_kernel<true>, dim3(a.gx * a.gy), dim3(BLOCK), 0, s, a);
-    else hipLaunchKernelGGL(blend_fwd_kernel<false>, dim3(a.gx * a.gy), dim3(BLOCK), 0, s, a);
+    if (a.stats) hipLaunchKernelGGL(blend_fwd_kernel<true>, dim3(a.map_len), dim3(BLOCK), 0, s, a);
+    else hipLaunchKernelGGL(blend_fwd_kernel<false>, dim3(a.map_len), dim3(BLOCK), 0, s, a);
 }
 
 }  // namespace surfel

@@ -352,6 +352,72 @@ __global__ void __launch_bounds__(256) emit_instances_kernel(int P, float* rec, 
 }
 
 // ---------------------------------------------------------------------------------------------
+// tile_order: which tile every blend workgroup takes (BlendFwdArgs / BlendBwdArgs::tile_map).
+// Uniform frames (random splats): workgroup b -> xcd_tile(b): every XCD (b % 8) walks a contiguous run of tiles, neighbours share
+// surfel records in its private L2.  Object-centred / trained frames break both assumptions behind that: a few hundred tiles hold
+// lists of thousands of instances while most hold none, so (a) the XCDs that own the image's middle rows do most of the work and
+// (b) the heaviest tiles, started last, run alone at one wave per SIMD — measured on the trained leg: blend_bwd at 0.25 of the VALU
+// issue peak against 0.47 (C2) and 0.61 (C4) on random frames (profiles/r03_trained_roofline.md).  For such frames the tiles are
+// handed out longest-first and dealt round-robin over the XCDs: groups of 4 horizontally adjacent tiles (they still share records)
+// are bucketed by the length class of their lists, the buckets are laid out from the longest class down, and sorted group k goes
+// to XCD k % 8 — workgroup b = (i << 3) | xcd takes tile (i % 4) of sorted group (i / 4) * 8 + xcd.  Which frame is which is decided
+// here, on the device, from the lists themselves.  The map only schedules: results do not depend on it.
+// One workgroup; the map holds 32 * ceil(groups / 8) entries, -1 = no tile.
+// ---------------------------------------------------------------------------------------------
+constexpr int TO_CLASSES = 24;
+__device__ __forceinline__ int len_class(uint32_t len) { return len < 16u ? 0 : min(TO_CLASSES - 1, 32 - __clz(len >> 4)); }
+
+__global__ void __launch_bounds__(1024) tile_order_kernel(const uint2* __restrict__ ranges, int gx, int gy, int* __restrict__ map, int map_len,
+                                                          int force) {
+    __shared__ uint32_t s_cnt[TO_CLASSES], s_off[TO_CLASSES], s_xw[8], s_max, s_uniform;
+    const int n = gx * gy, ggx = (gx + 3) >> 2, G = ggx * gy;
+    const int tid = threadIdx.x;
+    if (tid < TO_CLASSES) s_cnt[tid] = 0u;
+    if (tid < 8) s_xw[tid] = 0u;
+    if (tid == 0) s_max = 0u;
+    __syncthreads();
+    const int q = n >> 3, r = n & 7;      // xcd_tile's runs: XCD x owns q + 1 tiles if x < r, else q
+    for (int g = tid; g < G; g += 1024) {
+        const int ty = g / ggx, tx0 = (g - ty * ggx) << 2;
+        uint32_t len4 = 0;
+        for (int j = 0; j < 4 && tx0 + j < gx; j++) {
+            const int t = ty * gx + tx0 + j;
+            const uint2 rg = ranges[t];
+            const uint32_t len = rg.y - rg.x;
+            len4 += len;
+            const int x = t < r * (q + 1) ? t / (q + 1) : r + (q > 0 ? (t - r * (q + 1)) / q : 0);
+            atomicAdd(&s_xw[min(x, 7)], len);
+            atomicMax(&s_max, len);
+        }
+        atomicAdd(&s_cnt[len_class(len4)], 1u);
+    }
+    __syncthreads();
+    if (tid == 0) {
+        unsigned long long total = 0, mx = 0;
+        for (int x = 0; x < 8; x++) { total += s_xw[x]; mx = mx > s_xw[x] ? mx : s_xw[x]; }
+        // uniform: the busiest XCD holds at most 15 % more than its share and no list is longer than 4 average lists
+        const bool uniform = total == 0 || (mx * 8ull * 100ull <= total * 115ull && (unsigned long long)s_max * n <= 4ull * total);
+        s_uniform = force == 1 ? 1u : (force == 2 ? 0u : (uniform ? 1u : 0u));
+        uint32_t run = 0;
+        for (int c = TO_CLASSES - 1; c >= 0; c--) { s_off[c] = run; run += s_cnt[c]; }
+    }
+    __syncthreads();
+    if (s_uniform) {
+        for (int b = tid; b < map_len; b += 1024) map[b] = b < n ? xcd_tile(b, n) : -1;
+        return;
+    }
+    for (int b = tid; b < map_len; b += 1024) map[b] = -1;
+    __syncthreads();
+    for (int g = tid; g < G; g += 1024) {
+        const int ty = g / ggx, tx0 = (g - ty * ggx) << 2;
+        uint32_t len4 = 0;
+        for (int j = 0; j < 4 && tx0 + j < gx; j++) { const uint2 rg = ranges[ty * gx + tx0 + j]; len4 += rg.y - rg.x; }
+        const uint32_t k = atomicAdd(&s_off[len_class(len4)], 1u);
+        for (int j = 0; j < 4 && tx0 + j < gx; j++) map[((((k >> 3) << 2) + j) << 3) | (k & 7u)] = ty * gx + tx0 + j;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // tile_ranges: boundaries of each tile's run in the sorted tile-id list (ranges pre-zeroed).
 // ---------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) tile_ranges_kernel(int64_t R, const uint32_t* __restrict__ keys, uint2* __restrict__ ranges) {
@@ -808,6 +874,10 @@ __global__ void __launch_bounds__(256) tile_ranges_devn_kernel(const uint32_t* _
 }
 void launch_tile_ranges_devn(size_t cap, const uint32_t* n_dev, const uint32_t* keys, uint2* ranges, hipStream_t s) {
     if (cap > 0) hipLaunchKernelGGL(tile_ranges_devn_kernel, dim3((unsigned)((cap + 255) / 256)), dim3(256), 0, s, n_dev, (uint32_t)cap, keys, ranges);
+}
+int tile_map_len(int gx, int gy) { return 32 * ((((gx + 3) >> 2) * gy + 7) / 8); }
+void launch_tile_order(const uint2* ranges, int gx, int gy, int* map, int force, hipStream_t s) {
+    hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(1024), 0, s, ranges, gx, gy, map, tile_map_len(gx, gy), force);
 }
 void launch_tile_ranges(int64_t R, const uint32_t* keys, uint2* ranges, hipStream_t s) {
     if (R > 0) hipLaunchKernelGGL(tile_ranges_kernel, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, s, R, keys, ranges);

@@ -37,6 +37,11 @@ OPT_ZERO_RECORDS = 1 << 18     # backward: zero gradient records behind a tile's
 OPT_BWD_SCAN = 1 << 15         # scan walk (lanes = instances); deterministic, not bit-identical to rows / quad
 
 
+def opt_tile_order(mode):
+    """per-call "tile_order" (0 auto, 1 XCD-contiguous, 2 longest lists first) in the debug word (SURFEL_OPT_TILE_ORDER)"""
+    return ((int(mode) + 1) & 3) << 19
+
+
 def opt_tile_sort(mode):
     return ((mode + 1) & 3) << 9
 

@@ -47,6 +47,7 @@ extern "C" {
 #define SURFEL_OPT_EXACT_BINNING  (1 << 16)            /* forward: "capacity_binning" = 0 for this call (binning buffers sized after a host wait for the instance count) */
 #define SURFEL_OPT_TILE_CUTS      (1 << 17)            /* backward: no gradient records behind a tile's saturation point, preprocess_bwd tests the tile cuts (default: R >= 2^21) */
 #define SURFEL_OPT_ZERO_RECORDS   (1 << 18)            /* backward: zero records behind a tile's saturation point (default: R < 2^21); bit-identical to the cuts */
+#define SURFEL_OPT_TILE_ORDER(m)  ((((m) + 1) & 3) << 19)  /* forward: "tile_order" = m (0, 1, 2) for this call (the matching backward follows the forward) */
 #define SURFEL_OPT_BWD_SCAN       (1 << 15)            /* backward: scan walk ("bwd_variant" = 3) for this call; deterministic, NOT bit-identical to rows / quad */
 
 /* Allocator callback: return a device pointer to `bytes` bytes, 256-byte aligned, valid until the
@@ -168,6 +169,13 @@ int surfel_debug_sort_pairs(surfel_alloc_fn scratch_alloc, void* scratch_user, u
  *          the faster walk per tile instance is launched alone in between; 0: both kernels are launched every call and the device decides from the frame's
  *          totals (rows iff tile instances <= 4 x emitting surfels) — also what happens before both walks have been timed and
  *          while the stream is being captured into a graph.
+ *   "tile_order" (default 0): which tile every blend workgroup takes.  1: workgroup b -> XCD b % 8 walks a contiguous run of tiles
+ *          (neighbouring tiles share surfel records in that XCD's L2) — right for frames whose tiles hold similar lists; 2: groups of
+ *          4 adjacent tiles, longest lists first, dealt round-robin over the XCDs — right for object-centred / trained frames, where a
+ *          few hundred tiles hold lists of thousands of instances (the trained leg's blend kernels ran at 0.25 of the VALU issue peak
+ *          with order 1: the XCDs owning the image's middle rows did the work, the heaviest tiles finished alone); 0: decided per
+ *          frame on the device from the lists (busiest XCD > 1.15x its share, or a list > 4 average lists -> 2).  Scheduling only:
+ *          results are bit-identical (tests/test_gpu_parity.py::test_tile_order_is_scheduling_only).
  *   "capacity_binning" (default 1): frames on the per-tile-depth-sort path with <= 2^20 tile instances size their binning buffers
  *          from the largest instance count recent frames of the same size produced (+ 1/8 head room) instead of waiting for this
  *          frame's count in the middle of the forward: scan, emission and the tile sort's histograms run as ONE kernel right behind

@@ -443,6 +443,60 @@ def test_heavy_surfels_are_gathered_by_the_wave():
         assert f >= 0.985 and cs >= 0.99999, "%s: %.5f of elements within tolerance, cosine %.8f" % (k, f, cs)
 
 
+def _clustered_scene(P=30000, W=400, H=304, seed=17, shrink=0.3):
+    """Surfels pulled towards the view axis: the image's centre tiles hold long lists, most tiles none (an object-centred frame)."""
+    import synthetic
+    sc = synthetic.make_scene(P, W, H, seed=seed, px_radius=6.0, z_near=2.0, z_far=8.0)
+    V = sc["viewmatrix"].astype(np.float64)                      # row-vector convention: p_view = [p, 1] @ V
+    pv = np.concatenate([sc["means3D"].astype(np.float64), np.ones((P, 1))], 1) @ V
+    pv[:, :2] *= shrink
+    sc["means3D"] = (pv @ np.linalg.inv(V))[:, :3].astype(np.float32)
+    sc["opacities"] = np.full_like(sc["opacities"], 0.15)        # faint: long lists are walked to their end
+    return sc
+
+
+@pytest.mark.parametrize("kind", ["clustered", "uniform"])
+def test_tile_order_is_scheduling_only(kind):
+    """Which tile a blend workgroup takes (tile_order_kernel: XCD-contiguous runs | groups of 4 tiles, longest lists first, round-robin
+    over the XCDs | decided per frame on the device) only schedules: images and gradients BIT-IDENTICAL under all three settings and
+    every backward walk; the device picks the longest-first order for the clustered frame and the contiguous one for the uniform frame
+    (white box: the map at the end of the image buffer)."""
+    import surfel_native as n
+    sc = _clustered_scene() if kind == "clustered" else _scene((30000, 400, 304), seed=17, px_radius=4.0)
+    a = scene_args(sc)
+    rng = np.random.default_rng(6)
+    gC = rng.normal(size=(3, a["H"], a["W"])).astype(np.float32); gO = rng.normal(size=(7, a["H"], a["W"])).astype(np.float32)
+    gx, gy = (a["W"] + 15) // 16, (a["H"] + 15) // 16
+    map_len = 32 * ((((gx + 3) // 4) * gy + 7) // 8)
+    res, maps = [], []
+    for mode in (1, 2, 0):
+        run = HipRun(a, debug=n.opt_tile_order(mode)).forward()
+        buf = run.ia.last()
+        maps.append(None)
+        img = (run.color.cpu().numpy(), run.others.cpu().numpy(), run.radii.cpu().numpy(), run.R)
+        gs = []
+        for walk in (n.OPT_BWD_ROWS, n.OPT_BWD_QUAD, n.OPT_BWD_SCAN):
+            run.debug = walk
+            gs.append(run.backward(gC, gO))
+        # the map: last allocation of the image buffer (ImgState::carve), 256-B aligned
+        al = lambda v: (v + 255) // 256 * 256
+        off = al(al(al((gx * gy + 64 + 1) * 8) + 12 * a["W"] * a["H"]) + 8 * a["W"] * a["H"])
+        tm = buf[off:off + 4 * map_len].view(run.torch.int32).cpu().numpy()
+        assert sorted(tm[tm >= 0].tolist()) == list(range(gx * gy)), "the map must hold every tile exactly once"
+        maps[-1] = tm
+        res.append((img, gs))
+    (i0, g0) = res[0]
+    for (i1, g1) in res[1:]:
+        assert i0[3] == i1[3] and all(np.array_equal(x, y) for x, y in zip(i0[:3], i1[:3])), "images differ with the tile order"
+        for ga, gb in zip(g0, g1):
+            for k in ga:
+                assert np.array_equal(ga[k], gb[k]), "dL/d%s differs with the tile order" % k
+    contiguous, balanced, auto = maps
+    assert not np.array_equal(contiguous, balanced)
+    # (the longest-first order places groups of one length class with atomics: only its being chosen is checked, not its entries)
+    assert np.array_equal(auto, contiguous) == (kind == "uniform"), "device-side choice for the %s frame" % kind
+
+
 def test_capacity_binning_is_identical():
     """Capacity binning (binning buffers sized from the previous frames' instance counts, fused scan + emission + histogram kernel,
     sort passes / tile ranges with the count on the device, no host wait in the middle of the forward) against the exact-size path:
