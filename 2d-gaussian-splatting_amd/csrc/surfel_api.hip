@@ -633,12 +633,16 @@ int surfel_rasterize_backward(surfel_alloc_fn scratch_alloc, void* scratch_user,
     // per-instance gradient records: blend_bwd writes the record of every instance up to its tile's cut exactly once (no memset, no
     // atomics); the cuts (8 B per tile) sit behind the records
     const size_t grec_bytes = align_up((size_t)(R > 0 ? R : 1) * GREC_F * sizeof(float));
-    float* grec = static_cast<float*>(scratch_alloc(scratch_user, grec_bytes + (size_t)gx * gy * sizeof(uint2)));
+    const size_t cut_bytes = align_up((size_t)gx * gy * sizeof(uint2));
+    float* grec = static_cast<float*>(scratch_alloc(scratch_user, grec_bytes + cut_bytes + (size_t)P));
     if (!grec) return fail(SURFEL_E_ALLOC, "gradient record allocation failed");
     // tile cuts instead of zero records: only where the records that are never written are worth a test in front of every fetch
     // (measured: +17 us on preprocess_bwd at 0.5 M instances / 1.7 per surfel, -4 % on blend_bwd and preprocess_bwd at 8 M / 4 per surfel)
     const bool use_cut = (debug_in & SURFEL_OPT_TILE_CUTS) ? true : ((debug_in & SURFEL_OPT_ZERO_RECORDS) ? false : R >= ((int64_t)1 << 21));
     uint2* cut = use_cut ? reinterpret_cast<uint2*>(reinterpret_cast<char*>(grec) + grec_bytes) : nullptr;
+    // ... and one byte per surfel "has a record at all" (crowded frames stage a few per cent of their instances: most surfels none)
+    uint8_t* has_rec = use_cut ? reinterpret_cast<uint8_t*>(grec) + grec_bytes + cut_bytes : nullptr;
+    if (has_rec) HIP_TRY(hipMemsetAsync(has_rec, 0, (size_t)P, s));
     StageTimer tm(debug, s);
 
     BlendBwdArgs bb{};
@@ -646,7 +650,7 @@ int surfel_rasterize_backward(surfel_alloc_fn scratch_alloc, void* scratch_user,
     bb.ranges = img.ranges; bb.point_list = bin.point_list; bb.rec = geom.rec; bb.bg = background;
     bb.final_T = img.final_T; bb.n_contrib = img.n_contrib; bb.dL_dpix = dL_dout_color; bb.dL_dothers = dL_dout_others;
     bb.tile_map = img.tile_map; bb.map_len = tile_map_len(gx, gy);      // the forward's tile order (its lists are the backward's lists)
-    bb.grec = grec; bb.cut = cut; bb.depths = geom.depths; bb.variant = opt_variant; bb.stats = g_blend_stats; bb.totals = img.total;
+    bb.grec = grec; bb.cut = cut; bb.has_rec = has_rec; bb.depths = geom.depths; bb.variant = opt_variant; bb.stats = g_blend_stats; bb.totals = img.total;
     if (R > 0) {
         WalkTuner* tuner = nullptr;
         int probe = -1;
@@ -673,7 +677,7 @@ int surfel_rasterize_backward(surfel_alloc_fn scratch_alloc, void* scratch_user,
     pb.coop = (debug_in & SURFEL_OPT_PBWD_COOP) ? 1 : ((debug_in & SURFEL_OPT_PBWD_THREAD) ? 0 : ((R >= (int64_t)6 * P && R >= ((int64_t)32 << 20)) ? 1 : 0));
     pb.means3D = means3D; pb.radii = radii; pb.shs = shs; pb.clamped = geom.clamped; pb.scales = scales; pb.rotations = rotations;
     pb.transMat_precomp = transMat_precomp; pb.viewmatrix = viewmatrix; pb.projmatrix = projmatrix; pb.campos = cam_pos;
-    pb.rec = geom.rec; pb.tiles_touched = geom.tiles_touched; pb.grec = grec; pb.cut = cut; pb.depths = geom.depths; pb.gx = gx;
+    pb.rec = geom.rec; pb.tiles_touched = geom.tiles_touched; pb.grec = grec; pb.cut = cut; pb.has_rec = has_rec; pb.depths = geom.depths; pb.gx = gx;
     pb.dL_dtransMat = dL_dtransMat; pb.dL_dnormal = dL_dnormal; pb.dL_dopacity = dL_dopacity; pb.dL_dcolors = dL_dcolors;
     pb.dL_dsh = dL_dsh; pb.dL_dmeans2D = dL_dmeans2D; pb.dL_dmeans3D = dL_dmeans3D; pb.dL_dscales = dL_dscales; pb.dL_drots = dL_drots;
     tm.begin();

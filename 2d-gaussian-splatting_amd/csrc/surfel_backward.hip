@@ -249,6 +249,7 @@ __global__ void __launch_bounds__(BLOCK, ROWS_WAVES) blend_bwd_rows_kernel(Blend
                 const int pos = hi - (int)threadIdx.x;
                 const uint32_t id = a.point_list[range.x + pos - 1];
                 const float4* __restrict__ src = reinterpret_cast<const float4*>(a.rec + (size_t)id * REC_F);
+                if (a.has_rec) a.has_rec[id] = 1;      // every staged instance gets a record (finish_tail)
                 const float4 v0 = src[0], v1 = src[1], v2 = src[2], v3 = src[3], v4 = src[4], v5 = src[5], v6 = src[6];
                 s_rec[threadIdx.x * 5 + 0] = v0; s_rec[threadIdx.x * 5 + 1] = v1; s_rec[threadIdx.x * 5 + 2] = v2;
                 s_rec[threadIdx.x * 5 + 3] = v3; s_rec[threadIdx.x * 5 + 4] = v4;
@@ -424,6 +425,7 @@ __global__ void __launch_bounds__(BLOCK) blend_bwd_quad_kernel(BlendBwdArgs a) {
             if ((int)threadIdx.x < mb) {
                 const uint32_t id = a.point_list[range.x + (hi - threadIdx.x) - 1];
                 const float4* __restrict__ src = reinterpret_cast<const float4*>(a.rec + (size_t)id * REC_F);
+                if (a.has_rec) a.has_rec[id] = 1;
                 const float4 v0 = src[0], v1 = src[1], v2 = src[2], v3 = src[3], v4 = src[4], v5 = src[5], v6 = src[6];
                 s_rec[threadIdx.x * 5 + 0] = v0; s_rec[threadIdx.x * 5 + 1] = v1; s_rec[threadIdx.x * 5 + 2] = v2;
                 s_rec[threadIdx.x * 5 + 3] = v3; s_rec[threadIdx.x * 5 + 4] = v4;

@@ -141,6 +141,7 @@ __global__ void __launch_bounds__(BLOCK, SCAN_MIN_WG) blend_bwd_scan_kernel(Blen
         if (ft < min(SB, maxc)) {
             const uint32_t id = a.point_list[range.x + (maxc - ft) - 1];
             const float4* __restrict__ src = recq + (size_t)id * REC_Q;
+            if (a.has_rec && fh == 0) a.has_rec[id] = 1;      // every staged instance gets a record (finish_tail)
             if (fh == 0) { pa = src[0]; pb = src[1]; pc = src[3]; pd = src[4]; } else { pa = src[2]; pb = src[5]; pc = src[6]; }
         }
         if (maxc - SB > 0 && ft < min(SB, maxc - SB)) nid = a.point_list[range.x + (maxc - SB - ft) - 1];
@@ -173,6 +174,7 @@ __global__ void __launch_bounds__(BLOCK, SCAN_MIN_WG) blend_bwd_scan_kernel(Blen
             const float4* __restrict__ recq = reinterpret_cast<const float4*>(a.rec);
             if (ft < min(SB, hi - SB)) {
                 const float4* __restrict__ src = recq + (size_t)nid * REC_Q;
+                if (a.has_rec && fh == 0) a.has_rec[nid] = 1;
                 if (fh == 0) { pa = src[0]; pb = src[1]; pc = src[3]; pd = src[4]; } else { pa = src[2]; pb = src[5]; pc = src[6]; }
             }
             if (hi - 2 * SB > 0 && ft < min(SB, hi - 2 * SB)) nid = a.point_list[range.x + (hi - 2 * SB - ft) - 1];

@@ -37,6 +37,7 @@ struct BlendBwdArgs {
     const float* dL_dpix; const float* dL_dothers;
     float* grec;      // [R][GREC_F] per-instance gradient records: the records of a tile's list positions <= its cut are written exactly once, the rest never
     uint2* cut;       // [tiles] (depth bits, surfel index + 1) of the last instance of every tile that has a record, or NULL: every instance gets a record (surfel_blend_bwd.h: finish_tail)
+    uint8_t* has_rec;      // with cut: [P] zeroed by the caller; set for every surfel that gets at least one record (preprocess_bwd skips the others)
     const float* depths;   // [P] view depths (the sort key's source)
     int variant;      // 0: per-DPP-row walk, 1: per-wave (8x8 quad) walk, 2: both launched, the device picks from the frame's totals (0 / 1 / 2 bit-identical); 3: scan walk
     const uint32_t* totals;      // [2 * R_SLOTS] partial sums written by preprocess: tile instances | visible surfels
@@ -52,7 +53,7 @@ struct PreprocessBwdArgs {
     const float* scales; const float* rotations; const float* transMat_precomp;
     const float* viewmatrix; const float* projmatrix; const float* campos;
     const float* rec; const uint32_t* tiles_touched; const float* grec;
-    const uint2* cut; const float* depths; int gx;      // which of a surfel's instance records exist (BlendBwdArgs::cut); cut == NULL: all of them
+    const uint2* cut; const uint8_t* has_rec; const float* depths; int gx;      // which of a surfel's instance records exist (BlendBwdArgs::cut); cut == NULL: all of them
     float* dL_dtransMat; float* dL_dnormal; float* dL_dopacity; float* dL_dcolors; float* dL_dsh;
     float* dL_dmeans2D; float* dL_dmeans3D; float* dL_dscales; float* dL_drots;
 };

@@ -497,7 +497,7 @@ __global__ void __launch_bounds__(256) preprocess_bwd_kernel(PreprocessBwdArgs a
     {
         const int lane = threadIdx.x & 63;
         uint32_t hb = 0, hc = 0, hd = 0, hr = 0;
-        if (i < a.P && a.radii[i] > 0) {
+        if (i < a.P && a.radii[i] > 0 && (!CUT || a.has_rec[i])) {      // (CUT: a surfel no tile staged has no record at all)
             hc = a.tiles_touched[i];
             if (hc > HEAVY_MIN) {
                 hb = __float_as_uint(a.rec[(size_t)i * REC_F + 18]);
@@ -546,7 +546,7 @@ __global__ void __launch_bounds__(256) preprocess_bwd_kernel(PreprocessBwdArgs a
     if (COOP) {
         const int lane = threadIdx.x & 63, wbase = threadIdx.x & ~63;
         uint32_t beg = 0, cnt = 0, dbits = 0, rbits = 0;
-        if (i < a.P && a.radii[i] > 0 && !heavy) {
+        if (i < a.P && a.radii[i] > 0 && !heavy && (!CUT || a.has_rec[i])) {
             beg = __float_as_uint(a.rec[(size_t)i * REC_F + 18]);          // q4.z: inst_base patched by emit_instances
             rbits = __float_as_uint(a.rec[(size_t)i * REC_F + 19]);        // q4.w: emitted tile rect
             cnt = a.tiles_touched[i];
@@ -646,6 +646,7 @@ __global__ void __launch_bounds__(256) preprocess_bwd_kernel(PreprocessBwdArgs a
         g[16] = v4.x; g[17] = v4.y;
     } else if (!heavy) {
     if (CUT) {
+        if (a.has_rec[i]) {
         RecWalk rw;
         rw.init(__float_as_uint(a.depths[i]), (uint32_t)i, __float_as_uint(r4.w), a.gx);
         uint32_t k = beg;
@@ -666,6 +667,7 @@ __global__ void __launch_bounds__(256) preprocess_bwd_kernel(PreprocessBwdArgs a
             const float4* __restrict__ src = reinterpret_cast<const float4*>(a.grec + (size_t)k * GREC_F);
             const float4 v0 = src[0], v1 = src[1], v2 = src[2], v3 = src[3], v4 = src[4];
             add_rec(v0, v1, v2, v3, v4);
+        }
         }
     } else {
         uint32_t k = beg;
@@ -896,8 +898,10 @@ __global__ void __launch_bounds__(256) colour_gradients_kernel(PreprocessBwdArgs
         const uint32_t beg = __float_as_uint(a.rec[(size_t)i * REC_F + 18]);
         const uint32_t end = beg + a.tiles_touched[i];
         RecWalk rw;
+        bool end_skip = false;
         rw.init(__float_as_uint(a.depths[i]), (uint32_t)i, __float_as_uint(a.rec[(size_t)i * REC_F + 19]), a.gx);
-        for (uint32_t k = beg; k < end; k++, rw.next()) {
+        if (a.cut && !a.has_rec[i]) end_skip = true;
+        for (uint32_t k = beg; k < end && !end_skip; k++, rw.next()) {
             if (a.cut && !rw.has_record(a.cut)) continue;
             const float* __restrict__ src = a.grec + (size_t)k * GREC_F;
             const float v0 = src[15];
