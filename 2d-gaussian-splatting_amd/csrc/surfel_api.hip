@@ -503,12 +503,12 @@ int64_t surfel_rasterize_forward(surfel_alloc_fn geom_alloc, void* geom_user, su
             tm.begin();
             launch_tile_depth_sort(gx * gy, ce->maxR, img.ranges, bin.point_list, geom.dkey_a, bin.vals_alt, bin.keys_a, bin.keys_b, s);
             STAGE_END(tm, ST_TSORT);
-            launch_tile_order(img.ranges, gx, gy, img.tile_map, opt_tile_order, s);
+            launch_tile_order(img.ranges, gx, gy, img.tile_map, img.total + 2 * R_SLOTS + 1, opt_tile_order, s);
             BlendFwdArgs ba{};
             ba.W = width; ba.H = height; ba.gx = gx; ba.gy = gy;
             ba.ranges = img.ranges; ba.point_list = bin.point_list; ba.rec = geom.rec; ba.bg = background;
             ba.out_color = out_color; ba.out_others = out_others; ba.final_T = img.final_T; ba.n_contrib = img.n_contrib;
-            ba.tile_map = img.tile_map; ba.map_len = map_len;
+            ba.tile_map = img.tile_map; ba.map_flag = img.total + 2 * R_SLOTS + 1; ba.map_len = map_len;
             ba.stats = g_blend_stats;
             tm.begin();
             launch_blend_fwd(ba, s);
@@ -588,12 +588,12 @@ int64_t surfel_rasterize_forward(surfel_alloc_fn geom_alloc, void* geom_user, su
         bin = BinState::carve(bin_base, 0, 0, nullptr);
     }
 
-    launch_tile_order(img.ranges, gx, gy, img.tile_map, opt_tile_order, s);
+    launch_tile_order(img.ranges, gx, gy, img.tile_map, img.total + 2 * R_SLOTS + 1, opt_tile_order, s);
     BlendFwdArgs ba{};
     ba.W = width; ba.H = height; ba.gx = gx; ba.gy = gy;
     ba.ranges = img.ranges; ba.point_list = bin.point_list; ba.rec = geom.rec; ba.bg = background;
     ba.out_color = out_color; ba.out_others = out_others; ba.final_T = img.final_T; ba.n_contrib = img.n_contrib;
-    ba.tile_map = img.tile_map; ba.map_len = map_len;
+    ba.tile_map = img.tile_map; ba.map_flag = img.total + 2 * R_SLOTS + 1; ba.map_len = map_len;
     ba.stats = g_blend_stats;
     tm.begin();
     launch_blend_fwd(ba, s);
@@ -649,7 +649,7 @@ int surfel_rasterize_backward(surfel_alloc_fn scratch_alloc, void* scratch_user,
     bb.W = width; bb.H = height; bb.gx = gx; bb.gy = gy;
     bb.ranges = img.ranges; bb.point_list = bin.point_list; bb.rec = geom.rec; bb.bg = background;
     bb.final_T = img.final_T; bb.n_contrib = img.n_contrib; bb.dL_dpix = dL_dout_color; bb.dL_dothers = dL_dout_others;
-    bb.tile_map = img.tile_map; bb.map_len = tile_map_len(gx, gy);      // the forward's tile order (its lists are the backward's lists)
+    bb.tile_map = img.tile_map; bb.map_flag = img.total + 2 * R_SLOTS + 1; bb.map_len = tile_map_len(gx, gy);      // the forward's tile order (its lists are the backward's lists)
     bb.grec = grec; bb.cut = cut; bb.has_rec = has_rec; bb.depths = geom.depths; bb.variant = opt_variant; bb.stats = g_blend_stats; bb.totals = img.total;
     if (R > 0) {
         WalkTuner* tuner = nullptr;

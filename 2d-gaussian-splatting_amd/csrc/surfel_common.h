@@ -108,6 +108,13 @@ __device__ __forceinline__ int xcd_tile(int b, int n) {
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + i;
 }
 
+// The tile a blend workgroup takes: the frame's longest-first map where tile_order_kernel wrote one (surfel_preprocess.hip), the
+// XCD-contiguous order otherwise; -1: none (the grid covers the map's length).
+__device__ __forceinline__ int block_tile(const int* __restrict__ map, const uint32_t* __restrict__ map_flag, int b, int n) {
+    if (map_flag[0] != 0u) return map[b];
+    return b < n ? xcd_tile(b, n) : -1;
+}
+
 // ---- footprint culling ---------------------------------------------------------------------------
 // The pixels a surfel can touch with alpha >= 1/255 lie inside  E U D :  E = the projected sqrt(rmax)-sigma ellipse
 // {d = p - e : d^T S^-1 d <= 1} (rho3d <= rmax), D = the low-pass disc (rho2d <= rmax), both inflated for fp32

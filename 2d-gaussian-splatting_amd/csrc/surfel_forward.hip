@@ -20,7 +20,7 @@ template <bool STATS>
 __global__ void __launch_bounds__(BLOCK) blend_fwd_kernel(BlendFwdArgs a) {
     __shared__ float4 s_rec[BLOCK * 5];
     __shared__ __attribute__((aligned(8))) uint32_t s_mask[16 * MSTRIDE];    // [sub-tile][word]
-    const int tile = a.tile_map[blockIdx.x];      // (tile_order_kernel: XCD-contiguous runs on uniform frames, longest lists first otherwise)
+    const int tile = block_tile(a.tile_map, a.map_flag, blockIdx.x, a.gx * a.gy);      // (tile_order_kernel: XCD-contiguous runs on uniform frames, longest lists first otherwise)
     if (tile < 0) return;
     const int tx = tile % a.gx, ty = tile / a.gx;
     int lx, ly, sub;

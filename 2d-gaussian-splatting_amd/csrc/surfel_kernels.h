@@ -25,7 +25,7 @@ struct BlendFwdArgs {
     int W, H, gx, gy;
     const uint2* ranges; const uint32_t* point_list; const float* rec; const float* bg;
     float* out_color; float* out_others; float* final_T; uint32_t* n_contrib;
-    const int* tile_map; int map_len;      // tile of every workgroup (tile_order_kernel; -1: none), and the grid size
+    const int* tile_map; const uint32_t* map_flag; int map_len;      // tile of every workgroup where map_flag[0] != 0 (tile_order_kernel; -1: none), xcd_tile order otherwise; the grid size
     unsigned long long* stats;   // optional [8]: [6] += (pixel, surfel) pairs composited (surfel_debug_set_blend_stats)
 };
 
@@ -33,7 +33,7 @@ struct BlendBwdArgs {
     int W, H, gx, gy;
     const uint2* ranges; const uint32_t* point_list; const float* rec; const float* bg;
     const float* final_T; const uint32_t* n_contrib;
-    const int* tile_map; int map_len;      // as BlendFwdArgs
+    const int* tile_map; const uint32_t* map_flag; int map_len;      // as BlendFwdArgs
     const float* dL_dpix; const float* dL_dothers;
     float* grec;      // [R][GREC_F] per-instance gradient records: the records of a tile's list positions <= its cut are written exactly once, the rest never
     uint2* cut;       // [tiles] (depth bits, surfel index + 1) of the last instance of every tile that has a record, or NULL: every instance gets a record (surfel_blend_bwd.h: finish_tail)
@@ -64,7 +64,7 @@ void launch_emit_instances(int P, float* rec, const uint32_t* rects, const uint3
 void launch_tile_ranges(int64_t R, const uint32_t* keys, uint2* ranges, hipStream_t s);
 int tile_map_len(int gx, int gy);
 // force: 0 decide on the device, 1 always the XCD-contiguous order, 2 always longest-first round-robin
-void launch_tile_order(const uint2* ranges, int gx, int gy, int* map, int force, hipStream_t s);
+void launch_tile_order(const uint2* ranges, int gx, int gy, int* map, uint32_t* map_flag /* zeroed */, int force, hipStream_t s);
 void launch_blend_fwd(const BlendFwdArgs& a, hipStream_t s);
 void launch_mark_visible(int P, const float* means3D, const float* vm, uint8_t* present, hipStream_t s);
 void launch_blend_bwd(const BlendBwdArgs& a, hipStream_t s);

@@ -364,57 +364,122 @@ __global__ void __launch_bounds__(256) emit_instances_kernel(int P, float* rec, 
 // here, on the device, from the lists themselves.  The map only schedules: results do not depend on it.
 // One workgroup; the map holds 32 * ceil(groups / 8) entries, -1 = no tile.
 // ---------------------------------------------------------------------------------------------
-constexpr int TO_CLASSES = 24;
+constexpr int TO_CLASSES = 24, TO_THREADS = 1024, TO_WAVES = TO_THREADS / 64;
 __device__ __forceinline__ int len_class(uint32_t len) { return len < 16u ? 0 : min(TO_CLASSES - 1, 32 - __clz(len >> 4)); }
 
-__global__ void __launch_bounds__(1024) tile_order_kernel(const uint2* __restrict__ ranges, int gx, int gy, int* __restrict__ map, int map_len,
-                                                          int force) {
-    __shared__ uint32_t s_cnt[TO_CLASSES], s_off[TO_CLASSES], s_xw[8], s_max, s_uniform;
+// map_flag[0] = 1 and map[] filled: longest-first order; map_flag[0] = 0: the blend kernels use xcd_tile (no map is written).
+// No same-address atomics anywhere (2 600 LDS atomics on 9 addresses made a first version of this kernel 14 us long): sums and maxima
+// go through wave shuffles, the per-XCD work through a block scan of the list lengths, the placement ranks through ballots.
+__global__ void __launch_bounds__(TO_THREADS) tile_order_kernel(const uint2* __restrict__ ranges, int gx, int gy, int* __restrict__ map, int map_len,
+                                                                uint32_t* __restrict__ map_flag, int force) {
+    __shared__ uint32_t s_wsum[TO_WAVES], s_wmax[TO_WAVES], s_bound[9], s_uniform;
+    __shared__ uint32_t s_cnt[TO_CLASSES], s_off[TO_CLASSES], s_wcnt[TO_WAVES][TO_CLASSES];
     const int n = gx * gy, ggx = (gx + 3) >> 2, G = ggx * gy;
-    const int tid = threadIdx.x;
-    if (tid < TO_CLASSES) s_cnt[tid] = 0u;
-    if (tid < 8) s_xw[tid] = 0u;
-    if (tid == 0) s_max = 0u;
-    __syncthreads();
-    const int q = n >> 3, r = n & 7;      // xcd_tile's runs: XCD x owns q + 1 tiles if x < r, else q
-    for (int g = tid; g < G; g += 1024) {
-        const int ty = g / ggx, tx0 = (g - ty * ggx) << 2;
-        uint32_t len4 = 0;
-        for (int j = 0; j < 4 && tx0 + j < gx; j++) {
-            const int t = ty * gx + tx0 + j;
-            const uint2 rg = ranges[t];
-            const uint32_t len = rg.y - rg.x;
-            len4 += len;
-            const int x = t < r * (q + 1) ? t / (q + 1) : r + (q > 0 ? (t - r * (q + 1)) / q : 0);
-            atomicAdd(&s_xw[min(x, 7)], len);
-            atomicMax(&s_max, len);
-        }
-        atomicAdd(&s_cnt[len_class(len4)], 1u);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // ---- 1. instances per XCD under the contiguous order, longest list: thread t owns tiles [t k, (t + 1) k)
+    const int k = (n + TO_THREADS - 1) / TO_THREADS;
+    const int q = n >> 3, r = n & 7;      // xcd_tile's runs: XCD x owns q + 1 tiles if x < r, else q; run x starts at tile B(x)
+    uint32_t sum = 0, mx = 0;
+    for (int j = 0; j < k; j++) {
+        const int t = tid * k + j;
+        if (t < n) { const uint2 rg = ranges[t]; const uint32_t len = rg.y - rg.x; sum += len; mx = max(mx, len); }
     }
+    uint32_t x = sum;                      // inclusive scan of the chunk sums over the workgroup
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const uint32_t y = __shfl_up(x, o); if (lane >= o) x += y; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, o));
+    if (lane == 63) s_wsum[wave] = x;
+    if (lane == 0) s_wmax[wave] = mx;
+    __syncthreads();
+    uint32_t pre = x - sum;                // instances of the tiles ahead of this thread's chunk
+    for (int w = 0; w < wave; w++) pre += s_wsum[w];
+    for (int j = 0; j < k; j++) {          // a chunk that holds the first tile of an XCD's run publishes the prefix there
+        const int t = tid * k + j;
+        if (t < n) {
+#pragma unroll
+            for (int xc = 0; xc < 8; xc++) {
+                const int B = xc < r ? xc * (q + 1) : r * (q + 1) + (xc - r) * q;
+                if (t == B) s_bound[xc] = pre;
+            }
+            const uint2 rg = ranges[t];
+            pre += rg.y - rg.x;
+        }
+    }
+    if (tid == TO_THREADS - 1) s_bound[8] = pre;      // (the last thread's running prefix ends at the total)
+    if (tid < TO_CLASSES) s_cnt[tid] = 0u;
     __syncthreads();
     if (tid == 0) {
-        unsigned long long total = 0, mx = 0;
-        for (int x = 0; x < 8; x++) { total += s_xw[x]; mx = mx > s_xw[x] ? mx : s_xw[x]; }
+        uint32_t total = 0, maxlen = 0;
+        for (int w = 0; w < TO_WAVES; w++) { total += s_wsum[w]; maxlen = max(maxlen, s_wmax[w]); }
+        uint32_t busiest = 0;
+        for (int xc = 0; xc < 8; xc++) {
+            const uint32_t lo = q == 0 && xc >= r ? total : s_bound[xc];
+            const uint32_t hi = xc == 7 ? total : (q == 0 && xc + 1 >= r ? total : s_bound[xc + 1]);
+            busiest = max(busiest, hi - lo);
+        }
         // uniform: the busiest XCD holds at most 15 % more than its share and no list is longer than 4 average lists
-        const bool uniform = total == 0 || (mx * 8ull * 100ull <= total * 115ull && (unsigned long long)s_max * n <= 4ull * total);
+        const bool uniform = total == 0u || ((unsigned long long)busiest * 800ull <= (unsigned long long)total * 115ull &&
+                                             (unsigned long long)maxlen * (unsigned long long)n <= 4ull * total);
         s_uniform = force == 1 ? 1u : (force == 2 ? 0u : (uniform ? 1u : 0u));
-        uint32_t run = 0;
-        for (int c = TO_CLASSES - 1; c >= 0; c--) { s_off[c] = run; run += s_cnt[c]; }
+        if (s_uniform) map_flag[0] = 0u;   // xcd_tile order
     }
     __syncthreads();
-    if (s_uniform) {
-        for (int b = tid; b < map_len; b += 1024) map[b] = b < n ? xcd_tile(b, n) : -1;
-        return;
-    }
-    for (int b = tid; b < map_len; b += 1024) map[b] = -1;
-    __syncthreads();
-    for (int g = tid; g < G; g += 1024) {
+    if (s_uniform) return;
+    // ---- 2. longest-first order over groups of 4 horizontally adjacent tiles
+    for (int b = tid; b < map_len; b += TO_THREADS) map[b] = -1;
+    auto group_class = [&](int g) {
         const int ty = g / ggx, tx0 = (g - ty * ggx) << 2;
         uint32_t len4 = 0;
         for (int j = 0; j < 4 && tx0 + j < gx; j++) { const uint2 rg = ranges[ty * gx + tx0 + j]; len4 += rg.y - rg.x; }
-        const uint32_t k = atomicAdd(&s_off[len_class(len4)], 1u);
-        for (int j = 0; j < 4 && tx0 + j < gx; j++) map[((((k >> 3) << 2) + j) << 3) | (k & 7u)] = ty * gx + tx0 + j;
+        return len_class(len4);
+    };
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    // 2a. groups per class (one LDS atomic per (wave, class present in the wave))
+    for (int g0 = 0; g0 < G; g0 += TO_THREADS) {
+        const int g = g0 + tid;
+        const int c = g < G ? group_class(g) : -1;
+        unsigned long long rest = __ballot(c >= 0);
+        while (rest) {
+            const int cc = __shfl(c, __builtin_ctzll(rest));
+            const unsigned long long m = __ballot(c == cc);
+            if (lane == __builtin_ctzll(m)) atomicAdd(&s_cnt[cc], (uint32_t)__popcll(m));
+            rest &= ~m;
+        }
     }
+    __syncthreads();
+    if (tid == 0) {
+        uint32_t run = 0;
+        for (int c = TO_CLASSES - 1; c >= 0; c--) { s_off[c] = run; run += s_cnt[c]; }
+    }
+    // 2b. placement, 1024 groups at a time: position = class offset + groups of the class in earlier waves + rank inside the wave
+    // (ballots) — the order inside a class is the groups' own order, so spatial neighbours stay neighbours and the map is deterministic
+    for (int g0 = 0; g0 < G; g0 += TO_THREADS) {
+        for (int i = tid; i < TO_WAVES * TO_CLASSES; i += TO_THREADS) (&s_wcnt[0][0])[i] = 0u;
+        __syncthreads();
+        const int g = g0 + tid;
+        const int c = g < G ? group_class(g) : -1;
+        uint32_t rank = 0;
+        unsigned long long rest = __ballot(c >= 0);
+        while (rest) {
+            const int cc = __shfl(c, __builtin_ctzll(rest));
+            const unsigned long long m = __ballot(c == cc);
+            if (c == cc) rank = (uint32_t)__popcll(m & lt);
+            if (lane == __builtin_ctzll(m)) s_wcnt[wave][cc] = (uint32_t)__popcll(m);
+            rest &= ~m;
+        }
+        __syncthreads();
+        if (c >= 0) {
+            uint32_t kpos = s_off[c] + rank;
+            for (int w = 0; w < wave; w++) kpos += s_wcnt[w][c];
+            const int ty = g / ggx, tx0 = (g - ty * ggx) << 2;
+            for (int j = 0; j < 4 && tx0 + j < gx; j++) map[((((kpos >> 3) << 2) + j) << 3) | (kpos & 7u)] = ty * gx + tx0 + j;
+        }
+        __syncthreads();
+        if (tid < TO_CLASSES) { uint32_t add = 0; for (int w = 0; w < TO_WAVES; w++) add += s_wcnt[w][tid]; s_off[tid] += add; }
+        __syncthreads();
+    }
+    if (tid == 0) map_flag[0] = 1u;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -878,8 +943,8 @@ void launch_tile_ranges_devn(size_t cap, const uint32_t* n_dev, const uint32_t* 
     if (cap > 0) hipLaunchKernelGGL(tile_ranges_devn_kernel, dim3((unsigned)((cap + 255) / 256)), dim3(256), 0, s, n_dev, (uint32_t)cap, keys, ranges);
 }
 int tile_map_len(int gx, int gy) { return 32 * ((((gx + 3) >> 2) * gy + 7) / 8); }
-void launch_tile_order(const uint2* ranges, int gx, int gy, int* map, int force, hipStream_t s) {
-    hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(1024), 0, s, ranges, gx, gy, map, tile_map_len(gx, gy), force);
+void launch_tile_order(const uint2* ranges, int gx, int gy, int* map, uint32_t* map_flag, int force, hipStream_t s) {
+    hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(TO_THREADS), 0, s, ranges, gx, gy, map, tile_map_len(gx, gy), map_flag, force);
 }
 void launch_tile_ranges(int64_t R, const uint32_t* keys, uint2* ranges, hipStream_t s) {
     if (R > 0) hipLaunchKernelGGL(tile_ranges_kernel, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, s, R, keys, ranges);
