@@ -29,7 +29,7 @@ unsigned long long* g_blend_stats = nullptr;   // surfel_debug_set_blend_stats
 thread_local int64_t g_last_R = -1; thread_local int g_last_W = 0, g_last_H = 0;   // auto heuristic (speed only; results identical; a stale
                                                                                     // value from another device / stream only costs one slower frame)
 // capacity binning: the largest instance count recent frames of a size produced (per host thread; speed only)
-struct CapEntry { int W = 0, H = 0; int64_t maxR = -1; };
+struct CapEntry { int W = 0, H = 0; int64_t maxR = -1; unsigned frames = 0; int uniform_streak = 0; };
 thread_local CapEntry g_caps[4];
 thread_local unsigned g_cap_next = 0;
 int g_opt_capacity = 1;    // surfel_set_option("capacity_binning", .)
@@ -39,7 +39,7 @@ CapEntry* cap_entry(int W, int H, bool create) {
     for (auto& c : g_caps) if (c.W == W && c.H == H) return &c;
     if (!create) return nullptr;
     CapEntry* c = &g_caps[g_cap_next++ % 4];
-    c->W = W; c->H = H; c->maxR = -1;
+    c->W = W; c->H = H; c->maxR = -1; c->frames = 0; c->uniform_streak = 0;
     return c;
 }
 thread_local float g_stage_ms[16];
@@ -280,9 +280,31 @@ uint32_t* pinned_u32() {
     PerDevice* pd = per_device();
     if (!pd) return nullptr;
     if (!pd->pinned) {
-        if (hipHostMalloc(reinterpret_cast<void**>(&pd->pinned), sizeof(uint32_t) * R_SLOTS, hipHostMallocDefault) != hipSuccess) pd->pinned = nullptr;
+        // R_SLOTS partial instance totals (D2H copy target) + one tile-order verdict word per capacity-table entry (written by the device)
+        if (hipHostMalloc(reinterpret_cast<void**>(&pd->pinned), sizeof(uint32_t) * (R_SLOTS + 4), hipHostMallocMapped) != hipSuccess) pd->pinned = nullptr;
+        else for (int k = 0; k < R_SLOTS + 4; k++) pd->pinned[k] = 0u;
     }
     return pd->pinned;
+}
+
+// tile_order_kernel costs ~8 us even when it only finds the frame uniform (one workgroup, a global round trip, the launch itself) —
+// 1.3 % of a C2 step.  Frames of a size that keeps coming out uniform therefore run it only every 8th frame (the blend kernels use
+// the XCD-contiguous order when no map was written); frames with uneven lists, where the map pays, run it always.  The verdicts
+// reach the host through a pinned word the kernel writes (no copy, no wait; a stale value only delays the policy by a frame).
+void run_tile_order(CapEntry* ce, const uint2* ranges, int gx, int gy, int* map, uint32_t* map_flag, int opt, hipStream_t s) {
+    if (opt == 1) return;                  // XCD-contiguous order: the flag word is zero
+    uint32_t* hv = pinned_u32();
+    const int slot = ce ? (int)(ce - g_caps) : 0;
+    uint32_t* verdict = nullptr;
+    if (hv && opt == 0) {
+        const uint32_t v = hv[R_SLOTS + slot];
+        if (v == 1u) ce->uniform_streak = ce->uniform_streak < 1000 ? ce->uniform_streak + 1 : 1000;
+        else if (v == 2u) ce->uniform_streak = 0;
+        void* dv = nullptr;
+        if (hipHostGetDevicePointer(&dv, hv + R_SLOTS + slot, 0) == hipSuccess) verdict = static_cast<uint32_t*>(dv);
+        if (verdict && ce->uniform_streak >= 4 && (ce->frames & 7u) != 0u) return;
+    }
+    launch_tile_order(ranges, gx, gy, map, map_flag, opt, verdict, s);
 }
 
 int higher_msb(uint32_t n) {   // number of bits needed to represent values < n
@@ -421,6 +443,8 @@ int64_t surfel_rasterize_forward(surfel_alloc_fn geom_alloc, void* geom_user, su
     int64_t R = 0;
     GeomState geom{};
     BinState bin{};
+    CapEntry* tile_ce = cap_entry(width, height, true);      // per-size history (capacity, tile-order verdicts) of this host thread
+    tile_ce->frames++;
     if (P > 0) {
         // scratch sizes (host-side queries only): [depth-sort scratch | scan state]
         const size_t psort_bytes = align_up(radix_sort_scratch_bytes((size_t)P));
@@ -503,7 +527,7 @@ int64_t surfel_rasterize_forward(surfel_alloc_fn geom_alloc, void* geom_user, su
             tm.begin();
             launch_tile_depth_sort(gx * gy, ce->maxR, img.ranges, bin.point_list, geom.dkey_a, bin.vals_alt, bin.keys_a, bin.keys_b, s);
             STAGE_END(tm, ST_TSORT);
-            launch_tile_order(img.ranges, gx, gy, img.tile_map, img.total + 2 * R_SLOTS + 1, opt_tile_order, s);
+            run_tile_order(tile_ce, img.ranges, gx, gy, img.tile_map, img.total + 2 * R_SLOTS + 1, opt_tile_order, s);
             BlendFwdArgs ba{};
             ba.W = width; ba.H = height; ba.gx = gx; ba.gy = gy;
             ba.ranges = img.ranges; ba.point_list = bin.point_list; ba.rec = geom.rec; ba.bg = background;
@@ -588,7 +612,7 @@ int64_t surfel_rasterize_forward(surfel_alloc_fn geom_alloc, void* geom_user, su
         bin = BinState::carve(bin_base, 0, 0, nullptr);
     }
 
-    launch_tile_order(img.ranges, gx, gy, img.tile_map, img.total + 2 * R_SLOTS + 1, opt_tile_order, s);
+    run_tile_order(tile_ce, img.ranges, gx, gy, img.tile_map, img.total + 2 * R_SLOTS + 1, opt_tile_order, s);
     BlendFwdArgs ba{};
     ba.W = width; ba.H = height; ba.gx = gx; ba.gy = gy;
     ba.ranges = img.ranges; ba.point_list = bin.point_list; ba.rec = geom.rec; ba.bg = background;

@@ -64,7 +64,8 @@ void launch_emit_instances(int P, float* rec, const uint32_t* rects, const uint3
 void launch_tile_ranges(int64_t R, const uint32_t* keys, uint2* ranges, hipStream_t s);
 int tile_map_len(int gx, int gy);
 // force: 0 decide on the device, 1 always the XCD-contiguous order, 2 always longest-first round-robin
-void launch_tile_order(const uint2* ranges, int gx, int gy, int* map, uint32_t* map_flag /* zeroed */, int force, hipStream_t s);
+// verdict: optional device-visible word that receives 1 (uniform frame) / 2 (uneven lists)
+void launch_tile_order(const uint2* ranges, int gx, int gy, int* map, uint32_t* map_flag /* zeroed */, int force, uint32_t* verdict, hipStream_t s);
 void launch_blend_fwd(const BlendFwdArgs& a, hipStream_t s);
 void launch_mark_visible(int P, const float* means3D, const float* vm, uint8_t* present, hipStream_t s);
 void launch_blend_bwd(const BlendBwdArgs& a, hipStream_t s);

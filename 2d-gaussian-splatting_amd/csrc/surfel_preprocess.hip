@@ -371,7 +371,7 @@ __device__ __forceinline__ int len_class(uint32_t len) { return len < 16u ? 0 : 
 // No same-address atomics anywhere (2 600 LDS atomics on 9 addresses made a first version of this kernel 14 us long): sums and maxima
 // go through wave shuffles, the per-XCD work through a block scan of the list lengths, the placement ranks through ballots.
 __global__ void __launch_bounds__(TO_THREADS) tile_order_kernel(const uint2* __restrict__ ranges, int gx, int gy, int* __restrict__ map, int map_len,
-                                                                uint32_t* __restrict__ map_flag, int force) {
+                                                                uint32_t* __restrict__ map_flag, int force, uint32_t* __restrict__ verdict) {
     __shared__ uint32_t s_wsum[TO_WAVES], s_wmax[TO_WAVES], s_bound[9], s_uniform;
     __shared__ uint32_t s_cnt[TO_CLASSES], s_off[TO_CLASSES], s_wcnt[TO_WAVES][TO_CLASSES];
     const int n = gx * gy, ggx = (gx + 3) >> 2, G = ggx * gy;
@@ -423,6 +423,7 @@ __global__ void __launch_bounds__(TO_THREADS) tile_order_kernel(const uint2* __r
                                              (unsigned long long)maxlen * (unsigned long long)n <= 4ull * total);
         s_uniform = force == 1 ? 1u : (force == 2 ? 0u : (uniform ? 1u : 0u));
         if (s_uniform) map_flag[0] = 0u;   // xcd_tile order
+        if (verdict) verdict[0] = uniform ? 1u : 2u;      // (pinned host word: the caller skips this launch on frames of a size that keeps coming out uniform)
     }
     __syncthreads();
     if (s_uniform) return;
@@ -943,8 +944,8 @@ void launch_tile_ranges_devn(size_t cap, const uint32_t* n_dev, const uint32_t* 
     if (cap > 0) hipLaunchKernelGGL(tile_ranges_devn_kernel, dim3((unsigned)((cap + 255) / 256)), dim3(256), 0, s, n_dev, (uint32_t)cap, keys, ranges);
 }
 int tile_map_len(int gx, int gy) { return 32 * ((((gx + 3) >> 2) * gy + 7) / 8); }
-void launch_tile_order(const uint2* ranges, int gx, int gy, int* map, uint32_t* map_flag, int force, hipStream_t s) {
-    hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(TO_THREADS), 0, s, ranges, gx, gy, map, tile_map_len(gx, gy), map_flag, force);
+void launch_tile_order(const uint2* ranges, int gx, int gy, int* map, uint32_t* map_flag, int force, uint32_t* verdict, hipStream_t s) {
+    hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(TO_THREADS), 0, s, ranges, gx, gy, map, tile_map_len(gx, gy), map_flag, force, verdict);
 }
 void launch_tile_ranges(int64_t R, const uint32_t* keys, uint2* ranges, hipStream_t s) {
     if (R > 0) hipLaunchKernelGGL(tile_ranges_kernel, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, s, R, keys, ranges);
