@@ -30,7 +30,10 @@ constexpr float T_EPS = 0.0001f;
 //   q4 = g    b    inst_base(u32 bits)  rect(u32 bits: x0 | y0<<10 | w<<20)
 //   q5 = ecx  ecy  Sxx  Sxy     conservative footprint of {alpha >= 1/255} (cull only, never changes results):
 //   q6 = Syy  r2^2 det  -       ellipse {d^T S^-1 d <= 1} about (ecx,ecy)  U  disc of radius r2 about xy
-constexpr int REC_F = 28;
+#ifndef SURFEL_REC_F
+#define SURFEL_REC_F 28
+#endif
+constexpr int REC_F = SURFEL_REC_F;      // floats per record: 28 (packed) or 32 (one 128-B line per record; measured: profiles/r03_record_stride.md)
 constexpr float FOOT_UNBOUNDED = 1.0e30f;   // Sxx >= this: the footprint is the whole image
 constexpr int REC_Q = REC_F / 4;
 // Per-(tile,surfel) gradient record written by blend-backward, summed by preprocess-backward:
