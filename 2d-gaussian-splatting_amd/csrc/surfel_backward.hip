@@ -13,6 +13,8 @@
 //   quad          : a wave (8x8 pixels) walks the instances its quad overlaps, one per visit, wave-wide reduction
 //                   (38 DPP adds + 5 permlane swaps), per-wave LDS partials.  Round 1's kernel; the faster walk on wide footprints.
 // Which of the two runs is decided by the caller (surfel_api.hip: timed probes, `bwd_tune`) or, for variant 2, on the device.
+// A third walk with another structure (lanes = instances, DPP row scans; not bit-identical to these two) lives in
+// surfel_backward_scan.hip.  What happens to the instances behind a tile's saturation point: surfel_blend_bwd.h (finish_tail).
 // Semantics: oracle/surfel_oracle.c stages 4-5 (restating the absent diff-surfel-rasterization).
 #include "surfel_blend_bwd.h"
 

@@ -261,7 +261,10 @@ __device__ __forceinline__ uint32_t preprocess_one(const PreprocessArgs& a, cons
 // here so the small D2H copy can be issued right after this kernel and the host wakes up, allocates and enqueues
 // the rest of the forward WHILE the device is still depth-sorting.  One atomic per workgroup, spread over
 // R_SLOTS counters (same-address device-scope atomics serialise at ~10 ns each); the host adds the slots.
-__global__ void __launch_bounds__(256) preprocess_fwd_kernel(PreprocessArgs a) {
+#ifndef PRE_FWD_MINWG
+#define PRE_FWD_MINWG 4
+#endif
+__global__ void __launch_bounds__(256, PRE_FWD_MINWG) preprocess_fwd_kernel(PreprocessArgs a) {
     __shared__ uint32_t s_tot[4], s_vis[4];
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     for (uint32_t w = (uint32_t)i; w < a.zero_a_words; w += gridDim.x * blockDim.x) a.zero_a[w] = 0u;
@@ -554,8 +557,11 @@ __device__ __forceinline__ void store3(float* p, size_t i, float x, float y, flo
 // fixed, so the sums are reproducible, and both record gathers treat heavy surfels the same way (they stay bit-identical).
 constexpr uint32_t HEAVY_MIN = 128;
 
+#ifndef PRE_BWD_MINWG
+#define PRE_BWD_MINWG 4
+#endif
 template <bool COOP, bool CUT>
-__global__ void __launch_bounds__(256) preprocess_bwd_kernel(PreprocessBwdArgs a) {
+__global__ void __launch_bounds__(256, PRE_BWD_MINWG) preprocess_bwd_kernel(PreprocessBwdArgs a) {
     __shared__ float4 s_sum[COOP ? 256 * 5 : 1];
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     float4 hs0 = make_float4(0.f, 0.f, 0.f, 0.f), hs1 = hs0, hs2 = hs0, hs3 = hs0, hs4 = hs0;

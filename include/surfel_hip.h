@@ -99,7 +99,8 @@ int64_t surfel_rasterize_forward(
  *   dL_dsh[P,M,3] (may be NULL: skipped — callers that rebuild it from dL_dcolors, include/surfel_train.h), dL_dscales[P,2],
  *   dL_drots[P,4].  dL_dnormal and — unless transMat_precomp is given — dL_dtransMat are intermediates of the chain rule that no
  *   caller of the reference's Python API receives: either may be NULL and is then not written (saves 48 B/surfel of stores).
- * `scratch_alloc` provides the per-instance gradient records (R * 80 bytes, each written exactly once);
+ * `scratch_alloc` provides the per-instance gradient records (R * 80 bytes + 8 bytes per tile + 1 byte per surfel; a record is written
+ * at most once — on frames with >= 2^21 instances the records behind a tile's saturation point are never written and never read);
  * gradients are accumulated without atomics, so results are bit-reproducible run to run.
  */
 int surfel_rasterize_backward(
