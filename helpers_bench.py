@@ -186,13 +186,15 @@ def config_leg(dev, workload, steps=20, warmup=5):
     return out
 
 
+GARDEN_GT = int(os.environ.get("GARDEN_GT", 1_500_000)); GARDEN_INIT = int(os.environ.get("GARDEN_INIT", 1_600_000))
+GARDEN_VIEWS = int(os.environ.get("GARDEN_VIEWS", 24)); GARDEN_ITERS = int(os.environ.get("GARDEN_ITERS", 2500)); GARDEN_PX = float(os.environ.get("GARDEN_PX", 0.012))
 TRAINED_PRESETS = {
     # name: ground-truth surfels, initial random points, views, (W, H), iterations of the reference schedule (untimed), gt disc scale
     "trained": dict(n_gt=200_000, n_init=200_000, n_views=48, res=(800, 800), train_iters=6000, px_scale=0.035, init="cube"),
     # BASELINE configs[3]'s per-GPU shape (Mip-NeRF360 garden: ~2 M surfels, 1600x1060) on post-densification statistics: the capture
     # is dense enough for the densification to settle above a million surfels
     # is dense enough, and the initial points lie near its surface (as SfM points do), for the densification to settle above a million
-    "garden": dict(n_gt=1_500_000, n_init=1_600_000, n_views=24, res=(1600, 1060), train_iters=2500, px_scale=0.012, init="surface"),
+    "garden": dict(n_gt=GARDEN_GT, n_init=GARDEN_INIT, n_views=GARDEN_VIEWS, res=(1600, 1060), train_iters=GARDEN_ITERS, px_scale=GARDEN_PX, init="surface"),
 }
 
 
