@@ -63,6 +63,11 @@ __device__ __forceinline__ float row_scan_add_excl(float x) {
 // every lane — the last lane of a row writes the pixel's state, the others a scratch area behind it — and idle lanes park a
 // (never read) slot as well.
 constexpr int STATE_SCRATCH = 49;      // float4s: 16 steps x 16 B + 64 lanes x 8 B
+// The 4 rows of a wave read 4 different pixels' records in one instruction (a broadcast inside each row).  With the natural row
+// strides (16 x 48 B = 192 dwords, 16 x 16 B = 64 dwords: both 0 mod 64 banks) the four addresses fell on the same banks — a 4-way
+// conflict on every read of every step: 16.2 M of the kernel's LDS conflict cycles per launch at C2 against 1.4 M for the rows walk
+// (profiles/r03gscan_C2_pmc.json).  One float4 of padding per row moves the rows 4 banks apart.
+constexpr int PIX_ROW = 16 * 3 + 1, STATE_ROW = 16 + 1;
 // -DSCAN_TIMING (diagnostic build): the instrumented kernel accumulates shader-clock ticks per phase of every wave instead of the lane
 // counters — stats[0] staging + lists, [1] walk, [2] wait at the barrier behind the walk, [3] flush, [4] wait behind the flush,
 // [5] record write, [6] whole kernel, [7] waves (scripts/bwd_ab.py prints them as scan_raw).
@@ -80,8 +85,8 @@ template <bool STATS>
 __global__ void __launch_bounds__(BLOCK, SCAN_MIN_WG) blend_bwd_scan_kernel(BlendBwdArgs a) {
     __shared__ float4 s_rec[SB * 5];                          // 10 KB: q0-q4 of the staged instances
     __shared__ float4 s_slot[BLOCK * 5];                      // 20 KB: the round's partial records, one per walking lane
-    __shared__ float4 s_pix[BLOCK * 3];                       // 12 KB
-    __shared__ float4 s_state[BLOCK + STATE_SCRATCH];         // 4.8 KB
+    __shared__ float4 s_pix[16 * PIX_ROW];                    // 12.3 KB
+    __shared__ float4 s_state[16 * STATE_ROW + STATE_SCRATCH];      // 5.1 KB
     __shared__ unsigned long long s_bal[16][SB / 64];         // per sub-tile: the staged instances on its list
     __shared__ uint8_t s_list[16][SB];                        // per sub-tile: its list (staged indices, back to front)
     __shared__ uint4 s_rank[SB];                              // per staged instance: its rank on each of the 16 lists (0xff: not on it)
@@ -111,19 +116,20 @@ __global__ void __launch_bounds__(BLOCK, SCAN_MIN_WG) blend_bwd_scan_kernel(Blen
         int m = px.last;
         m = max(m, __shfl_xor(m, 1)); m = max(m, __shfl_xor(m, 2)); m = max(m, __shfl_xor(m, 4)); m = max(m, __shfl_xor(m, 8));
         if (i16 == 0) s_rowlast[srow] = m;
-        s_pix[tid * 3 + 0] = make_float4(px.gC0, px.gC1, px.gC2, px.g_depth);
-        s_pix[tid * 3 + 1] = make_float4(px.gN0, px.gN1, px.gN2, px.g_med);
-        s_pix[tid * 3 + 2] = make_float4(px.final_A * px.g_dist, -2.f * px.fM1 * px.g_dist, FMA(px.fM2, px.g_dist, px.g_alpha), __int_as_float(px.last));
-        s_state[tid] = make_float4(px.T, px.X, __int_as_float(px.medc), 0.f);
+        float4* const mine = s_pix + srow * PIX_ROW + i16 * 3;
+        mine[0] = make_float4(px.gC0, px.gC1, px.gC2, px.g_depth);
+        mine[1] = make_float4(px.gN0, px.gN1, px.gN2, px.g_med);
+        mine[2] = make_float4(px.final_A * px.g_dist, -2.f * px.fM1 * px.g_dist, FMA(px.fM2, px.g_dist, px.g_alpha), __int_as_float(px.last));
+        s_state[srow * STATE_ROW + i16] = make_float4(px.T, px.X, __int_as_float(px.medc), 0.f);
         const int maxc0 = block_max(px.last, &s_max);         // (its barriers also publish s_rowlast and s_pix)
         (void)maxc0;
     }
     const int maxc = s_max;
     const float sx0 = (float)(tx * TILE + (lx & ~3)), sy0 = (float)(ty * TILE + (ly & ~3));      // the sub-tile's first pixel
-    const float4* const prow = s_pix + (srow * 16) * 3;       // the sub-tile's 16 pixel records
-    const float4* const srd = s_state + srow * 16;            // ... and states
+    const float4* const prow = s_pix + srow * PIX_ROW;        // the sub-tile's 16 pixel records
+    const float4* const srd = s_state + srow * STATE_ROW;     // ... and states
     // where this lane's state writes go: the row's last lane advances the pixel's (T, X), every other lane hits scratch
-    float2* const swr = i16 == 15 ? reinterpret_cast<float2*>(s_state + srow * 16) : reinterpret_cast<float2*>(s_state + BLOCK) + lane;
+    float2* const swr = i16 == 15 ? reinterpret_cast<float2*>(s_state + srow * STATE_ROW) : reinterpret_cast<float2*>(s_state + 16 * STATE_ROW) + lane;
 
     // flush ownership: thread (t, half) adds up values [0, 12) or [12, 20) of staged instance t
     const int ft = tid & (SB - 1), fh = tid >> 7;
