@@ -136,7 +136,11 @@ def time_trainer(tr, steps, warmup, prime=15, workload=None):
     for name, v in (("rows", 0), ("quad", 1), ("scan", 3)):
         lib.surfel_set_option(b"bwd_variant", v)
         tr.pipe.debug = 2
-        for _ in range(6):
+        # every walk's window sees the SAME views in the same order (the views of a capture differ 2-3x in instance count: windows
+        # over different random views are not comparable)
+        if hasattr(tr, "_rng") and hasattr(tr, "_stack"):
+            tr._rng.seed(90210); tr._stack = []
+        for _ in range(8):
             tr.step()
         torch.cuda.synchronize()
         t = surfel_native.collect_stage_times()
