@@ -138,6 +138,10 @@ def time_trainer(tr, steps, warmup, prime=15, workload=None):
         tr.pipe.debug = 2
         # every walk's window sees the SAME views in the same order (the views of a capture differ 2-3x in instance count: windows
         # over different random views are not comparable)
+        for _ in range(3):      # (cold code: the first launches of a walk that has not run yet are 25 % slower)
+            tr.step()
+        torch.cuda.synchronize()
+        surfel_native.collect_stage_times()
         if hasattr(tr, "_rng") and hasattr(tr, "_stack"):
             tr._rng.seed(90210); tr._stack = []
         for _ in range(8):
