@@ -78,6 +78,7 @@ void launch_knn(int P, const float* points, float* out, void* scratch, size_t sc
 size_t knn_scratch_bytes(int P);
 size_t radix_sort_scratch_bytes(size_t n);
 void set_large_sort_impl(int v);      // for n > 2^20 — 0: three launches per pass (own), 1: rocprim::radix_sort_pairs, 2: auto (default)
+void set_fat_sort(int v);             // look-back passes (<= 2^20 items): 1 (default) 8192-item tiles staged through LDS, 0 2048-item tiles
 int radix_sort_passes(size_t n, int begin_bit, int end_bit);
 int radix_sort_result_buffer(size_t n, int begin_bit, int end_bit);
 int radix_sort_pairs_u32(uint32_t* keys_a, uint32_t* vals_a, uint32_t* keys_b, uint32_t* vals_b, size_t n, int begin_bit, int end_bit,

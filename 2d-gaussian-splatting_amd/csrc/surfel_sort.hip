@@ -290,6 +290,137 @@ __global__ void __launch_bounds__(RS_THREADS) os_pass_kernel(const uint32_t* __r
     }
 }
 
+// ---- the look-back pass for <= 2^20 items, fat tiles -------------------------------------------------------------------------
+// Same algorithm as os_pass_kernel<true>, 1024 threads x 8 items = 8192-item tiles, and the tile's items go through LDS in
+// tile-local sorted order before they are stored.  Measured on the thin (2048-item) pass at 0.5 M items (r03g_C2_kernel_stats):
+// 18.5 us for the 4-bit digit, 30.5 us for the 8-bit digit — the difference is the scatter: a thin tile holds 8 items per 8-bit
+// digit, stored by whichever lane ranked them (64 different lines per store instruction).  Here a digit's run in a tile is
+// 32 items = one 128-B line, written by consecutive lanes; and the look-back chain is a quarter as long.
+constexpr int FT_THREADS = 1024, FT_IPT = 8, FT_TILE = FT_THREADS * FT_IPT, FT_WAVES = FT_THREADS / 64;
+constexpr int FT_LB = 32;      // look-back window: at most 128 tiles exist, all resident and publishing at about the same moment
+int g_fat_sort = 1;
+void set_fat_sort(int v) { g_fat_sort = v != 0; }
+static inline uint32_t ft_nblocks(size_t n) { return (uint32_t)((n + FT_TILE - 1) / FT_TILE); }
+
+__global__ void __launch_bounds__(FT_THREADS) os_pass_fat_kernel(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ vals,
+                                                                 uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out, uint32_t n,
+                                                                 int shift, uint32_t mask, const uint32_t* __restrict__ ghist,
+                                                                 uint32_t* __restrict__ status, uint32_t* __restrict__ ticket,
+                                                                 const uint32_t* __restrict__ n_dev, int hstride) {
+    __shared__ uint32_t s_cnt[FT_WAVES][RS_RADIX];      // per-wave digit counts -> then per-wave tile-local offsets
+    __shared__ uint2 s_item[FT_TILE];                   // (key, value) in tile-local sorted order
+    __shared__ uint32_t s_gbase[RS_RADIX];              // global slot of a digit's first item of this tile, minus its tile-local slot
+    __shared__ uint32_t s_w[4][2];
+    __shared__ uint32_t s_tile;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t d_t = threadIdx.x;                   // (threads < 256) the digit this thread owns in the offset phases
+    if (threadIdx.x == 0) s_tile = atomicAdd(ticket, 1u);
+    for (int i = threadIdx.x; i < FT_WAVES * RS_RADIX; i += FT_THREADS) (&s_cnt[0][0])[i] = 0u;
+    __syncthreads();
+    const uint32_t tile = s_tile;
+    if (n_dev) n = min(n, *n_dev);
+    if (tile * (uint32_t)FT_TILE >= n) return;
+    const uint32_t wbase = tile * (uint32_t)FT_TILE + wave * (64 * FT_IPT);
+    uint32_t k[FT_IPT], v[FT_IPT], rank[FT_IPT];
+#pragma unroll
+    for (int it = 0; it < FT_IPT; it++) {
+        const uint32_t e = wbase + it * 64 + lane;
+        const bool valid = e < n;
+        k[it] = valid ? keys[e] : 0xffffffffu;
+        v[it] = valid ? vals[e] : 0u;
+    }
+#pragma unroll
+    for (int it = 0; it < FT_IPT; it++) {
+        const uint32_t e = wbase + it * 64 + lane;
+        const bool valid = e < n;
+        const uint32_t d = (k[it] >> shift) & mask;
+        unsigned long long mm = __ballot(valid);
+#pragma unroll
+        for (int b = 0; b < RS_BITS; b++) {
+            const bool bit = (d >> b) & 1u;
+            const unsigned long long bal = __ballot(bit);
+            mm &= bit ? bal : ~bal;
+        }
+        if (!valid) mm = 0ull;
+        const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(mm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mm, 0u));
+        const uint32_t prev = valid ? s_cnt[wave][d] : 0u;   // same-wave LDS ops are program-ordered
+        rank[it] = prev + below;
+        if (valid && below == 0) s_cnt[wave][d] = prev + (uint32_t)__popcll(mm);
+    }
+    __syncthreads();
+    uint32_t cw[FT_WAVES], cnt = 0, excl = 0, tot = 0, x = 0, y = 0;      // (threads < 256: one digit each)
+    if (threadIdx.x < RS_RADIX) {
+#pragma unroll
+        for (int w = 0; w < FT_WAVES; w++) { cw[w] = s_cnt[w][d_t]; cnt += cw[w]; }
+        uint32_t* my = status + (size_t)tile * RS_RADIX + d_t;
+        if (tile == 0) {
+            st_agent(my, cnt | ST_PREFIX);
+        } else {
+            st_agent(my, cnt | ST_AGG);
+            int p = (int)tile - 1;
+            bool done = false;
+            while (!done) {      // (see os_pass_kernel)
+                uint32_t w[FT_LB];
+#pragma unroll
+                for (int i = 0; i < FT_LB; i++) w[i] = (p - i >= 0) ? ld_agent(status + (size_t)(p - i) * RS_RADIX + d_t) : ST_PREFIX;
+                int used = 0;
+#pragma unroll
+                for (int i = 0; i < FT_LB; i++) {
+                    if (!done && used == i) {
+                        if ((w[i] >> 30) != 0u) {
+                            excl += w[i] & ST_VALUE;
+                            used = i + 1;
+                            if (w[i] & ST_PREFIX) done = true;
+                        }
+                    }
+                }
+                p -= used;
+                if (!done && used == 0) __builtin_amdgcn_s_sleep(1);
+            }
+            st_agent(my, (excl + cnt) | ST_PREFIX);
+        }
+        // exclusive scans over the digits: of the digit totals (global start of a digit) and of this tile's counts (tile-local start)
+        tot = ghist[(size_t)d_t * hstride];
+        x = tot; y = cnt;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t xa = __shfl_up(x, o), ya = __shfl_up(y, o);
+            if (lane >= o) { x += xa; y += ya; }
+        }
+        if (lane == 63) { s_w[wave][0] = x; s_w[wave][1] = y; }
+    }
+    __syncthreads();
+    if (threadIdx.x < RS_RADIX) {
+        uint32_t goff = x - tot + excl, loff = y - cnt;
+        for (int w = 0; w < wave; w++) { goff += s_w[w][0]; loff += s_w[w][1]; }
+        s_gbase[d_t] = goff - loff;
+        uint32_t run = loff;
+#pragma unroll
+        for (int w = 0; w < FT_WAVES; w++) { s_cnt[w][d_t] = run; run += cw[w]; }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < FT_IPT; it++) {
+        const uint32_t e = wbase + it * 64 + lane;
+        if (e < n) {
+            const uint32_t d = (k[it] >> shift) & mask;
+            s_item[s_cnt[wave][d] + rank[it]] = make_uint2(k[it], v[it]);
+        }
+    }
+    __syncthreads();
+    const uint32_t items = min((uint32_t)FT_TILE, n - tile * (uint32_t)FT_TILE);
+#pragma unroll
+    for (int it = 0; it < FT_IPT; it++) {
+        const uint32_t q = (uint32_t)it * FT_THREADS + threadIdx.x;
+        if (q < items) {
+            const uint2 kv = s_item[q];
+            const uint32_t dst = s_gbase[(kv.x >> shift) & mask] + q;
+            keys_out[dst] = kv.x;
+            vals_out[dst] = kv.y;
+        }
+    }
+}
+
 // The look-back head (ghist + tickets) has to be zero when a sort starts.  Callers whose previous kernel can clear
 // radix_sort_head_words(n) words at the start of the scratch pass head_zeroed = true and save the memset launch.
 size_t radix_sort_head_words(size_t n) { return rs_onesweep(n) ? RS_HEAD_WORDS : 0; }
@@ -523,8 +654,12 @@ int radix_sort_pairs_u32(uint32_t* keys_a, uint32_t* vals_a, uint32_t* keys_b, u
         const uint32_t mask = (1u << nb) - 1u;
         const uint32_t* kin = cur ? keys_b : keys_a; const uint32_t* vin = cur ? vals_b : vals_a;
         uint32_t* kout = cur ? keys_a : keys_b; uint32_t* vout = cur ? vals_a : vals_b;
-        hipLaunchKernelGGL(os_pass_kernel<true>, dim3(nblocks), dim3(RS_THREADS), 0, s, kin, vin, kout, vout, (uint32_t)n, bit, mask,
-                           ghist + p * RS_RADIX, status + (size_t)p * nblocks * RS_RADIX, ticket + p, nblocks, (const uint32_t*)nullptr, 1);
+        if (g_fat_sort)
+            hipLaunchKernelGGL(os_pass_fat_kernel, dim3(ft_nblocks(n)), dim3(FT_THREADS), 0, s, kin, vin, kout, vout, (uint32_t)n, bit, mask,
+                               ghist + p * RS_RADIX, status + (size_t)p * nblocks * RS_RADIX, ticket + p, (const uint32_t*)nullptr, 1);
+        else
+            hipLaunchKernelGGL(os_pass_kernel<true>, dim3(nblocks), dim3(RS_THREADS), 0, s, kin, vin, kout, vout, (uint32_t)n, bit, mask,
+                               ghist + p * RS_RADIX, status + (size_t)p * nblocks * RS_RADIX, ticket + p, nblocks, (const uint32_t*)nullptr, 1);
         cur ^= 1;
     }
     return cur;
@@ -615,8 +750,12 @@ int radix_sort_pairs_u32_devn(uint32_t* keys_a, uint32_t* vals_a, uint32_t* keys
         const uint32_t mask = (1u << nb) - 1u;
         const uint32_t* kin = cur ? keys_b : keys_a; const uint32_t* vin = cur ? vals_b : vals_a;
         uint32_t* kout = cur ? keys_a : keys_b; uint32_t* vout = cur ? vals_a : vals_b;
-        hipLaunchKernelGGL(os_pass_kernel<true>, dim3(nblocks), dim3(RS_THREADS), 0, s, kin, vin, kout, vout, (uint32_t)cap, bit, mask,
-                           ghist + (size_t)p * RS_RADIX * BE_HSTRIDE, status + (size_t)p * nblocks * RS_RADIX, ticket + p, nblocks, n_dev, BE_HSTRIDE);
+        if (g_fat_sort)
+            hipLaunchKernelGGL(os_pass_fat_kernel, dim3(ft_nblocks(cap)), dim3(FT_THREADS), 0, s, kin, vin, kout, vout, (uint32_t)cap, bit, mask,
+                               ghist + (size_t)p * RS_RADIX * BE_HSTRIDE, status + (size_t)p * nblocks * RS_RADIX, ticket + p, n_dev, BE_HSTRIDE);
+        else
+            hipLaunchKernelGGL(os_pass_kernel<true>, dim3(nblocks), dim3(RS_THREADS), 0, s, kin, vin, kout, vout, (uint32_t)cap, bit, mask,
+                               ghist + (size_t)p * RS_RADIX * BE_HSTRIDE, status + (size_t)p * nblocks * RS_RADIX, ticket + p, nblocks, n_dev, BE_HSTRIDE);
         cur ^= 1;
     }
     return cur;

@@ -781,20 +781,23 @@ def test_blend_stats_counters():
 
 @pytest.mark.parametrize("n,bits", [(1, (0, 32)), (63, (0, 32)), (2047, (0, 12)), (2048, (0, 32)), (2049, (3, 17)), (300_000, (0, 32)),
                                     (611_573, (0, 12)), (3_000_001, (0, 32)), (5_000_000, (0, 15)), (2_000_003, (7, 8)), (2_000_003, (5, 5)),
-                                    (4097, (31, 32)), (4097, (0, 0))])
+                                    (4097, (31, 32)), (4097, (0, 0)), (8191, (0, 32)), (8193, (0, 12)), (40_000, (0, 12)), (1_048_576, (0, 13))])
 def test_radix_sort_is_stable_and_exact(n, bits):
-    """The one-launch-per-pass radix sort (decoupled look-back) against numpy's stable argsort, incl. heavy duplicates; 1-bit and
-    empty key fields (the order is then the input order); large inputs also through rocprim::radix_sort_pairs."""
+    """The one-launch-per-pass radix sort (decoupled look-back; 8192-item tiles staged through LDS and the 2048-item form) against
+    numpy's stable argsort, incl. heavy duplicates; 1-bit and empty key fields (the order is then the input order); large inputs
+    also through rocprim::radix_sort_pairs."""
     import torch
     import surfel_native as nat
     lib = nat.load()
     dev = torch.device("cuda:0")
     rng = np.random.default_rng(n)
     lo, hi = bits
-    impls = (0, 1) if n > (1 << 20) else (0, 3)        # large inputs: the library's own passes and rocprim::radix_sort_pairs (3: rocPRIM at every size)
+    # large inputs: the library's own passes and rocprim::radix_sort_pairs (3: rocPRIM at every size); small ones: both tile sizes (4: thin)
+    impls = (0, 1) if n > (1 << 20) else (0, 4, 3)
     for trial in [(t, i) for i in impls for t in range(3)]:
         trial, impl = trial
-        assert lib.surfel_set_option(b"large_sort", impl) == 0
+        assert lib.surfel_set_option(b"fat_sort", 0 if impl == 4 else 1) == 0
+        assert lib.surfel_set_option(b"large_sort", 0 if impl == 4 else impl) == 0
         if trial == 0:
             keys = rng.integers(0, 2 ** 32, n, dtype=np.uint64).astype(np.uint32)
         elif trial == 1:   # few distinct keys: long same-digit runs, every tie must keep input order
@@ -812,6 +815,7 @@ def test_radix_sort_is_stable_and_exact(n, bits):
         assert np.array_equal(v.cpu().numpy().view(np.uint32), vals[order]), "trial %d impl %d: order differs" % (trial, impl)
         assert np.array_equal(k.cpu().numpy().view(np.uint32), keys[order])
     lib.surfel_set_option(b"large_sort", LARGE_SORT_DEFAULT)
+    lib.surfel_set_option(b"fat_sort", 1)
 
 
 def test_grad_arena_is_zero_copy_and_identical():
