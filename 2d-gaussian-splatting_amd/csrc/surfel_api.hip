@@ -24,6 +24,7 @@ int g_opt_tile_sort = 1;   // surfel_set_option("tile_depth_sort", .): 0 never, 
 int g_opt_bwd_variant = 2; // surfel_set_option("bwd_variant", .): 0 per-row walk, 1 per-quad walk, 2 auto (0 / 1 / 2 bit-identical), 3 scan walk, 4 auto over all three
 surfel_hook_fn g_colour_hook = nullptr;   // surfel_set_backward_hook
 void* g_colour_hook_user = nullptr;
+float* g_sink_accum = nullptr; float* g_sink_denom = nullptr; float* g_sink_maxr = nullptr;      // surfel_set_densify_sink
 int g_opt_bwd_tune = 1;    // surfel_set_option("bwd_tune", .): auto = timed probes (1) or the device-side rule alone (0)
 unsigned long long* g_blend_stats = nullptr;   // surfel_debug_set_blend_stats
 thread_local int64_t g_last_R = -1; thread_local int g_last_W = 0, g_last_H = 0;   // auto heuristic (speed only; results identical; a stale
@@ -369,6 +370,12 @@ int surfel_set_option(const char* name, int value) {
     return fail(SURFEL_E_INVALID, "unknown option");
 }
 
+int surfel_set_densify_sink(float* grad_accum, float* denom, float* max_radii) {
+    if ((grad_accum == nullptr) != (denom == nullptr) || (grad_accum == nullptr) != (max_radii == nullptr)) return fail(SURFEL_E_INVALID, "densify sink: all three arrays or none");
+    g_sink_accum = grad_accum; g_sink_denom = denom; g_sink_maxr = max_radii;
+    return 0;
+}
+
 int surfel_set_backward_hook(surfel_hook_fn colour_ready, void* user) {
     g_colour_hook = colour_ready; g_colour_hook_user = user;
     return 0;
@@ -400,6 +407,40 @@ int surfel_collect_stage_ms(float* sum_ms, int* count, int cap) {
     return 11;
 }
 
+// Lazily counted frames (SURFEL_OPT_LAZY_COUNT): a capacity-path forward that did not wait for its instance count.  The count is
+// collected by surfel_forward_count() — or by the next forward of this thread, which refuses to go on if that frame had overflowed
+// its capacity without anybody looking (its images were built from truncated lists).
+struct LazyPending { bool pending = false; int W = 0, H = 0, dev = -1; int64_t cap = 0; bool overflowed = false; int64_t R = 0; };
+thread_local LazyPending g_lazy;
+
+// waits for the pending count; returns the exact instance count (>= 0) and updates the per-size history, or a negative code
+int64_t lazy_finish() {
+    if (!g_lazy.pending) return g_lazy.R;
+    uint32_t* hR = pinned_u32();
+    hipEvent_t evR = r_event();
+    if (!hR || !evR) return fail(SURFEL_E_HIP, "pinned buffer / event creation failed");
+    HIP_TRY(hipEventSynchronize(evR));
+    int64_t R = 0;
+    for (int k = 0; k < R_SLOTS; k++) R += (int64_t)hR[k];
+    g_lazy.pending = false;
+    g_lazy.R = R;
+    g_lazy.overflowed = R > g_lazy.cap;
+    g_last_R = R; g_last_W = g_lazy.W; g_last_H = g_lazy.H;
+    CapEntry* ce = cap_entry(g_lazy.W, g_lazy.H, true);
+    ce->maxR = R > ce->maxR - ce->maxR / 64 ? R : ce->maxR - ce->maxR / 64;
+    return R;
+}
+
+int64_t surfel_forward_count(void) {
+    const int64_t R = lazy_finish();
+    if (R < 0) return R;
+    if (g_lazy.overflowed) {
+        g_lazy.overflowed = false;      // reported: the caller redoes the frame
+        return fail(SURFEL_E_OVERFLOW, "the lazily counted frame held more tile instances than its capacity: render it again (its outputs are incomplete)");
+    }
+    return R;
+}
+
 int64_t surfel_rasterize_forward(surfel_alloc_fn geom_alloc, void* geom_user, surfel_alloc_fn binning_alloc, void* binning_user,
                                  surfel_alloc_fn image_alloc, void* image_user, int P, int D, int M, const float* background,
                                  int width, int height, const float* means3D, const float* shs, const float* colors_precomp,
@@ -409,7 +450,13 @@ int64_t surfel_rasterize_forward(surfel_alloc_fn geom_alloc, void* geom_user, su
                                  float* out_others, int* radii, int debug, void* stream) {
     (void)tan_fovx; (void)tan_fovy; (void)prefiltered;
     g_stage_n = 0;
+    if (g_lazy.pending) { const int64_t r = lazy_finish(); if (r < 0) return r; }
+    if (g_lazy.overflowed) {
+        g_lazy.overflowed = false;
+        return fail(SURFEL_E_OVERFLOW, "the previous lazily counted frame overflowed its capacity and surfel_forward_count() was never called for it");
+    }
     // per-call option overrides ride in the upper bits of `debug` (include/surfel_hip.h); the low byte is the debug mode
+    const bool opt_lazy = (debug & SURFEL_OPT_LAZY_COUNT) != 0;
     const int opt_cull = (debug & SURFEL_OPT_NO_CULL) ? 0 : g_opt_cull;
     const int opt_tile_sort = ((debug >> 9) & 3) ? ((debug >> 9) & 3) - 1 : g_opt_tile_sort;
     const int opt_capacity = (debug & SURFEL_OPT_EXACT_BINNING) ? 0 : g_opt_capacity;
@@ -538,6 +585,12 @@ int64_t surfel_rasterize_forward(surfel_alloc_fn geom_alloc, void* geom_user, su
             tm.begin();
             launch_blend_fwd(ba, s);
             STAGE_END(tm, ST_BLEND);
+            if (opt_lazy) {      // the count stays on its way: surfel_forward_count() (or the next forward) collects it
+                g_lazy.pending = true; g_lazy.W = width; g_lazy.H = height; g_lazy.cap = cap; g_lazy.overflowed = false;
+                g_last_binning = 4;
+                HIP_TRY(hipGetLastError());
+                return cap;
+            }
             HIP_TRY(hipEventSynchronize(evR));      // preprocess finished long ago; the device still holds the rest of the forward
             for (int k = 0; k < R_SLOTS; k++) R += (int64_t)hR[k];
             g_last_binning = 1;
@@ -604,6 +657,7 @@ int64_t surfel_rasterize_forward(surfel_alloc_fn geom_alloc, void* geom_user, su
             }
         }
         g_last_R = R; g_last_W = width; g_last_H = height;
+        g_lazy.R = R;
         ce->maxR = R > ce->maxR - ce->maxR / 64 ? R : ce->maxR - ce->maxR / 64;      // the largest recent count, slowly forgotten
         if (blended) { HIP_TRY(hipGetLastError()); return R; }
     } else {
@@ -705,6 +759,7 @@ int surfel_rasterize_backward(surfel_alloc_fn scratch_alloc, void* scratch_user,
     pb.rec = geom.rec; pb.tiles_touched = geom.tiles_touched; pb.grec = grec; pb.cut = cut; pb.has_rec = has_rec; pb.depths = geom.depths; pb.gx = gx;
     pb.dL_dtransMat = dL_dtransMat; pb.dL_dnormal = dL_dnormal; pb.dL_dopacity = dL_dopacity; pb.dL_dcolors = dL_dcolors;
     pb.dL_dsh = dL_dsh; pb.dL_dmeans2D = dL_dmeans2D; pb.dL_dmeans3D = dL_dmeans3D; pb.dL_dscales = dL_dscales; pb.dL_drots = dL_drots;
+    pb.stat_accum = g_sink_accum; pb.stat_denom = g_sink_denom; pb.stat_maxr = g_sink_maxr;
     tm.begin();
     if (g_colour_hook) {      // dL/dcolour first, so the caller can start moving it while the geometry chain rule runs
         launch_colour_gradients(pb, s);

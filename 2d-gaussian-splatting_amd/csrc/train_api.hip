@@ -70,10 +70,12 @@ int surfel_train_loss_forward(int H, int W, const float* img, const float* gt, f
 
 int surfel_train_loss_backward(int H, int W, const float* img, const float* gt, const float* dmaps, float c_l1, float c_ssim, const float* allmap,
                                const float* cam, float depth_ratio, float c_normal, float c_dist, const float* g_dev, float* grad_img,
-                               float* grad_allmap, void* stream) {
+                               float* grad_allmap, const float* ssim_partials, const float* post_partials, float lambda_dssim,
+                               float lambda_normal, float lambda_dist, float* out6, float* total_out, void* stream) {
     if (H <= 0 || W <= 0 || !img || !gt || !dmaps || !allmap || !cam || !grad_img || !grad_allmap) return api_fail(SURFEL_E_INVALID, "bad arguments");
+    if (out6 && (!ssim_partials || !post_partials)) return api_fail(SURFEL_E_INVALID, "train_loss_backward: deferred loss scalars need both partial-sum arrays");
     launch_train_loss_bwd(H, W, img, gt, dmaps, c_l1, c_ssim, g_dev, grad_img, allmap, cam, depth_ratio, c_normal, c_dist, grad_allmap,
-                          static_cast<hipStream_t>(stream));
+                          ssim_partials, post_partials, lambda_dssim, lambda_normal, lambda_dist, out6, total_out, static_cast<hipStream_t>(stream));
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : api_fail(SURFEL_E_HIP, "train_loss_bwd", e);
 }

@@ -40,9 +40,13 @@ __global__ __launch_bounds__(256) void train_loss_bwd_kernel(int n_ssim, int n_s
                                                              float c_l1, float c_ssim, const float* __restrict__ g_dev, float* __restrict__ grad_img,
                                                              lossk::SsimWin win, const float* __restrict__ allmap, const float* __restrict__ cam,
                                                              float ratio, const float* __restrict__ gmaps, float c_normal, float c_dist,
-                                                             float* __restrict__ gall) {
+                                                             float* __restrict__ gall, lossk::LossFinalize fin) {
     __shared__ __attribute__((aligned(16))) char smem[cmax(lossk::ssim_bwd_lds<SR11>(), postk::post_bwd_lds())];
     const int b = blockIdx.x;
+    if (b == n_ssim_pad + n_post) {      // deferred loss scalars (fin.out != NULL: the grid has this one extra workgroup): the forward's
+        lossk::loss_finalize_body<256>(reinterpret_cast<float(*)[16]>(smem), fin);      // partial sums are final — it was an earlier launch
+        return;
+    }
     if (b < n_ssim_pad) {
         if (b < n_ssim) lossk::ssim_bwd_body<SR11>(smem, b, n_ssim, H, W, img, gt, dmaps, map_stride, c_l1, c_ssim, g_dev, g_dev, grad_img, win);
     } else {
@@ -65,12 +69,15 @@ void launch_train_loss_fwd(int H, int W, const float* img, const float* gt, floa
 
 void launch_train_loss_bwd(int H, int W, const float* img, const float* gt, const float* dmaps, float c_l1, float c_ssim, const float* g_dev,
                            float* grad_img, const float* allmap, const float* cam, float ratio, float c_normal, float c_dist, float* gall,
-                           hipStream_t s) {
+                           const float* ssim_partials, const float* post_partials, float lambda_dssim, float lambda_normal, float lambda_dist,
+                           float* out6, float* total_out, hipStream_t s) {
     lossk::SsimWin win;
     (void)ssim_window(11, &win);
     const int n_ssim = ssim_blocks(H, W) * 3, n_pad = (n_ssim + 7) / 8 * 8, n_post = post_blocks(H, W);
-    hipLaunchKernelGGL(train_loss_bwd_kernel, dim3(n_pad + n_post), dim3(256), 0, s, n_ssim, n_pad, n_post, H, W, img, gt, dmaps, (size_t)3 * H * W,
-                       c_l1, c_ssim, g_dev, grad_img, win, allmap, cam, ratio, (const float*)nullptr, c_normal, c_dist, gall);
+    const lossk::LossFinalize fin{ssim_partials, n_ssim, 1.f / (float)((size_t)3 * H * W), post_partials, n_post, 1.f / (float)((size_t)H * W),
+                                  lambda_dssim, lambda_normal, lambda_dist, out6, total_out};
+    hipLaunchKernelGGL(train_loss_bwd_kernel, dim3(n_pad + n_post + (out6 ? 1 : 0)), dim3(256), 0, s, n_ssim, n_pad, n_post, H, W, img, gt, dmaps,
+                       (size_t)3 * H * W, c_l1, c_ssim, g_dev, grad_img, win, allmap, cam, ratio, (const float*)nullptr, c_normal, c_dist, gall, fin);
 }
 
 }  // namespace surfel

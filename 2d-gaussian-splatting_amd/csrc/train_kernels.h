@@ -24,9 +24,11 @@ void launch_post_bwd(int H, int W, const float* allmap, const float* cam, float 
 // horizontally fused training loss (train_fused.hip): [3,H,W] image vs target (window 11) + allmap regularisers, one launch per direction
 void launch_train_loss_fwd(int H, int W, const float* img, const float* gt, float* dmaps, float* partials, const float* allmap, const float* cam,
                            float ratio, float* post_partials, hipStream_t s);
+// out6 != NULL: one extra workgroup of the launch computes the iteration's loss scalars from the forward's partial sums (deferred finalize)
 void launch_train_loss_bwd(int H, int W, const float* img, const float* gt, const float* dmaps, float c_l1, float c_ssim, const float* g_dev,
                            float* grad_img, const float* allmap, const float* cam, float ratio, float c_normal, float c_dist, float* gall,
-                           hipStream_t s);
+                           const float* ssim_partials, const float* post_partials, float lambda_dssim, float lambda_normal, float lambda_dist,
+                           float* out6, float* total_out, hipStream_t s);
 
 void launch_activate(int P, const float* theta, float* act, hipStream_t s);
 void launch_adam(int P, float* theta, const float* grad, float* m, float* v, float* act, const float* lr, float beta1, float beta2, float eps,

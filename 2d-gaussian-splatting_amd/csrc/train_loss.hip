@@ -53,37 +53,11 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __res
 // All loss scalars of an iteration in one workgroup, fixed summation order (train.py:72-88):
 // out = [Ll1, ssim, normal_err, dist, photometric, total],  photometric = (1-l)*Ll1 + l*(1-ssim),
 // total = photometric + lambda_normal*normal_err + lambda_dist*dist.   pb may be NULL (no regularisers this iteration).
-__global__ __launch_bounds__(1024) void loss_finalize_kernel(const float* __restrict__ pa, int na, float scale_a, const float* __restrict__ pb,
-                                                             int nb, float scale_b, float lambda_dssim, float lambda_normal,
-                                                             float lambda_dist, float* __restrict__ out, float* __restrict__ total_out) {
+__global__ __launch_bounds__(1024) void loss_finalize_kernel(LossFinalize f) {
     // 1024 threads, 8-byte loads: the ~2 000 + 2 500 partial pairs of an 800x800 frame are two or three loads per thread, all in
-    // flight at once; wave totals by xor-shuffles, the 16 wave totals added in wave order (a fixed order: same bits every run)
+    // flight at once (train_loss_body.h: loss_finalize_body)
     __shared__ float red[4][16];
-    const int tid = threadIdx.x;
-    const float2* __restrict__ pa2 = reinterpret_cast<const float2*>(pa);
-    const float2* __restrict__ pb2 = reinterpret_cast<const float2*>(pb);
-    float a0 = 0.f, a1 = 0.f, b0 = 0.f, b1 = 0.f;
-    for (int i = tid; i < na; i += 1024) { const float2 v = pa2[i]; a0 += v.x; a1 += v.y; }
-    if (pb) for (int i = tid; i < nb; i += 1024) { const float2 v = pb2[i]; b0 += v.x; b1 += v.y; }
-    a0 = wave_sum(a0); a1 = wave_sum(a1); b0 = wave_sum(b0); b1 = wave_sum(b1);
-    if ((tid & 63) == 0) { red[0][tid >> 6] = a0; red[1][tid >> 6] = a1; red[2][tid >> 6] = b0; red[3][tid >> 6] = b1; }
-    __syncthreads();
-    if (tid == 0) {
-        float t[4];
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            float acc = 0.f;
-#pragma unroll
-            for (int w = 0; w < 16; w++) acc += red[k][w];
-            t[k] = acc;
-        }
-        const float l1 = t[0] * scale_a, ss = t[1] * scale_a, ne = t[2] * scale_b, di = t[3] * scale_b;
-        const float ph = (1.f - lambda_dssim) * l1 + lambda_dssim * (1.f - ss);
-        out[0] = l1; out[1] = ss; out[2] = ne; out[3] = di; out[4] = ph;
-        const float tot = ph + lambda_normal * ne + lambda_dist * di;
-        out[5] = tot;
-        if (total_out) total_out[0] = tot;
-    }
+    loss_finalize_body<1024>(red, f);
 }
 
 }  // namespace
@@ -158,8 +132,8 @@ void launch_reduce_partials(const float* partials, int groups, int n, int stride
 
 void launch_loss_finalize(const float* pa, int na, float scale_a, const float* pb, int nb, float scale_b, float lambda_dssim,
                           float lambda_normal, float lambda_dist, float* out, float* total_out, hipStream_t s) {
-    hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(1024), 0, s, pa, na, scale_a, pb, nb, scale_b, lambda_dssim, lambda_normal,
-                       lambda_dist, out, total_out);
+    const LossFinalize f{pa, na, scale_a, pb, nb, scale_b, lambda_dssim, lambda_normal, lambda_dist, out, total_out};
+    hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(1024), 0, s, f);
 }
 
 }  // namespace surfel

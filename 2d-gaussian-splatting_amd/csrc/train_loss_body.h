@@ -238,6 +238,48 @@ __device__ __forceinline__ void ssim_bwd_body(char* smem, int vblock, int vgrid,
 }
 
 
+// All loss scalars of an iteration from the two partial-sum arrays (train.py:72-88), fixed summation order — that of 1024 threads
+// (strided partial sums, wave totals by xor-shuffles, the 16 wave totals added in wave order) whatever the calling workgroup's size
+// NT (1024: loss_finalize_kernel; 256: the extra workgroup of the fused backward plays four of those waves each): same bits.
+// out = [Ll1, ssim, normal_err, dist, photometric, total].  pb may be NULL (no regularisers).  red: 4 x 16 floats of LDS.
+struct LossFinalize {
+    const float* pa; int na; float scale_a; const float* pb; int nb; float scale_b;
+    float lambda_dssim, lambda_normal, lambda_dist; float* out; float* total_out;
+};
+
+template <int NT>
+__device__ __forceinline__ void loss_finalize_body(float (*red)[16], const LossFinalize& f) {
+    const int tid = threadIdx.x;
+    const float2* __restrict__ pa2 = reinterpret_cast<const float2*>(f.pa);
+    const float2* __restrict__ pb2 = reinterpret_cast<const float2*>(f.pb);
+#pragma unroll
+    for (int j = 0; j < 1024 / NT; j++) {
+        const int vt = tid + NT * j;
+        float a0 = 0.f, a1 = 0.f, b0 = 0.f, b1 = 0.f;
+        for (int i = vt; i < f.na; i += 1024) { const float2 v = pa2[i]; a0 += v.x; a1 += v.y; }
+        if (f.pb) for (int i = vt; i < f.nb; i += 1024) { const float2 v = pb2[i]; b0 += v.x; b1 += v.y; }
+        a0 = wave_sum(a0); a1 = wave_sum(a1); b0 = wave_sum(b0); b1 = wave_sum(b1);
+        if ((tid & 63) == 0) { red[0][vt >> 6] = a0; red[1][vt >> 6] = a1; red[2][vt >> 6] = b0; red[3][vt >> 6] = b1; }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        float t[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            float acc = 0.f;
+#pragma unroll
+            for (int w = 0; w < 16; w++) acc += red[k][w];
+            t[k] = acc;
+        }
+        const float l1 = t[0] * f.scale_a, ss = t[1] * f.scale_a, ne = t[2] * f.scale_b, di = t[3] * f.scale_b;
+        const float ph = (1.f - f.lambda_dssim) * l1 + f.lambda_dssim * (1.f - ss);
+        f.out[0] = l1; f.out[1] = ss; f.out[2] = ne; f.out[3] = di; f.out[4] = ph;
+        const float tot = ph + f.lambda_normal * ne + f.lambda_dist * di;
+        f.out[5] = tot;
+        if (f.total_out) f.total_out[0] = tot;
+    }
+}
+
 template <int SR> constexpr size_t ssim_fwd_lds() { return sizeof(float4) * (ST + 2 * SR) * HZP + sizeof(float2) * (ST + 2 * SR) * (ST + 2 * SR + 4) + sizeof(float) * (ST + 2 * SR) * ST + 32; }
 template <int SR> constexpr size_t ssim_bwd_lds() { return sizeof(float4) * (ST + 2 * SR) * HZP + (sizeof(float2) + sizeof(float)) * (ST + 2 * SR) * (ST + 2 * SR + 4); }
 

@@ -85,6 +85,15 @@ def _c(t):
     return t.contiguous()
 
 
+def finish_count():
+    """Collect the instance count of a lazily counted forward (debug bit surfel_native.OPT_LAZY_COUNT; include/surfel_hip.h:
+    surfel_forward_count) on the calling thread: returns it, or raises surfel_native.CapacityOverflow — the frame is then rendered
+    again with OPT_EXACT_BINNING and whatever was derived from it recomputed."""
+    global last_num_rendered
+    last_num_rendered = _n.forward_count()
+    return last_num_rendered
+
+
 def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, raster_settings):
     return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
                                      raster_settings)

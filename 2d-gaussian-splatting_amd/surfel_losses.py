@@ -191,7 +191,7 @@ class _TrainLoss(torch.autograd.Function):
     Returns (total, scalars) with scalars = [Ll1, ssim, normal_err, dist, photometric, total] (detached)."""
 
     @staticmethod
-    def forward(ctx, image, allmap, gt, cam, depth_ratio, lambda_dssim, lambda_normal, lambda_dist):
+    def forward(ctx, image, allmap, gt, cam, depth_ratio, lambda_dssim, lambda_normal, lambda_dist, defer_scalars=False):
         planes, H, W = _planes(image, gt)
         x = image.detach().contiguous().float(); y = gt.detach().contiguous().float()
         dev = x.device
@@ -222,9 +222,15 @@ class _TrainLoss(torch.autograd.Function):
                     # maps = NULL: only the two regulariser sums are needed (the backward recomputes from allmap)
                     _check(lib.surfel_render_post_forward(H, W, _n.ptr(am), _n.ptr(cam), float(depth_ratio), None, _n.ptr(pb), s),
                            "surfel_render_post_forward")
-            _check(lib.surfel_loss_finalize(_n.ptr(partials), planes * nblk, planes * H * W, _n.ptr(pb), npost, H * W, float(lambda_dssim),
-                                            float(lambda_normal) if reg else 0.0, float(lambda_dist) if reg else 0.0, _n.ptr(out), _n.ptr(total), s),
-                   "surfel_loss_finalize")
+            # defer_scalars: the loss scalars are written by an extra workgroup of the fused BACKWARD launch (valid once the backward has
+            # run: a training loop reads them after the step) — one launch less per iteration
+            ctx.deferred = None
+            if defer_scalars and reg and planes == 3 and FUSED_LOSS and (image.requires_grad or getattr(ctx, "manual", False)):
+                ctx.deferred = (partials, pb, out, total)
+            else:
+                _check(lib.surfel_loss_finalize(_n.ptr(partials), planes * nblk, planes * H * W, _n.ptr(pb), npost, H * W, float(lambda_dssim),
+                                                float(lambda_normal) if reg else 0.0, float(lambda_dist) if reg else 0.0, _n.ptr(out), _n.ptr(total), s),
+                       "surfel_loss_finalize")
         ctx.set_materialize_grads(False)
         ctx.k = (planes, H, W, float(depth_ratio), float(lambda_dssim), float(lambda_normal), float(lambda_dist), reg)
         ctx.shapes = (tuple(image.shape), None if allmap is None else tuple(allmap.shape))
@@ -237,7 +243,7 @@ class _TrainLoss(torch.autograd.Function):
         planes, H, W, ratio, lam, ln, ld, reg = ctx.k
         x, y, dmaps, am, cam = ctx.saved_tensors
         if g_total is None:
-            return None, None, None, None, None, None, None, None
+            return None, None, None, None, None, None, None, None, None
         dev = x.device
         lib = _n.load()
         N = float(planes * H * W)
@@ -248,8 +254,10 @@ class _TrainLoss(torch.autograd.Function):
         with torch.cuda.device(dev):
             if reg and planes == 3 and FUSED_LOSS:
                 grad_am = torch.empty_like(am)
+                fin = ctx.deferred or (None, None, None, None)
                 _check(lib.surfel_train_loss_backward(H, W, _n.ptr(x), _n.ptr(y), _n.ptr(dmaps), (1.0 - lam) / N, -lam / N, _n.ptr(am), _n.ptr(cam),
-                                                      ratio, ln / (H * W), ld / (H * W), _n.ptr(g), _n.ptr(grad_img), _n.ptr(grad_am), s),
+                                                      ratio, ln / (H * W), ld / (H * W), _n.ptr(g), _n.ptr(grad_img), _n.ptr(grad_am),
+                                                      _n.ptr(fin[0]), _n.ptr(fin[1]), lam, ln, ld, _n.ptr(fin[2]), _n.ptr(fin[3]), s),
                        "surfel_train_loss_backward")
             else:
                 _check(lib.surfel_l1_ssim_backward(planes, H, W, _n.ptr(x), _n.ptr(y), _n.ptr(dmaps), (1.0 - lam) / N, -lam / N, _n.ptr(g), _n.ptr(g),
@@ -258,18 +266,38 @@ class _TrainLoss(torch.autograd.Function):
                     grad_am = torch.empty_like(am)
                     _check(lib.surfel_render_post_backward(H, W, _n.ptr(am), _n.ptr(cam), ratio, None, ln / (H * W), ld / (H * W), _n.ptr(g),
                                                            _n.ptr(grad_am), s), "surfel_render_post_backward")
-        return grad_img.view(ctx.shapes[0]), grad_am, None, None, None, None, None, None
+        return grad_img.view(ctx.shapes[0]), grad_am, None, None, None, None, None, None, None
 
 
-def train_loss(image, allmap, gt_image, cam_consts, depth_ratio, lambda_dssim, lambda_normal, lambda_dist):
+def train_loss(image, allmap, gt_image, cam_consts, depth_ratio, lambda_dssim, lambda_normal, lambda_dist, defer_scalars=False):
     """Total loss of train.py:72-88 from the rasterizer's two outputs; cam_consts = the camera's 24-float block
-    (surfel_render.post_consts) or None when both regulariser weights are 0."""
+    (surfel_render.post_consts) or None when both regulariser weights are 0.
+    defer_scalars: the returned scalars (and the total's VALUE) are filled in by the backward launch instead of a finalize launch
+    of their own — for a training loop that calls backward right away and reads them afterwards; gradients do not depend on it."""
     if cam_consts is None:
         if lambda_normal != 0.0 or lambda_dist != 0.0:
             raise ValueError("regularisers need the camera constants")
         cam_consts = torch.empty(0, device=image.device)
         allmap = None
-    return _TrainLoss.apply(image, allmap, gt_image, cam_consts, depth_ratio, lambda_dssim, lambda_normal, lambda_dist)
+    return _TrainLoss.apply(image, allmap, gt_image, cam_consts, depth_ratio, lambda_dssim, lambda_normal, lambda_dist, defer_scalars)
+
+
+def train_loss_manual(image, allmap, gt_image, cam_consts, depth_ratio, lambda_dssim, lambda_normal, lambda_dist, defer_scalars=True):
+    """train_loss without autograd: returns (ctx, total, scalars); train_loss_manual_backward(ctx, g_total) then yields
+    (dL/dimage, dL/dallmap or None).  Same kernels, same bits as the autograd node (call under torch.no_grad())."""
+    if cam_consts is None:
+        if lambda_normal != 0.0 or lambda_dist != 0.0:
+            raise ValueError("regularisers need the camera constants")
+        cam_consts = torch.empty(0, device=image.device)
+        allmap = None
+    ctx = _n.ManualCtx()
+    total, out = _TrainLoss.forward(ctx, image, allmap, gt_image, cam_consts, depth_ratio, lambda_dssim, lambda_normal, lambda_dist, defer_scalars)
+    return ctx, total, out
+
+
+def train_loss_manual_backward(ctx, g_total):
+    g = _TrainLoss.backward(ctx, g_total, None)
+    return g[0], g[1]
 
 
 class _TrainLossBand(torch.autograd.Function):
@@ -342,7 +370,8 @@ class _TrainLossBand(torch.autograd.Function):
             if reg and planes == 3 and FUSED_LOSS:
                 grad_am = torch.empty_like(am)
                 _check(lib.surfel_train_loss_backward(He, W, _n.ptr(x), _n.ptr(y), _n.ptr(dmaps), (1.0 - lam) / N3, -lam / N3, _n.ptr(am), _n.ptr(cam),
-                                                      ratio, ln / N1, ld / N1, _n.ptr(g), _n.ptr(grad_img), _n.ptr(grad_am), s),
+                                                      ratio, ln / N1, ld / N1, _n.ptr(g), _n.ptr(grad_img), _n.ptr(grad_am),
+                                                      None, None, 0.0, 0.0, 0.0, None, None, s),
                        "surfel_train_loss_backward")
             else:
                 _check(lib.surfel_l1_ssim_backward(planes, He, W, _n.ptr(x), _n.ptr(y), _n.ptr(dmaps), (1.0 - lam) / N3, -lam / N3, _n.ptr(g), _n.ptr(g),

@@ -20,7 +20,7 @@ HOOK_FN = C.CFUNCTYPE(None, C.c_void_p)
 
 EXPORTS = ["surfel_abi_version", "surfel_last_error", "surfel_rasterize_forward", "surfel_rasterize_backward",
            "surfel_mark_visible", "surfel_knn_dist2", "surfel_last_stage_ms", "surfel_last_stage_ids", "surfel_stage_name",
-           "surfel_collect_stage_ms", "surfel_set_option", "surfel_debug_sort_pairs", "surfel_debug_set_blend_stats", "surfel_debug_walk_choice", "surfel_debug_last_binning", "surfel_set_backward_hook",
+           "surfel_collect_stage_ms", "surfel_set_option", "surfel_debug_sort_pairs", "surfel_debug_set_blend_stats", "surfel_debug_walk_choice", "surfel_debug_last_binning", "surfel_set_backward_hook", "surfel_set_densify_sink", "surfel_forward_count",
            # include/surfel_train.h
            "surfel_l1_ssim_forward", "surfel_l1_ssim_backward", "surfel_l1_ssim_forward_w", "surfel_l1_ssim_backward_w", "surfel_render_post_forward", "surfel_render_post_backward", "surfel_train_loss_forward", "surfel_train_loss_backward",
            "surfel_reduce_partials", "surfel_loss_finalize", "surfel_activate", "surfel_adam_step", "surfel_sh_grad_gather", "surfel_densify_stats"]
@@ -34,6 +34,8 @@ OPT_PBWD_THREAD = 1 << 14
 OPT_EXACT_BINNING = 1 << 16    # forward: size the binning buffers exactly (host wait for the instance count) for this call
 OPT_TILE_CUTS = 1 << 17        # backward: tile cuts instead of zero gradient records (default: R >= 2^21); bit-identical
 OPT_ZERO_RECORDS = 1 << 18     # backward: zero gradient records behind a tile's saturation point (default: R < 2^21)
+OPT_LAZY_COUNT = 1 << 21       # forward: do not wait for the instance count; forward_count() collects it (include/surfel_hip.h)
+E_OVERFLOW = -5
 OPT_BWD_SCAN = 1 << 15         # scan walk (lanes = instances); deterministic, not bit-identical to rows / quad
 
 
@@ -91,6 +93,10 @@ def load():
         lib.surfel_debug_walk_choice.argtypes = [i, i]
         lib.surfel_set_backward_hook.restype = i
         lib.surfel_set_backward_hook.argtypes = [HOOK_FN, vp]
+        lib.surfel_forward_count.restype = i64
+        lib.surfel_forward_count.argtypes = []
+        lib.surfel_set_densify_sink.restype = i
+        lib.surfel_set_densify_sink.argtypes = [vp, vp, vp]
         lib.surfel_set_option.restype = i
         lib.surfel_set_option.argtypes = [C.c_char_p, i]
         # ---- include/surfel_train.h
@@ -102,7 +108,7 @@ def load():
                            ("surfel_render_post_forward", [i, i, vp, vp, f, vp, vp, vp]),
                            ("surfel_render_post_backward", [i, i, vp, vp, f, vp, f, f, vp, vp, vp]),
                            ("surfel_train_loss_forward", [i, i, vp, vp, vp, vp, vp, vp, f, vp, vp]),
-                           ("surfel_train_loss_backward", [i, i, vp, vp, vp, f, f, vp, vp, f, f, f, vp, vp, vp, vp]),
+                           ("surfel_train_loss_backward", [i, i, vp, vp, vp, f, f, vp, vp, f, f, f, vp, vp, vp, vp, vp, f, f, f, vp, vp, vp]),
                            ("surfel_reduce_partials", [vp, i, i, i, f, vp, vp]),
                            ("surfel_loss_finalize", [vp, i, i, vp, i, i, f, f, f, vp, vp, vp]),
                            ("surfel_activate", [i, vp, vp, vp]),
@@ -138,6 +144,29 @@ def set_backward_hook(fn):
     thunk = HOOK_FN(lambda user: fn())
     lib.surfel_set_backward_hook(thunk, None)
     _hook_keepalive = thunk
+
+
+class CapacityOverflow(RuntimeError):
+    """a lazily counted frame held more tile instances than its capacity: render it again (OPT_EXACT_BINNING)"""
+
+
+def forward_count():
+    """surfel_forward_count: exact instance count of this thread's last forward; raises CapacityOverflow for a lazily counted frame
+    whose lists were truncated."""
+    r = load().surfel_forward_count()
+    if r == E_OVERFLOW:
+        raise CapacityOverflow(last_error())
+    if r < 0:
+        raise RuntimeError("surfel_forward_count failed: %s" % last_error())
+    return int(r)
+
+
+def set_densify_sink(accum, denom, max_radii):
+    """surfel_set_densify_sink: the next rasterizer backwards update the three [P] float32 statistics in place (None, None, None
+    removes the sink).  The caller keeps the tensors alive while the sink is set."""
+    rc = load().surfel_set_densify_sink(ptr(accum), ptr(denom), ptr(max_radii))
+    if rc < 0:
+        raise RuntimeError("surfel_set_densify_sink failed: %s" % last_error())
 
 
 def last_error():
@@ -187,8 +216,31 @@ def ptr(t):
     return None if t is None else C.c_void_p(t.data_ptr())
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def current_stream_ptr(device):
+    # (torch.cuda.current_stream() builds a Stream object per call: ~7 us of the ~400 us a training iteration costs on the host)
+    if _raw_stream is not None and device.index is not None:
+        return C.c_void_p(_raw_stream(device.index))
     return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+class ManualCtx:
+    """Stand-in for the autograd context when a caller drives forward() / backward() of the library's autograd Functions itself
+    (surfel_trainer: the iteration's chain is fixed — rasterizer -> loss -> loss backward -> rasterizer backward — and the autograd
+    engine, its worker-thread hand-over and the parameter gates cost more host time than all the launches together)."""
+    manual = True
+    needs_input_grad = ()
+
+    def save_for_backward(self, *tensors):
+        self.saved_tensors = tensors
+
+    def mark_non_differentiable(self, *tensors):
+        pass
+
+    def set_materialize_grads(self, value):
+        pass
 
 
 def stage_times():

@@ -194,10 +194,11 @@ def regularizers(allmap, viewpoint_camera, depth_ratio, lambda_normal, lambda_di
 
 
 # ------------------------------------------------------------------------------------------------ render()
-def rasterize(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, override_color=None, zero_means2D=True, band=None):
+def rasterize(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, override_color=None, zero_means2D=True, band=None, debug_bits=0):
     """The rasterizer call of render() (gaussian_renderer/__init__.py:27-106): returns (image, radii, allmap, means2D).
     means2D is only the sink of the densification statistic (its values are never read); zero_means2D=False skips the fill.
-    band = (y0, y1), multiples of 16: render only those image rows (tile-band sharding, surfel_dist.band_settings)."""
+    band = (y0, y1), multiples of 16: render only those image rows (tile-band sharding, surfel_dist.band_settings).
+    debug_bits: per-call library options (surfel_native.OPT_*) OR-ed into the settings' debug word."""
     means3D = pc.get_xyz
     screenspace_points = torch.zeros_like(means3D, requires_grad=True) if zero_means2D else torch.empty_like(means3D).requires_grad_(True)
     raster_settings = GaussianRasterizationSettings(
@@ -205,7 +206,7 @@ def rasterize(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, overri
         tanfovx=math.tan(viewpoint_camera.FoVx * 0.5), tanfovy=math.tan(viewpoint_camera.FoVy * 0.5), bg=bg_color,
         scale_modifier=scaling_modifier, viewmatrix=viewpoint_camera.world_view_transform,
         projmatrix=viewpoint_camera.full_proj_transform, sh_degree=pc.active_sh_degree, campos=viewpoint_camera.camera_center,
-        prefiltered=False, debug=int(getattr(pipe, "debug", 0)))
+        prefiltered=False, debug=int(getattr(pipe, "debug", 0)) | int(debug_bits))
     if band is not None:
         import surfel_dist
         raster_settings = surfel_dist.band_settings(raster_settings, int(band[0]), int(band[1]))
@@ -232,6 +233,32 @@ def rasterize(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, overri
     image, radii, allmap = rasterizer(means3D=means3D, means2D=screenspace_points, shs=shs, colors_precomp=colors_precomp,
                                       opacities=pc.get_opacity, scales=scales, rotations=rotations, cov3D_precomp=cov3D_precomp)
     return image, radii, allmap, screenspace_points
+
+
+def rasterize_manual(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, debug_bits=0):
+    """The rasterizer call of a training iteration without autograd (surfel_native.ManualCtx): the store's raw views go straight
+    into the forward, rasterize_manual_backward(ctx, dL/dimage, dL/dallmap) runs the backward — it writes the model's bound gradient
+    store (GaussianModel.bind) like the autograd path — and returns dL/dmeans2D, the densification statistic.  Native homography
+    and SH colours only (what train.py uses).  Returns (ctx, image, radii, allmap).  Call under torch.no_grad()."""
+    from diff_surfel_rasterization import _RasterizeGaussians
+    import surfel_native as _n
+    P = pc.P
+    rs = GaussianRasterizationSettings(
+        image_height=int(viewpoint_camera.image_height), image_width=int(viewpoint_camera.image_width),
+        tanfovx=math.tan(viewpoint_camera.FoVx * 0.5), tanfovy=math.tan(viewpoint_camera.FoVy * 0.5), bg=bg_color,
+        scale_modifier=scaling_modifier, viewmatrix=viewpoint_camera.world_view_transform,
+        projmatrix=viewpoint_camera.full_proj_transform, sh_degree=pc.active_sh_degree, campos=viewpoint_camera.camera_center,
+        prefiltered=False, debug=int(getattr(pipe, "debug", 0)) | int(debug_bits))
+    ctx = _n.ManualCtx()
+    none = pc._pv["xyz"].new_empty(0)
+    image, radii, allmap = _RasterizeGaussians.forward(ctx, pc._pv["xyz"], none, pc._pv["sh"].view(P, 16, 3), none, pc._av["opacity"],
+                                                       pc._av["scaling"], pc._av["rotation"], none, rs)
+    return ctx, image, radii, allmap
+
+
+def rasterize_manual_backward(ctx, grad_image, grad_allmap):
+    from diff_surfel_rasterization import _RasterizeGaussians
+    return _RasterizeGaussians.backward(ctx, grad_image, None, grad_allmap)[1]
 
 
 def render(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, override_color=None):

@@ -24,9 +24,9 @@ import torch.distributed as dist
 
 import surfel_dist
 import surfel_native as _n
-from surfel_losses import scalars_from_band_sums, train_loss, train_loss_band
+from surfel_losses import scalars_from_band_sums, train_loss, train_loss_band, train_loss_manual, train_loss_manual_backward
 from surfel_model import COLOUR_FLOATS, GEOM_FLOATS, GaussianModel, exchange_collectives, exchange_same_view
-from surfel_render import Camera, post_consts_rows, rasterize, render
+from surfel_render import Camera, post_consts_rows, rasterize, rasterize_manual, rasterize_manual_backward, render
 
 
 def optimization_params(**over):
@@ -167,6 +167,11 @@ class Trainer:
         self.last = {}
         self._epoch, self._epoch_views, self._epoch_campos, self._centers = -1, None, None, None
         self._one = torch.ones((), dtype=torch.float32, device=model.device)
+        self.stats_in_backward = os.environ.get("SURFEL_STATS_IN_BACKWARD", "0") != "0"      # densification statistics by the rasterizer's backward (surfel_set_densify_sink) instead of a launch of their own
+        self.defer_scalars = os.environ.get("SURFEL_DEFER_SCALARS", "1") != "0"      # loss scalars by the fused loss backward launch instead of a finalize launch
+        self.lazy_count = os.environ.get("SURFEL_LAZY_COUNT", "1") != "0"      # forward without the host wait for the instance count (step())
+        self.lazy_overflows = 0
+        self.manual_chain = os.environ.get("SURFEL_MANUAL_CHAIN", "1") != "0"      # forward / backward of the iteration driven without autograd (step())
         self.views_per_step = 1         # single process: > 1 = accumulate that many views per optimiser step (_step_accumulate)
         self.rebalance_every = 8        # bands: iterations between re-balancing the band edges (one small all-gather + D2H)
         self._row_weights = None        # bands: running mean of tile instances per 16-row tile row (host list) of frames of ...
@@ -280,20 +285,59 @@ class Trainer:
             scalars = scalars_from_band_sums(sums, float(3 * H * W), float(H * W), opt.lambda_dssim, lam_n, lam_d)
             halo_b = surfel_dist.halo_bytes(bounds, self.rank, H, W, 10 if reg else 3)
         else:
-            image, radii, allmap, means2D = rasterize(cam, m, self.pipe, self.background, zero_means2D=False)
-            loss, scalars = train_loss(image, allmap if reg else None, cam.original_image, cam.post_consts() if reg else None,
-                                       self.pipe.depth_ratio, opt.lambda_dssim, lam_n, lam_d)
             halo_b = 0
         self.wire = surfel_dist.wire_bytes_per_step(m.P, self.world, self.sharding, stats_live, halo_b)
-        early = self._probe_early_gather() and self._async_exchange and not bands and it < opt.iterations
-        if early:
-            self._early, self._early_err = None, None
-            _n.set_backward_hook(self._on_colour_ready)
-        try:
-            torch.autograd.backward(loss, grad_tensors=self._one)        # cached seed gradient: no ones_like fill per iteration
-        finally:
+        early = (not bands) and self._probe_early_gather() and self._async_exchange and it < opt.iterations
+        # Lazily counted forward (include/surfel_hip.h: SURFEL_OPT_LAZY_COUNT): the host does not wait for the frame's instance count in
+        # the middle of the iteration — it enqueues loss and backward behind the forward and collects the count afterwards, when it has
+        # long arrived; a frame that overflowed its binning capacity (rare) is rendered again with exact sizes, loss and backward with
+        # it, before anything irreversible (statistics, optimiser step, collectives) has happened.
+        lazy = self.lazy_count and not bands and not early
+        # (optional) the view's densification statistics (train.py:126-128) updated by the rasterizer's backward itself, from the
+        # dL/dmeans2D it has just formed — not with a lazy count (a frame that is redone would be counted twice) nor with bands (the
+        # statistic is the norm of the SUM over bands, known only after the all-reduce)
+        sink = stats_live and not bands and self.stats_in_backward and not lazy
+        # The iteration's chain is fixed (rasterizer -> loss -> loss backward -> rasterizer backward): driven by hand
+        # (surfel_native.ManualCtx) it costs a fraction of the host time autograd spends on it — engine, worker-thread hand-over, five
+        # parameter gates — with the same kernels and bits; compute_cov3D_python trains through PyTorch code and needs autograd.
+        manual = self.manual_chain and not bands and not getattr(self.pipe, "compute_cov3D_python", False)
+        g2d = None
+        for bits in ((_n.OPT_LAZY_COUNT, _n.OPT_EXACT_BINNING) if lazy else (0,)):
+            if manual:
+                with torch.no_grad():
+                    rctx, image, radii, allmap = rasterize_manual(cam, m, self.pipe, self.background, debug_bits=bits)
+                    lctx, loss, scalars = train_loss_manual(image, allmap if reg else None, cam.original_image, cam.post_consts() if reg else None,
+                                                            self.pipe.depth_ratio, opt.lambda_dssim, lam_n, lam_d, defer_scalars=self.defer_scalars)
+            elif not bands:
+                image, radii, allmap, means2D = rasterize(cam, m, self.pipe, self.background, zero_means2D=False, debug_bits=bits)
+                loss, scalars = train_loss(image, allmap if reg else None, cam.original_image, cam.post_consts() if reg else None,
+                                           self.pipe.depth_ratio, opt.lambda_dssim, lam_n, lam_d, defer_scalars=self.defer_scalars)      # (read after the backward below)
             if early:
-                _n.set_backward_hook(None)
+                self._early, self._early_err = None, None
+                _n.set_backward_hook(self._on_colour_ready)
+            if sink:
+                _n.set_densify_sink(m.xyz_gradient_accum, m.denom, m.max_radii2D)
+            try:
+                if manual:
+                    with torch.no_grad():
+                        g_img, g_am = train_loss_manual_backward(lctx, self._one)
+                        g2d = rasterize_manual_backward(rctx, g_img, g_am)
+                else:
+                    torch.autograd.backward(loss, grad_tensors=self._one)        # cached seed gradient: no ones_like fill per iteration
+            finally:
+                if sink:
+                    _n.set_densify_sink(None, None, None)
+                if early:
+                    _n.set_backward_hook(None)
+            if not lazy:
+                break
+            try:
+                import diff_surfel_rasterization as dsr
+                dsr.finish_count()
+                break
+            except _n.CapacityOverflow:
+                self.lazy_overflows += 1
+                lazy = False      # second pass: exact binning, count known when the forward returns
         if self._early_err is not None:
             # the early all-gather could not be launched from inside the backward: dL/dcolour is final regardless (the split
             # kernel ran), so the step continues with the gather-after-backward form and the early form stays off
@@ -314,7 +358,8 @@ class Trainer:
                     self._timed_wait(w_same)
                 self._rebalance_bands(cam)
             if stats_live:
-                m.add_densification_stats(arena2d if bands else means2D.grad, radii=radii)
+                if not sink:
+                    m.add_densification_stats(arena2d if bands else (g2d if manual else means2D.grad), radii=radii)
                 rebuilt = self._schedule_events(it, bands)
             if it < opt.iterations and not rebuilt:     # re-created parameters carry no gradient in the reference: no update
                 if bands:

@@ -34,6 +34,7 @@ extern "C" {
 #define SURFEL_E_ALLOC   (-2)   /* allocator callback returned NULL */
 #define SURFEL_E_HIP     (-3)   /* a HIP call or kernel failed (message has the hipError string) */
 #define SURFEL_E_LIMIT   (-4)   /* size exceeds an internal limit (e.g. > 2^32-1 tile instances) */
+#define SURFEL_E_OVERFLOW (-5)  /* a lazily counted frame (SURFEL_OPT_LAZY_COUNT) held more instances than its capacity: render it again */
 
 /* The `debug` argument of the rasterizer entry points: low byte = debug mode (0 off, 1 synchronise + check after every stage,
  * 2 / 3 record stage timing events), upper bits = PER-CALL option overrides, so callers (tests above all) need not flip the
@@ -48,6 +49,7 @@ extern "C" {
 #define SURFEL_OPT_TILE_CUTS      (1 << 17)            /* backward: no gradient records behind a tile's saturation point, preprocess_bwd tests the tile cuts (default: R >= 2^21) */
 #define SURFEL_OPT_ZERO_RECORDS   (1 << 18)            /* backward: zero records behind a tile's saturation point (default: R < 2^21); bit-identical to the cuts */
 #define SURFEL_OPT_TILE_ORDER(m)  ((((m) + 1) & 3) << 19)  /* forward: "tile_order" = m (0, 1, 2) for this call (the matching backward follows the forward) */
+#define SURFEL_OPT_LAZY_COUNT     (1 << 21)            /* forward: do not wait for the instance count (see surfel_forward_count) */
 #define SURFEL_OPT_BWD_SCAN       (1 << 15)            /* backward: scan walk ("bwd_variant" = 3) for this call; deterministic, NOT bit-identical to rows / quad */
 
 /* Allocator callback: return a device pointer to `bytes` bytes, 256-byte aligned, valid until the
@@ -195,6 +197,13 @@ int surfel_set_option(const char* name, int value);
  * kernel on `stream` — and only then enqueues the per-surfel chain rule, which no longer touches dL_dcolors.  All other outputs
  * are unchanged.  Reference counterpart: none (the reference trains on one GPU); this serves the view-parallel exchange of
  * surfel_trainer.py. */
+/* Densification statistics at the source (process-wide; NULLs remove it).  While set, every surfel_rasterize_backward also applies
+ * the reference's add_densification_stats (scene/gaussian_model.py:405-407, called from train.py:126-128) to the three [P] float
+ * arrays, for the surfels with radii > 0:  grad_accum += |dL_dmeans2D[:, :2]|,  denom += 1,  max_radii = max(max_radii, radii)
+ * — the bits surfel_densify_stats (include/surfel_train.h) produces from the same dL_dmeans2D, without the extra launch.  A trainer
+ * sets it around the backward of a training view and removes it afterwards. */
+int surfel_set_densify_sink(float* grad_accum, float* denom, float* max_radii);
+
 typedef void (*surfel_hook_fn)(void* user);
 int surfel_set_backward_hook(surfel_hook_fn colour_ready, void* user);
 
@@ -204,8 +213,23 @@ int surfel_set_backward_hook(surfel_hook_fn colour_ready, void* user);
  * with a composited pair — or NULL to switch the instrumented kernels off again. */
 int surfel_debug_set_blend_stats(void* dev_u64x8);
 
+/* Lazily counted frames.  surfel_rasterize_forward normally returns the exact number of tile instances — the one host wait of a
+ * forward (the capacity path waits once everything is enqueued, but it waits).  With SURFEL_OPT_LAZY_COUNT in `debug`, a frame on the
+ * capacity path returns at once with its CAPACITY (an upper bound: pass it on to surfel_rasterize_backward as num_rendered) and the
+ * host runs ahead of the device; frames that take the exact path ignore the flag.  The caller owes the library one call of
+ *     surfel_forward_count()
+ * on the same thread before it lets the frame's results take effect (a trainer: after the backward, before the optimiser step):
+ * it returns the exact count, or SURFEL_E_OVERFLOW if the frame held more instances than its capacity — its lists were truncated,
+ * images and gradients are incomplete, and the caller renders the frame again (SURFEL_OPT_EXACT_BINNING) and recomputes what it
+ * derived from it.  Rare: the capacity is the largest count of the recent frames of that size plus 1/8.  A forward that finds the
+ * previous lazy frame overflowed and unchecked fails with SURFEL_E_OVERFLOW instead of going on.  Without a pending lazy frame the
+ * function returns the count of this thread's last forward.  Reference counterpart: num_rendered, the first return value of
+ * rasterize_gaussians (diff-surfel-rasterization/rasterize_points.cu [UPSTREAM-RECALL]), which the reference reads back
+ * synchronously. */
+int64_t surfel_forward_count(void);
+
 /* Debug: how the last forward of this thread sized its binning buffers — 0 exact (host wait for the count), 1 capacity,
- * 2 capacity overflowed and the frame was redone with exact sizes. */
+ * 2 capacity overflowed and the frame was redone with exact sizes, 4 capacity with a lazily collected count (SURFEL_OPT_LAZY_COUNT). */
 int surfel_debug_last_binning(void);
 
 /* Debug: the walk the "bwd_tune" probes currently favour for frames of this size on the current device (the most used entry of

@@ -101,7 +101,12 @@ int surfel_train_loss_forward(int H, int W, const float* img, const float* gt, f
                               const float* allmap, const float* cam, float depth_ratio, float* post_partials, void* stream);
 int surfel_train_loss_backward(int H, int W, const float* img, const float* gt, const float* dmaps, float c_l1, float c_ssim,
                                const float* allmap, const float* cam, float depth_ratio, float c_normal, float c_dist,
-                               const float* g_dev, float* grad_img, float* grad_allmap, void* stream);
+                               const float* g_dev, float* grad_img, float* grad_allmap,
+                               /* deferred loss scalars: with out6 != NULL one extra workgroup of this launch does what
+                                * surfel_loss_finalize does with the forward's two partial-sum arrays (same order, same bits), for a
+                                * caller that reads the scalars only after the backward (a training loop) and saves that launch */
+                               const float* ssim_partials, const float* post_partials, float lambda_dssim, float lambda_normal,
+                               float lambda_dist, float* out6, float* total_out, void* stream);
 
 /* out[g*stride + k] = scale * sum_i partials[(g*n + i)*stride + k], fixed summation order. groups*stride <= 65535. */
 int surfel_reduce_partials(const float* partials, int groups, int n, int stride, float scale, float* out, void* stream);

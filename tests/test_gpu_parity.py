@@ -549,6 +549,65 @@ def test_capacity_binning_is_identical():
     same(empty, empty_exact, "empty frame")
 
 
+def test_lazily_counted_forward():
+    """SURFEL_OPT_LAZY_COUNT (include/surfel_hip.h): a capacity-path forward that returns its capacity without waiting for the instance
+    count; surfel_forward_count() delivers the exact count later.  Images and — with the capacity passed on as num_rendered — the
+    gradients are BIT-IDENTICAL to the waiting forward's; a frame that overflows its capacity is reported (SURFEL_E_OVERFLOW) and,
+    if nobody asks, stops the next forward."""
+    import surfel_native as n
+    import synthetic
+    lib = n.load()
+    W, H = 336, 176      # (a frame size no other test uses: the capacity history is this test's own)
+
+    def run(sc, flags):
+        a = scene_args(sc)
+        r = HipRun(a, debug=flags | n.opt_tile_sort(2)).forward()
+        kind = lib.surfel_debug_last_binning()
+        return a, r, kind
+
+    def grads(a, r):
+        gC = np.random.default_rng(1).normal(size=(3, a["H"], a["W"])).astype(np.float32)
+        gO = np.random.default_rng(2).normal(size=(7, a["H"], a["W"])).astype(np.float32)
+        return r.backward(gC, gO)
+
+    sc = synthetic.make_scene(20000, W, H, seed=3, px_radius=4.0)
+    a, exact, k0 = run(sc, n.OPT_EXACT_BINNING)
+    assert k0 == 0 and n.forward_count() == exact.R
+    g_exact = grads(a, exact)
+    _, lazy0, k1 = run(sc, n.OPT_LAZY_COUNT)
+    assert k1 == 4 and lazy0.R >= exact.R and lazy0.R % 16384 == 0, (k1, lazy0.R, exact.R)      # the capacity, not the count
+    assert n.forward_count() == exact.R
+    assert n.forward_count() == exact.R                       # (no pending frame: the last count again)
+    assert np.array_equal(lazy0.color.cpu().numpy(), exact.color.cpu().numpy()) and np.array_equal(lazy0.others.cpu().numpy(), exact.others.cpu().numpy())
+    g_lazy = grads(a, lazy0)
+    for k in g_exact:
+        assert np.array_equal(g_exact[k], g_lazy[k]), "dL/d%s differs with num_rendered = capacity" % k
+    # a frame without the count collected: the next forward collects it silently
+    _, lazy1, k2 = run(sc, n.OPT_LAZY_COUNT)
+    _, lazy2, k3 = run(sc, n.OPT_LAZY_COUNT)
+    assert (k2, k3) == (4, 4) and n.forward_count() == exact.R
+    # overflow: four times the surfels at the same frame size
+    sc2 = synthetic.make_scene(80000, W, H, seed=5, px_radius=4.0)
+    _, over, k4 = run(sc2, n.OPT_LAZY_COUNT)
+    assert k4 == 4
+    with pytest.raises(n.CapacityOverflow):
+        n.forward_count()
+    a2, redo, k5 = run(sc2, n.OPT_EXACT_BINNING)
+    assert k5 == 0 and redo.R > over.R
+    _, lazy3, k6 = run(sc2, n.OPT_LAZY_COUNT)                 # the capacity has grown
+    assert k6 == 4 and n.forward_count() == redo.R
+    assert np.array_equal(lazy3.color.cpu().numpy(), redo.color.cpu().numpy())
+    # an overflow nobody looked at stops the next forward
+    sc3 = synthetic.make_scene(200000, W, H, seed=6, px_radius=4.0)
+    _, over2, k7 = run(sc3, n.OPT_LAZY_COUNT)
+    assert k7 == 4
+    a3 = scene_args(sc3)
+    with pytest.raises(AssertionError, match="overflowed"):
+        HipRun(a3, debug=n.opt_tile_sort(2)).forward()
+    _, ok, k8 = run(sc3, 0)                                   # reported once: the thread goes on
+    assert k8 in (0, 1, 2) and ok.R > redo.R
+
+
 def _walk_scene(kind, seed=31):
     import synthetic
     if kind == "C1":

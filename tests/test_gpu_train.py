@@ -414,8 +414,9 @@ def test_single_node_train_loss_matches_reference_sum(gt, ratio):
 @pytest.mark.parametrize("hw", [(64, 80), (101, 77), (800, 800)])
 def test_fused_loss_launches_keep_the_bits(hw):
     """The training loss's two halves in one launch per direction (csrc/train_fused.hip: SSIM workgroups and post-processing
-    workgroups of one grid, the same kernel bodies over one LDS workspace) against the four separate launches: loss scalars and both
-    gradients BIT-IDENTICAL, also on frame sizes that are no multiple of either tile."""
+    workgroups of one grid, the same kernel bodies over one LDS workspace; the loss scalars by a finalize launch or by an extra
+    workgroup of the backward launch) against the four separate launches: loss scalars and both gradients BIT-IDENTICAL, also on frame sizes
+    that are no multiple of either tile."""
     import torch
     import surfel_losses as L
     import surfel_render as R
@@ -432,16 +433,93 @@ def test_fused_loss_launches_keep_the_bits(hw):
     consts = cam.post_consts()
     res = []
     try:
-        for fused in (False, True):
+        # separate launches | fused halves + finalize launch | fused halves, loss scalars deferred to an extra workgroup of the backward
+        for fused, defer in ((False, False), (True, False), (True, True), (False, True)):
             L.FUSED_LOSS = fused
             x = img.clone().requires_grad_(True); am = allmap.clone().requires_grad_(True)
-            total, sc = L.train_loss(x, am, tgt, consts, 0.7, 0.2, 0.05, 100.0)
-            (1.5 * total).backward()
+            total, sc = L.train_loss(x, am, tgt, consts, 0.7, 0.2, 0.05, 100.0, defer_scalars=defer)
+            total.backward(torch.full((), 1.5, device=d))
             res.append((total.detach().clone(), sc.clone(), x.grad.clone(), am.grad.clone()))
     finally:
         L.FUSED_LOSS = True
-    for a, b in zip(*res):
-        assert torch.isfinite(a).all() and torch.equal(a, b)
+    for other in res[1:]:
+        for a, b in zip(res[0], other):
+            assert torch.isfinite(a).all() and torch.equal(a, b)
+
+
+def test_densification_statistics_by_the_backward_are_identical():
+    """surfel_set_densify_sink: the rasterizer's backward applies train.py:126-128 (max_radii2D, xyz_gradient_accum, denom for the
+    surfels the view saw) itself — same statistics, same parameters, BIT for bit, as the separate surfel_densify_stats launch on
+    the dL/dmeans2D it returns; also with the transMat_precomp-free default path only (the trainer's)."""
+    import torch
+    import surfel_trainer as TR
+    d = dev()
+    bg = torch.zeros(3, device=d)
+    gt_model = TR.synthetic_object(3000, d, seed=1, px_scale=0.06)
+    cams = TR.capture_views(gt_model, TR.orbit_cameras(4, 128, 96, device=d), bg)
+    out = []
+    for sink in (False, True):
+        m = TR.synthetic_object(3000, d, seed=2, px_scale=0.05)
+        m.spatial_lr_scale = 1.0
+        tr = TR.Trainer(m, cams, TR.optimization_params(dist_from_iter=0, normal_from_iter=0, lambda_dist=10.0, densify_from_iter=10 ** 9),
+                        TR.pipeline_params(depth_ratio=1.0))
+        tr.stats_in_backward = sink
+        for _ in range(5):
+            tr.step()
+        torch.cuda.synchronize()
+        out.append((m.xyz_gradient_accum.clone(), m.denom.clone(), m.max_radii2D.clone(), m.theta.clone()))
+    assert float(out[0][1].sum()) > 0 and float(out[0][0].abs().sum()) > 0
+    for a, b in zip(*out):
+        assert torch.equal(a, b)
+
+
+def test_trainer_with_lazily_counted_forwards_is_identical():
+    """Trainer.lazy_count: the iteration without the host wait for the instance count (forward returns its capacity, the count is
+    collected after the backward) trains to the same bits as the waiting form — also when a frame is reported as overflowed and the
+    iteration's forward, loss and backward are redone (forced here: the collection is made to fail once).  Trainer.manual_chain: the
+    iteration's forward / backward chain driven by hand (surfel_native.ManualCtx) against torch.autograd driving it: same bits."""
+    import torch
+    import diff_surfel_rasterization as dsr
+    import surfel_native as n
+    import surfel_trainer as TR
+    d = dev()
+    bg = torch.zeros(3, device=d)
+    gt_model = TR.synthetic_object(3000, d, seed=1, px_scale=0.06)
+    cams = TR.capture_views(gt_model, TR.orbit_cameras(4, 144, 96, device=d), bg)
+    out = []
+    real = dsr.finish_count
+    for mode in ("wait", "lazy", "lazy+redo", "wait+autograd", "lazy+autograd"):
+        m = TR.synthetic_object(3000, d, seed=2, px_scale=0.05)
+        m.spatial_lr_scale = 1.0
+        tr = TR.Trainer(m, cams, TR.optimization_params(dist_from_iter=2, normal_from_iter=0, lambda_dist=10.0, densify_from_iter=10 ** 9),
+                        TR.pipeline_params(depth_ratio=1.0))
+        tr.lazy_count = not mode.startswith("wait")
+        tr.manual_chain = "autograd" not in mode      # the chain driven by hand (default) | through torch.autograd
+        calls = [0]
+
+        def fake():
+            calls[0] += 1
+            r = real()
+            if calls[0] == 3:
+                raise n.CapacityOverflow("forced")
+            return r
+        if mode == "lazy+redo":
+            dsr.finish_count = fake
+        try:
+            scal = []
+            for _ in range(5):
+                tr.step()
+                scal.append(tr.last["scalars"].clone())
+        finally:
+            dsr.finish_count = real
+        torch.cuda.synchronize()
+        assert tr.lazy_overflows == (1 if mode == "lazy+redo" else 0)
+        if mode.startswith("lazy"):
+            assert n.load().surfel_debug_last_binning() in (0, 4)
+        out.append((m.theta.clone(), m.m.clone(), m.v.clone(), m.xyz_gradient_accum.clone(), m.denom.clone(), torch.stack(scal)))
+    for other in out[1:]:
+        for a, b in zip(out[0], other):
+            assert torch.equal(a, b)
 
 
 def test_render_python_covariance_and_override_color_paths():

@@ -32,24 +32,37 @@ def trainer(monkeypatch):
     import surfel_trainer as TR
     calls = []
 
-    def fake_rasterize(cam, m, pipe, bg, zero_means2D=True):
-        calls.append(("raster", cam.uid))
+    def fake_rasterize(cam, m, pipe, bg, zero_means2D=True, debug_bits=0):
+        calls.append(("raster", cam.uid, debug_bits))
         m2 = torch.zeros(m.P, 3, requires_grad=True)
         img = torch.zeros(3, 4, 4, requires_grad=True)
         return img, torch.ones(m.P, dtype=torch.int32), torch.zeros(7, 4, 4, requires_grad=True), m2
 
-    def fake_train_loss(image, allmap, gt, cam, ratio, l_dssim, l_n, l_d):
+    def fake_train_loss(image, allmap, gt, cam, ratio, l_dssim, l_n, l_d, defer_scalars=False):
         calls.append(("loss", allmap is not None, cam is not None, l_n, l_d))
         return image.sum() * 0.0, torch.zeros(6)
 
+    import diff_surfel_rasterization as dsr
+    counts = []
+
+    def fake_finish_count():
+        counts.append(len(calls))
+        if fake_finish_count.overflow_at and len(counts) in fake_finish_count.overflow_at:
+            import surfel_native
+            raise surfel_native.CapacityOverflow("forced")
+        return 1
+    fake_finish_count.overflow_at = ()
     monkeypatch.setattr(TR, "rasterize", fake_rasterize)
     monkeypatch.setattr(TR, "train_loss", fake_train_loss)
+    monkeypatch.setattr(dsr, "finish_count", fake_finish_count)
     cams = [types.SimpleNamespace(uid=i, original_image=torch.zeros(3, 4, 4), camera_center=torch.zeros(3), post_consts=lambda: torch.zeros(24))
             for i in range(4)]
     m = FakeModel()
     opt = TR.optimization_params(iterations=60, densify_from_iter=10, densification_interval=10, densify_until_iter=45, opacity_reset_interval=30,
                                  dist_from_iter=5, normal_from_iter=20, lambda_dist=100.0, lambda_normal=0.05)
     tr = TR.Trainer(m, cams, opt, TR.pipeline_params(depth_ratio=1.0), extent=3.0)
+    tr._fake_finish_count = fake_finish_count
+    tr.manual_chain = False      # (the faked pieces are the autograd path's; the hand-driven chain is compared with it on the GPU)
     return tr, m, calls, opt
 
 
@@ -84,16 +97,43 @@ def test_loop_schedules_match_reference(trainer):
     assert m.active_sh_degree == 0                                                      # no multiple of 1000 reached (train.py:61-62)
 
 
+def test_lazily_counted_iterations_redo_an_overflowing_frame(trainer):
+    """Trainer.lazy_count (default): every iteration renders once with OPT_LAZY_COUNT and collects the count after the backward; an
+    iteration whose frame is reported as overflowed renders the same view again with exact binning and repeats loss and backward —
+    before the statistics and the optimiser step, which still happen once."""
+    import surfel_native as n
+    tr, m, calls, opt = trainer
+    assert tr.lazy_count
+    tr._fake_finish_count.overflow_at = (3,)
+    for it in range(1, 6):
+        n0, c0 = len(m.log), len(calls)
+        tr.step()
+        rast = [c for c in calls[c0:] if c[0] == "raster"]
+        loss = [c for c in calls[c0:] if c[0] == "loss"]
+        kinds = [e[0] for e in m.log[n0:]]
+        if it == 3:
+            assert [c[2] for c in rast] == [n.OPT_LAZY_COUNT, n.OPT_EXACT_BINNING] and rast[0][1] == rast[1][1] and len(loss) == 2
+        else:
+            assert [c[2] for c in rast] == [n.OPT_LAZY_COUNT] and len(loss) == 1
+        assert kinds.count("stats") == 1 and kinds.count("adam") == 1
+    assert tr.lazy_overflows == 1
+    tr.lazy_count = False
+    c0 = len(calls)
+    tr.step()
+    assert [c[2] for c in calls[c0:] if c[0] == "raster"] == [0]
+
+
 def test_white_background_resets_opacity_at_densify_start(monkeypatch):
     import surfel_trainer as TR
-    monkeypatch.setattr(TR, "rasterize", lambda cam, m, pipe, bg, zero_means2D=True: (torch.zeros(3, 4, 4, requires_grad=True),
+    monkeypatch.setattr(TR, "rasterize", lambda cam, m, pipe, bg, zero_means2D=True, debug_bits=0: (torch.zeros(3, 4, 4, requires_grad=True),
                                                                                       torch.ones(m.P, dtype=torch.int32), None, torch.zeros(m.P, 3, requires_grad=True)))
-    monkeypatch.setattr(TR, "train_loss", lambda image, *a: (image.sum() * 0.0, torch.zeros(6)))
+    monkeypatch.setattr(TR, "train_loss", lambda image, *a, **k: (image.sum() * 0.0, torch.zeros(6)))
     cams = [types.SimpleNamespace(uid=0, original_image=torch.zeros(3, 4, 4), camera_center=torch.zeros(3), post_consts=lambda: None)]
     m = FakeModel()
     opt = TR.optimization_params(iterations=12, densify_from_iter=10, densification_interval=5, opacity_reset_interval=1000, dist_from_iter=10 ** 6,
                                  normal_from_iter=10 ** 6)
     tr = TR.Trainer(m, cams, opt, white_background=True, extent=1.0)
+    tr.manual_chain = False
     assert tr.background.tolist() == [1.0, 1.0, 1.0]
     for _ in range(11):
         tr.step()
