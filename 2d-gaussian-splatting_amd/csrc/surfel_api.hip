@@ -25,6 +25,7 @@ int g_opt_bwd_variant = 2; // surfel_set_option("bwd_variant", .): 0 per-row wal
 surfel_hook_fn g_colour_hook = nullptr;   // surfel_set_backward_hook
 void* g_colour_hook_user = nullptr;
 float* g_sink_accum = nullptr; float* g_sink_denom = nullptr; float* g_sink_maxr = nullptr;      // surfel_set_densify_sink
+int g_opt_scan_large = 1;  // surfel_set_option("scan_large", .): auto takes the scan walk on frames with 2^21 <= R < 2^26 instances
 int g_opt_bwd_tune = 1;    // surfel_set_option("bwd_tune", .): auto = timed probes (1) or the device-side rule alone (0)
 unsigned long long* g_blend_stats = nullptr;   // surfel_debug_set_blend_stats
 thread_local int64_t g_last_R = -1; thread_local int g_last_W = 0, g_last_H = 0;   // auto heuristic (speed only; results identical; a stale
@@ -363,6 +364,7 @@ int surfel_set_option(const char* name, int value) {
     if (name && std::strcmp(name, "tile_depth_sort") == 0) { g_opt_tile_sort = value < 0 ? 0 : (value > 2 ? 2 : value); return 0; }
     if (name && std::strcmp(name, "large_sort") == 0) { set_large_sort_impl(value); return 0; }
     if (name && std::strcmp(name, "fat_sort") == 0) { set_fat_sort(value); return 0; }
+    if (name && std::strcmp(name, "scan_large") == 0) { g_opt_scan_large = value != 0; return 0; }
     if (name && std::strcmp(name, "bwd_variant") == 0) { g_opt_bwd_variant = value < 0 ? 0 : (value > 4 ? 4 : value); return 0; }
     if (name && std::strcmp(name, "bwd_tune") == 0) { g_opt_bwd_tune = value != 0; return 0; }
     if (name && std::strcmp(name, "capacity_binning") == 0) { g_opt_capacity = value != 0; return 0; }
@@ -735,7 +737,13 @@ int surfel_rasterize_backward(surfel_alloc_fn scratch_alloc, void* scratch_user,
         int probe = -1;
         std::unique_lock<std::mutex> tl(g_tuner_mu, std::defer_lock);
         if (opt_variant == 4) bb.variant = 2;      // (no verdict yet, stats mode, tuning off: rows + quad with the device rule)
-        if ((opt_variant == 2 || opt_variant == 4) && !g_blend_stats && g_opt_bwd_tune) {
+        // Large frames take the scan walk: with the same views in every walk's window it measured 7 % under the better of rows / quad on
+        // C4-synthetic (8 M instances: 0.944 vs 1.011 ms) and on the garden-sized trained state (1.17 vs 1.25 ms), at parity around
+        // 2 M instances and 11 % over on 0.5 M (profiles/r03_blend_bwd_scan.md).  A rule on R, not a timed choice: the walks differ in
+        // summation order, and which bits a frame gets must follow from the frame alone.  (>= 2^26 instances — C5 — not measured.)
+        const bool scan_rule = opt_variant == 2 && g_opt_scan_large && !g_blend_stats && R >= ((int64_t)1 << 21) && R < ((int64_t)1 << 26);
+        if (scan_rule) bb.variant = 3;
+        if ((opt_variant == 2 || opt_variant == 4) && !scan_rule && !g_blend_stats && g_opt_bwd_tune) {
             tl.lock();
             bb.variant = walk_tuner_pick(P, width, height, R, s, opt_variant == 4 ? 3 : 2, &tuner, &probe);
             if (probe >= 0) (void)hipEventRecord(tuner->e0[probe], s);

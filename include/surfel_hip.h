@@ -161,11 +161,13 @@ int surfel_debug_sort_pairs(surfel_alloc_fn scratch_alloc, void* scratch_user, u
  *   "bwd_variant" (default 2 = auto): blend-backward walk — 0: every DPP row of 16 lanes (a 4x4-pixel sub-tile) walks its own
  *          instance list, row totals gathered through private LDS slots; 1: every wave (8x8 pixels) walks one list (round 1's
  *          kernel).  Same per-pair arithmetic and the same summation tree: gradients are bit-identical
- *          (tests/test_gpu_parity.py::test_backward_variants_are_identical), so auto only ever changes speed.
+ *          (tests/test_gpu_parity.py::test_backward_variants_are_identical), so the choice between these two only ever changes
+ *          speed.  Frames with 2^21 <= R < 2^26 tile instances take walk 3 under auto ("scan_large", default 1: 7 % faster than
+ *          both on 8 M-instance frames; a rule on R, so the bits of a frame follow from the frame alone).
  *          3: the scan walk (surfel_backward_scan.hip: lanes are instances, DPP row scans carry the per-pixel recurrences, gradients
  *          accumulate in registers) — deterministic, but a different summation order: agrees with rows / quad to fp32 summation noise,
- *          not bit for bit; 5-13 % faster than both on wide-footprint / trained frames, 13 % slower on small random footprints
- *          (profiles/r03_blend_bwd_scan.md).  4: auto over all three walks by the same timed probes — fastest, but which bits a frame
+ *          not bit for bit; 7 % faster than both on frames of several million instances, at parity around 2 M, 11 % slower on
+ *          0.5 M instances of small random footprints (profiles/r03_blend_bwd_scan.md).  4: auto over all three walks by the same timed probes — fastest, but which bits a frame
  *          gets then depends on the probes' verdict.
  *   "bwd_tune" (default 1): how auto chooses.  1: per (device, width, height, octave of tile instances per surfel), two backward
  *          calls in every 32 are timed with HIP events on the launch stream (one per walk; polled later, never synchronised) and
