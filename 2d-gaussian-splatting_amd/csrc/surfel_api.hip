@@ -24,7 +24,6 @@ int g_opt_tile_sort = 1;   // surfel_set_option("tile_depth_sort", .): 0 never, 
 int g_opt_bwd_variant = 2; // surfel_set_option("bwd_variant", .): 0 per-row walk, 1 per-quad walk, 2 auto (0 / 1 / 2 bit-identical), 3 scan walk, 4 auto over all three
 surfel_hook_fn g_colour_hook = nullptr;   // surfel_set_backward_hook
 void* g_colour_hook_user = nullptr;
-float* g_sink_accum = nullptr; float* g_sink_denom = nullptr; float* g_sink_maxr = nullptr;      // surfel_set_densify_sink
 int g_opt_scan_large = 1;  // surfel_set_option("scan_large", .): auto takes the scan walk on frames with 2^21 <= R < 2^26 instances
 int g_opt_bwd_tune = 1;    // surfel_set_option("bwd_tune", .): auto = timed probes (1) or the device-side rule alone (0)
 unsigned long long* g_blend_stats = nullptr;   // surfel_debug_set_blend_stats
@@ -370,12 +369,6 @@ int surfel_set_option(const char* name, int value) {
     if (name && std::strcmp(name, "capacity_binning") == 0) { g_opt_capacity = value != 0; return 0; }
     if (name && std::strcmp(name, "tile_order") == 0) { g_opt_tile_order = value < 0 ? 0 : (value > 2 ? 2 : value); return 0; }
     return fail(SURFEL_E_INVALID, "unknown option");
-}
-
-int surfel_set_densify_sink(float* grad_accum, float* denom, float* max_radii) {
-    if ((grad_accum == nullptr) != (denom == nullptr) || (grad_accum == nullptr) != (max_radii == nullptr)) return fail(SURFEL_E_INVALID, "densify sink: all three arrays or none");
-    g_sink_accum = grad_accum; g_sink_denom = denom; g_sink_maxr = max_radii;
-    return 0;
 }
 
 int surfel_set_backward_hook(surfel_hook_fn colour_ready, void* user) {
@@ -767,7 +760,6 @@ int surfel_rasterize_backward(surfel_alloc_fn scratch_alloc, void* scratch_user,
     pb.rec = geom.rec; pb.tiles_touched = geom.tiles_touched; pb.grec = grec; pb.cut = cut; pb.has_rec = has_rec; pb.depths = geom.depths; pb.gx = gx;
     pb.dL_dtransMat = dL_dtransMat; pb.dL_dnormal = dL_dnormal; pb.dL_dopacity = dL_dopacity; pb.dL_dcolors = dL_dcolors;
     pb.dL_dsh = dL_dsh; pb.dL_dmeans2D = dL_dmeans2D; pb.dL_dmeans3D = dL_dmeans3D; pb.dL_dscales = dL_dscales; pb.dL_drots = dL_drots;
-    pb.stat_accum = g_sink_accum; pb.stat_denom = g_sink_denom; pb.stat_maxr = g_sink_maxr;
     tm.begin();
     if (g_colour_hook) {      // dL/dcolour first, so the caller can start moving it while the geometry chain rule runs
         launch_colour_gradients(pb, s);

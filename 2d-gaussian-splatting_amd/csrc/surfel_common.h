@@ -113,10 +113,6 @@ __device__ __forceinline__ int xcd_tile(int b, int n) {
 
 // The tile a blend workgroup takes: the frame's longest-first map where tile_order_kernel wrote one (surfel_preprocess.hip), the
 // XCD-contiguous order otherwise; -1: none (the grid covers the map's length).
-// norm of the dL/dmeans2D statistic as the densification consumer takes it (scene/gaussian_model.py:405-407: torch.norm of the
-// first components) — spelled with explicit FMAs so that every kernel that forms it rounds alike
-__device__ __forceinline__ float densify_norm(float gx, float gy, float gz) { return sqrtf(__fmaf_rn(gz, gz, __fmaf_rn(gy, gy, gx * gx))); }
-
 __device__ __forceinline__ int block_tile(const int* __restrict__ map, const uint32_t* __restrict__ map_flag, int b, int n) {
     if (map_flag[0] != 0u) return map[b];
     return b < n ? xcd_tile(b, n) : -1;

@@ -56,7 +56,6 @@ struct PreprocessBwdArgs {
     const uint2* cut; const uint8_t* has_rec; const float* depths; int gx;      // which of a surfel's instance records exist (BlendBwdArgs::cut); cut == NULL: all of them
     float* dL_dtransMat; float* dL_dnormal; float* dL_dopacity; float* dL_dcolors; float* dL_dsh;
     float* dL_dmeans2D; float* dL_dmeans3D; float* dL_dscales; float* dL_drots;
-    float* stat_accum; float* stat_denom; float* stat_maxr;      // densification statistics of the view, updated in place for radii > 0 (surfel_set_densify_sink), or NULL
 };
 
 void launch_preprocess_fwd(const PreprocessArgs& a, hipStream_t s);

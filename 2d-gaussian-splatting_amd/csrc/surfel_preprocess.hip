@@ -557,15 +557,6 @@ __device__ __forceinline__ void store3(float* p, size_t i, float x, float y, flo
 // fixed, so the sums are reproducible, and both record gathers treat heavy surfels the same way (they stay bit-identical).
 constexpr uint32_t HEAVY_MIN = 128;
 
-// train.py:126-128 (max_radii2D, xyz_gradient_accum, denom of the surfels the view saw) on the statistic this kernel has just formed
-// — the same update as densify_stats_kernel (train_optim.hip), without the extra launch and the re-read
-// (the three old values are loaded at the top of the kernel: fetched here, at its end, they cost the thread a memory round trip)
-__device__ __forceinline__ void densify_sink(const PreprocessBwdArgs& a, int i, float sx, float sy, float3 old) {
-    a.stat_accum[i] = old.x + densify_norm(sx, sy, 0.f);
-    a.stat_denom[i] = old.y + 1.f;
-    a.stat_maxr[i] = fmaxf(old.z, (float)a.radii[i]);
-}
-
 #ifndef PRE_BWD_MINWG
 #define PRE_BWD_MINWG 4
 #endif
@@ -677,8 +668,6 @@ __global__ void __launch_bounds__(256, PRE_BWD_MINWG) preprocess_bwd_kernel(Prep
     if (i >= a.P) return;
     const bool precomp = a.transMat_precomp != nullptr;
     const bool vis = a.radii[i] > 0;
-    float3 stat_old = make_float3(0.f, 0.f, 0.f);
-    if (a.stat_accum && vis) stat_old = make_float3(a.stat_accum[i], a.stat_denom[i], a.stat_maxr[i]);
     float4* __restrict__ gshq = (a.shs && a.dL_dsh) ? reinterpret_cast<float4*>(a.dL_dsh + (size_t)i * a.M * 3) : nullptr;
     if (!vis) {
         a.dL_dopacity[i] = 0.f;
@@ -806,18 +795,14 @@ __global__ void __launch_bounds__(256, PRE_BWD_MINWG) preprocess_bwd_kernel(Prep
         // the centre term is folded into dL/dtransMat, and the densification statistic uses the folded value
 #pragma unroll
         for (int q = 0; q < 9; q++) a.dL_dtransMat[9 * (size_t)i + q] = gT[q];
-        const float stx = gT[2] * T[8] * 0.5f * (float)a.W, sty = gT[5] * T[8] * 0.5f * (float)a.H;
-        store3(a.dL_dmeans2D, i, stx, sty, 0.f);
-        if (a.stat_accum) densify_sink(a, i, stx, sty, stat_old);
+        store3(a.dL_dmeans2D, i, gT[2] * T[8] * 0.5f * (float)a.W, gT[5] * T[8] * 0.5f * (float)a.H, 0.f);
     } else {
         if (a.dL_dtransMat) {      // an intermediate on this path (the chain rule below continues to scales / rotations): optional
 #pragma unroll
             for (int q = 0; q < 9; q++) a.dL_dtransMat[9 * (size_t)i + q] = g[q];
         }
         // densification statistic from the blend-stage dL/dT (before the centre term is folded in)
-        const float stx = g[2] * T[8] * 0.5f * (float)a.W, sty = g[5] * T[8] * 0.5f * (float)a.H;
-        store3(a.dL_dmeans2D, i, stx, sty, 0.f);
-        if (a.stat_accum) densify_sink(a, i, stx, sty, stat_old);
+        store3(a.dL_dmeans2D, i, g[2] * T[8] * 0.5f * (float)a.W, g[5] * T[8] * 0.5f * (float)a.H, 0.f);
         const float* __restrict__ vm = a.viewmatrix;
         float Pm[12];
         world2pix(a.projmatrix, a.W, a.H, Pm);

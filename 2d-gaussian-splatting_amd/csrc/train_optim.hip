@@ -9,7 +9,6 @@
 // groups, eps 1e-15), torch.optim.Adam's update rule, train.py:126-128 + gaussian_model.py:405-407 (statistics).
 #include <hip/hip_runtime.h>
 
-#include "surfel_common.h"
 #include "train_kernels.h"
 
 namespace surfel {
@@ -134,7 +133,7 @@ __global__ __launch_bounds__(256) void densify_stats_kernel(int P, const float* 
     const int r = radii[i];
     if (r <= 0) return;
     const float gx = g2d[3 * (size_t)i], gy = g2d[3 * (size_t)i + 1], gz = g2d[3 * (size_t)i + 2];
-    accum[i] += densify_norm(gx, gy, gz);
+    accum[i] += sqrtf(gx * gx + gy * gy + gz * gz);
     denom[i] += 1.f;
     maxr[i] = fmaxf(maxr[i], (float)r);
 }

@@ -167,7 +167,6 @@ class Trainer:
         self.last = {}
         self._epoch, self._epoch_views, self._epoch_campos, self._centers = -1, None, None, None
         self._one = torch.ones((), dtype=torch.float32, device=model.device)
-        self.stats_in_backward = os.environ.get("SURFEL_STATS_IN_BACKWARD", "0") != "0"      # densification statistics by the rasterizer's backward (surfel_set_densify_sink) instead of a launch of their own
         self.defer_scalars = os.environ.get("SURFEL_DEFER_SCALARS", "1") != "0"      # loss scalars by the fused loss backward launch instead of a finalize launch
         self.lazy_count = os.environ.get("SURFEL_LAZY_COUNT", "1") != "0"      # forward without the host wait for the instance count (step())
         self.lazy_overflows = 0
@@ -293,10 +292,6 @@ class Trainer:
         # long arrived; a frame that overflowed its binning capacity (rare) is rendered again with exact sizes, loss and backward with
         # it, before anything irreversible (statistics, optimiser step, collectives) has happened.
         lazy = self.lazy_count and not bands and not early
-        # (optional) the view's densification statistics (train.py:126-128) updated by the rasterizer's backward itself, from the
-        # dL/dmeans2D it has just formed — not with a lazy count (a frame that is redone would be counted twice) nor with bands (the
-        # statistic is the norm of the SUM over bands, known only after the all-reduce)
-        sink = stats_live and not bands and self.stats_in_backward and not lazy
         # The iteration's chain is fixed (rasterizer -> loss -> loss backward -> rasterizer backward): driven by hand
         # (surfel_native.ManualCtx) it costs a fraction of the host time autograd spends on it — engine, worker-thread hand-over, five
         # parameter gates — with the same kernels and bits; compute_cov3D_python trains through PyTorch code and needs autograd.
@@ -315,8 +310,6 @@ class Trainer:
             if early:
                 self._early, self._early_err = None, None
                 _n.set_backward_hook(self._on_colour_ready)
-            if sink:
-                _n.set_densify_sink(m.xyz_gradient_accum, m.denom, m.max_radii2D)
             try:
                 if manual:
                     with torch.no_grad():
@@ -325,8 +318,6 @@ class Trainer:
                 else:
                     torch.autograd.backward(loss, grad_tensors=self._one)        # cached seed gradient: no ones_like fill per iteration
             finally:
-                if sink:
-                    _n.set_densify_sink(None, None, None)
                 if early:
                     _n.set_backward_hook(None)
             if not lazy:
@@ -358,8 +349,7 @@ class Trainer:
                     self._timed_wait(w_same)
                 self._rebalance_bands(cam)
             if stats_live:
-                if not sink:
-                    m.add_densification_stats(arena2d if bands else (g2d if manual else means2D.grad), radii=radii)
+                m.add_densification_stats(arena2d if bands else (g2d if manual else means2D.grad), radii=radii)
                 rebuilt = self._schedule_events(it, bands)
             if it < opt.iterations and not rebuilt:     # re-created parameters carry no gradient in the reference: no update
                 if bands:

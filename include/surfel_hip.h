@@ -199,13 +199,6 @@ int surfel_set_option(const char* name, int value);
  * kernel on `stream` — and only then enqueues the per-surfel chain rule, which no longer touches dL_dcolors.  All other outputs
  * are unchanged.  Reference counterpart: none (the reference trains on one GPU); this serves the view-parallel exchange of
  * surfel_trainer.py. */
-/* Densification statistics at the source (process-wide; NULLs remove it).  While set, every surfel_rasterize_backward also applies
- * the reference's add_densification_stats (scene/gaussian_model.py:405-407, called from train.py:126-128) to the three [P] float
- * arrays, for the surfels with radii > 0:  grad_accum += |dL_dmeans2D[:, :2]|,  denom += 1,  max_radii = max(max_radii, radii)
- * — the bits surfel_densify_stats (include/surfel_train.h) produces from the same dL_dmeans2D, without the extra launch.  A trainer
- * sets it around the backward of a training view and removes it afterwards. */
-int surfel_set_densify_sink(float* grad_accum, float* denom, float* max_radii);
-
 typedef void (*surfel_hook_fn)(void* user);
 int surfel_set_backward_hook(surfel_hook_fn colour_ready, void* user);
 

@@ -447,32 +447,6 @@ def test_fused_loss_launches_keep_the_bits(hw):
             assert torch.isfinite(a).all() and torch.equal(a, b)
 
 
-def test_densification_statistics_by_the_backward_are_identical():
-    """surfel_set_densify_sink: the rasterizer's backward applies train.py:126-128 (max_radii2D, xyz_gradient_accum, denom for the
-    surfels the view saw) itself — same statistics, same parameters, BIT for bit, as the separate surfel_densify_stats launch on
-    the dL/dmeans2D it returns; also with the transMat_precomp-free default path only (the trainer's)."""
-    import torch
-    import surfel_trainer as TR
-    d = dev()
-    bg = torch.zeros(3, device=d)
-    gt_model = TR.synthetic_object(3000, d, seed=1, px_scale=0.06)
-    cams = TR.capture_views(gt_model, TR.orbit_cameras(4, 128, 96, device=d), bg)
-    out = []
-    for sink in (False, True):
-        m = TR.synthetic_object(3000, d, seed=2, px_scale=0.05)
-        m.spatial_lr_scale = 1.0
-        tr = TR.Trainer(m, cams, TR.optimization_params(dist_from_iter=0, normal_from_iter=0, lambda_dist=10.0, densify_from_iter=10 ** 9),
-                        TR.pipeline_params(depth_ratio=1.0))
-        tr.stats_in_backward = sink
-        for _ in range(5):
-            tr.step()
-        torch.cuda.synchronize()
-        out.append((m.xyz_gradient_accum.clone(), m.denom.clone(), m.max_radii2D.clone(), m.theta.clone()))
-    assert float(out[0][1].sum()) > 0 and float(out[0][0].abs().sum()) > 0
-    for a, b in zip(*out):
-        assert torch.equal(a, b)
-
-
 def test_trainer_with_lazily_counted_forwards_is_identical():
     """Trainer.lazy_count: the iteration without the host wait for the instance count (forward returns its capacity, the count is
     collected after the backward) trains to the same bits as the waiting form — also when a frame is reported as overflowed and the
