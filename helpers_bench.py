@@ -118,11 +118,25 @@ def time_trainer(tr, steps, warmup, prime=15, workload=None):
     for _ in range(prime + warmup):
         tr.step()
     torch.cuda.synchronize()
+    import gc
+    ms0 = torch.cuda.memory_stats(tr.model.device)
+    gc0 = [g["collections"] for g in gc.get_stats()]
+    host = []
     t0 = time.perf_counter()
     for _ in range(steps):
+        h0 = time.perf_counter()
         tr.step()
+        host.append(time.perf_counter() - h0)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    ms1 = torch.cuda.memory_stats(tr.model.device)
+    # hipMalloc / hipFree inside the timed window (the caching allocator missing: views of a capture differ in instance count, so
+    # buffer sizes change from step to step) and the host's own time per step (enqueue only; the device runs behind)
+    alloc = {"device_allocs": int(ms1.get("num_device_alloc", 0) - ms0.get("num_device_alloc", 0)),
+             "device_frees": int(ms1.get("num_device_free", 0) - ms0.get("num_device_free", 0)),
+             "alloc_retries": int(ms1.get("num_alloc_retries", 0) - ms0.get("num_alloc_retries", 0)),
+             "host_ms_per_step_median": round(sorted(host)[len(host) // 2] * 1e3, 4), "host_ms_per_step_max": round(max(host) * 1e3, 4),
+             "python_gc_collections_gen012": [g["collections"] - c for g, c in zip(gc.get_stats(), gc0)]}
     surfel_native.collect_stage_times()
     tr.pipe.debug = 2
     for _ in range(max(5, steps // 2)):
@@ -174,7 +188,8 @@ def time_trainer(tr, steps, warmup, prime=15, workload=None):
     return {"roofline": roof, "instances_staged": Rs, "ms_per_step": round(dt / steps * 1e3, 4), "iters_per_s": round(steps / dt, 2), "steps": steps, "P": int(tr.model.P),
             "visible": int((tr.last["radii"] > 0).sum().item()), "instances_R": R, "inst_per_tile": round(R / tiles, 1),
             "inst_per_surfel": round(R / max(1, int(tr.model.P)), 2), "loss": round(float(tr.last["loss"]), 5),
-            "kernels_ms": {k: round(v[0] / v[1], 4) for k, v in st.items()}, "blend_bwd_ms_by_walk": ab, "blend_bwd_lanes_by_walk": lanes}
+            "kernels_ms": {k: round(v[0] / v[1], 4) for k, v in st.items()}, "blend_bwd_ms_by_walk": ab, "blend_bwd_lanes_by_walk": lanes,
+            "lazy_overflows": int(getattr(tr, "lazy_overflows", 0)), "timed_window": alloc}
 
 
 def config_leg(dev, workload, steps=20, warmup=5):
