@@ -42,12 +42,13 @@ __global__ __launch_bounds__(256) void train_loss_bwd_kernel(int n_ssim, int n_s
                                                              float ratio, const float* __restrict__ gmaps, float c_normal, float c_dist,
                                                              float* __restrict__ gall, lossk::LossFinalize fin) {
     __shared__ __attribute__((aligned(16))) char smem[cmax(lossk::ssim_bwd_lds<SR11>(), postk::post_bwd_lds())];
-    const int b = blockIdx.x;
-    if (b == n_ssim_pad + n_post) {      // deferred loss scalars (fin.out != NULL: the grid has this one extra workgroup): the forward's
-        lossk::loss_finalize_body<256>(reinterpret_cast<float(*)[16]>(smem), fin);      // partial sums are final — it was an earlier launch
-        return;
-    }
-    if (b < n_ssim_pad) {
+    int b = blockIdx.x;
+    if (fin.out) {      // deferred loss scalars: the grid starts with 8 extra workgroups (8: the others keep their XCD, b % 8); the first one
+        if (b == 0) lossk::loss_finalize_body<256>(reinterpret_cast<float(*)[16]>(smem), fin);      // reduces the forward's partial sums —
+        if (b < 8) return;                                                                         // final since that earlier launch — while
+        b -= 8;                                                                                    // the rest of the grid does its work
+    }                                                                                              // (as the LAST workgroup it ran alone
+    if (b < n_ssim_pad) {                                                                          // behind everything: +10 us on the kernel)
         if (b < n_ssim) lossk::ssim_bwd_body<SR11>(smem, b, n_ssim, H, W, img, gt, dmaps, map_stride, c_l1, c_ssim, g_dev, g_dev, grad_img, win);
     } else {
         postk::post_bwd_body(smem, b - n_ssim_pad, n_post, H, W, allmap, cam, ratio, gmaps, c_normal, c_dist, g_dev, gall);
@@ -76,7 +77,7 @@ void launch_train_loss_bwd(int H, int W, const float* img, const float* gt, cons
     const int n_ssim = ssim_blocks(H, W) * 3, n_pad = (n_ssim + 7) / 8 * 8, n_post = post_blocks(H, W);
     const lossk::LossFinalize fin{ssim_partials, n_ssim, 1.f / (float)((size_t)3 * H * W), post_partials, n_post, 1.f / (float)((size_t)H * W),
                                   lambda_dssim, lambda_normal, lambda_dist, out6, total_out};
-    hipLaunchKernelGGL(train_loss_bwd_kernel, dim3(n_pad + n_post + (out6 ? 1 : 0)), dim3(256), 0, s, n_ssim, n_pad, n_post, H, W, img, gt, dmaps,
+    hipLaunchKernelGGL(train_loss_bwd_kernel, dim3(n_pad + n_post + (out6 ? 8 : 0)), dim3(256), 0, s, n_ssim, n_pad, n_post, H, W, img, gt, dmaps,
                        (size_t)3 * H * W, c_l1, c_ssim, g_dev, grad_img, win, allmap, cam, ratio, (const float*)nullptr, c_normal, c_dist, gall, fin);
 }
 
