@@ -74,7 +74,9 @@ def roofline_object(per_kernel, workload, P, V, R, Rs, W, H, n_pass):
     valu = None
     try:
         import glob
-        pm = sorted(glob.glob(os.path.join(REPO, "profiles", "r*_%s_pmc.json" % workload)))[-1]
+        # (the PMC file of the same profiling run the traffic figure came from — same code, same forced walk; else the newest)
+        tag_file = os.path.join(REPO, "profiles", "%s_%s_pmc.json" % (json.load(open(tf)).get(workload, {}).get("_tag", "?"), workload)) if os.path.exists(tf) else ""
+        pm = tag_file if os.path.exists(tag_file) else sorted(glob.glob(os.path.join(REPO, "profiles", "r*_%s_pmc.json" % workload)))[-1]
         pj = json.load(open(pm))
         n_inst = max([v.get("SQ_INSTS_VALU", 0.0) for k, v in pj.items() if k.startswith(dom)] or [0.0]) or None
         if n_inst:
