@@ -24,6 +24,7 @@ int g_opt_tile_sort = 1;   // surfel_set_option("tile_depth_sort", .): 0 never, 
 int g_opt_bwd_variant = 2; // surfel_set_option("bwd_variant", .): 0 per-row walk, 1 per-quad walk, 2 auto (0 / 1 / 2 bit-identical), 3 scan walk, 4 auto over all three
 surfel_hook_fn g_colour_hook = nullptr;   // surfel_set_backward_hook
 void* g_colour_hook_user = nullptr;
+int g_opt_host_total = 1;  // surfel_set_option("host_total", .): capacity path — 1: bin_emit_kernel stores the instance total into mapped pinned memory, 0: D2H copy kernel (measurement)
 int g_opt_scan_large = 1;  // surfel_set_option("scan_large", .): auto takes the scan walk on frames with 2^21 <= R < 2^26 instances
 int g_opt_bwd_tune = 1;    // surfel_set_option("bwd_tune", .): auto = timed probes (1) or the device-side rule alone (0)
 unsigned long long* g_blend_stats = nullptr;   // surfel_debug_set_blend_stats
@@ -262,11 +263,13 @@ int walk_tuner_pick(int P, int W, int H, int64_t R, hipStream_t s, int nwalks, W
 // One event + one pinned read-back buffer per (host thread, device): a thread that rasterizes on a second GPU gets its own pair
 // instead of recording an event created on another device.
 constexpr int kMaxDevices = 32;
+constexpr int kPinnedTotal = R_SLOTS + 4;      // word of the pinned buffer that receives a capacity-path frame's instance total
 struct PerDevice { hipEvent_t ev = nullptr; uint32_t* pinned = nullptr; };
-PerDevice* per_device() {
+PerDevice* per_device(int dev = -1) {      // dev < 0: the calling thread's current device
     thread_local PerDevice tab[kMaxDevices];
-    int d = 0;
-    if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= kMaxDevices) return nullptr;
+    int d = dev;
+    if (d < 0 && hipGetDevice(&d) != hipSuccess) return nullptr;
+    if (d < 0 || d >= kMaxDevices) return nullptr;
     return &tab[d];
 }
 
@@ -282,8 +285,9 @@ uint32_t* pinned_u32() {
     if (!pd) return nullptr;
     if (!pd->pinned) {
         // R_SLOTS partial instance totals (D2H copy target) + one tile-order verdict word per capacity-table entry (written by the device)
-        if (hipHostMalloc(reinterpret_cast<void**>(&pd->pinned), sizeof(uint32_t) * (R_SLOTS + 4), hipHostMallocMapped) != hipSuccess) pd->pinned = nullptr;
-        else for (int k = 0; k < R_SLOTS + 4; k++) pd->pinned[k] = 0u;
+        // + the instance total of a capacity-path frame (written by bin_emit_kernel: kPinnedTotal)
+        if (hipHostMalloc(reinterpret_cast<void**>(&pd->pinned), sizeof(uint32_t) * (R_SLOTS + 8), hipHostMallocMapped) != hipSuccess) pd->pinned = nullptr;
+        else for (int k = 0; k < R_SLOTS + 8; k++) pd->pinned[k] = 0u;
     }
     return pd->pinned;
 }
@@ -364,6 +368,7 @@ int surfel_set_option(const char* name, int value) {
     if (name && std::strcmp(name, "large_sort") == 0) { set_large_sort_impl(value); return 0; }
     if (name && std::strcmp(name, "fat_sort") == 0) { set_fat_sort(value); return 0; }
     if (name && std::strcmp(name, "scan_large") == 0) { g_opt_scan_large = value != 0; return 0; }
+    if (name && std::strcmp(name, "host_total") == 0) { g_opt_host_total = value != 0; return 0; }
     if (name && std::strcmp(name, "bwd_variant") == 0) { g_opt_bwd_variant = value < 0 ? 0 : (value > 4 ? 4 : value); return 0; }
     if (name && std::strcmp(name, "bwd_tune") == 0) { g_opt_bwd_tune = value != 0; return 0; }
     if (name && std::strcmp(name, "capacity_binning") == 0) { g_opt_capacity = value != 0; return 0; }
@@ -405,18 +410,21 @@ int surfel_collect_stage_ms(float* sum_ms, int* count, int cap) {
 // Lazily counted frames (SURFEL_OPT_LAZY_COUNT): a capacity-path forward that did not wait for its instance count.  The count is
 // collected by surfel_forward_count() — or by the next forward of this thread, which refuses to go on if that frame had overflowed
 // its capacity without anybody looking (its images were built from truncated lists).
-struct LazyPending { bool pending = false; int W = 0, H = 0, dev = -1; int64_t cap = 0; bool overflowed = false; int64_t R = 0; };
+struct LazyPending { bool pending = false; int W = 0, H = 0, dev = -1; int64_t cap = 0; bool overflowed = false, host_total = false; int64_t R = 0; };
 thread_local LazyPending g_lazy;
 
 // waits for the pending count; returns the exact instance count (>= 0) and updates the per-size history, or a negative code
 int64_t lazy_finish() {
     if (!g_lazy.pending) return g_lazy.R;
-    uint32_t* hR = pinned_u32();
-    hipEvent_t evR = r_event();
-    if (!hR || !evR) return fail(SURFEL_E_HIP, "pinned buffer / event creation failed");
+    // (the pair of the device the frame was rendered on — the thread may have made another device current since)
+    PerDevice* pd = per_device(g_lazy.dev);
+    uint32_t* hR = pd ? pd->pinned : nullptr;
+    hipEvent_t evR = pd ? pd->ev : nullptr;
+    if (!hR || !evR) return fail(SURFEL_E_HIP, "pinned buffer / event of the lazily counted frame's device not found");
     HIP_TRY(hipEventSynchronize(evR));
     int64_t R = 0;
-    for (int k = 0; k < R_SLOTS; k++) R += (int64_t)hR[k];
+    if (g_lazy.host_total) R = (int64_t)hR[kPinnedTotal];
+    else for (int k = 0; k < R_SLOTS; k++) R += (int64_t)hR[k];
     g_lazy.pending = false;
     g_lazy.R = R;
     g_lazy.overflowed = R > g_lazy.cap;
@@ -480,7 +488,8 @@ int64_t surfel_rasterize_forward(surfel_alloc_fn geom_alloc, void* geom_user, su
     void* img_base = image_alloc(image_user, img_bytes);
     if (!img_base) return fail(SURFEL_E_ALLOC, "image buffer allocation failed");
     ImgState img = ImgState::carve(img_base, width, height, nullptr);
-    HIP_TRY(hipMemsetAsync(img.ranges, 0, sizeof(uint2) * ((size_t)gx * gy + R_SLOTS + 1), s));
+    // (the carved span up to the next array: a multiple of 256 B, so the runtime needs ONE fill kernel, not an aligned part + a tail)
+    HIP_TRY(hipMemsetAsync(img.ranges, 0, (size_t)(reinterpret_cast<char*>(img.final_T) - reinterpret_cast<char*>(img.ranges)), s));
 
     StageTimer tm(debug, s);
     int64_t R = 0;
@@ -548,8 +557,11 @@ int64_t surfel_rasterize_forward(surfel_alloc_fn geom_alloc, void* geom_user, su
         uint32_t* hR = pinned_u32();
         hipEvent_t evR = r_event();
         if (!hR || !evR) return fail(SURFEL_E_HIP, "pinned buffer / event creation failed");
-        HIP_TRY(hipMemcpyAsync(hR, img.total, sizeof(uint32_t) * R_SLOTS, hipMemcpyDeviceToHost, s));
-        HIP_TRY(hipEventRecord(evR, s));
+        const bool host_total = cap > 0 && g_opt_host_total;      // capacity path: bin_emit_kernel stores the total into the mapped pinned buffer itself — no copy kernel
+        if (!host_total) {
+            HIP_TRY(hipMemcpyAsync(hR, img.total, sizeof(uint32_t) * R_SLOTS, hipMemcpyDeviceToHost, s));
+            HIP_TRY(hipEventRecord(evR, s));
+        }
 
         bool blended = false;
         if (cap > 0) {
@@ -559,7 +571,8 @@ int64_t surfel_rasterize_forward(surfel_alloc_fn geom_alloc, void* geom_user, su
             uint32_t* vb = odd ? bin.point_list : bin.vals_alt;
             tm.begin();
             launch_bin_emit(P, geom.tiles_touched, geom.rects, geom.offsets, geom.rec, bin.keys_a, va, gx, (size_t)cap, bin.sort_temp, end_bit,
-                            img.total + 2 * R_SLOTS, s);
+                            img.total + 2 * R_SLOTS, host_total ? hR + kPinnedTotal : nullptr, s);
+            if (host_total) HIP_TRY(hipEventRecord(evR, s));
             STAGE_END(tm, ST_EMIT);
             tm.begin();
             const int wk = radix_sort_pairs_u32_devn(bin.keys_a, va, bin.keys_b, vb, (size_t)cap, end_bit, n_dev, bin.sort_temp, s);
@@ -581,13 +594,15 @@ int64_t surfel_rasterize_forward(surfel_alloc_fn geom_alloc, void* geom_user, su
             launch_blend_fwd(ba, s);
             STAGE_END(tm, ST_BLEND);
             if (opt_lazy) {      // the count stays on its way: surfel_forward_count() (or the next forward) collects it
-                g_lazy.pending = true; g_lazy.W = width; g_lazy.H = height; g_lazy.cap = cap; g_lazy.overflowed = false;
+                g_lazy.pending = true; g_lazy.W = width; g_lazy.H = height; g_lazy.cap = cap; g_lazy.overflowed = false; g_lazy.host_total = host_total;
+                if (hipGetDevice(&g_lazy.dev) != hipSuccess) g_lazy.dev = -1;
                 g_last_binning = 4;
                 HIP_TRY(hipGetLastError());
                 return cap;
             }
-            HIP_TRY(hipEventSynchronize(evR));      // preprocess finished long ago; the device still holds the rest of the forward
-            for (int k = 0; k < R_SLOTS; k++) R += (int64_t)hR[k];
+            HIP_TRY(hipEventSynchronize(evR));      // the emission finished long ago; the device still holds the rest of the forward
+            if (host_total) R = (int64_t)hR[kPinnedTotal];
+            else for (int k = 0; k < R_SLOTS; k++) R += (int64_t)hR[k];
             g_last_binning = 1;
             blended = R <= cap;
             if (!blended) {      // overflow: the frame is redone with exact sizes below (same results as if it had taken that path at once)

@@ -93,7 +93,8 @@ bool capacity_binning_ok(size_t cap, int end_bit);
 size_t capacity_sort_scratch_bytes(size_t cap, int end_bit);
 size_t bin_emit_head_words();                 // words at the start of the capacity path's sort scratch that must be zero
 void launch_bin_emit(int P, const uint32_t* tiles_touched, const uint32_t* rects, const uint32_t* block_totals, float* rec, uint32_t* keys, uint32_t* vals,
-                     int gx, size_t cap, void* sort_scratch /* head zeroed */, int end_bit, uint32_t* n_out, hipStream_t s);
+                     int gx, size_t cap, void* sort_scratch /* head zeroed */, int end_bit, uint32_t* n_out, uint32_t* n_host /* host-visible copy of the total, or NULL */,
+                     hipStream_t s);
 int radix_sort_pairs_u32_devn(uint32_t* keys_a, uint32_t* vals_a, uint32_t* keys_b, uint32_t* vals_b, size_t cap, int end_bit, const uint32_t* n_dev,
                               void* scratch, hipStream_t s);
 void launch_tile_ranges_devn(size_t cap, const uint32_t* n_dev, const uint32_t* keys, uint2* ranges, hipStream_t s);

@@ -686,7 +686,8 @@ __global__ void __launch_bounds__(BE_THREADS) bin_emit_kernel(int P, const uint3
                                                               const uint32_t* __restrict__ block_totals, uint32_t nblock_totals, float* __restrict__ rec,
                                                               uint32_t* __restrict__ keys, uint32_t* __restrict__ vals, int gx, uint32_t cap,
                                                               uint32_t* __restrict__ ghist, uint32_t* __restrict__ sort_status,
-                                                              uint32_t sort_status_words, int passes, int end_bit, uint32_t* __restrict__ n_out) {
+                                                              uint32_t sort_status_words, int passes, int end_bit, uint32_t* __restrict__ n_out,
+                                                              uint32_t* __restrict__ n_host) {
     constexpr int NW = BE_THREADS / 64;
     __shared__ uint32_t s_w[NW], s_p[NW];
     __shared__ uint32_t s_h[2][RS_RADIX];
@@ -709,7 +710,10 @@ __global__ void __launch_bounds__(BE_THREADS) bin_emit_kernel(int P, const uint3
     uint32_t off = x - n;
 #pragma unroll
     for (int w = 0; w < NW; w++) off += s_p[w] + (w < wave ? s_w[w] : 0u);
-    if (k == (uint32_t)P - 1u) n_out[0] = off + n;      // the instance total, for the kernels that follow
+    if (k == (uint32_t)P - 1u) {
+        n_out[0] = off + n;      // the instance total, for the kernels that follow ...
+        if (n_host) n_host[0] = off + n;      // ... and for the host (mapped pinned word: no copy kernel in the stream)
+    }
     const uint32_t mask0 = (1u << min(RS_BITS, end_bit)) - 1u;
     const uint32_t mask1 = passes > 1 ? (1u << min(RS_BITS, end_bit - RS_BITS)) - 1u : 0u;
     if (n) {
@@ -765,11 +769,11 @@ size_t bin_emit_sort_status_words(size_t cap, int end_bit) { return (size_t)radi
 size_t capacity_sort_scratch_bytes(size_t cap, int end_bit) { return (bin_emit_head_words() + bin_emit_sort_status_words(cap, end_bit)) * sizeof(uint32_t) + 256; }
 
 void launch_bin_emit(int P, const uint32_t* tiles_touched, const uint32_t* rects, const uint32_t* block_totals, float* rec, uint32_t* keys, uint32_t* vals,
-                     int gx, size_t cap, void* sort_scratch, int end_bit, uint32_t* n_out, hipStream_t s) {
+                     int gx, size_t cap, void* sort_scratch, int end_bit, uint32_t* n_out, uint32_t* n_host, hipStream_t s) {
     uint32_t* ghist = static_cast<uint32_t*>(sort_scratch);
     hipLaunchKernelGGL(bin_emit_kernel, dim3((unsigned)((P + BE_THREADS - 1) / BE_THREADS)), dim3(BE_THREADS), 0, s, P, tiles_touched, rects, block_totals,
                        (uint32_t)((P + 255) / 256), rec, keys, vals, gx, (uint32_t)cap, ghist, ghist + bin_emit_head_words(), (uint32_t)bin_emit_sort_status_words(cap, end_bit),
-                       radix_sort_passes(cap, 0, end_bit), end_bit, n_out);
+                       radix_sort_passes(cap, 0, end_bit), end_bit, n_out, n_host);
 }
 
 }  // namespace surfel
