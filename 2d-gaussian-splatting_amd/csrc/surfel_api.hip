@@ -748,7 +748,8 @@ int surfel_rasterize_backward(surfel_alloc_fn scratch_alloc, void* scratch_user,
         // Large frames take the scan walk: with the same views in every walk's window it measured 7 % under the better of rows / quad on
         // C4-synthetic (8 M instances: 0.944 vs 1.011 ms) and on the garden-sized trained state (1.17 vs 1.25 ms), at parity around
         // 2 M instances and 11 % over on 0.5 M (profiles/r03_blend_bwd_scan.md).  A rule on R, not a timed choice: the walks differ in
-        // summation order, and which bits a frame gets must follow from the frame alone.  (>= 2^26 instances — C5 — not measured.)
+        // summation order, and which bits a frame gets must follow from the frame alone.  (C5, 1.3e8 instances of which 4 % are staged:
+        // scan 3.19 vs 3.13 ms — no gain, hence the upper bound.)
         const bool scan_rule = opt_variant == 2 && g_opt_scan_large && !g_blend_stats && R >= ((int64_t)1 << 21) && R < ((int64_t)1 << 26);
         if (scan_rule) bb.variant = 3;
         if ((opt_variant == 2 || opt_variant == 4) && !scan_rule && !g_blend_stats && g_opt_bwd_tune) {
