@@ -18,6 +18,9 @@ bool ssim_window(int window, lossk::SsimWin* w);      // train_loss.hip
 namespace {
 
 constexpr int SR11 = 5;      // the reference's window_size = 11 (loss_utils.py:43)
+#ifndef LOSS_PAD_LDS
+#define LOSS_PAD_LDS 0       // diagnostic builds: extra LDS bytes per workgroup (occupancy experiments, python build.py --variant)
+#endif
 constexpr size_t cmax(size_t a, size_t b) { return a > b ? a : b; }
 
 // grid = [n_ssim SSIM workgroups, padded to a multiple of 8 so that the post-processing part keeps its XCD mapping | n_post workgroups]
@@ -26,7 +29,7 @@ __global__ __launch_bounds__(256) void train_loss_fwd_kernel(int n_ssim, int n_s
                                                              float* __restrict__ partials, lossk::SsimWin win, const float* __restrict__ allmap,
                                                              const float* __restrict__ cam, float ratio, float* __restrict__ maps,
                                                              float* __restrict__ post_partials) {
-    __shared__ __attribute__((aligned(16))) char smem[cmax(lossk::ssim_fwd_lds<SR11>(), postk::post_fwd_lds())];
+    __shared__ __attribute__((aligned(16))) char smem[cmax(lossk::ssim_fwd_lds<SR11>(), postk::post_fwd_lds()) + LOSS_PAD_LDS];
     const int b = blockIdx.x;
     if (b < n_ssim_pad) {
         if (b < n_ssim) lossk::ssim_fwd_body<SR11>(smem, b, n_ssim, H, W, img, gt, dmaps, map_stride, partials, win);
@@ -41,7 +44,7 @@ __global__ __launch_bounds__(256) void train_loss_bwd_kernel(int n_ssim, int n_s
                                                              lossk::SsimWin win, const float* __restrict__ allmap, const float* __restrict__ cam,
                                                              float ratio, const float* __restrict__ gmaps, float c_normal, float c_dist,
                                                              float* __restrict__ gall, lossk::LossFinalize fin) {
-    __shared__ __attribute__((aligned(16))) char smem[cmax(lossk::ssim_bwd_lds<SR11>(), postk::post_bwd_lds())];
+    __shared__ __attribute__((aligned(16))) char smem[cmax(lossk::ssim_bwd_lds<SR11>(), postk::post_bwd_lds()) + LOSS_PAD_LDS];
     int b = blockIdx.x;
     if (fin.out) {      // deferred loss scalars: the grid starts with 8 extra workgroups (8: the others keep their XCD, b % 8); the first one
         if (b == 0) lossk::loss_finalize_body<256>(reinterpret_cast<float(*)[16]>(smem), fin);      // reduces the forward's partial sums —
