@@ -131,6 +131,21 @@ int main() {
     int moved = 0;
     for (size_t k = 0; k < t1.size(); k++) { CHECK(std::isfinite(t1[k])); moved += t1[k] != theta[k]; }
     CHECK(moved > P);                                          // every surfel with a gradient moved by ~lr (first Adam step)
+    // a lazily counted frame (SURFEL_OPT_LAZY_COUNT): the forward returns its capacity (>= R, an upper bound the backward can size
+    // its buffers from), surfel_forward_count() then delivers the exact count; same image
+    {
+        CHECK(surfel_forward_count() == R);                    // (no pending frame: the last forward's count)
+        float* color2 = static_cast<float*>(dev_alloc(nullptr, sizeof(float) * 3 * W * H));
+        const int64_t cap = surfel_rasterize_forward(dev_alloc, nullptr, dev_alloc, nullptr, dev_alloc, nullptr, P, D, M, d_bg, W, H, d_means, d_shs, nullptr,
+                                                     d_opac, d_scales, 1.f, d_rots, nullptr, d_view, d_proj, d_campos, tanx, tany, 0, color2, out_others,
+                                                     radii, SURFEL_OPT_LAZY_COUNT | SURFEL_OPT_TILE_SORT(2), nullptr);
+        CHECK(cap >= R);
+        CHECK(surfel_debug_last_binning() == 4 || cap == R);   // (4: the capacity path took the flag; otherwise the exact path ignored it)
+        CHECK(surfel_forward_count() == R);
+        CHECK(hipDeviceSynchronize() == hipSuccess);
+        const auto col2 = download(color2, (size_t)3 * W * H);
+        for (size_t k = 0; k < col.size(); k++) CHECK(col2[k] == col[k]);
+    }
     // argument errors come back as codes + message, never as crashes
     CHECK(surfel_rasterize_forward(dev_alloc, nullptr, dev_alloc, nullptr, dev_alloc, nullptr, P, D, M, d_bg, W, H, d_means, d_shs, d_means /* both colour sources */,
                                    d_opac, d_scales, 1.f, d_rots, nullptr, d_view, d_proj, d_campos, tanx, tany, 0, out_color, out_others, radii, 0, nullptr) ==
