@@ -24,6 +24,7 @@ int g_opt_tile_sort = 1;   // surfel_set_option("tile_depth_sort", .): 0 never, 
 int g_opt_bwd_variant = 2; // surfel_set_option("bwd_variant", .): 0 per-row walk, 1 per-quad walk, 2 auto (0 / 1 / 2 bit-identical), 3 scan walk, 4 auto over all three
 surfel_hook_fn g_colour_hook = nullptr;   // surfel_set_backward_hook
 void* g_colour_hook_user = nullptr;
+int g_opt_pbwd_coop = -1;  // surfel_set_option("pbwd_coop", .): record gather of preprocess_bwd — -1 by rule (R >= 6 P and R >= 2^25), 0 per thread, 1 wave-cooperative
 int g_opt_host_total = 1;  // surfel_set_option("host_total", .): capacity path — 1: bin_emit_kernel stores the instance total into mapped pinned memory, 0: D2H copy kernel (measurement)
 int g_opt_scan_large = 1;  // surfel_set_option("scan_large", .): auto takes the scan walk on frames with 2^21 <= R < 2^26 instances
 int g_opt_bwd_tune = 1;    // surfel_set_option("bwd_tune", .): auto = timed probes (1) or the device-side rule alone (0)
@@ -369,6 +370,7 @@ int surfel_set_option(const char* name, int value) {
     if (name && std::strcmp(name, "fat_sort") == 0) { set_fat_sort(value); return 0; }
     if (name && std::strcmp(name, "scan_large") == 0) { g_opt_scan_large = value != 0; return 0; }
     if (name && std::strcmp(name, "host_total") == 0) { g_opt_host_total = value != 0; return 0; }
+    if (name && std::strcmp(name, "pbwd_coop") == 0) { g_opt_pbwd_coop = value < 0 ? -1 : (value != 0); return 0; }
     if (name && std::strcmp(name, "bwd_variant") == 0) { g_opt_bwd_variant = value < 0 ? 0 : (value > 4 ? 4 : value); return 0; }
     if (name && std::strcmp(name, "bwd_tune") == 0) { g_opt_bwd_tune = value != 0; return 0; }
     if (name && std::strcmp(name, "capacity_binning") == 0) { g_opt_capacity = value != 0; return 0; }
@@ -770,7 +772,7 @@ int surfel_rasterize_backward(surfel_alloc_fn scratch_alloc, void* scratch_user,
     pb.P = P; pb.D = D; pb.M = M; pb.W = width; pb.H = height; pb.scale_modifier = scale_modifier;
     // record gather: per thread, or by the wave when a surfel holds many records AND the records (80 B each) overflow the 256 MB
     // Infinity Cache (measured: the cooperative form wins at C5 only, and loses 30 - 85 % on small frames); bit-identical sums
-    pb.coop = (debug_in & SURFEL_OPT_PBWD_COOP) ? 1 : ((debug_in & SURFEL_OPT_PBWD_THREAD) ? 0 : ((R >= (int64_t)6 * P && R >= ((int64_t)32 << 20)) ? 1 : 0));
+    pb.coop = (debug_in & SURFEL_OPT_PBWD_COOP) ? 1 : ((debug_in & SURFEL_OPT_PBWD_THREAD) ? 0 : (g_opt_pbwd_coop >= 0 ? g_opt_pbwd_coop : ((R >= (int64_t)6 * P && R >= ((int64_t)32 << 20)) ? 1 : 0)));
     pb.means3D = means3D; pb.radii = radii; pb.shs = shs; pb.clamped = geom.clamped; pb.scales = scales; pb.rotations = rotations;
     pb.transMat_precomp = transMat_precomp; pb.viewmatrix = viewmatrix; pb.projmatrix = projmatrix; pb.campos = cam_pos;
     pb.rec = geom.rec; pb.tiles_touched = geom.tiles_touched; pb.grec = grec; pb.cut = cut; pb.has_rec = has_rec; pb.depths = geom.depths; pb.gx = gx;

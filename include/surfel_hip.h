@@ -181,6 +181,9 @@ int surfel_debug_sort_pairs(surfel_alloc_fn scratch_alloc, void* scratch_user, u
  *          with order 1: the XCDs owning the image's middle rows did the work, the heaviest tiles finished alone); 0: decided per
  *          frame on the device from the lists (busiest XCD > 1.15x its share, or a list > 4 average lists -> 2).  Scheduling only:
  *          results are bit-identical (tests/test_gpu_parity.py::test_tile_order_is_scheduling_only).
+ *   "pbwd_coop" (default -1): record gather of the per-surfel backward — -1: by rule (wave-cooperative where R >= 6 P and R >= 2^25,
+ *          per thread otherwise; measured again in round 3: the cooperative form loses 15 % at C2H and 25 % at C4), 0 / 1: forced.
+ *          Bit-identical either way (tests/test_gpu_parity.py::test_record_gather_variants_are_identical).
  *   "capacity_binning" (default 1): frames on the per-tile-depth-sort path with <= 2^20 tile instances size their binning buffers
  *          from the largest instance count recent frames of the same size produced (+ 1/8 head room) instead of waiting for this
  *          frame's count in the middle of the forward: scan, emission and the tile sort's histograms run as ONE kernel right behind
