@@ -181,6 +181,10 @@ int surfel_debug_sort_pairs(surfel_alloc_fn scratch_alloc, void* scratch_user, u
  *          with order 1: the XCDs owning the image's middle rows did the work, the heaviest tiles finished alone); 0: decided per
  *          frame on the device from the lists (busiest XCD > 1.15x its share, or a list > 4 average lists -> 2).  Scheduling only:
  *          results are bit-identical (tests/test_gpu_parity.py::test_tile_order_is_scheduling_only).
+ *   "fat_sort" (default 1): look-back sort passes over <= 2^20 items use 8192-item tiles staged through LDS (0: 2048-item tiles);
+ *          "host_total" (default 1): capacity-path frames store their instance total into mapped pinned memory from the emission
+ *          kernel (0: a device-to-host copy in the stream).  Speed only (tests/test_gpu_parity.py::test_radix_sort_is_stable_and_exact
+ *          runs both tile sizes).
  *   "pbwd_coop" (default -1): record gather of the per-surfel backward — -1: by rule (wave-cooperative where R >= 6 P and R >= 2^25,
  *          per thread otherwise; measured again in round 3: the cooperative form loses 15 % at C2H and 25 % at C4), 0 / 1: forced.
  *          Bit-identical either way (tests/test_gpu_parity.py::test_record_gather_variants_are_identical).
