@@ -195,6 +195,101 @@ def test_trainer_collectives_world2():
     assert all(a != b for a, b in zip(res[0][5], res[1][5]))       # distinct views per step across ranks
 
 
+def _lazy_redo_worker(rank, world, port, q):
+    """Whole Trainer.step()s over gloo with the device pieces faked: rank 1 is told once that its lazily counted frame overflowed."""
+    import os
+    import sys
+    import types
+    import torch
+    import torch.distributed as dist
+    here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(here, "2d-gaussian-splatting_amd"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import diff_surfel_rasterization as dsr
+        import surfel_native as n
+        import surfel_trainer as TR
+        P = 7
+        log, calls, finishes = [], [], []
+
+        class FakeModel:
+            device = torch.device("cpu")
+            step_count = 0
+            active_sh_degree = 0
+            theta = m = v = None
+
+            def __init__(self):
+                self.P = P
+                self.grad = torch.arange(P * 58, dtype=torch.float32) * (rank + 1)
+                self.gcol = torch.full((P, 3), float(rank + 1))
+                self.xyz_gradient_accum, self.denom, self.max_radii2D = torch.zeros(P, 1), torch.zeros(P, 1), torch.zeros(P)
+
+            def update_learning_rate(self, it): pass
+            def oneupSHdegree(self): pass
+            def bind(self, sh_grad=True): pass
+            def refresh_activations(self): pass
+            def training_setup(self, opt): pass
+            def add_densification_stats(self, g, radii=None): log.append("stats")
+            def optimizer_step(self, grad_scale=1.0, colour_grads=None, parts=3): log.append(("adam", grad_scale, tuple(colour_grads[1].shape)))
+
+        def fake_rasterize(cam, m, pipe, bg, zero_means2D=True, debug_bits=0):
+            calls.append((cam.uid, debug_bits))
+            return (torch.zeros(3, 4, 4, requires_grad=True), torch.ones(m.P, dtype=torch.int32), torch.zeros(7, 4, 4, requires_grad=True),
+                    torch.zeros(m.P, 3, requires_grad=True))
+
+        def fake_finish():
+            finishes.append(len(calls))
+            if rank == 1 and len(finishes) == 2:
+                raise n.CapacityOverflow("forced")
+            return 1
+        TR.rasterize = fake_rasterize
+        TR.train_loss = lambda image, *a, **k: (image.sum() * 0.0, torch.zeros(6))
+        dsr.finish_count = fake_finish
+        cams = [types.SimpleNamespace(uid=i, original_image=torch.zeros(3, 4, 4), camera_center=torch.full((3,), float(i)), post_consts=lambda: torch.zeros(24))
+                for i in range(4)]
+        opt = TR.optimization_params(iterations=50, densify_from_iter=10 ** 6, dist_from_iter=0, normal_from_iter=0, lambda_dist=1.0)
+        tr = TR.Trainer(FakeModel(), cams, opt, TR.pipeline_params(depth_ratio=1.0), extent=1.0)
+        tr.manual_chain = False
+        assert tr._exchange and not tr._async_exchange and tr.lazy_count
+        for _ in range(4):
+            tr.step()
+        q.put((rank, calls, [e for e in log if e != "stats"], log.count("stats"), tr.lazy_overflows, float(tr.model.grad[:10 * P].sum())))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_lazy_redo_on_one_rank_keeps_the_collectives_in_step():
+    """View-parallel training with lazily counted forwards (Trainer.lazy_count): a rank whose frame overflowed renders, evaluates and
+    back-propagates again BEFORE the iteration's collectives — the other rank simply waits there; every rank still issues one
+    exchange, one statistics update and one optimiser step per iteration (two gloo processes, device pieces faked)."""
+    import torch.multiprocessing as mp
+    import surfel_native as n
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_lazy_redo_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=180) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    P = 7
+    for rank, calls, adams, nstats, overflows, gsum in res:
+        bits = [b for _, b in calls]
+        if rank == 0:
+            assert bits == [n.OPT_LAZY_COUNT] * 4 and overflows == 0
+        else:
+            assert bits == [n.OPT_LAZY_COUNT, n.OPT_LAZY_COUNT, n.OPT_EXACT_BINNING, n.OPT_LAZY_COUNT, n.OPT_LAZY_COUNT] and overflows == 1
+            assert calls[1][0] == calls[2][0]                      # the same view again
+        assert len(adams) == 4 and nstats == 4
+        assert all(a == ("adam", 0.5, (2, P, 3)) for a in adams)   # averaged over the two views, both ranks' colour gradients gathered
+    assert res[0][5] == res[1][5]                                  # the geometry prefix was all-reduced the same number of times on both ranks
+    views0, views1 = [c[0] for c in res[0][1]], [c[0] for c in res[1][1] if c[1] != n.OPT_EXACT_BINNING]
+    assert all(a != b for a, b in zip(views0, views1))             # distinct views per iteration across the ranks
+
+
 def _gather_bands_worker(rank, world, port, q):
     import os
     import torch
