@@ -677,6 +677,7 @@ int64_t surfel_rasterize_forward(surfel_alloc_fn geom_alloc, void* geom_user, su
         void* bin_base = binning_alloc(binning_user, 256);
         if (!bin_base) return fail(SURFEL_E_ALLOC, "binning buffer allocation failed");
         bin = BinState::carve(bin_base, 0, 0, nullptr);
+        g_lazy.R = 0;      // (surfel_forward_count of an empty scene)
     }
 
     run_tile_order(tile_ce, img.ranges, gx, gy, img.tile_map, img.total + 2 * R_SLOTS + 1, opt_tile_order, s);
