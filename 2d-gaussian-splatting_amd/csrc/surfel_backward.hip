@@ -204,6 +204,7 @@ __global__ void __launch_bounds__(BLOCK, ROWS_WAVES) blend_bwd_rows_kernel(Blend
     __shared__ int s_rowlast[16];                             // per row: the largest `last` of its 16 pixels
     __shared__ int s_max;
     if (a.variant == 2 && !auto_picks_rows(a)) return;
+    if (frame_overflowed(a.n_dev, a.n_cap)) return;
 #ifdef ROWS_TIMING
     const long long tm_start = __builtin_readcyclecounter();
 #endif
@@ -397,6 +398,7 @@ __global__ void __launch_bounds__(BLOCK) blend_bwd_quad_kernel(BlendBwdArgs a) {
     __shared__ int s_quadlast[4];                    // per quad (= wave): the largest `last` of its 64 pixels
     __shared__ int s_max;
     if (a.variant == 2 && auto_picks_rows(a)) return;
+    if (frame_overflowed(a.n_dev, a.n_cap)) return;
     const int tile = block_tile(a.tile_map, a.map_flag, blockIdx.x, a.gx * a.gy);
     if (tile < 0) return;
     const int tx = tile % a.gx, ty = tile / a.gx;

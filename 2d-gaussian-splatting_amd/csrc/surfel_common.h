@@ -91,6 +91,13 @@ __device__ __forceinline__ bool pair_hit(float pxf, float pyf, const float4 q0, 
     return pair_intersect(q1.z, q1.w, q2.x, q2.w, h);
 }
 
+// A lazily counted capacity-path frame whose instance total exceeded its capacity (include/surfel_hip.h: SURFEL_OPT_LAZY_COUNT): its
+// lists are truncated and its records' first-instance slots run past the gradient-record allocation.  The caller redoes the frame
+// once it has collected the count; until then every backward kernel it may already have enqueued must touch nothing.
+__device__ __forceinline__ bool frame_overflowed(const uint32_t* __restrict__ n_dev, uint32_t n_cap) {
+    return n_dev != nullptr && n_dev[0] > n_cap;
+}
+
 struct Rect { int x0, y0, x1, y1; };
 
 __device__ __forceinline__ Rect tile_rect(float px, float py, int r, int gx, int gy) {

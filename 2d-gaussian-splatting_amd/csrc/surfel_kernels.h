@@ -41,6 +41,8 @@ struct BlendBwdArgs {
     const float* depths;   // [P] view depths (the sort key's source)
     int variant;      // 0: per-DPP-row walk, 1: per-wave (8x8 quad) walk, 2: both launched, the device picks from the frame's totals (0 / 1 / 2 bit-identical); 3: scan walk
     const uint32_t* totals;      // [2 * R_SLOTS] partial sums written by preprocess: tile instances | visible surfels
+    const uint32_t* n_dev; uint32_t n_cap;      // capacity path: the frame's instance total on the device and the record capacity (= num_rendered).  n_dev[0] > n_cap:
+                                                // a lazily counted frame that overflowed — its lists are truncated, the caller redoes it: every backward kernel returns at once
     unsigned long long* stats;   // optional [4]: lane slots issued, useful (pixel, surfel) lanes, wave visits, row / quad visits
 };
 
@@ -54,6 +56,7 @@ struct PreprocessBwdArgs {
     const float* viewmatrix; const float* projmatrix; const float* campos;
     const float* rec; const uint32_t* tiles_touched; const float* grec;
     const uint2* cut; const uint8_t* has_rec; const float* depths; int gx;      // which of a surfel's instance records exist (BlendBwdArgs::cut); cut == NULL: all of them
+    const uint32_t* n_dev; uint32_t n_cap;      // as BlendBwdArgs: an overflowed frame's first-instance slots point past the records — nothing is read, nothing written
     float* dL_dtransMat; float* dL_dnormal; float* dL_dopacity; float* dL_dcolors; float* dL_dsh;
     float* dL_dmeans2D; float* dL_dmeans3D; float* dL_dscales; float* dL_drots;
 };

@@ -563,6 +563,7 @@ constexpr uint32_t HEAVY_MIN = 128;
 template <bool COOP, bool CUT>
 __global__ void __launch_bounds__(256, PRE_BWD_MINWG) preprocess_bwd_kernel(PreprocessBwdArgs a) {
     __shared__ float4 s_sum[COOP ? 256 * 5 : 1];
+    if (frame_overflowed(a.n_dev, a.n_cap)) return;      // (uniform: before any barrier)
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     float4 hs0 = make_float4(0.f, 0.f, 0.f, 0.f), hs1 = hs0, hs2 = hs0, hs3 = hs0, hs4 = hs0;
     bool heavy = false;
@@ -964,7 +965,7 @@ void launch_mark_visible(int P, const float* means3D, const float* vm, uint8_t* 
 // contiguous, so the lines fetched here are the ones preprocess_bwd reads next.
 __global__ void __launch_bounds__(256) colour_gradients_kernel(PreprocessBwdArgs a) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= a.P) return;
+    if (i >= a.P || frame_overflowed(a.n_dev, a.n_cap)) return;
     float c0 = 0.f, c1 = 0.f, c2 = 0.f;
     if (a.radii[i] > 0) {
         const uint32_t beg = __float_as_uint(a.rec[(size_t)i * REC_F + 18]);

@@ -695,24 +695,27 @@ __global__ void __launch_bounds__(BE_THREADS) bin_emit_kernel(int P, const uint3
     const uint32_t k = blockIdx.x * BE_THREADS + threadIdx.x;
     if (threadIdx.x < 2 * RS_RADIX) s_h[threadIdx.x >> 8][threadIdx.x & (RS_RADIX - 1)] = 0u;
     for (uint32_t w = k; w < sort_status_words; w += gridDim.x * BE_THREADS) sort_status[w] = 0u;
+    // Every addition of the scan SATURATES at 0xffffffff: a frame with >= 2^32 tile instances (far beyond any capacity: <= 2^20) must
+    // come out as "overflowed", not as a small wrapped total that passes the host's R <= cap check with truncated lists.
+    auto sat = [](uint32_t a, uint32_t b) { const uint32_t c = a + b; return c < a ? 0xffffffffu : c; };
     uint32_t pre = 0;                              // instances of the surfels ahead of this workgroup (preprocess workgroups of 256)
     const uint32_t ahead = min(nblock_totals, blockIdx.x * (uint32_t)(BE_THREADS / 256));
-    for (uint32_t j = threadIdx.x; j < ahead; j += BE_THREADS) pre += block_totals[j];
+    for (uint32_t j = threadIdx.x; j < ahead; j += BE_THREADS) pre = sat(pre, block_totals[j]);
     const uint32_t n = k < (uint32_t)P ? tiles_touched[k] : 0u;
     uint32_t x = n;                                // inclusive scan over the workgroup
 #pragma unroll
-    for (int o = 1; o < 64; o <<= 1) { const uint32_t y = __shfl_up(x, o); if (lane >= o) x += y; }
+    for (int o = 1; o < 64; o <<= 1) { const uint32_t y = __shfl_up(x, o); if (lane >= o) x = sat(x, y); }
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) pre += __shfl_xor(pre, o);
+    for (int o = 32; o > 0; o >>= 1) pre = sat(pre, __shfl_xor(pre, o));
     if (lane == 63) s_w[wave] = x;
     if (lane == 0) s_p[wave] = pre;
     __syncthreads();
-    uint32_t off = x - n;
+    uint32_t off = x - n;                          // (x saturated: off is an under-estimate >= 2^32 - 1 - n, still far above any capacity)
 #pragma unroll
-    for (int w = 0; w < NW; w++) off += s_p[w] + (w < wave ? s_w[w] : 0u);
+    for (int w = 0; w < NW; w++) off = sat(off, sat(s_p[w], w < wave ? s_w[w] : 0u));
     if (k == (uint32_t)P - 1u) {
-        n_out[0] = off + n;      // the instance total, for the kernels that follow ...
-        if (n_host) n_host[0] = off + n;      // ... and for the host (mapped pinned word: no copy kernel in the stream)
+        n_out[0] = sat(off, n);      // the instance total, for the kernels that follow ...
+        if (n_host) n_host[0] = sat(off, n);      // ... and for the host (mapped pinned word: no copy kernel in the stream)
     }
     const uint32_t mask0 = (1u << min(RS_BITS, end_bit)) - 1u;
     const uint32_t mask1 = passes > 1 ? (1u << min(RS_BITS, end_bit - RS_BITS)) - 1u : 0u;
@@ -723,7 +726,7 @@ __global__ void __launch_bounds__(BE_THREADS) bin_emit_kernel(int P, const uint3
         int xx = 0, yy = 0;
         for (uint32_t t = 0; t < n; t++) {
             const uint32_t key = (uint32_t)((y0 + yy) * gx + (x0 + xx));
-            if (off + t < cap) {      // (an overflowing frame is redone by the caller; what is sorted here stays consistent and in bounds)
+            if (off < cap && t < cap - off) {      // (an overflowing frame is redone by the caller; what is sorted here stays consistent and in bounds)
                 keys[off + t] = key; vals[off + t] = k;
                 atomicAdd(&s_h[0][key & mask0], 1u);
                 if (passes > 1) atomicAdd(&s_h[1][(key >> RS_BITS) & mask1], 1u);

@@ -191,7 +191,7 @@ class Trainer:
         # slower rank decides for all: _probe_early_gather) — results are bit-identical either way.
         self.early_gather = True if rehearse_exchange else ("auto" if (self.world > 1 and self._async_exchange and sharding == "views") else False)
         self.early_gather_probe = None      # {"early_ms": .., "late_ms": .., "choice": ..} once decided
-        self._eg_events, self._eg_first = [], None
+        self._eg_events, self._eg_first, self._eg_failed = [], None, False
         self._early, self._early_err = None, None
         # fused SH path (default): the rasterizer's backward skips the 192 B/surfel SH gradients, the optimiser kernel rebuilds them
         # from the 12 B/surfel colour gradients.  Always on under view-parallel training (that is how the gradients are exchanged).
@@ -334,7 +334,13 @@ class Trainer:
             # kernel ran), so the step continues with the gather-after-backward form and the early form stays off
             import warnings
             warnings.warn("early colour all-gather disabled after: %r" % (self._early_err,))
-            self.early_gather, self._early, self._early_err = False, None, None
+            if self.early_gather == "auto":
+                # mid-probe: the other ranks still expect this rank in the verdict's all-reduce (_probe_early_gather) — keep the state
+                # machine running, take the late form from here on, and vote "early = never" when the verdict is due
+                self._eg_failed = True
+            else:
+                self.early_gather = False
+            self._early, self._early_err = None, None
         self.last = dict(loss=scalars[5], scalars=scalars, points=m.P, radii=radii)     # [Ll1, ssim, normal_err, dist, photometric, total] on the device
         with torch.no_grad():
             rebuilt = False
@@ -395,7 +401,12 @@ class Trainer:
         if self.early_gather != "auto":
             return bool(self.early_gather)
         if self._eg_first is None:
-            self._eg_first = self.iteration + self.EG_WARM
+            # the two windows must time the same kind of iteration: start behind the warm-up at the first iteration from which
+            # 2 x EG_LEN iterations hold no densification / opacity reset (a function of the iteration number: the same on every rank)
+            first = self.iteration + self.EG_WARM
+            while any(self._is_event_iteration(first + k) for k in range(2 * self.EG_LEN + 1)):
+                first += 1
+            self._eg_first = first
         ph = self.iteration - self._eg_first
         if ph < 0:
             return False
@@ -404,7 +415,7 @@ class Trainer:
             ev.record()
             self._eg_events.append(ev)
         if ph < self.EG_LEN:
-            return True
+            return not self._eg_failed      # (a rank whose early gather failed takes the late form: the same collectives, later)
         if ph < 2 * self.EG_LEN:
             return False
         try:
@@ -413,12 +424,21 @@ class Trainer:
             t = torch.tensor([e0.elapsed_time(e1), e1.elapsed_time(e2)], dtype=torch.float32, device=self.model.device)
         except Exception:      # noqa: BLE001 — no timing, no early gather; every rank still joins the collective below
             t = torch.tensor([1.0, 0.0], dtype=torch.float32, device=self.model.device)
+        if self._eg_failed:      # this rank cannot launch the early gather: MAX over the ranks turns every rank's verdict to "late"
+            t = torch.tensor([3.0e38, 0.0], dtype=torch.float32, device=self.model.device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         early_ms, late_ms = (float(x) / self.EG_LEN for x in t.tolist())
         self.early_gather = self.decide_early_gather(early_ms, late_ms)
         self.early_gather_probe = {"early_ms_per_step": round(early_ms, 4), "late_ms_per_step": round(late_ms, 4), "choice": "early" if self.early_gather else "late"}
         self._eg_events = []
         return self.early_gather
+
+    def _is_event_iteration(self, it):
+        """Does iteration `it` densify / prune or reset the opacities (_schedule_events)?  Those iterations cost more and skip the optimiser step."""
+        opt = self.opt
+        if it < opt.densify_until_iter and it > opt.densify_from_iter and it % opt.densification_interval == 0:
+            return True
+        return it < opt.densify_until_iter and (it % opt.opacity_reset_interval == 0 or (self.white_background and it == opt.densify_from_iter))
 
     def _on_colour_ready(self):
         """Called by the C library inside the rasterizer's backward (autograd's thread, the forward's stream) once dL/dcolour is

@@ -223,7 +223,10 @@ int surfel_debug_set_blend_stats(void* dev_u64x8);
  * on the same thread before it lets the frame's results take effect (a trainer: after the backward, before the optimiser step):
  * it returns the exact count, or SURFEL_E_OVERFLOW if the frame held more instances than its capacity — its lists were truncated,
  * images and gradients are incomplete, and the caller renders the frame again (SURFEL_OPT_EXACT_BINNING) and recomputes what it
- * derived from it.  Rare: the capacity is the largest count of the recent frames of that size plus 1/8.  A forward that finds the
+ * derived from it.  surfel_rasterize_backward may be called on such a frame BEFORE the count is collected (that is the point of
+ * the flag): the frame's real total is on the device, every backward kernel compares it with num_rendered and returns at once when
+ * the frame overflowed — nothing is read or written past the gradient records sized from the capacity, the gradient outputs are
+ * left as they were.  Rare: the capacity is the largest count of the recent frames of that size plus 1/8.  A forward that finds the
  * previous lazy frame overflowed and unchecked fails with SURFEL_E_OVERFLOW instead of going on.  Without a pending lazy frame the
  * function returns the count of this thread's last forward.  Reference counterpart: num_rendered, the first return value of
  * rasterize_gaussians (diff-surfel-rasterization/rasterize_points.cu [UPSTREAM-RECALL]), which the reference reads back

@@ -590,6 +590,14 @@ def test_lazily_counted_forward():
     sc2 = synthetic.make_scene(80000, W, H, seed=5, px_radius=4.0)
     _, over, k4 = run(sc2, n.OPT_LAZY_COUNT)
     assert k4 == 4
+    # the backward of the overflowed frame BEFORE anybody collected its count (what Trainer.step does): num_rendered is the capacity,
+    # the records' first-instance slots run past the gradient records sized from it — every backward kernel must return at once
+    # (rows, quad, scan walks; both record gathers): the poisoned outputs stay untouched, nothing faults
+    for bits in (n.OPT_BWD_ROWS, n.OPT_BWD_QUAD, n.OPT_BWD_SCAN, n.OPT_PBWD_COOP, n.OPT_TILE_CUTS):
+        over.debug = n.OPT_LAZY_COUNT | n.opt_tile_sort(2) | bits
+        g_over = grads(scene_args(sc2), over)
+        for k, v in g_over.items():
+            assert np.isnan(v).all(), "backward of an overflowed frame wrote dL/d%s (%s)" % (k, bits)
     with pytest.raises(n.CapacityOverflow):
         n.forward_count()
     a2, redo, k5 = run(sc2, n.OPT_EXACT_BINNING)

@@ -154,3 +154,18 @@ def test_early_gather_is_a_measured_choice(trainer):
     # the probe's schedule (events and the collective are device-side: checked on the GPU box by the RCCL rehearsal)
     tr.early_gather, tr.iteration, tr._eg_first = "auto", 10, 12
     assert tr._probe_early_gather() is False                                       # still warming up
+    # the probe windows avoid densification / opacity-reset iterations: with an event every 5 iterations no window of
+    # 2 x EG_LEN + 1 iterations is free while the statistics are live, so the probe starts behind the last event (35; densify_until_iter = 40)
+    tr.early_gather, tr._eg_first, tr._eg_events = "auto", None, []
+    tr.opt.densify_from_iter, tr.opt.densification_interval, tr.opt.densify_until_iter, tr.opt.opacity_reset_interval = 0, 5, 40, 3000
+    tr.iteration = 10
+    assert tr._is_event_iteration(15) and not tr._is_event_iteration(16) and not tr._is_event_iteration(45)
+    assert tr._probe_early_gather() is False and tr._eg_first == 36
+    tr.opt.densification_interval = 100
+    tr._eg_first = None
+    assert tr._probe_early_gather() is False and tr._eg_first == 12
+    # a rank whose early gather failed keeps the probe's state machine running (the verdict's all-reduce needs every rank) but takes
+    # the late form — the same collectives, issued behind the backward
+    tr._eg_failed = False
+    assert tr._eg_failed is False
+
