@@ -368,6 +368,7 @@ int surfel_set_option(const char* name, int value) {
     if (name && std::strcmp(name, "tile_depth_sort") == 0) { g_opt_tile_sort = value < 0 ? 0 : (value > 2 ? 2 : value); return 0; }
     if (name && std::strcmp(name, "large_sort") == 0) { set_large_sort_impl(value); return 0; }
     if (name && std::strcmp(name, "fat_sort") == 0) { set_fat_sort(value); return 0; }
+    if (name && std::strcmp(name, "fwd_pipe") == 0) { set_fwd_pipe(value); return 0; }
     if (name && std::strcmp(name, "scan_large") == 0) { g_opt_scan_large = value != 0; return 0; }
     if (name && std::strcmp(name, "host_total") == 0) { g_opt_host_total = value != 0; return 0; }
     if (name && std::strcmp(name, "pbwd_coop") == 0) { g_opt_pbwd_coop = value < 0 ? -1 : (value != 0); return 0; }

@@ -208,6 +208,9 @@ __global__ void __launch_bounds__(BLOCK, ROWS_WAVES) blend_bwd_rows_kernel(Blend
 #ifdef ROWS_TIMING
     const long long tm_start = __builtin_readcyclecounter();
 #endif
+#ifdef BLEND_TRACE
+    const unsigned long long trace_t0 = wall_clock64();
+#endif
     const int tile = block_tile(a.tile_map, a.map_flag, blockIdx.x, a.gx * a.gy);
     if (tile < 0) return;
     const int tx = tile % a.gx, ty = tile / a.gx;
@@ -318,6 +321,8 @@ __global__ void __launch_bounds__(BLOCK, ROWS_WAVES) blend_bwd_rows_kernel(Blend
                 row_reduce20(gv, z);
 #ifdef ROWS_TIMING
                 tm_nvis++;
+#elif defined(BLEND_TRACE)
+                // (per-workgroup times only: the per-visit counters would dominate them)
 #else
                 if (STATS) {
                     const unsigned long long okb = __ballot(ok), ab = __ballot(actc);
@@ -376,6 +381,13 @@ __global__ void __launch_bounds__(BLOCK, ROWS_WAVES) blend_bwd_rows_kernel(Blend
             TM(tm_flush)
         }
     }
+#ifdef BLEND_TRACE
+    #ifdef ROWS_TIMING
+    if (STATS) trace_wg(a.stats, 65536, trace_t0, tile, maxc, tm_stage, tm_walk, tm_bar + tm_flush, tm_nvis);
+#else
+    if (STATS) trace_wg(a.stats, 65536, trace_t0, tile, maxc);
+#endif
+#endif
 #ifdef ROWS_TIMING
     if (STATS && lane == 0) {
         atomicAdd(&a.stats[2], (unsigned long long)tm_nvis); atomicAdd(&a.stats[4], (unsigned long long)tm_flush);

@@ -98,6 +98,27 @@ __device__ __forceinline__ bool frame_overflowed(const uint32_t* __restrict__ n_
     return n_dev != nullptr && n_dev[0] > n_cap;
 }
 
+// -DBLEND_TRACE (diagnostic build, scripts/wg_trace.py): the instrumented blend kernels leave, per workgroup, [start, end] in 100 MHz
+// ticks, the hardware ids (HW_ID | XCC_ID << 32) and (tile | list length << 32) behind the 16 counters of the stats buffer.
+#ifdef BLEND_TRACE
+constexpr int TRACE_W = 8;      // u64 words per workgroup
+__device__ __forceinline__ void trace_wg(unsigned long long* stats, int slot_base, unsigned long long t0, int tile, int n,
+                                         long long c_stage = 0, long long c_walk = 0, long long c_bar = 0, long long iters = 0) {
+    if (threadIdx.x == 0) {      // (the phase cycles are wave 0's)
+        unsigned hw, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        unsigned long long* d = stats + 16 + TRACE_W * (size_t)(slot_base + blockIdx.x);
+        d[0] = t0; d[1] = wall_clock64(); d[2] = (unsigned long long)hw | ((unsigned long long)xcc << 32);
+        d[3] = (unsigned long long)(unsigned)tile | ((unsigned long long)(unsigned)n << 32);
+        d[4] = (unsigned long long)c_stage; d[5] = (unsigned long long)c_walk; d[6] = (unsigned long long)c_bar; d[7] = (unsigned long long)iters;
+    }
+}
+#define TRACE_TM(acc) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); const long long t_ = __builtin_readcyclecounter(); acc += t_ - ttm_t; ttm_t = t_; }
+#else
+#define TRACE_TM(acc)
+#endif
+
 struct Rect { int x0, y0, x1, y1; };
 
 __device__ __forceinline__ Rect tile_rect(float px, float py, int r, int gx, int gy) {
@@ -132,6 +153,11 @@ __device__ __forceinline__ int block_tile(const int* __restrict__ map, const uin
 // a blend visit, so it can afford the exact geometry: for a horizontal strip of pixel rows the x-interval of
 // (E U D) /\ strip is closed-form (the extreme points of an ellipse inside a strip are its global extreme points
 // clamped to the strip), and a block of pixel columns is hit iff it meets that interval.
+// v_sqrt_f32 (1 ulp) instead of the correctly rounded sqrtf (a dozen instructions with its refinement and denormal scaling; 13 of
+// them per staged instance were half of the staging arithmetic): the footprint is conservative by construction — the ellipse is
+// inflated by 0.2 % + 0.3 px in preprocess, every interval by 1e-3 px here — so an ulp of the half-width changes no culling decision
+// that matters (tests/test_gpu_parity.py::test_culling_is_exact holds the images to the uncullled bits).
+__device__ __forceinline__ float foot_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
 struct Foot {
     float ecx, ecy, syy, det, k, isyy, hy, yR;   // ellipse
     float dcx, dcy, r2sq;                        // disc
@@ -143,7 +169,7 @@ __device__ __forceinline__ Foot make_foot(const float4 q2, const float4 q5, cons
     f.unbounded = q5.z >= FOOT_UNBOUNDED;
     f.isyy = __builtin_amdgcn_rcpf(q6.x);
     f.k = q5.w * f.isyy;                         // dx/dy of the ellipse's centre line
-    f.hy = sqrtf(q6.x);
+    f.hy = foot_sqrt(q6.x);
     f.yR = q5.w * __builtin_amdgcn_rsqf(q5.z);   // y of the rightmost point (leftmost: -yR)
     f.dcx = q2.y; f.dcy = q2.z; f.r2sq = q6.y;
     return f;
@@ -154,13 +180,13 @@ __device__ __forceinline__ void foot_strip(const Foot& f, float Y0, float Y1, fl
     const float a0 = fmaxf(Y0 - f.ecy, -f.hy), a1 = fminf(Y1 - f.ecy, f.hy);
     if (a0 <= a1) {
         const float yr = fminf(fmaxf(f.yR, a0), a1), yl = fminf(fmaxf(-f.yR, a0), a1);
-        xmax = f.ecx + f.k * yr + sqrtf(fmaxf(f.det * (f.syy - yr * yr), 0.f)) * f.isyy + 1e-3f;
-        xmin = f.ecx + f.k * yl - sqrtf(fmaxf(f.det * (f.syy - yl * yl), 0.f)) * f.isyy - 1e-3f;
+        xmax = f.ecx + f.k * yr + foot_sqrt(fmaxf(f.det * (f.syy - yr * yr), 0.f)) * f.isyy + 1e-3f;
+        xmin = f.ecx + f.k * yl - foot_sqrt(fmaxf(f.det * (f.syy - yl * yl), 0.f)) * f.isyy - 1e-3f;
     }
     const float dy = fmaxf(fmaxf(Y0 - f.dcy, f.dcy - Y1), 0.f);
     const float h2 = f.r2sq - dy * dy;
     if (h2 >= 0.f) {
-        const float h = sqrtf(h2);
+        const float h = foot_sqrt(h2) * 1.000001f;
         xmin = fminf(xmin, f.dcx - h); xmax = fmaxf(xmax, f.dcx + h);
     }
     if (f.unbounded) { xmin = -3.0e38f; xmax = 3.0e38f; }

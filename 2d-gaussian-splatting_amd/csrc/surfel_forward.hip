@@ -20,6 +20,10 @@ template <bool STATS>
 __global__ void __launch_bounds__(BLOCK) blend_fwd_kernel(BlendFwdArgs a) {
     __shared__ float4 s_rec[BLOCK * 5];
     __shared__ __attribute__((aligned(8))) uint32_t s_mask[16 * MSTRIDE];    // [sub-tile][word]
+#ifdef BLEND_TRACE
+    const unsigned long long trace_t0 = wall_clock64();
+    long long ttm_t = __builtin_readcyclecounter(), ttm_stage = 0, ttm_walk = 0, ttm_bar = 0, ttm_it = 0, ttm_s0 = 0, ttm_s1 = 0, ttm_s2 = 0;
+#endif
     const int tile = block_tile(a.tile_map, a.map_flag, blockIdx.x, a.gx * a.gy);      // (tile_order_kernel: XCD-contiguous runs on uniform frames, longest lists first otherwise)
     if (tile < 0) return;
     const int tx = tile % a.gx, ty = tile / a.gx;
@@ -43,15 +47,28 @@ __global__ void __launch_bounds__(BLOCK) blend_fwd_kernel(BlendFwdArgs a) {
 
     for (int base = 0; base < n; base += BLOCK) {
         if (__syncthreads_count(done) == BLOCK) break;
+        TRACE_TM(ttm_bar)
         const int m = min(BLOCK, n - base);
         unsigned ov = 0;
         if ((int)threadIdx.x < m) {
             const uint32_t id = a.point_list[range.x + base + threadIdx.x];
+#ifdef BLEND_TRACE
+            asm volatile("" :: "v"(id));
+            TRACE_TM(ttm_s0)
+#endif
             const float4* __restrict__ src = reinterpret_cast<const float4*>(a.rec + (size_t)id * REC_F);
             const float4 v0 = src[0], v1 = src[1], v2 = src[2], v3 = src[3], v4 = src[4], v5 = src[5], v6 = src[6];
+#ifdef BLEND_TRACE
+            asm volatile("" :: "v"(v0.x), "v"(v1.x), "v"(v2.x), "v"(v3.x), "v"(v4.x), "v"(v5.x), "v"(v6.x));
+            TRACE_TM(ttm_s1)
+#endif
             s_rec[threadIdx.x * 5 + 0] = v0; s_rec[threadIdx.x * 5 + 1] = v1; s_rec[threadIdx.x * 5 + 2] = v2;
             s_rec[threadIdx.x * 5 + 3] = v3; s_rec[threadIdx.x * 5 + 4] = v4;
             ov = subtile_overlap(make_foot(v2, v5, v6), tx * TILE, ty * TILE);
+#ifdef BLEND_TRACE
+            asm volatile("" :: "v"(ov));
+            TRACE_TM(ttm_s2)
+#endif
         }
         // per-sub-tile bitmasks of the 64 instances this staging wave holds (words 2*wave, 2*wave+1)
 #pragma unroll
@@ -59,7 +76,9 @@ __global__ void __launch_bounds__(BLOCK) blend_fwd_kernel(BlendFwdArgs a) {
             const unsigned long long b = __ballot((ov >> s) & 1u);
             if (lane == 0) *reinterpret_cast<unsigned long long*>(&s_mask[s * MSTRIDE + 2 * wave]) = b;
         }
+        TRACE_TM(ttm_stage)
         __syncthreads();
+        TRACE_TM(ttm_bar)
         const int nw = (m + 31) >> 5;                 // mask words in use
         // row walk state: cur = unvisited instances of word widx, next = word widx+1 (prefetched)
         int widx = 0;
@@ -70,6 +89,9 @@ __global__ void __launch_bounds__(BLOCK) blend_fwd_kernel(BlendFwdArgs a) {
         }
         for (;;) {
             if (!__any((cur != 0u) | (widx < nw - 1))) break;
+#ifdef BLEND_TRACE
+            ttm_it++;
+#endif
             const bool act = cur != 0u;
             const int j = (widx << 5) + __builtin_ctz(cur | 0x80000000u);
             cur &= cur - 1u;
@@ -104,7 +126,11 @@ __global__ void __launch_bounds__(BLOCK) blend_fwd_kernel(BlendFwdArgs a) {
             }
             if (cur == 0u && widx < nw - 1) { widx++; cur = next; next = mrow[widx + 1]; }
         }
+        TRACE_TM(ttm_walk)
     }
+#ifdef BLEND_TRACE
+    if (STATS) trace_wg(a.stats, 0, trace_t0, tile, n, (ttm_s0 << 40) | (ttm_s1 << 20) | ttm_s2, ttm_walk, (ttm_stage << 24) | ttm_bar, ttm_it);
+#endif
     if (STATS) {      // stats[6] += composited pairs (the backward's stats[1] must count the same set)
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) npairs += __shfl_xor(npairs, o);
@@ -126,7 +152,268 @@ __global__ void __launch_bounds__(BLOCK) blend_fwd_kernel(BlendFwdArgs a) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// blend_fwd, software-pipelined staging ("pipe", the default; round 4).
+//
+// What the per-workgroup trace of the kernel above showed (scripts/wg_trace.py, profiles/r04_wg_trace.md): on a trained frame the
+// slowest tile spends 41 % of its life STAGING — surfel ids -> 112-B record gather (two dependent global round trips per batch,
+// issued by every resident workgroup at the same moment: the CU's fetch path, ~11 B/clk, is the bound) -> footprint test -> masks
+// -> barrier — and only then walks; its VALU sits idle meanwhile (0.23 of the issue peak over the launch), and nothing else is
+// resident to fill in: an object-centred frame has ~1 000 non-empty tiles, 4 per CU.  Here the records of batch b+1 travel while
+// batch b is walked:
+//   * batches of 128 instances, TWO record buffers in LDS, filled by LDS-DMA (global_load_lds_dwordx4: global -> LDS without a
+//     VGPR, asynchronous, completion by vmcnt) in structure-of-arrays order ([quarter][instance]: the DMA writes base + 16 * lane);
+//     the ids of the batch after that wait in one VGPR;
+//   * wave (g, h) = (wave & 1, wave >> 1) issues the DMA for instances [64 g, 64 g + 64) of the next batch — quarters 0-2 (h = 0) or
+//     3-4 (h = 1), plus quarter 2 and PRIVATE copies of quarters 5-6 (the footprint conic) for the mask bits it computes itself: when
+//     it has finished its walk it waits for ITS OWN loads (no barrier), tests the footprints of its 64 instances against the
+//     sub-tiles of pixel rows 8 h .. 8 h + 7 and leaves the ballots in the other mask buffer;
+//   * ONE barrier per batch (the walk of batch b is over everywhere <=> buffer b is free, masks and records of b+1 are complete).
+// The walk itself, and therefore every output bit, is the kernel above's (tests/test_gpu_parity.py::test_forward_kernels_are_identical).
+// ---------------------------------------------------------------------------------------------
+constexpr int NB = 128;                 // instances per batch
+constexpr int PMSTRIDE = 4;             // a row's four mask words: one aligned 16-B read
+
+__device__ __forceinline__ unsigned lds_offset(const void* p) {
+    return (unsigned)(uintptr_t)(const __attribute__((address_space(3))) void*)p;
+}
+// 16 B per lane, global -> LDS at (wave-uniform) lds_base + 16 * lane.  M0 carries the LDS base and is compiler-reserved: saved and
+// restored inside the statement.  hipcc does not count this load: the issuer waits with an explicit s_waitcnt vmcnt.
+__device__ __forceinline__ void dma16(const void* gsrc, unsigned lds_base) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_base) : "memory");
+}
+__device__ __forceinline__ void dma4(const void* gsrc, unsigned lds_base) {      // 4 B per lane -> lds_base + 4 * lane
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_base) : "memory");
+}
+// sub-tile bits (id = 4 * by + bx) of the two 4-row strips by = 2 h, 2 h + 1
+__device__ __forceinline__ unsigned subtile_overlap_half(const Foot& f, int tile_x0, int tile_y0, int h) {
+    unsigned ov = 0;
+#pragma unroll
+    for (int b = 0; b < 2; b++) {
+        const int by = 2 * h + b;
+        float xmin, xmax;
+        foot_strip(f, (float)(tile_y0 + 4 * by), (float)(tile_y0 + 4 * by + 3), xmin, xmax);
+        xmin -= (float)tile_x0; xmax -= (float)tile_x0;
+#pragma unroll
+        for (int bx = 0; bx < 4; bx++) ov |= (xmin <= (float)(4 * bx + 3) && xmax >= (float)(4 * bx)) ? (1u << (4 * b + bx)) : 0u;
+    }
+    return ov;
+}
+
+template <bool STATS>
+__global__ void __launch_bounds__(BLOCK) blend_fwd_pipe_kernel(BlendFwdArgs a) {
+    __shared__ float4 s_rec[2][5][NB];                 // 20 KB: q0-q4 of two batches, [buffer][quarter][instance]
+    __shared__ float4 s_foot[4][2][64];                // 8 KB: per wave, q5 / q6 of the 64 instances whose masks it computes
+    __shared__ __attribute__((aligned(16))) uint32_t s_mask[2][16 * PMSTRIDE];     // [buffer][sub-tile][word]
+    __shared__ int s_alldone[2][4];
+    __shared__ uint32_t s_list[4][4][NB / 4 + 1];      // 2.1 KB: per wave and DPP row, the staged indices (bytes) of the row's visits of this batch
+    __shared__ uint32_t s_ids[4][64];                  // 1 KB: per wave, the surfel ids of its 64 instances of the batch after next (DMA as well:
+                                                       // a load hipcc tracks would make it wait for vmcnt(0) — i.e. for the record DMA — at its next use)
+#ifdef BLEND_TRACE
+    const unsigned long long trace_t0 = wall_clock64();
+    long long ttm_t = __builtin_readcyclecounter(), ttm_stage = 0, ttm_walk = 0, ttm_bar = 0, ttm_it = 0;
+#endif
+    const int tile = block_tile(a.tile_map, a.map_flag, blockIdx.x, a.gx * a.gy);
+    if (tile < 0) return;
+    const int tx = tile % a.gx, ty = tile / a.gx;
+    int lx, ly, sub;
+    thread_pixel(threadIdx.x, lx, ly, sub);
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int g = wave & 1, h = wave >> 1;
+    const int pxi = tx * TILE + lx, pyi = ty * TILE + ly;
+    const bool inside = pxi < a.W && pyi < a.H;
+    const float pxf = (float)pxi, pyf = (float)pyi;
+    const uint2 range = a.ranges[tile];
+    const int n = (int)(range.y - range.x);
+
+    bool done = !inside;
+    float T = 1.f, C0 = 0.f, C1 = 0.f, C2 = 0.f, N0 = 0.f, N1 = 0.f, N2 = 0.f;
+    float D = 0.f, M1 = 0.f, M2 = 0.f, dist = 0.f, med = 0.f;
+    uint32_t last = 0, medc = 0;
+    unsigned npairs = 0;
+    constexpr float MC1 = FAR_N / (FAR_N - NEAR_N);
+    for (int k = lane; k < 4 * (NB / 4 + 1); k += 64) (&s_list[wave][0][0])[k] = 0u;      // (bytes past a list's end are read as indices: any valid one will do)
+    const unsigned rec_base = lds_offset(&s_rec[0][0][0]) + 1024u * (unsigned)g;      // + buffer * 10240 + quarter * 2048
+    const unsigned foot_base = lds_offset(&s_foot[wave][0][0]);
+    const char* const recb = reinterpret_cast<const char*>(a.rec);
+    // this wave's share of a batch's DMA: the records of instances [64 g, 64 g + 64) of the batch that starts at list position `base`
+    auto issue = [&](int base, int buf, uint32_t id) {
+        if (base + 64 * g + lane < n) {
+            const char* src = recb + (size_t)id * (REC_F * 4);
+            const unsigned dst = rec_base + 10240u * (unsigned)buf;
+            if (h == 0) { dma16(src, dst); dma16(src + 16, dst + 2048u); dma16(src + 32, dst + 4096u); }
+            else { dma16(src + 48, dst + 6144u); dma16(src + 64, dst + 8192u); dma16(src + 32, dst + 4096u); }
+            dma16(src + 80, foot_base); dma16(src + 96, foot_base + 1024u);
+        }
+    };
+    // ... and, once they have landed, of its masks: sub-tiles of strips 2 h, 2 h + 1 x its 64 instances -> words 2 g, 2 g + 1
+    auto masks = [&](int base, int buf) {
+        unsigned ov = 0;
+        if (base + 64 * g + lane < n) {
+            const float4 v2 = s_rec[buf][2][64 * g + lane], v5 = s_foot[wave][0][lane], v6 = s_foot[wave][1][lane];
+            ov = subtile_overlap_half(make_foot(v2, v5, v6), tx * TILE, ty * TILE, h);
+        }
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const unsigned long long b = __ballot((ov >> k) & 1u);
+            if (lane == 0) *reinterpret_cast<unsigned long long*>(&s_mask[buf][(8 * h + k) * PMSTRIDE + 2 * g]) = b;
+        }
+    };
+    const unsigned ids_base = lds_offset(&s_ids[wave][0]);
+    auto issue_ids = [&](int base) {      // ids of this wave's instances of the batch at `base` -> s_ids[wave] (read back, into a register, before the next ones are requested)
+        const int k = base + 64 * g + lane;
+        if (k < n) dma4(a.point_list + range.x + k, ids_base);
+    };
+
+    if (n > 0) {
+        {
+            const int k = 64 * g + lane;
+            const uint32_t id0 = k < n ? a.point_list[range.x + k] : 0u;      // (the one load hipcc tracks: waited for before any DMA is issued)
+            issue(0, 0, id0);
+        }
+        issue_ids(NB);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        masks(0, 0);
+        TRACE_TM(ttm_stage)
+        __syncthreads();
+        TRACE_TM(ttm_bar)
+        for (int base = 0, buf = 0; base < n; base += NB, buf ^= 1) {
+            const bool more = base + NB < n;
+            if (more) {      // next batch's records (their ids landed with this batch's records), and the ids of the batch behind it
+                const uint32_t idn = s_ids[wave][lane];
+                asm volatile("s_waitcnt lgkmcnt(0)" : : "v"(idn) : "memory");      // the ids are in registers before the DMA below may overwrite them
+                issue(base + NB, buf ^ 1, idn);
+                issue_ids(base + 2 * NB);
+            }
+            // ---- the walk.  On frames with few resident waves the bound is the wave's own issue rate plus the LDS round trips it
+            // waits for (SQ counters of the batch-synchronous kernel on a trained frame: 40 % of the wave-cycles issuing, 18 % stalled
+            // on issue, 42 % parked at s_waitcnt / barriers).  So: (1) each row's mask is expanded ONCE per batch into a byte list of
+            // staged indices, by the row's own lanes — a visit then costs a byte extract instead of find-first-set / clear / word
+            // refill / two votes, and the loop is a counted loop (trip count = the longest of the wave's four lists); (2) the record of
+            // visit v + 1 is read from LDS while visit v is being computed.  Visit order per row = list order = mask-bit order: the
+            // results are the mask walk's, bit for bit.
+            const float4* R = &s_rec[buf][0][0];
+            uint32_t* const lrow = &s_list[wave][lane >> 4][0];
+            int len;
+            {
+                const int i16 = lane & 15;
+                const uint4 mw = *reinterpret_cast<const uint4*>(&s_mask[buf][sub * PMSTRIDE]);
+                const unsigned long long db = __ballot(done);      // a row whose 16 pixels are all saturated skips the batch
+                const bool rowdone = (((unsigned)(db >> (lane & 48))) & 0xffffu) == 0xffffu;
+                len = rowdone ? 0 : (int)(__popc(mw.x) + __popc(mw.y) + __popc(mw.z) + __popc(mw.w));
+                const uint32_t wsel = (i16 & 8) ? ((i16 & 4) ? mw.w : mw.z) : ((i16 & 4) ? mw.y : mw.x);
+                const uint32_t byte = (wsel >> (8 * (i16 & 3))) & 0xffu;      // instances 8 i16 .. 8 i16 + 7 of the row's mask
+                int off = __popc(byte);                                    // exclusive prefix over the row's 16 lanes
+                int t;
+                t = __builtin_amdgcn_update_dpp(0, off, 0x111, 0xf, 0xf, true); off += t;      // row_shr:1
+                t = __builtin_amdgcn_update_dpp(0, off, 0x112, 0xf, 0xf, true); off += t;      // row_shr:2
+                t = __builtin_amdgcn_update_dpp(0, off, 0x114, 0xf, 0xf, true); off += t;      // row_shr:4
+                t = __builtin_amdgcn_update_dpp(0, off, 0x118, 0xf, 0xf, true); off += t;      // row_shr:8
+                off -= __popc(byte);
+                uint8_t* const lb = reinterpret_cast<uint8_t*>(lrow);
+#pragma unroll
+                for (int k = 0; k < 8; k++)
+                    if ((byte >> k) & 1u) lb[off + __popc(byte & ((1u << k) - 1u))] = (uint8_t)(8 * i16 + k);
+            }
+            int niter = max(max(__builtin_amdgcn_readlane(len, 0), __builtin_amdgcn_readlane(len, 16)),
+                            max(__builtin_amdgcn_readlane(len, 32), __builtin_amdgcn_readlane(len, 48)));
+            if (niter > 0) {
+                uint32_t jw = lrow[0];
+                int j = (int)(jw & 0xffu);
+                float4 q0 = R[j], q1 = R[NB + j], q2 = R[2 * NB + j], q3 = R[3 * NB + j];
+                float2 q4 = *reinterpret_cast<const float2*>(&R[4 * NB + j]);
+                for (int i = 0; i < niter; i += 4) {
+                    const uint32_t jw_next = lrow[(i >> 2) + 1];      // (one word past the longest list: allocated, never used)
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        if (i + k >= niter) break;
+#ifdef BLEND_TRACE
+                        ttm_it++;
+#endif
+                        const bool act = i + k < len;
+                        // the next visit's record: on its way while this one is computed
+                        const int jn = (int)(k < 3 ? (jw >> (8 * (k + 1))) & 0xffu : jw_next & 0xffu);
+                        const float4 n0 = R[jn], n1 = R[NB + jn], n2 = R[2 * NB + jn], n3 = R[3 * NB + jn];
+                        const float2 n4 = *reinterpret_cast<const float2*>(&R[4 * NB + jn]);
+                        Hit hh;
+                        const bool hit = pair_hit(pxf, pyf, q0, q1, q2, hh);
+                        const float depth = hh.depth, alpha = hh.alpha;
+                        const bool ok = act & (!done) & hit;
+                        const float testT = T * (1.f - alpha);
+                        const bool term = ok & (testT < T_EPS);      // the terminating surfel is not composited
+                        done |= term;
+                        if (ok & !term) {
+                            if (STATS) npairs++;
+                            const uint32_t contributor = (uint32_t)(base + j + 1);
+                            const float w_ = alpha * T;
+                            const float mm = MC1 - (MC1 * NEAR_N) * SURFEL_RCP(depth);
+                            dist += (mm * (mm * (1.f - T) - 2.f * M1) + M2) * w_;
+                            D += depth * w_;
+                            M1 += mm * w_;
+                            M2 += mm * mm * w_;
+                            if (T > 0.5f) { med = depth; medc = contributor; }
+                            N0 += q3.x * w_; N1 += q3.y * w_; N2 += q3.z * w_;
+                            C0 += q3.w * w_; C1 += q4.x * w_; C2 += q4.y * w_;
+                            T = testT;
+                            last = contributor;
+                        }
+                        q0 = n0; q1 = n1; q2 = n2; q3 = n3; q4 = n4; j = jn;
+                    }
+                    jw = jw_next;
+                    if (__all(done)) break;
+                }
+            }
+            TRACE_TM(ttm_walk)
+            if (more) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's own DMA of the next batch
+                masks(base + NB, buf ^ 1);
+            }
+            const int wave_done = __all(done) ? 1 : 0;      // (evaluated by the whole wave, not under the lane-0 branch)
+            if (lane == 0) s_alldone[buf][wave] = wave_done;
+            TRACE_TM(ttm_stage)
+            __syncthreads();
+            TRACE_TM(ttm_bar)
+            if ((s_alldone[buf][0] & s_alldone[buf][1] & s_alldone[buf][2] & s_alldone[buf][3]) != 0) break;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (a DMA issued for a batch that saturation made unnecessary must land before the LDS is handed back)
+    }
+#ifdef BLEND_TRACE
+    if (STATS) trace_wg(a.stats, 0, trace_t0, tile, n, ttm_stage, ttm_walk, ttm_bar, ttm_it);
+#endif
+    if (STATS) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) npairs += __shfl_xor(npairs, o);
+        if (lane == 0) atomicAdd(&a.stats[6], (unsigned long long)npairs);
+    }
+    if (inside) {
+        const size_t HW = (size_t)a.H * a.W;
+        const size_t pix = (size_t)pyi * a.W + pxi;
+        a.final_T[pix] = T; a.final_T[HW + pix] = M1; a.final_T[2 * HW + pix] = M2;
+        a.n_contrib[pix] = last; a.n_contrib[HW + pix] = medc;
+        a.out_color[pix] = C0 + T * a.bg[0];
+        a.out_color[HW + pix] = C1 + T * a.bg[1];
+        a.out_color[2 * HW + pix] = C2 + T * a.bg[2];
+        a.out_others[pix] = D;
+        a.out_others[HW + pix] = 1.f - T;
+        a.out_others[2 * HW + pix] = N0; a.out_others[3 * HW + pix] = N1; a.out_others[4 * HW + pix] = N2;
+        a.out_others[5 * HW + pix] = med;
+        a.out_others[6 * HW + pix] = dist;
+    }
+}
+
+static int g_fwd_pipe = 1;      // surfel_set_option("fwd_pipe", .): 1 pipelined staging (default), 0 the batch-synchronous kernel
+void set_fwd_pipe(int v) { g_fwd_pipe = v != 0; }
+
 void launch_blend_fwd(const BlendFwdArgs& a, hipStream_t s) {
+    if (g_fwd_pipe) {
+        if (a.stats) hipLaunchKernelGGL(blend_fwd_pipe_kernel<true>, dim3(a.map_len), dim3(BLOCK), 0, s, a);
+        else hipLaunchKernelGGL(blend_fwd_pipe_kernel<false>, dim3(a.map_len), dim3(BLOCK), 0, s, a);
+        return;
+    }
     if (a.stats) hipLaunchKernelGGL(blend_fwd_kernel<true>, dim3(a.map_len), dim3(BLOCK), 0, s, a);
     else hipLaunchKernelGGL(blend_fwd_kernel<false>, dim3(a.map_len), dim3(BLOCK), 0, s, a);
 }

@@ -70,6 +70,7 @@ int tile_map_len(int gx, int gy);
 // verdict: optional device-visible word that receives 1 (uniform frame) / 2 (uneven lists)
 void launch_tile_order(const uint2* ranges, int gx, int gy, int* map, uint32_t* map_flag /* zeroed */, int force, uint32_t* verdict, hipStream_t s);
 void launch_blend_fwd(const BlendFwdArgs& a, hipStream_t s);
+void set_fwd_pipe(int v);             // 1 (default): software-pipelined staging (LDS-DMA of the next batch under the walk), 0: batch-synchronous kernel
 void launch_mark_visible(int P, const float* means3D, const float* vm, uint8_t* present, hipStream_t s);
 void launch_blend_bwd(const BlendBwdArgs& a, hipStream_t s);
 void launch_blend_bwd_scan(const BlendBwdArgs& a, hipStream_t s);      // variant 3 (surfel_backward_scan.hip)
