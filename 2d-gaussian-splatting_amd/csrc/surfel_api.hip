@@ -26,7 +26,7 @@ surfel_hook_fn g_colour_hook = nullptr;   // surfel_set_backward_hook
 void* g_colour_hook_user = nullptr;
 int g_opt_pbwd_coop = -1;  // surfel_set_option("pbwd_coop", .): record gather of preprocess_bwd — -1 by rule (R >= 6 P and R >= 2^25), 0 per thread, 1 wave-cooperative
 int g_opt_host_total = 1;  // surfel_set_option("host_total", .): capacity path — 1: bin_emit_kernel stores the instance total into mapped pinned memory, 0: D2H copy kernel (measurement)
-int g_opt_scan_large = 1;  // surfel_set_option("scan_large", .): auto takes the scan walk on frames with 2^21 <= R < 2^26 instances
+int g_opt_scan_large = 1;  // surfel_set_option("scan_large", .): auto lets the device rule hand frames to the scan walk (2^21 <= R < 2^26 instances, or >= 6 instances per emitting surfel)
 int g_opt_bwd_tune = 1;    // surfel_set_option("bwd_tune", .): auto = timed probes (1) or the device-side rule alone (0)
 unsigned long long* g_blend_stats = nullptr;   // surfel_debug_set_blend_stats
 thread_local int64_t g_last_R = -1; thread_local int g_last_W = 0, g_last_H = 0;   // auto heuristic (speed only; results identical; a stale
@@ -752,14 +752,14 @@ int surfel_rasterize_backward(surfel_alloc_fn scratch_alloc, void* scratch_user,
         int probe = -1;
         std::unique_lock<std::mutex> tl(g_tuner_mu, std::defer_lock);
         if (opt_variant == 4) bb.variant = 2;      // (no verdict yet, stats mode, tuning off: rows + quad with the device rule)
-        // Large frames take the scan walk: with the same views in every walk's window it measured 7 % under the better of rows / quad on
-        // C4-synthetic (8 M instances: 0.944 vs 1.011 ms) and on the garden-sized trained state (1.17 vs 1.25 ms), at parity around
-        // 2 M instances and 11 % over on 0.5 M (profiles/r03_blend_bwd_scan.md).  A rule on R, not a timed choice: the walks differ in
-        // summation order, and which bits a frame gets must follow from the frame alone.  (C5, 1.3e8 instances of which 4 % are staged:
-        // scan 3.19 vs 3.13 ms — no gain, hence the upper bound.)
-        const bool scan_rule = opt_variant == 2 && g_opt_scan_large && !g_blend_stats && R >= ((int64_t)1 << 21) && R < ((int64_t)1 << 26);
-        if (scan_rule) bb.variant = 3;
-        if ((opt_variant == 2 || opt_variant == 4) && !scan_rule && !g_blend_stats && g_opt_bwd_tune) {
+        // The scan walk takes the frames whose footprints span many tiles and the large ones — decided ON THE DEVICE from the frame's
+        // totals (surfel_blend_bwd.h: device_picks_scan; the host of a lazily counted frame knows neither R nor the emitting surfels):
+        // the scan kernel is launched beside the rows / quad kernel the tuner picked and all but one of them return at once (~4 us).
+        // A rule, not a timed choice: the walks differ in summation order, and which bits a frame gets must follow from the frame alone.
+        // (C5, 1.3e8 instances of which 4 % are staged: scan 3.19 vs 3.13 ms — no gain, hence the rule's upper bound on R.)
+        const bool scan_rule = opt_variant == 2 && g_opt_scan_large && !g_blend_stats;
+        bb.scan_rule = scan_rule ? 1 : 0;
+        if ((opt_variant == 2 || opt_variant == 4) && !g_blend_stats && g_opt_bwd_tune) {
             tl.lock();
             bb.variant = walk_tuner_pick(P, width, height, R, s, opt_variant == 4 ? 3 : 2, &tuner, &probe);
             if (probe >= 0) (void)hipEventRecord(tuner->e0[probe], s);

@@ -204,6 +204,7 @@ __global__ void __launch_bounds__(BLOCK, ROWS_WAVES) blend_bwd_rows_kernel(Blend
     __shared__ int s_rowlast[16];                             // per row: the largest `last` of its 16 pixels
     __shared__ int s_max;
     if (a.variant == 2 && !auto_picks_rows(a)) return;
+    if (a.scan_rule && device_picks_scan(a)) return;
     if (frame_overflowed(a.n_dev, a.n_cap)) return;
 #ifdef ROWS_TIMING
     const long long tm_start = __builtin_readcyclecounter();
@@ -410,6 +411,7 @@ __global__ void __launch_bounds__(BLOCK) blend_bwd_quad_kernel(BlendBwdArgs a) {
     __shared__ int s_quadlast[4];                    // per quad (= wave): the largest `last` of its 64 pixels
     __shared__ int s_max;
     if (a.variant == 2 && auto_picks_rows(a)) return;
+    if (a.scan_rule && device_picks_scan(a)) return;
     if (frame_overflowed(a.n_dev, a.n_cap)) return;
     const int tile = block_tile(a.tile_map, a.map_flag, blockIdx.x, a.gx * a.gy);
     if (tile < 0) return;
@@ -518,6 +520,7 @@ __global__ void __launch_bounds__(BLOCK) blend_bwd_quad_kernel(BlendBwdArgs a) {
 void launch_blend_bwd(const BlendBwdArgs& a, hipStream_t s) {
     const dim3 grid(a.map_len), block(BLOCK);
     if (a.variant == 3) { launch_blend_bwd_scan(a, s); return; }
+    if (a.scan_rule) launch_blend_bwd_scan(a, s);      // (returns at once unless the device rule picks it; the kernels below do the opposite)
     if (a.variant != 1) {
         if (a.stats) hipLaunchKernelGGL(blend_bwd_rows_kernel<true>, grid, block, 0, s, a);
         else hipLaunchKernelGGL(blend_bwd_rows_kernel<false>, grid, block, 0, s, a);

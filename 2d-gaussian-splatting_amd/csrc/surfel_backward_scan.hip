@@ -102,6 +102,7 @@ __global__ void __launch_bounds__(BLOCK, SCAN_MIN_WG) blend_bwd_scan_kernel(Blen
     long long tm_stage = 0, tm_walk = 0, tm_bar1 = 0, tm_flush = 0, tm_bar2 = 0, tm_rec = 0, tm_t = tm_start;
 #endif
     const int tid = threadIdx.x;
+    if (a.scan_rule && a.variant != 3 && !device_picks_scan(a)) return;
     if (frame_overflowed(a.n_dev, a.n_cap)) return;
     const int tile = block_tile(a.tile_map, a.map_flag, blockIdx.x, a.gx * a.gy);
     if (tile < 0) return;

@@ -40,6 +40,7 @@ struct BlendBwdArgs {
     uint8_t* has_rec;      // with cut: [P] zeroed by the caller; set for every surfel that gets at least one record (preprocess_bwd skips the others)
     const float* depths;   // [P] view depths (the sort key's source)
     int variant;      // 0: per-DPP-row walk, 1: per-wave (8x8 quad) walk, 2: both launched, the device picks from the frame's totals (0 / 1 / 2 bit-identical); 3: scan walk
+    int scan_rule;    // 1: the scan kernel AND the rows / quad kernel selected by `variant` are launched; the device decides from `totals` which one runs (surfel_blend_bwd.h: device_picks_scan)
     const uint32_t* totals;      // [2 * R_SLOTS] partial sums written by preprocess: tile instances | visible surfels
     const uint32_t* n_dev; uint32_t n_cap;      // capacity path: the frame's instance total on the device and the record capacity (= num_rendered).  n_dev[0] > n_cap:
                                                 // a lazily counted frame that overflowed — its lists are truncated, the caller redoes it: every backward kernel returns at once

@@ -29,6 +29,20 @@ def tile_row_instances():
     return (r[..., 1] - r[..., 0]).sum(1)
 
 
+IMG_HEAD_U2 = 64 + 1      # uint2 slots behind the tile ranges in the image buffer's zeroed head (csrc/surfel_api.hip: ImgState::carve):
+                          # 2 x 64 partial counters, the capacity path's instance total + the tile-map flag
+
+
+def image_layout(width, height):
+    """White-box byte offsets into the image buffer: (gx, gy, final_T, n_contrib, tile_map) — for tests and statistics only."""
+    gx, gy = (width + 15) // 16, (height + 15) // 16
+    al = lambda v: (v + 255) // 256 * 256
+    final_T = al((gx * gy + IMG_HEAD_U2) * 8)
+    n_contrib = al(final_T + 12 * width * height)
+    tile_map = al(n_contrib + 8 * width * height)
+    return gx, gy, final_T, n_contrib, tile_map
+
+
 def staged_instances(width, height):
     """Σ over tiles of the deepest list position any pixel of the tile composited (max n_contrib) of the most recent forward: the
     instances a blend pass has to read — the rest of a tile's list lies behind its saturation point.  White-box read of the image
@@ -36,8 +50,7 @@ def staged_instances(width, height):
     if _last_image is None:
         return None
     buf, gx, gy = _last_image
-    al = lambda v: (v + 255) // 256 * 256
-    off = al(al((gx * gy + 64 + 1) * 8) + 12 * width * height)
+    off = image_layout(width, height)[3]
     last = buf[off:off + 4 * width * height].view(torch.int32).view(height, width)
     pad = torch.zeros((gy * 16, gx * 16), dtype=torch.int32, device=buf.device)
     pad[:height, :width] = last

@@ -21,7 +21,8 @@ for kind in sys.argv[1:] or ["huge_faint", "long_lists"]:
         run = HipRun(a).forward()
         gx, gy = (a["W"] + 15) // 16, (a["H"] + 15) // 16
         al = lambda v: (v + 255) // 256 * 256
-        off = al((gx * gy + 64 + 1) * 8)
+        import diff_surfel_rasterization as dsr
+        off = dsr.image_layout(a["W"], a["H"])[2]
         HW = a["W"] * a["H"]
         buf = run.ia.last()
         ranges = buf[:gx * gy * 8].view(run.torch.int32).view(-1, 2).cpu().numpy()

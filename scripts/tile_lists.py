@@ -20,10 +20,9 @@ def frame_stats(W, H):
     import torch
     import diff_surfel_rasterization as dsr
     buf, gx, gy = dsr._last_image
-    al = lambda v: (v + 255) // 256 * 256
     ranges = buf[:gx * gy * 8].view(torch.int32).view(gy * gx, 2)
     n = (ranges[:, 1] - ranges[:, 0]).cpu().numpy()
-    off = al(al((gx * gy + 64 + 1) * 8) + 12 * W * H)
+    off = dsr.image_layout(W, H)[3]
     last = buf[off:off + 4 * W * H].view(torch.int32).view(H, W)
     pad = torch.zeros((gy * 16, gx * 16), dtype=torch.int32, device=buf.device)
     pad[:H, :W] = last
