@@ -98,6 +98,36 @@ def roofline_object(per_kernel, workload, P, V, R, Rs, W, H, n_pass):
                                  for k, v in per_kernel.items() if v > 0}}
 
 
+def step_roofline(kernels_ms, ms_per_step, workload, P, V, R, Rs, W, H):
+    """The whole iteration against the chip: sum of the ALGORITHMIC bytes of the rasterizer's stages + the training kernels' bytes
+    (loss: 3 passes over the 10-channel maps + target; Adam: 28 B per parameter float over 58 floats per surfel) / ms_per_step / HBM peak,
+    and the sum of the issued VALU wave-instructions of the committed PMC pass of this workload / step / the fp32 issue peak."""
+    if not kernels_ms or not P:
+        return None
+    tiles = ((W + 15) // 16) * ((H + 15) // 16)
+    n_pass = -(-(32 + max(1, (tiles - 1).bit_length())) // 8)
+    ras = sum(algorithmic_bytes(k, P, V or P, R or 0, W, H, n_pass, Rs) for k in kernels_ms)
+    train = 3 * (10 + 3) * 4 * W * H * 2 + 58 * 28 * P
+    total = ras + train
+    out = {"algorithmic_bytes_per_step": int(total), "of_which_rasterizer": int(ras), "achieved_GBps": round(total / (ms_per_step * 1e-3) / 1e9, 1),
+           "frac_of_hbm_peak": round(total / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "sum_kernels_ms": round(sum(kernels_ms.values()), 4)}
+    try:
+        import glob
+        pm = sorted(glob.glob(os.path.join(REPO, "profiles", "r*_%s_pmc.json" % workload)))[-1]
+        pj = json.load(open(pm))
+        # (per-launch means of the committed pass; every kernel of the iteration runs once per step except the tile sort's two passes;
+        # kernels that are not part of the steady-state step — knn, the one-off activation — are left out)
+        valu = sum(v.get("SQ_INSTS_VALU", 0.0) * (2.0 if "os_pass" in k else 1.0) for k, v in pj.items()
+                   if isinstance(v, dict) and not any(x in k for x in ("knn", "activate_kernel", "mark_visible")))
+        if valu > 0:
+            out["valu_wave_insts_per_step"] = int(valu)
+            out["valu_frac_of_issue_peak"] = round(valu / (ms_per_step * 1e-3) / 1e9 / 1228.9, 4)
+            out["valu_source"] = os.path.basename(pm)
+    except Exception:
+        pass
+    return out
+
+
 def _respawn(n):
     """Re-execute this command line under torch.distributed.run with n ranks on this node; returns its exit code."""
     import socket
@@ -149,6 +179,8 @@ def main():
     ap.add_argument("--no-train-iter", action="store_true", help="(kept for older scripts; the timed step IS the training iteration)")
     ap.add_argument("--no-scale-leg", action="store_true", help="N > 1: skip the second weak-scaling line (C4 per GPU)")
     ap.add_argument("--no-legs", action="store_true", help="skip the extra N = 1 workload legs (C4-synthetic, heavy-footprint C2H, trained state)")
+    ap.add_argument("--no-full-train", action="store_true", help="skip the config-3 full-train leg (30 000 iterations of the reference schedule, ~30 - 60 s)")
+    ap.add_argument("--no-sweep", action="store_true", help="skip the 1080p forward sweep over P = 0.3 ... 10 M surfels")
     ap.add_argument("--quick", action="store_true", help="headline leg only (= --no-legs --no-cpu-baseline --no-1080p --no-raster-only)")
     ap.add_argument("--sharding", choices=("views", "bands"), default="views",
                     help="N > 1: 'views' = one view per GPU per iteration (weak scaling, default); 'bands' = tile-band sharding of ONE view "
@@ -160,7 +192,7 @@ def main():
     # ---- launch contract: `python bench.py --gpus N` run DIRECTLY must time N ranks.  Without a torch.distributed.run
     # environment this process re-executes itself under it (one rank per GPU, rendezvous on 127.0.0.1) and relays the result.
     if args.quick:
-        args.no_legs = args.no_cpu_baseline = args.no_1080p = args.no_raster_only = True
+        args.no_legs = args.no_cpu_baseline = args.no_1080p = args.no_raster_only = args.no_full_train = args.no_sweep = True
     if "WORLD_SIZE" not in os.environ:
         if args.gpus > 1:
             raise SystemExit(_respawn(args.gpus))
@@ -305,7 +337,8 @@ def main():
                                                      "note": "wire bytes = ring-algorithm bytes per GPU per step by collective; exposed = mean time the "
                                                              "compute stream spent waiting on the collectives (events around the stream waits)"},
                "loss_first": round(loss_first, 5), "loss_last": round(loss_last, 5),
-               "train_Msplats_per_s": round((1 if bands else world) * P * args.steps / dt / 1e6, 2), "roofline": roof}
+               "train_Msplats_per_s": round((1 if bands else world) * P * args.steps / dt / 1e6, 2), "roofline": roof,
+               "step_roofline": step_roofline(per_kernel, ms_per_step, args.workload, P, V, R, Rs, W, H)}
 
     if world > 1:
         dist.barrier()
@@ -357,6 +390,13 @@ def main():
         from helpers_bench import fwd_1080p
         out["fwd_1080p"] = fwd_1080p(dev)
 
+    if rank == 0 and world == 1 and not args.no_sweep:      # the metric's forward sweep at 1080p
+        try:
+            from helpers_bench import fwd_1080p_sweep
+            out["fwd_1080p_sweep"] = fwd_1080p_sweep(dev)
+        except Exception as e:      # noqa: BLE001 — an extra must not cost the run its headline
+            out["fwd_1080p_sweep"] = {"error": repr(e)}
+
     # ---- more workloads through the same full iteration (N=1 only): BASELINE configs[3]'s per-GPU shape, a heavy-footprint
     # synthetic, and a TRAINED state (post-densification statistics) — VERDICT r1 weak #5
     if rank == 0 and world == 1 and not args.no_legs:
@@ -368,6 +408,23 @@ def main():
                 out["legs"][leg] = trained_leg(dev, leg, steps=30 if leg == "trained" else 20, warmup=5)
             else:
                 out["legs"][leg] = config_leg(dev, leg, steps=30 if leg == "C2H" else 20, warmup=5)
+
+        # north_star's 1-GPU target shape (Mip-NeRF360 garden: BASELINE configs[3], scripts/m360_eval.py:40-46 / utils/camera_utils.py:25-33 of the
+        # reference) next to the C2 headline, at top level: the garden-sized trained state's full iteration
+        gl = out["legs"].get("garden")
+        if isinstance(gl, dict) and "ms_per_step" in gl:
+            out["headline_garden"] = {"metric": "train iters/sec, full iteration", "value": gl["iters_per_s"], "unit": "train-iters/s", "ms_per_step": gl["ms_per_step"],
+                                      "workload": gl.get("workload"), "P": gl.get("P"), "instances_R": gl.get("instances_R"), "instances_staged": gl.get("instances_staged"),
+                                      "roofline": gl.get("roofline"), "step_roofline": step_roofline(gl.get("kernels_ms"), gl["ms_per_step"], "garden", gl.get("P"), gl.get("visible"),
+                                                                                                   gl.get("instances_R"), gl.get("instances_staged"), 1600, 1060)}
+
+    # ---- BASELINE configs[2] as a full train: the reference's 30 000-iteration schedule incl. densification and opacity resets
+    if rank == 0 and world == 1 and not args.no_full_train:
+        try:
+            from helpers_bench import full_train_leg
+            out["full_train_config3"] = full_train_leg(dev)
+        except Exception as e:      # noqa: BLE001
+            out["full_train_config3"] = {"error": repr(e)}
 
     # ---- CPU baselines, rank 0 / N=1 only: the oracle's fp32 OpenMP port of the rasterizer on the headline workload shape, and
     # BASELINE configs[0]: the dense pure-PyTorch rasterizer at C1

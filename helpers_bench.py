@@ -121,14 +121,22 @@ def time_trainer(tr, steps, warmup, prime=15, workload=None):
     import gc
     ms0 = torch.cuda.memory_stats(tr.model.device)
     gc0 = [g["collections"] for g in gc.get_stats()]
-    host = []
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        h0 = time.perf_counter()
-        tr.step()
-        host.append(time.perf_counter() - h0)
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
+    retimed = False
+    for attempt in range(2):
+        host = []
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            h0 = time.perf_counter()
+            tr.step()
+            host.append(time.perf_counter() - h0)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        # a single host stall (tens of ms: seen on boxes of the pool with unchanged kernel times and no allocation, GC run or overflow
+        # inside the window) must not be reported as the leg's step time: the window is timed ONCE more and the repeat is flagged
+        if attempt == 0 and max(host) > 20.0 * sorted(host)[len(host) // 2] and max(host) > 0.3 * dt:
+            retimed = True
+            continue
+        break
     ms1 = torch.cuda.memory_stats(tr.model.device)
     # hipMalloc / hipFree inside the timed window (the caching allocator missing: views of a capture differ in instance count, so
     # buffer sizes change from step to step) and the host's own time per step (enqueue only; the device runs behind)
@@ -136,7 +144,8 @@ def time_trainer(tr, steps, warmup, prime=15, workload=None):
              "device_frees": int(ms1.get("num_device_free", 0) - ms0.get("num_device_free", 0)),
              "alloc_retries": int(ms1.get("num_alloc_retries", 0) - ms0.get("num_alloc_retries", 0)),
              "host_ms_per_step_median": round(sorted(host)[len(host) // 2] * 1e3, 4), "host_ms_per_step_max": round(max(host) * 1e3, 4),
-             "python_gc_collections_gen012": [g["collections"] - c for g, c in zip(gc.get_stats(), gc0)]}
+             "python_gc_collections_gen012": [g["collections"] - c for g, c in zip(gc.get_stats(), gc0)],
+             "window_retimed_after_host_stall": retimed}
     surfel_native.collect_stage_times()
     tr.pipe.debug = 2
     for _ in range(max(5, steps // 2)):
@@ -394,3 +403,120 @@ def raster_fwd_bwd(dev, workload="C2", iters=40, warmup=10):
     dt = time.perf_counter() - t0
     return {"workload": "%s-synthetic, rasterizer forward+backward only, N(0,1) upstream gradients" % workload,
             "ms_per_view": round(dt / iters * 1e3, 4), "views_per_s": round(iters / dt, 2), "Msplats_per_s": round(P * iters / dt / 1e6, 2)}
+
+
+def fwd_1080p_sweep(dev, sizes=(300_000, 1_000_000, 2_000_000, 5_000_000, 10_000_000), iters=8, warmup=3):
+    """forward-only throughput at 1920x1080 over P in {0.3, 1, 2, 5, 10} M random surfels (the 1 M point is
+    fwd_1080p's workload): Msplats/s and M tile instances/s per size."""
+    import torch
+    import synthetic
+    import diff_surfel_rasterization as dsr
+    from diff_surfel_rasterization import GaussianRasterizationSettings, GaussianRasterizer
+    W, H = 1920, 1080
+    out = []
+    for P in sizes:
+        zf = synthetic.CONFIGS["1080p_1M"][3]
+        sc = synthetic.make_scene(int(P), W, H, seed=0, z_far=zf)
+        t = lambda x: torch.as_tensor(np.ascontiguousarray(x)).to(dev)
+        rs = GaussianRasterizationSettings(image_height=H, image_width=W, tanfovx=sc["tanfovx"], tanfovy=sc["tanfovy"], bg=t(sc["bg"]),
+                                           scale_modifier=1.0, viewmatrix=t(sc["viewmatrix"]), projmatrix=t(sc["projmatrix"]),
+                                           sh_degree=3, campos=t(sc["campos"]), prefiltered=False, debug=False)
+        rast = GaussianRasterizer(raster_settings=rs)
+        means3D, shs, opac, scales, rots = (t(sc[k]) for k in ("means3D", "shs", "opacities", "scales", "rotations"))
+        del sc
+        means2D = torch.zeros_like(means3D)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ms = []
+        with torch.no_grad():
+            for i in range(warmup + iters):
+                e0.record()
+                rast(means3D=means3D, means2D=means2D, shs=shs, colors_precomp=None, opacities=opac, scales=scales, rotations=rots, cov3D_precomp=None)
+                e1.record()
+                torch.cuda.synchronize()
+                if i >= warmup:
+                    ms.append(e0.elapsed_time(e1))
+        med = float(np.median(ms))
+        R = int(dsr.last_num_rendered)
+        out.append({"P": int(P), "ms_median": round(med, 4), "Msplats_per_s": round(P / (med * 1e-3) / 1e6, 1), "instances_R": R,
+                    "Minst_per_s": round(R / (med * 1e-3) / 1e6, 1)})
+        del means3D, shs, opac, scales, rots, means2D, rast
+        torch.cuda.empty_cache()
+    return {"workload": "forward only (preprocess .. blend incl. sort) at 1920x1080, random surfels (synthetic.make_scene), median of %d calls" % iters, "sizes": out}
+
+
+def full_train_leg(dev, iterations=30_000, res=(800, 600), n_views=49, n_gt=60_000, n_init=40_000, max_seconds=240.0):
+    """BASELINE configs[2] as a FULL TRAIN: the reference's 30 000-iteration schedule (arguments/__init__.py:75-95: densification
+    500 -> 15 000 every 100, opacity reset every 3 000, position-lr decay over 30 000) with the DTU settings of scripts/dtu_eval.py:23
+    (depth_ratio 1, lambda_dist 1000; lambda_normal 0.05 from 7 000, distortion from 3 000: train.py:80-81) on an 800x600 synthetic
+    capture of 49 views (the DTU scans' view count) initialised from random points (scene/dataset_readers.py:236-242) — the whole
+    loop of train.py:54-140 including what the steady-state legs leave out: densify / clone / split / prune and the opacity resets
+    (torch indexing on the parameter store, host-driven), timed separately (a device synchronisation on each side of the ~150 events).
+    Reports wall seconds, iterations/s per phase, surfels over time, PSNR (train views / 8 held-out views)."""
+    import torch
+    import surfel_model
+    import surfel_trainer as TR
+    import diff_surfel_rasterization as dsr
+    W, H = res
+    torch.manual_seed(0)
+    bg = torch.zeros(3, device=dev)
+    gt = TR.synthetic_object(n_gt, dev, seed=3, px_scale=0.03)
+    cams = TR.capture_views(gt, TR.orbit_cameras(n_views + 8, W, H, device=dev), bg)
+    del gt
+    train_cams, test_cams = cams[:n_views], cams[n_views:]
+    extent = TR.cameras_extent(train_cams)
+    rng = np.random.default_rng(1)
+    pcd = type("PCD", (), {})()
+    pcd.points = (rng.random((n_init, 3)) * 2.6 - 1.3).astype(np.float32)
+    pcd.colors = rng.random((n_init, 3)).astype(np.float32)
+    model = surfel_model.GaussianModel(3, device=dev)
+    model.create_from_pcd(pcd, spatial_lr_scale=extent)
+    opt = TR.optimization_params(iterations=iterations, lambda_dist=1000.0, lambda_normal=0.05)
+    tr = TR.Trainer(model, train_cams, opt, TR.pipeline_params(depth_ratio=1.0), extent=extent)
+    psnr0 = tr.evaluate(train_cams[:8])[0]
+    # time spent in the schedule's events (densify_and_prune, reset_opacity): wrap them, synchronising on both sides
+    ev = {"densify_prune_s": 0.0, "densify_prune_calls": 0, "opacity_reset_s": 0.0, "opacity_reset_calls": 0}
+
+    def timed(fn, key):
+        def wrapper(*a, **k):
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            r = fn(*a, **k)
+            torch.cuda.synchronize()
+            ev[key + "_s"] += time.perf_counter() - t0; ev[key + "_calls"] += 1
+            return r
+        return wrapper
+    model.densify_and_prune = timed(model.densify_and_prune, "densify_prune")
+    model.reset_opacity = timed(model.reset_opacity, "opacity_reset")
+    phases = [("warm-up (1 - 500)", 500), ("densification (501 - 15 000)", opt.densify_until_iter), ("refinement (15 001 - 30 000)", iterations)]
+    points, phase_out = [[0, int(model.P)]], []
+    torch.cuda.synchronize()
+    t_start = time.perf_counter()
+    it, cut = 0, False
+    for name, until in phases:
+        t0, it0, ev0 = time.perf_counter(), it, dict(ev)
+        while it < min(until, iterations):
+            tr.step(); it += 1
+            if it % 1000 == 0:
+                points.append([it, int(model.P)])
+                if time.perf_counter() - t_start > max_seconds:      # (bounded: a slow box must not cost the bench its other legs)
+                    cut = True
+                    break
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        phase_out.append({"phase": name, "iterations": it - it0, "wall_s": round(dt, 2), "iters_per_s": round((it - it0) / max(dt, 1e-9), 1),
+                          "of_which_densify_prune_s": round(ev["densify_prune_s"] - ev0["densify_prune_s"], 3),
+                          "of_which_opacity_reset_s": round(ev["opacity_reset_s"] - ev0["opacity_reset_s"], 3), "points_at_end": int(model.P)})
+        if cut:
+            break
+    wall = time.perf_counter() - t_start
+    out = {"workload": "config-3 full train: %d iterations of the reference schedule on a synthetic %dx%d capture (%d train views, %d random initial points, "
+                       "ground truth = %d surfels), depth_ratio 1, lambda_dist 1000 from 3 000, lambda_normal 0.05 from 7 000, densify 500 -> 15 000 / 100, "
+                       "opacity reset / 3 000" % (it, W, H, n_views, n_init, n_gt),
+           "iterations_done": it, "completed": not cut, "wall_s": round(wall, 2), "iters_per_s": round(it / wall, 1), "phases": phase_out,
+           "events": {k: (round(v, 3) if isinstance(v, float) else v) for k, v in ev.items()},
+           "points_over_time": points, "points_final": int(model.P), "lazy_overflows": int(tr.lazy_overflows),
+           "psnr_init": round(psnr0, 2), "psnr_train": round(tr.evaluate(train_cams[:8])[0], 2), "psnr_heldout": round(tr.evaluate(test_cams)[0], 2)}
+    del tr, model
+    dsr.set_grad_arena(None)
+    torch.cuda.empty_cache()
+    return out
+
