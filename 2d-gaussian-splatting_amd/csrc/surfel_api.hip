@@ -32,17 +32,25 @@ unsigned long long* g_blend_stats = nullptr;   // surfel_debug_set_blend_stats
 thread_local int64_t g_last_R = -1; thread_local int g_last_W = 0, g_last_H = 0;   // auto heuristic (speed only; results identical; a stale
                                                                                     // value from another device / stream only costs one slower frame)
 // capacity binning: the largest instance count recent frames of a size produced (per host thread; speed only)
-struct CapEntry { int W = 0, H = 0; int64_t maxR = -1; unsigned frames = 0; int uniform_streak = 0; };
-thread_local CapEntry g_caps[4];
+// (16 entries: a COLMAP capture mixes a handful of resolutions; an evicted size falls back to the exact path + a host wait for one
+// frame — counted, surfel_debug_capacity_evictions.  boost: head room doubles (1/8 -> 1/4 -> 1/2) while frames of the size keep
+// overflowing — views of one capture differ 2-3x in instance count — and decays after 256 frames without an overflow.)
+struct CapEntry { int W = 0, H = 0; int64_t maxR = -1; unsigned frames = 0; int uniform_streak = 0; int boost = 0; unsigned last_overflow = 0; };
+constexpr int kCapEntries = 16;
+thread_local CapEntry g_caps[kCapEntries];
 thread_local unsigned g_cap_next = 0;
+thread_local int g_cap_evictions = 0;
 int g_opt_capacity = 1;    // surfel_set_option("capacity_binning", .)
 int g_opt_tile_order = 0;  // surfel_set_option("tile_order", .): 0 decided per frame on the device, 1 XCD-contiguous runs, 2 longest lists first
 thread_local int g_last_binning = 0;      // 0 exact-size path, 1 capacity path, 2 capacity path overflowed and the frame was redone (surfel_debug_last_binning)
 CapEntry* cap_entry(int W, int H, bool create) {
     for (auto& c : g_caps) if (c.W == W && c.H == H) return &c;
     if (!create) return nullptr;
-    CapEntry* c = &g_caps[g_cap_next++ % 4];
-    c->W = W; c->H = H; c->maxR = -1; c->frames = 0; c->uniform_streak = 0;
+    CapEntry* c = &g_caps[g_cap_next++ % kCapEntries];
+    if (c->W != 0) g_cap_evictions++;
+    *c = CapEntry{};
+    c->W = W; c->H = H;
+    c->frames = ~0u;      // (marks "just created": the caller clears the slot's pinned tile-order verdict, run_tile_order)
     return c;
 }
 thread_local float g_stage_ms[16];
@@ -254,7 +262,10 @@ int walk_tuner_pick(int P, int W, int H, int64_t R, hipStream_t s, int nwalks, W
     const unsigned phase = t->calls++ % kTunePeriod;
     if (phase >= kTuneFirst && phase < kTuneFirst + (unsigned)nwalks && !t->pending[phase - kTuneFirst]) {
         const int v = (int)(phase - kTuneFirst);
-        if (!t->e0[v] && (hipEventCreate(&t->e0[v]) != hipSuccess || hipEventCreate(&t->e1[v]) != hipSuccess)) { t->e0[v] = nullptr; return t->choice >= 0 ? t->choice : 2; }
+        if (!t->e0[v]) {
+            if (hipEventCreate(&t->e0[v]) != hipSuccess) { t->e0[v] = nullptr; return t->choice >= 0 ? t->choice : 2; }
+            if (hipEventCreate(&t->e1[v]) != hipSuccess) { (void)hipEventDestroy(t->e0[v]); t->e0[v] = t->e1[v] = nullptr; return t->choice >= 0 ? t->choice : 2; }
+        }
         *out = t; *probe = v;
         return kWalkVariant[v];
     }
@@ -264,7 +275,7 @@ int walk_tuner_pick(int P, int W, int H, int64_t R, hipStream_t s, int nwalks, W
 // One event + one pinned read-back buffer per (host thread, device): a thread that rasterizes on a second GPU gets its own pair
 // instead of recording an event created on another device.
 constexpr int kMaxDevices = 32;
-constexpr int kPinnedTotal = R_SLOTS + 4;      // word of the pinned buffer that receives a capacity-path frame's instance total
+constexpr int kPinnedTotal = R_SLOTS + kCapEntries;      // word of the pinned buffer that receives a capacity-path frame's instance total
 struct PerDevice { hipEvent_t ev = nullptr; uint32_t* pinned = nullptr; };
 PerDevice* per_device(int dev = -1) {      // dev < 0: the calling thread's current device
     thread_local PerDevice tab[kMaxDevices];
@@ -287,8 +298,8 @@ uint32_t* pinned_u32() {
     if (!pd->pinned) {
         // R_SLOTS partial instance totals (D2H copy target) + one tile-order verdict word per capacity-table entry (written by the device)
         // + the instance total of a capacity-path frame (written by bin_emit_kernel: kPinnedTotal)
-        if (hipHostMalloc(reinterpret_cast<void**>(&pd->pinned), sizeof(uint32_t) * (R_SLOTS + 8), hipHostMallocMapped) != hipSuccess) pd->pinned = nullptr;
-        else for (int k = 0; k < R_SLOTS + 8; k++) pd->pinned[k] = 0u;
+        if (hipHostMalloc(reinterpret_cast<void**>(&pd->pinned), sizeof(uint32_t) * (R_SLOTS + kCapEntries + 8), hipHostMallocMapped) != hipSuccess) pd->pinned = nullptr;
+        else for (int k = 0; k < R_SLOTS + kCapEntries + 8; k++) pd->pinned[k] = 0u;
     }
     return pd->pinned;
 }
@@ -394,6 +405,7 @@ int surfel_debug_walk_choice(int width, int height) {
     return choice;
 }
 int surfel_debug_last_binning(void) { return g_last_binning; }
+int surfel_debug_capacity_evictions(void) { return g_cap_evictions; }
 int surfel_debug_set_blend_stats(void* dev_u64x8) { g_blend_stats = static_cast<unsigned long long*>(dev_u64x8); return 0; }
 
 int surfel_collect_stage_ms(float* sum_ms, int* count, int cap) {
@@ -433,6 +445,8 @@ int64_t lazy_finish() {
     g_lazy.overflowed = R > g_lazy.cap;
     g_last_R = R; g_last_W = g_lazy.W; g_last_H = g_lazy.H;
     CapEntry* ce = cap_entry(g_lazy.W, g_lazy.H, true);
+    if (ce->frames == ~0u) ce->frames = 0;
+    if (g_lazy.overflowed) { if (ce->boost < 2) ce->boost++; ce->last_overflow = ce->frames; }
     ce->maxR = R > ce->maxR - ce->maxR / 64 ? R : ce->maxR - ce->maxR / 64;
     return R;
 }
@@ -499,7 +513,12 @@ int64_t surfel_rasterize_forward(surfel_alloc_fn geom_alloc, void* geom_user, su
     GeomState geom{};
     BinState bin{};
     CapEntry* tile_ce = cap_entry(width, height, true);      // per-size history (capacity, tile-order verdicts) of this host thread
+    if (tile_ce->frames == ~0u) {      // a (re-)used slot must not inherit the previous size's tile-order verdict
+        tile_ce->frames = 0;
+        if (uint32_t* hv = pinned_u32()) hv[R_SLOTS + (int)(tile_ce - g_caps)] = 0u;
+    }
     tile_ce->frames++;
+    if (tile_ce->boost > 0 && tile_ce->frames - tile_ce->last_overflow > 256u) { tile_ce->boost--; tile_ce->last_overflow = tile_ce->frames; }
     if (P > 0) {
         // scratch sizes (host-side queries only): [depth-sort scratch | scan state]
         const size_t psort_bytes = align_up(radix_sort_scratch_bytes((size_t)P));
@@ -538,7 +557,7 @@ int64_t surfel_rasterize_forward(surfel_alloc_fn geom_alloc, void* geom_user, su
         CapEntry* ce = cap_entry(width, height, true);
         int64_t cap = 0;
         if (opt_capacity && per_tile == 1 && ce->maxR >= 0 && debug != 1) {
-            cap = ce->maxR + ce->maxR / 8 + 4096;
+            cap = ce->maxR + (ce->maxR >> (3 - ce->boost)) + 4096;
             cap = (cap + 16383) / 16384 * 16384;      // stable sizes for the caller's caching allocator
             if (cap > ((int64_t)1 << 20) || !capacity_binning_ok((size_t)cap, end_bit)) cap = 0;
         }
@@ -610,6 +629,8 @@ int64_t surfel_rasterize_forward(surfel_alloc_fn geom_alloc, void* geom_user, su
             blended = R <= cap;
             if (!blended) {      // overflow: the frame is redone with exact sizes below (same results as if it had taken that path at once)
                 g_last_binning = 2;
+                if (ce->boost < 2) ce->boost++;
+                ce->last_overflow = ce->frames;
                 HIP_TRY(hipMemsetAsync(img.ranges, 0, sizeof(uint2) * (size_t)gx * gy, s));
             }
         }

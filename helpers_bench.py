@@ -145,7 +145,7 @@ def time_trainer(tr, steps, warmup, prime=15, workload=None):
              "alloc_retries": int(ms1.get("num_alloc_retries", 0) - ms0.get("num_alloc_retries", 0)),
              "host_ms_per_step_median": round(sorted(host)[len(host) // 2] * 1e3, 4), "host_ms_per_step_max": round(max(host) * 1e3, 4),
              "python_gc_collections_gen012": [g["collections"] - c for g, c in zip(gc.get_stats(), gc0)],
-             "window_retimed_after_host_stall": retimed}
+             "window_retimed_after_host_stall": retimed, "capacity_table_evictions": int(surfel_native.load().surfel_debug_capacity_evictions())}
     surfel_native.collect_stage_times()
     tr.pipe.debug = 2
     for _ in range(max(5, steps // 2)):

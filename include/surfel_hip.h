@@ -237,6 +237,10 @@ int64_t surfel_forward_count(void);
  * 2 capacity overflowed and the frame was redone with exact sizes, 4 capacity with a lazily collected count (SURFEL_OPT_LAZY_COUNT). */
 int surfel_debug_last_binning(void);
 
+/* Debug: how often this host thread's per-frame-size history (binning capacity, tile-order verdicts; 16 sizes) had to drop a size to
+ * make room for another one.  A dropped size costs its next frame the exact path and a host wait — speed only. */
+int surfel_debug_capacity_evictions(void);
+
 /* Debug: the walk the "bwd_tune" probes currently favour for frames of this size on the current device (the most used entry of
  * that size) — 0 per-row, 1 per-quad, -1 not decided yet (fewer than two timed calls have completed). */
 int surfel_debug_walk_choice(int width, int height);

@@ -25,6 +25,8 @@ pytestmark = pytest.mark.gpu
 IMG_ATOL, IMG_RTOL, IMG_FRAC = 1e-4, 1e-4, 0.999
 LARGE_SORT_DEFAULT = 2          # surfel_set_option("large_sort") default of the library (profiles/r02_large_sort.md)
 G_RTOL, G_FRAC, G_COS = 2e-3, 0.999, 0.9999
+GOLDEN_IMG_FRAC, GOLDEN_G_FRAC, GOLDEN_G_COS = 0.9995, 0.997, 0.99999      # test_golden_fixture: measured 1.00000 / 1.00000 / 1.0000000 on every tensor (512 surfels, 64x48)
+TRAINED_G_FRAC = 0.992     # test_trained_state_parity: measured 0.99565 (means3D) ... 0.99963 (sh) on every walk, the fp32 CPU run of the oracle 0.99510 ... 0.99959
 
 
 def _scene(name_or_dims, seed=0, **kw):
@@ -110,12 +112,17 @@ def test_golden_fixture(golden):
     run = HipRun(a).forward()
     assert 0 < run.R <= int(golden["oracle_R"])
     assert np.array_equal(run.radii.cpu().numpy(), golden["oracle_radii"])
-    assert frac_close(run.color.cpu().numpy(), golden["oracle_color"], IMG_ATOL, IMG_RTOL) >= 0.998
-    assert frac_close(run.others.cpu().numpy()[:5], golden["oracle_others"][:5], IMG_ATOL, IMG_RTOL) >= 0.998
+    fc = frac_close(run.color.cpu().numpy(), golden["oracle_color"], IMG_ATOL, IMG_RTOL)
+    fo = frac_close(run.others.cpu().numpy()[:5], golden["oracle_others"][:5], IMG_ATOL, IMG_RTOL)
+    print("golden: pixel frac colour %.5f, allmap[0:5] %.5f" % (fc, fo))
+    assert fc >= GOLDEN_IMG_FRAC and fo >= GOLDEN_IMG_FRAC
     g = run.backward(golden["grad_color"], golden["grad_others"])
     for k, ref in [("means3D", golden["oracle_dL_dmeans3D"]), ("scales", golden["oracle_dL_dscales"]),
                    ("rots", golden["oracle_dL_drots"]), ("opacity", golden["oracle_dL_dopacity"]), ("sh", golden["oracle_dL_dsh"])]:
-        assert cosine(g[k].reshape(ref.shape), ref) >= 0.999, k
+        x = g[k].reshape(ref.shape)
+        fr, cs = frac_close(x, ref, 1e-4 * np.abs(ref).mean(), G_RTOL), cosine(x, ref)
+        print("golden dL/d%s: frac %.5f cosine %.7f" % (k, fr, cs))
+        assert fr >= GOLDEN_G_FRAC and cs >= GOLDEN_G_COS, "%s: frac %.5f cosine %.7f" % (k, fr, cs)
     # the reference's own in-tree transMat (gaussian_renderer/__init__.py:64-75) fed as cov3D_precomp must
     # render the same colour image as the native scale/rotation path (SURVEY.md §4 self-consistency)
     run2 = HipRun(a, transMat_precomp=golden["ref_cov3D_precomp"]).forward()
@@ -171,7 +178,8 @@ def test_config_sizes(name):
             scale = np.abs(ref).mean()
             f, f32 = frac_close(x, ref, 1e-4 * scale, G_RTOL), frac_close(r32, ref, 1e-4 * scale, G_RTOL)
             cs, cs32 = cosine(x, ref), cosine(r32, ref)
-            assert f >= 0.985 and f >= f32 - 0.002, "%s %s: hip %.5f, cpu-fp32 %.5f" % (walk, k, f, f32)
+            # (bar = the measured minimum — 0.99006, C2 dL/drots; C3 0.99172, C4 0.99602, C1 0.99727 — minus 0.3 %)
+            assert f >= 0.987 and f >= f32 - 0.002, "%s %s: hip %.5f, cpu-fp32 %.5f" % (walk, k, f, f32)
             # the cosine of the ill-conditioned tensors (the means2D statistic above all) is dominated by a handful of edge-on
             # surfels whose fp32 value swings with the last bit of T; like `f`, it is judged against the fp32 CPU run as well
             assert cs >= 0.999 or cs >= cs32 - 1e-3, "%s %s cosine hip %.7f, cpu-fp32 %.7f" % (walk, k, cs, cs32)
@@ -190,6 +198,81 @@ def test_config_sizes(name):
             assert np.array_equal(r2.color.cpu().numpy(), base[1]) and np.array_equal(r2.others.cpu().numpy(), base[2]), mode
             for k in g2:
                 assert np.array_equal(g2[k], base[4][k]), "%s: dL/d%s differs on binning path %d" % (name, k, mode)
+
+
+def test_trained_state_parity():
+    """The regime that dominates every realistic leg: a TRAINED state — wide faint discs, needles, early
+    saturation, hundreds of instances on the centre tiles — at 800x800, not random surfels.  1 500 iterations of the reference
+    schedule (densification from 500) on a synthetic capture, then one training view of that model: all ten channels and every
+    gradient of the rows / quad / scan walks against the fp64 oracle, with the fp32 CPU run of the same algorithm as the yardstick
+    (as test_config_sizes); the measured fractions are printed."""
+    import torch
+    import surfel_native as n
+    import surfel_model
+    import surfel_trainer as TR
+    from oracle.surfel_oracle import Oracle
+    d = torch.device("cuda:0")
+    W = H = 800
+    torch.manual_seed(0)
+    bg = torch.zeros(3, device=d)
+    gt = TR.synthetic_object(120_000, d, seed=0, px_scale=0.035)
+    cams = TR.capture_views(gt, TR.orbit_cameras(24, W, H, device=d), bg)
+    del gt
+    extent = TR.cameras_extent(cams)
+    rng = np.random.default_rng(0)
+    pcd = type("PCD", (), {})()
+    pcd.points = (rng.random((120_000, 3)) * 2.6 - 1.3).astype(np.float32)
+    pcd.colors = rng.random((120_000, 3)).astype(np.float32)
+    model = surfel_model.GaussianModel(3, device=d)
+    model.create_from_pcd(pcd, spatial_lr_scale=extent)
+    tr = TR.Trainer(model, cams, TR.optimization_params(iterations=1500, lambda_dist=100.0, position_lr_max_steps=1500, dist_from_iter=300, normal_from_iter=700),
+                    TR.pipeline_params(depth_ratio=1.0), extent=extent)
+    for _ in range(1499):
+        tr.step()
+    torch.cuda.synchronize()
+    cam = cams[3]
+    f = lambda t: t.detach().float().cpu().numpy()
+    a = dict(bg=np.zeros(3, np.float32), means3D=f(model.get_xyz), opacities=f(model.get_opacity), scales=f(model.get_scaling), rotations=f(model.get_rotation),
+             shs=f(model.get_features), viewmatrix=f(cam.world_view_transform), projmatrix=f(cam.full_proj_transform), campos=f(cam.camera_center),
+             tanfovx=float(np.tan(cam.FoVx * 0.5)), tanfovy=float(np.tan(cam.FoVy * 0.5)), W=W, H=H, sh_degree=int(model.active_sh_degree), scale_modifier=1.0)
+    P = a["means3D"].shape[0]
+    del tr, model
+    import diff_surfel_rasterization as dsr
+    dsr.set_grad_arena(None)
+    run = HipRun(a).forward()
+    dk = run.depths()
+    o64, o32 = Oracle("f64"), Oracle("f32")
+    R, col, oth, radii, st = oracle_forward(o64, a, depth_key=dk)
+    R32, col32, oth32, radii32, st32 = oracle_forward(o32, a, depth_key=dk)
+    gx, gy = (W + 15) // 16, (H + 15) // 16
+    ranges = run.ia.last()[:gx * gy * 8].view(torch.int32).view(-1, 2).cpu().numpy()
+    lens = ranges[:, 1] - ranges[:, 0]
+    print("trained state: %d surfels, R %d (%.1f per surfel), longest tile list %d, empty tiles %d of %d" % (P, run.R, run.R / P, lens.max(), int((lens == 0).sum()), lens.size))
+    assert P > 30_000 and run.R > 4 * P and lens.max() > 300      # the regime: many instances per surfel, long centre lists
+    _check_binning(run, R, radii)
+    _check_depths(run, st, radii)
+    c = run.color.cpu().numpy(); o = run.others.cpu().numpy()
+    assert np.isfinite(c).all() and np.isfinite(o).all()
+    for nm, x, x32, ref in [("color", c, col32, col)] + [("others%d" % i, o[i], oth32[i], oth[i]) for i in range(7)]:
+        fr, f32 = frac_close(x, ref, IMG_ATOL, IMG_RTOL), frac_close(x32, ref, IMG_ATOL, IMG_RTOL)
+        print("trained %s: pixel frac hip %.5f cpu-fp32 %.5f" % (nm, fr, f32))
+        assert fr >= 0.998 and fr >= f32 - 0.002, "%s: hip %.5f, cpu-fp32 %.5f" % (nm, fr, f32)
+    rg = np.random.default_rng(9)
+    gC = rg.normal(size=col.shape).astype(np.float32); gO = rg.normal(size=oth.shape).astype(np.float32)
+    og, og32 = o64.rasterize_backward(st, gC, gO), o32.rasterize_backward(st32, gC, gO)
+    for walk, flag in (("rows", n.OPT_BWD_ROWS), ("quad", n.OPT_BWD_QUAD), ("scan", n.OPT_BWD_SCAN), ("auto", 0)):
+        run.debug = flag
+        g = run.backward(gC, gO)
+        for k, ref, r32 in [("means3D", og.dL_dmeans3D, og32.dL_dmeans3D), ("scales", og.dL_dscales, og32.dL_dscales), ("rots", og.dL_drots, og32.dL_drots),
+                            ("opacity", og.dL_dopacity, og32.dL_dopacity), ("sh", og.dL_dsh, og32.dL_dsh), ("means2D", og.dL_dmean2D, og32.dL_dmean2D)]:
+            x = g[k].reshape(ref.shape)
+            assert np.isfinite(x).all(), k
+            scale = np.abs(ref).mean()
+            fr, f32 = frac_close(x, ref, 1e-4 * scale, G_RTOL), frac_close(r32, ref, 1e-4 * scale, G_RTOL)
+            cs, cs32 = cosine(x, ref), cosine(r32, ref)
+            print("trained %s %s: frac hip %.5f cpu-fp32 %.5f | cosine hip %.7f cpu-fp32 %.7f" % (walk, k, fr, f32, cs, cs32))
+            assert fr >= TRAINED_G_FRAC and fr >= f32 - 0.003, "%s %s: hip %.5f, cpu-fp32 %.5f" % (walk, k, fr, f32)
+            assert cs >= 0.999 or cs >= cs32 - 1e-3, "%s %s cosine hip %.7f, cpu-fp32 %.7f" % (walk, k, cs, cs32)
 
 
 def test_config_c5_stress():
