@@ -72,7 +72,8 @@ constexpr int PIX_ROW = 16 * 3 + 1, STATE_ROW = 16 + 1;
 // counters — stats[0] staging + lists, [1] walk, [2] wait at the barrier behind the walk, [3] flush, [4] wait behind the flush,
 // [5] record write, [6] whole kernel, [7] waves (scripts/bwd_ab.py prints them as scan_raw).
 #ifdef SCAN_TIMING
-#define TM(acc) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); const long long t_ = __builtin_readcyclecounter(); acc += t_ - tm_t; tm_t = t_; }
+// (no vmcnt wait: the next batch's record loads and the gradient-record stores stay in flight across the phases, as in the production kernel)
+#define TM(acc) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); const long long t_ = __builtin_readcyclecounter(); acc += t_ - tm_t; tm_t = t_; }
 #define LANE_STATS false
 #else
 #define TM(acc)
@@ -99,7 +100,7 @@ __global__ void __launch_bounds__(BLOCK, SCAN_MIN_WG) blend_bwd_scan_kernel(Blen
 #endif
 #ifdef SCAN_TIMING
     const long long tm_start = __builtin_readcyclecounter();
-    long long tm_stage = 0, tm_walk = 0, tm_bar1 = 0, tm_flush = 0, tm_bar2 = 0, tm_rec = 0, tm_t = tm_start;
+    long long tm_stage = 0, tm_walk = 0, tm_bar1 = 0, tm_flush = 0, tm_bar2 = 0, tm_rec = 0, tm_bar0 = 0, tm_lists = 0, tm_t = tm_start;
 #endif
     const int tid = threadIdx.x;
     if (a.scan_rule && a.variant != 3 && !device_picks_scan(a)) return;
@@ -172,6 +173,10 @@ __global__ void __launch_bounds__(BLOCK, SCAN_MIN_WG) blend_bwd_scan_kernel(Blen
                 ovr &= live;
             }
         }
+#ifdef SCAN_TIMING
+        asm volatile("" :: "v"(ovr));
+        TM(tm_rec)      // top barrier + the wait for the prefetched records + LDS writes + footprint test
+#endif
         if (pend) {                           // the previous batch's gradient records
             float4* __restrict__ dst = reinterpret_cast<float4*>(a.grec + pend_slot * GREC_F);
             if (fh == 0) { dst[0] = f0; dst[1] = f1; dst[2] = f2; }
@@ -194,7 +199,9 @@ __global__ void __launch_bounds__(BLOCK, SCAN_MIN_WG) blend_bwd_scan_kernel(Blen
                 if (lane == 0) s_bal[s][wave - 2] = b;
             }
         }
+        TM(tm_stage)
         __syncthreads();
+        TM(tm_bar0)
         if (fh == 1) {                        // (the threads that hold the footprints)
             // rank of this instance on every list it is on = instances ahead of it (staged order = back to front) on that list
             uint32_t rk[4] = {~0u, ~0u, ~0u, ~0u};
@@ -222,7 +229,7 @@ __global__ void __launch_bounds__(BLOCK, SCAN_MIN_WG) blend_bwd_scan_kernel(Blen
         const uint32_t fcm = s_cmm[ft];
         const int fcmin = (int)(fcm & 255u), fcmax = (int)(fcm >> 8);
 
-        TM(tm_stage)
+        TM(tm_lists)
         for (int c = 0; c < nrounds; c++) {
             const int idx = c * CH + i16;
             const bool valid = idx < n_row;
@@ -340,7 +347,7 @@ __global__ void __launch_bounds__(BLOCK, SCAN_MIN_WG) blend_bwd_scan_kernel(Blen
         // ---- the batch's gradient records: every staged instance gets one (zeros if no pixel took it)
         pend = ft < mb;
         if (pend) pend_slot = grec_slot(s_rec[ft * 5 + 4], tx, ty);
-        TM(tm_rec)
+        TM(tm_lists)
     }
     if (pend) {
         float4* __restrict__ dst = reinterpret_cast<float4*>(a.grec + pend_slot * GREC_F);
@@ -351,7 +358,7 @@ __global__ void __launch_bounds__(BLOCK, SCAN_MIN_WG) blend_bwd_scan_kernel(Blen
     if (STATS && lane == 0) {
         atomicAdd(&a.stats[0], (unsigned long long)tm_stage); atomicAdd(&a.stats[1], (unsigned long long)tm_walk);
         atomicAdd(&a.stats[2], (unsigned long long)tm_bar1); atomicAdd(&a.stats[3], (unsigned long long)tm_flush);
-        atomicAdd(&a.stats[4], (unsigned long long)tm_bar2); atomicAdd(&a.stats[5], (unsigned long long)tm_rec);
+        atomicAdd(&a.stats[4], (unsigned long long)(tm_bar2 + tm_bar0 + tm_lists)); atomicAdd(&a.stats[5], (unsigned long long)tm_rec);
         atomicAdd(&a.stats[6], (unsigned long long)(__builtin_readcyclecounter() - tm_start)); atomicAdd(&a.stats[7], 1ull);
     }
 #endif

@@ -162,12 +162,11 @@ __global__ void __launch_bounds__(BLOCK) blend_fwd_kernel(BlendFwdArgs a) {
 // resident to fill in: an object-centred frame has ~1 000 non-empty tiles, 4 per CU.  Here the records of batch b+1 travel while
 // batch b is walked:
 //   * batches of 128 instances, TWO record buffers in LDS, filled by LDS-DMA (global_load_lds_dwordx4: global -> LDS without a
-//     VGPR, asynchronous, completion by vmcnt) in structure-of-arrays order ([quarter][instance]: the DMA writes base + 16 * lane);
-//     the ids of the batch after that wait in one VGPR;
-//   * wave (g, h) = (wave & 1, wave >> 1) issues the DMA for instances [64 g, 64 g + 64) of the next batch — quarters 0-2 (h = 0) or
-//     3-4 (h = 1), plus quarter 2 and PRIVATE copies of quarters 5-6 (the footprint conic) for the mask bits it computes itself: when
-//     it has finished its walk it waits for ITS OWN loads (no barrier), tests the footprints of its 64 instances against the
-//     sub-tiles of pixel rows 8 h .. 8 h + 7 and leaves the ballots in the other mask buffer;
+//     VGPR, asynchronous, completion by vmcnt); the ids of the batch after that arrive the same way;
+//   * wave w issues the DMA for instances [32 w, 32 w + 32) of the next batch, seven neighbouring lanes per 112-B record (whole
+//     records, contiguous in LDS as in memory: a tenth of the cache lines per instruction of a quarter-per-instruction gather);
+//     when it has finished its walk it waits for ITS OWN loads (no barrier), tests the footprints of those 32 instances against
+//     the 16 sub-tiles (lane = instance x half of the tile) and leaves the ballots in the other mask buffer;
 //   * ONE barrier per batch (the walk of batch b is over everywhere <=> buffer b is free, masks and records of b+1 are complete).
 // The walk itself, and therefore every output bit, is the kernel above's (tests/test_gpu_parity.py::test_forward_kernels_are_identical).
 // ---------------------------------------------------------------------------------------------
@@ -204,14 +203,14 @@ __device__ __forceinline__ unsigned subtile_overlap_half(const Foot& f, int tile
     return ov;
 }
 
+static_assert(REC_Q == 7, "the DMA's piece -> record arithmetic assumes 112-B records");
 template <bool STATS>
 __global__ void __launch_bounds__(BLOCK) blend_fwd_pipe_kernel(BlendFwdArgs a) {
-    __shared__ float4 s_rec[2][5][NB];                 // 20 KB: q0-q4 of two batches, [buffer][quarter][instance]
-    __shared__ float4 s_foot[4][2][64];                // 8 KB: per wave, q5 / q6 of the 64 instances whose masks it computes
+    __shared__ float4 s_rec[2][NB][REC_Q];             // 28 KB: the whole 112-B records of two batches, [buffer][instance][quarter]
     __shared__ __attribute__((aligned(16))) uint32_t s_mask[2][16 * PMSTRIDE];     // [buffer][sub-tile][word]
     __shared__ int s_alldone[2][4];
     __shared__ uint32_t s_list[4][4][NB / 4 + 1];      // 2.1 KB: per wave and DPP row, the staged indices (bytes) of the row's visits of this batch
-    __shared__ uint32_t s_ids[4][64];                  // 1 KB: per wave, the surfel ids of its 64 instances of the batch after next (DMA as well:
+    __shared__ uint32_t s_ids[4][32];                  // per wave, the surfel ids of its 32 instances of the batch after next (DMA as well:
                                                        // a load hipcc tracks would make it wait for vmcnt(0) — i.e. for the record DMA — at its next use)
 #ifdef BLEND_TRACE
     const unsigned long long trace_t0 = wall_clock64();
@@ -223,7 +222,6 @@ __global__ void __launch_bounds__(BLOCK) blend_fwd_pipe_kernel(BlendFwdArgs a) {
     int lx, ly, sub;
     thread_pixel(threadIdx.x, lx, ly, sub);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-    const int g = wave & 1, h = wave >> 1;
     const int pxi = tx * TILE + lx, pyi = ty * TILE + ly;
     const bool inside = pxi < a.W && pyi < a.H;
     const float pxf = (float)pxi, pyf = (float)pyi;
@@ -237,44 +235,50 @@ __global__ void __launch_bounds__(BLOCK) blend_fwd_pipe_kernel(BlendFwdArgs a) {
     unsigned npairs = 0;
     constexpr float MC1 = FAR_N / (FAR_N - NEAR_N);
     for (int k = lane; k < 4 * (NB / 4 + 1); k += 64) (&s_list[wave][0][0])[k] = 0u;      // (bytes past a list's end are read as indices: any valid one will do)
-    const unsigned rec_base = lds_offset(&s_rec[0][0][0]) + 1024u * (unsigned)g;      // + buffer * 10240 + quarter * 2048
-    const unsigned foot_base = lds_offset(&s_foot[wave][0][0]);
     const char* const recb = reinterpret_cast<const char*>(a.rec);
-    // this wave's share of a batch's DMA: the records of instances [64 g, 64 g + 64) of the batch that starts at list position `base`
-    auto issue = [&](int base, int buf, uint32_t id) {
-        if (base + 64 * g + lane < n) {
-            const char* src = recb + (size_t)id * (REC_F * 4);
-            const unsigned dst = rec_base + 10240u * (unsigned)buf;
-            if (h == 0) { dma16(src, dst); dma16(src + 16, dst + 2048u); dma16(src + 32, dst + 4096u); }
-            else { dma16(src + 48, dst + 6144u); dma16(src + 64, dst + 8192u); dma16(src + 32, dst + 4096u); }
-            dma16(src + 80, foot_base); dma16(src + 96, foot_base + 1024u);
+    // This wave's share of a batch's DMA: the records of instances [32 wave, 32 wave + 32) of the batch that starts at list position
+    // `base` — nine records (63 sixteen-byte pieces) per wave-wide DMA instruction, four instructions:
+    // seven neighbouring lanes fetch one record's 112 contiguous bytes (one or two cache lines per record and instruction, ~10 - 18
+    // lines per instruction) and the pieces land in LDS in the same order (the DMA writes base + 16 * lane), i.e. as whole records.
+    // (One record quarter per instruction — lane = record — touched 64 lines per instruction and each line up to seven times.)
+    const unsigned rec_base = lds_offset(&s_rec[0][32 * wave][0]);
+    const int dma_r = (lane * 9363) >> 16, dma_off = 16 * (lane - REC_Q * dma_r);      // lane / 7 (exact below 224), byte offset of the lane's piece
+    auto issue = [&](int base, int buf) {
+        const unsigned dst = __builtin_amdgcn_readfirstlane(rec_base + (unsigned)(NB * REC_Q * 16) * (unsigned)buf);
+#pragma unroll
+        for (int i = 0; i < 4; i++) {      // instruction i: records 9 i .. 9 i + 8 of the wave's 32, lanes 0 .. 62
+            const int r = 9 * i + dma_r;
+            if (lane < 63 && r < 32 && base + 32 * wave + r < n) {
+                const uint32_t id = s_ids[wave][r];
+                dma16(recb + (size_t)id * (REC_F * 4) + dma_off, dst + (unsigned)(9 * REC_Q * 16) * (unsigned)i);
+            }
         }
     };
-    // ... and, once they have landed, of its masks: sub-tiles of strips 2 h, 2 h + 1 x its 64 instances -> words 2 g, 2 g + 1
+    // ... and, once they have landed, of its masks: lane = (instance, half of the tile): the sub-tiles of pixel rows 8 half .. 8 half + 7
+    // x its 32 instances -> word `wave` of those sub-tiles' masks
     auto masks = [&](int base, int buf) {
         unsigned ov = 0;
-        if (base + 64 * g + lane < n) {
-            const float4 v2 = s_rec[buf][2][64 * g + lane], v5 = s_foot[wave][0][lane], v6 = s_foot[wave][1][lane];
-            ov = subtile_overlap_half(make_foot(v2, v5, v6), tx * TILE, ty * TILE, h);
-        }
+        const int j = 32 * wave + (lane & 31), half = lane >> 5;
+        if (base + j < n) ov = subtile_overlap_half(make_foot(s_rec[buf][j][2], s_rec[buf][j][5], s_rec[buf][j][6]), tx * TILE, ty * TILE, half);
 #pragma unroll
         for (int k = 0; k < 8; k++) {
             const unsigned long long b = __ballot((ov >> k) & 1u);
-            if (lane == 0) *reinterpret_cast<unsigned long long*>(&s_mask[buf][(8 * h + k) * PMSTRIDE + 2 * g]) = b;
+            if (lane == 0) { s_mask[buf][k * PMSTRIDE + wave] = (uint32_t)b; s_mask[buf][(8 + k) * PMSTRIDE + wave] = (uint32_t)(b >> 32); }
         }
     };
-    const unsigned ids_base = lds_offset(&s_ids[wave][0]);
-    auto issue_ids = [&](int base) {      // ids of this wave's instances of the batch at `base` -> s_ids[wave] (read back, into a register, before the next ones are requested)
-        const int k = base + 64 * g + lane;
-        if (k < n) dma4(a.point_list + range.x + k, ids_base);
+    const unsigned ids_base = __builtin_amdgcn_readfirstlane(lds_offset(&s_ids[wave][0]));
+    auto issue_ids = [&](int base) {      // ids of this wave's instances of the batch at `base` -> s_ids[wave] (consumed by issue() before the next ones are requested)
+        const int k = base + 32 * wave + lane;
+        if (lane < 32 && k < n) dma4(a.point_list + range.x + k, ids_base);
     };
 
     if (n > 0) {
         {
-            const int k = 64 * g + lane;
-            const uint32_t id0 = k < n ? a.point_list[range.x + k] : 0u;      // (the one load hipcc tracks: waited for before any DMA is issued)
-            issue(0, 0, id0);
+            const int k = 32 * wave + lane;      // (the one load hipcc tracks: waited for before any DMA is issued)
+            if (lane < 32) s_ids[wave][lane] = k < n ? a.point_list[range.x + k] : 0u;
         }
+        issue(0, 0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // (the ids are in registers before the DMA below may overwrite them)
         issue_ids(NB);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         masks(0, 0);
@@ -284,9 +288,8 @@ __global__ void __launch_bounds__(BLOCK) blend_fwd_pipe_kernel(BlendFwdArgs a) {
         for (int base = 0, buf = 0; base < n; base += NB, buf ^= 1) {
             const bool more = base + NB < n;
             if (more) {      // next batch's records (their ids landed with this batch's records), and the ids of the batch behind it
-                const uint32_t idn = s_ids[wave][lane];
-                asm volatile("s_waitcnt lgkmcnt(0)" : : "v"(idn) : "memory");      // the ids are in registers before the DMA below may overwrite them
-                issue(base + NB, buf ^ 1, idn);
+                issue(base + NB, buf ^ 1);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 issue_ids(base + 2 * NB);
             }
             // ---- the walk.  On frames with few resident waves the bound is the wave's own issue rate plus the LDS round trips it
@@ -296,7 +299,7 @@ __global__ void __launch_bounds__(BLOCK) blend_fwd_pipe_kernel(BlendFwdArgs a) {
             // refill / two votes, and the loop is a counted loop (trip count = the longest of the wave's four lists); (2) the record of
             // visit v + 1 is read from LDS while visit v is being computed.  Visit order per row = list order = mask-bit order: the
             // results are the mask walk's, bit for bit.
-            const float4* R = &s_rec[buf][0][0];
+            const float4* R = &s_rec[buf][0][0];      // R[REC_Q * j + quarter]
             uint32_t* const lrow = &s_list[wave][lane >> 4][0];
             int len;
             {
@@ -324,8 +327,8 @@ __global__ void __launch_bounds__(BLOCK) blend_fwd_pipe_kernel(BlendFwdArgs a) {
             if (niter > 0) {
                 uint32_t jw = lrow[0];
                 int j = (int)(jw & 0xffu);
-                float4 q0 = R[j], q1 = R[NB + j], q2 = R[2 * NB + j], q3 = R[3 * NB + j];
-                float2 q4 = *reinterpret_cast<const float2*>(&R[4 * NB + j]);
+                float4 q0 = R[REC_Q * j], q1 = R[REC_Q * j + 1], q2 = R[REC_Q * j + 2], q3 = R[REC_Q * j + 3];
+                float2 q4 = *reinterpret_cast<const float2*>(&R[REC_Q * j + 4]);
                 for (int i = 0; i < niter; i += 4) {
                     const uint32_t jw_next = lrow[(i >> 2) + 1];      // (one word past the longest list: allocated, never used)
 #pragma unroll
@@ -337,8 +340,8 @@ __global__ void __launch_bounds__(BLOCK) blend_fwd_pipe_kernel(BlendFwdArgs a) {
                         const bool act = i + k < len;
                         // the next visit's record: on its way while this one is computed
                         const int jn = (int)(k < 3 ? (jw >> (8 * (k + 1))) & 0xffu : jw_next & 0xffu);
-                        const float4 n0 = R[jn], n1 = R[NB + jn], n2 = R[2 * NB + jn], n3 = R[3 * NB + jn];
-                        const float2 n4 = *reinterpret_cast<const float2*>(&R[4 * NB + jn]);
+                        const float4 n0 = R[REC_Q * jn], n1 = R[REC_Q * jn + 1], n2 = R[REC_Q * jn + 2], n3 = R[REC_Q * jn + 3];
+                        const float2 n4 = *reinterpret_cast<const float2*>(&R[REC_Q * jn + 4]);
                         Hit hh;
                         const bool hit = pair_hit(pxf, pyf, q0, q1, q2, hh);
                         const float depth = hh.depth, alpha = hh.alpha;

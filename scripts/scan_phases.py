@@ -19,7 +19,7 @@ for wl in sys.argv[1:] or ["trained"]:
     torch.cuda.synchronize()
     lib.surfel_debug_set_blend_stats(None)
     s = st.cpu().numpy().astype(float)
-    names = ["staging+lists", "walk", "barrier behind walk", "flush", "barrier behind flush", "record write"]
+    names = ["stores of the previous records + next loads issued + ballots", "walk", "barrier behind walk", "flush", "other barriers + ranks/lists", "top barrier + wait for the prefetched records + LDS writes + footprint test"]
     tot = s[6]
     print(json.dumps({"workload": wl, "waves": int(s[7]), "cycles_per_wave": round(tot / max(1, s[7])), **{n: round(s[i] / tot, 3) for i, n in enumerate(names)}}), flush=True)
     del tr
