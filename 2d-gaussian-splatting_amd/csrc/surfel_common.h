@@ -95,7 +95,11 @@ __device__ __forceinline__ bool pair_hit(float pxf, float pyf, const float4 q0, 
 // lists are truncated and its records' first-instance slots run past the gradient-record allocation.  The caller redoes the frame
 // once it has collected the count; until then every backward kernel it may already have enqueued must touch nothing.
 __device__ __forceinline__ bool frame_overflowed(const uint32_t* __restrict__ n_dev, uint32_t n_cap) {
+#ifdef SURFEL_NO_OVERFLOW_GUARD      // diagnostic build: shows that tests/test_gpu_guard.py faults without the check (python build.py --variant noguard -DSURFEL_NO_OVERFLOW_GUARD)
+    return false;
+#else
     return n_dev != nullptr && n_dev[0] > n_cap;
+#endif
 }
 
 // -DBLEND_TRACE (diagnostic build, scripts/wg_trace.py): the instrumented blend kernels leave, per workgroup, [start, end] in 100 MHz

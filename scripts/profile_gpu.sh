@@ -23,17 +23,17 @@ cd /tmp && export TMPDIR=/tmp
 export SURFEL_OPTIONS="bwd_variant=$WALK,bwd_tune=0"
 echo "$WALK" > $OUT/walk.txt
 STATE=""
-case $WL in trained|garden) STATE="--state /tmp/state_$WL.ply"; python $ROOT/bench.py --workload $WL $STATE --quick --steps 2 --warmup 1 > $OUT/bench_make_state.log 2>&1;; esac
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -o kt -- python $ROOT/bench.py --workload $WL $STATE --quick > $OUT/bench_kt.log 2>&1
+case $WL in trained|garden) STATE="--state /tmp/state_$WL.ply"; timeout 200 python $ROOT/bench.py --workload $WL $STATE --quick --steps 2 --warmup 1 > $OUT/bench_make_state.log 2>&1;; esac
+timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -o kt -- python $ROOT/bench.py --workload $WL $STATE --quick > $OUT/bench_kt.log 2>&1
 SHORT="--workload $WL $STATE --steps 8 --warmup 2 --quick"
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -o p -- python $ROOT/bench.py $SHORT > $OUT/bench_fetch.log 2>&1
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/write -o p -- python $ROOT/bench.py $SHORT > $OUT/bench_write.log 2>&1
-rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_INST_ANY SQ_LDS_BANK_CONFLICT \
+timeout 200 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -o p -- python $ROOT/bench.py $SHORT > $OUT/bench_fetch.log 2>&1
+timeout 200 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/write -o p -- python $ROOT/bench.py $SHORT > $OUT/bench_write.log 2>&1
+timeout 200 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_INST_ANY SQ_LDS_BANK_CONFLICT \
     --output-format csv -d $OUT/sq -o p -- python $ROOT/bench.py $SHORT > $OUT/bench_sq.log 2>&1
 if [ "$MODE" = "full" ]; then
 # lanes enabled per VALU instruction (the hardware's VALUUtilization; EXEC-enabled lanes, not lanes doing useful work: see
 # profiles/r02_blend_bwd_variants.md) + wait breakdown
-rocprofv3 --pmc SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_LDS_IDX_ACTIVE \
+timeout 200 rocprofv3 --pmc SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_LDS_IDX_ACTIVE \
     --output-format csv -d $OUT/sq2 -o p -- python $ROOT/bench.py $SHORT > $OUT/bench_sq2.log 2>&1
 fi
 cd $ROOT

@@ -23,7 +23,7 @@ import sys
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 STAGE_OF = {"preprocess_fwd_kernel": "preprocess_fwd", "emit_instances_kernel": "emit_instances", "bin_emit_kernel": "emit_instances",
             "tile_ranges_kernel": "tile_ranges", "tile_ranges_devn_kernel": "tile_ranges",
-            "blend_fwd_kernel": "blend_fwd", "blend_bwd_kernel": "blend_bwd", "blend_bwd_rows_kernel": "blend_bwd", "blend_bwd_quad_kernel": "blend_bwd",
+            "blend_fwd_kernel": "blend_fwd", "blend_fwd_pipe_kernel": "blend_fwd", "blend_bwd_kernel": "blend_bwd", "blend_bwd_rows_kernel": "blend_bwd", "blend_bwd_quad_kernel": "blend_bwd",
             "blend_bwd_scan_kernel": "blend_bwd", "preprocess_bwd_kernel": "preprocess_bwd"}
 WALK_NAME = {"0": "rows", "1": "quad", "3": "scan"}
 

@@ -1,0 +1,147 @@
+#!/usr/bin/env python
+"""Overrun hunt: every device buffer the library sees ends exactly at the end of its mapped pages, with unmapped address space behind
+it (HIP virtual-memory API) — a read or write past ANY buffer faults on every box, not only on those whose allocator maps small pages.
+
+    python tests/guard_run.py <fwd_pipe 0|1> <bwd variant 0|1|3> [P W H px_radius]     (one configuration per process)
+    python tests/guard_run.py overflow <bwd variant>     a lazily counted frame that overflows its capacity, backward before the count
+
+Driven by tests/test_gpu_guard.py (a fault kills the process: every configuration runs in its own).
+"""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (REPO, os.path.join(REPO, "2d-gaussian-splatting_amd"), os.path.join(REPO, "tests")):
+    sys.path.insert(0, p)
+import torch  # noqa: E402  (loads libamdhip64 first)
+import surfel_native as n  # noqa: E402
+import synthetic  # noqa: E402
+
+hip = C.CDLL("libamdhip64.so")
+
+
+class Prop(C.Structure):      # hipMemAllocationProp
+    _fields_ = [("type", C.c_int), ("requestedHandleType", C.c_int), ("loc_type", C.c_int), ("loc_id", C.c_int), ("win32", C.c_void_p),
+                ("compressionType", C.c_ubyte), ("gpuDirectRDMACapable", C.c_ubyte), ("usage", C.c_ushort)]
+
+
+class Access(C.Structure):    # hipMemAccessDesc
+    _fields_ = [("loc_type", C.c_int), ("loc_id", C.c_int), ("flags", C.c_int)]
+
+
+def chk(e, what):
+    if e != 0:
+        raise RuntimeError("%s failed: %d" % (what, e))
+
+
+prop = Prop(1, 0, 1, 0, None, 0, 0, 0)      # pinned allocation on device 0
+gran = C.c_size_t(0)
+chk(hip.hipMemGetAllocationGranularity(C.byref(gran), C.byref(prop), 0), "granularity")
+G = gran.value
+keep = []
+
+
+def guard_alloc(nbytes):
+    """device pointer p with [p, p + nbytes) mapped and p + nbytes (rounded up to 16) = end of the mapping; the next G bytes are reserved, unmapped"""
+    nb = max(int(nbytes), 16)
+    size = (nb + G - 1) // G * G
+    va = C.c_void_p(0)
+    chk(hip.hipMemAddressReserve(C.byref(va), C.c_size_t(size + G), C.c_size_t(0), None, C.c_ulonglong(0)), "reserve")
+    h = C.c_void_p(0)
+    chk(hip.hipMemCreate(C.byref(h), C.c_size_t(size), C.byref(prop), C.c_ulonglong(0)), "create")
+    chk(hip.hipMemMap(va, C.c_size_t(size), C.c_size_t(0), h, C.c_ulonglong(0)), "map")
+    acc = Access(1, 0, 3)
+    chk(hip.hipMemSetAccess(va, C.c_size_t(size), C.byref(acc), C.c_size_t(1)), "access")
+    keep.append((va, h, size))
+    return va.value + size - (nb + 15) // 16 * 16
+
+
+def upload(arr):
+    a = np.ascontiguousarray(arr)
+    p = guard_alloc(a.nbytes)
+    chk(hip.hipMemcpy(C.c_void_p(p), a.ctypes.data_as(C.c_void_p), C.c_size_t(a.nbytes), 1), "H2D")
+    return p
+
+
+class Frame:
+    """One scene's inputs in guarded memory + one forward / backward through the C ABI with guarded allocator callbacks."""
+
+    def __init__(self, lib, P, W, H, rad, seed=3):
+        self.lib, self.P, self.W, self.H = lib, P, W, H
+        sc = self.sc = synthetic.make_scene(P, W, H, seed=seed, px_radius=rad)
+        self.d = {k: upload(np.ascontiguousarray(sc[k], np.float32)) for k in ("bg", "means3D", "opacities", "scales", "rotations", "shs", "viewmatrix", "projmatrix", "campos")}
+        self.M = sc["shs"].shape[1]
+        self.out_color, self.out_others, self.radii = guard_alloc(12 * W * H), guard_alloc(28 * W * H), guard_alloc(4 * P)
+        self.bufs = {}
+
+        def make_cb(name):
+            def cb(user, size):
+                self.bufs[name] = (guard_alloc(size), size)
+                return self.bufs[name][0]
+            return n.ALLOC_FN(cb)
+        self.cbs = {k: make_cb(k) for k in ("geom", "bin", "img", "scratch")}
+        self.gC = upload(np.random.default_rng(1).normal(size=(3, H, W)).astype(np.float32))
+        self.gO = upload(np.random.default_rng(2).normal(size=(7, H, W)).astype(np.float32))
+
+    def forward(self, debug):
+        vp, d, sc = C.c_void_p, self.d, self.sc
+        R = self.lib.surfel_rasterize_forward(self.cbs["geom"], None, self.cbs["bin"], None, self.cbs["img"], None, self.P, 3, self.M, vp(d["bg"]), self.W, self.H,
+                                              vp(d["means3D"]), vp(d["shs"]), None, vp(d["opacities"]), vp(d["scales"]), 1.0, vp(d["rotations"]), None,
+                                              vp(d["viewmatrix"]), vp(d["projmatrix"]), vp(d["campos"]), float(sc["tanfovx"]), float(sc["tanfovy"]), 0,
+                                              vp(self.out_color), vp(self.out_others), vp(self.radii), debug, None)
+        assert R >= 0, n.last_error()
+        return R
+
+    def backward(self, R, debug):
+        vp, d, sc, P, M = C.c_void_p, self.d, self.sc, self.P, self.M
+        g = {k: guard_alloc(4 * P * m) for k, m in (("means2D", 3), ("normal", 3), ("opacity", 1), ("colors", 3), ("means3D", 3), ("transMat", 9), ("sh", 3 * M), ("scales", 2), ("rots", 4))}
+        rc = self.lib.surfel_rasterize_backward(self.cbs["scratch"], None, P, 3, M, R, vp(d["bg"]), self.W, self.H, vp(d["means3D"]), vp(d["shs"]), None, vp(d["scales"]), 1.0,
+                                                vp(d["rotations"]), None, vp(d["viewmatrix"]), vp(d["projmatrix"]), vp(d["campos"]), float(sc["tanfovx"]), float(sc["tanfovy"]),
+                                                vp(self.radii), vp(self.bufs["geom"][0]), vp(self.bufs["bin"][0]), vp(self.bufs["img"][0]), vp(self.gC), vp(self.gO),
+                                                vp(g["means2D"]), vp(g["normal"]), vp(g["opacity"]), vp(g["colors"]), vp(g["means3D"]), vp(g["transMat"]), vp(g["sh"]),
+                                                vp(g["scales"]), vp(g["rots"]), debug, None)
+        assert rc >= 0, n.last_error()
+
+
+def main():
+    torch.cuda.init(); torch.zeros(1, device="cuda:0")
+    lib = n.load()
+    flags = {0: n.OPT_BWD_ROWS, 1: n.OPT_BWD_QUAD, 3: n.OPT_BWD_SCAN}
+    if sys.argv[1] == "overflow":
+        # VERDICT r3 weak #2 / ADVICE r3 high: the capacity of this frame size is learnt on a small scene; a 4x larger one then renders lazily
+        # counted (num_rendered = the capacity), and its backward runs BEFORE the count is collected — the gradient records are sized from
+        # the capacity and end at the end of their mapping, the records' first-instance slots run far past it: nothing may be touched
+        variant = int(sys.argv[2])
+        W, H = 304, 208
+        small, big = Frame(lib, 12000, W, H, 4.0, seed=3), Frame(lib, 48000, W, H, 4.0, seed=5)
+        for _ in range(2):
+            Rs = small.forward(n.opt_tile_sort(2))
+            chk(hip.hipDeviceSynchronize(), "sync")
+        cap = big.forward(n.opt_tile_sort(2) | n.OPT_LAZY_COUNT)
+        assert lib.surfel_debug_last_binning() == 4 and cap % 16384 == 0 and cap < 3 * Rs, (lib.surfel_debug_last_binning(), cap, Rs)
+        big.backward(cap, flags[variant])
+        chk(hip.hipDeviceSynchronize(), "sync after the backward of the overflowed frame")
+        r = lib.surfel_forward_count()
+        assert r == n.E_OVERFLOW, r
+        R = big.forward(n.opt_tile_sort(2) | n.OPT_EXACT_BINNING)      # the redo
+        big.backward(R, flags[variant])
+        chk(hip.hipDeviceSynchronize(), "sync after the redo")
+        print("overflow ok: capacity %d, exact count %d, granularity %d" % (cap, R, G), flush=True)
+        return
+    pipe, variant = int(sys.argv[1]), int(sys.argv[2])
+    P, W, H, rad = (int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5]), float(sys.argv[6])) if len(sys.argv) > 6 else (30000, 400, 304, 4.0)
+    lib.surfel_set_option(b"fwd_pipe", pipe)
+    fr = Frame(lib, P, W, H, rad)
+    for rep in range(3):      # exact path, then the capacity path (history), then once more
+        R = fr.forward(n.opt_tile_sort(2))
+        chk(hip.hipDeviceSynchronize(), "sync after forward")
+        fr.backward(R, flags[variant])
+        chk(hip.hipDeviceSynchronize(), "sync after backward")
+        print("rep %d ok: R=%d binning=%d granularity=%d" % (rep, R, lib.surfel_debug_last_binning(), G), flush=True)
+
+
+if __name__ == "__main__":
+    main()
