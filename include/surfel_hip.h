@@ -162,8 +162,10 @@ int surfel_debug_sort_pairs(surfel_alloc_fn scratch_alloc, void* scratch_user, u
  *          instance list, row totals gathered through private LDS slots; 1: every wave (8x8 pixels) walks one list (round 1's
  *          kernel).  Same per-pair arithmetic and the same summation tree: gradients are bit-identical
  *          (tests/test_gpu_parity.py::test_backward_variants_are_identical), so the choice between these two only ever changes
- *          speed.  Frames with 2^21 <= R < 2^26 tile instances take walk 3 under auto ("scan_large", default 1: 7 % faster than
- *          both on 8 M-instance frames; a rule on R, so the bits of a frame follow from the frame alone).
+ *          speed.  Under auto ("scan_large", default 1) the scan walk (3) is launched beside the rows / quad kernel and the DEVICE
+ *          decides from the frame's totals which one runs: frames with >= 6 tile instances per emitting surfel (trained / wide-footprint
+ *          frames: -13 % / -5 %) or with 2^21 <= R < 2^26 tile instances (-7 % at 8 M instances) take walk 3, the other kernel returns at
+ *          once — a rule on the frame, so the bits of a frame follow from the frame alone.
  *          3: the scan walk (surfel_backward_scan.hip: lanes are instances, DPP row scans carry the per-pixel recurrences, gradients
  *          accumulate in registers) — deterministic, but a different summation order: agrees with rows / quad to fp32 summation noise,
  *          not bit for bit; 7 % faster than both on frames of several million instances, at parity around 2 M, 11 % slower on
@@ -177,10 +179,13 @@ int surfel_debug_sort_pairs(surfel_alloc_fn scratch_alloc, void* scratch_user, u
  *   "tile_order" (default 0): which tile every blend workgroup takes.  1: workgroup b -> XCD b % 8 walks a contiguous run of tiles
  *          (neighbouring tiles share surfel records in that XCD's L2) — right for frames whose tiles hold similar lists; 2: groups of
  *          4 adjacent tiles, longest lists first, dealt round-robin over the XCDs — right for object-centred / trained frames, where a
- *          few hundred tiles hold lists of thousands of instances (the trained leg's blend kernels ran at 0.25 of the VALU issue peak
+ *          few hundred tiles hold the long lists (the trained leg's blend kernels ran at 0.25 of the VALU issue peak
  *          with order 1: the XCDs owning the image's middle rows did the work, the heaviest tiles finished alone); 0: decided per
  *          frame on the device from the lists (busiest XCD > 1.15x its share, or a list > 4 average lists -> 2).  Scheduling only:
  *          results are bit-identical (tests/test_gpu_parity.py::test_tile_order_is_scheduling_only).
+ *   "fwd_pipe" (default 1): blend forward kernel — 1: software-pipelined staging (LDS-DMA of the next batch's whole records under the
+ *          walk, per-row byte lists, LDS prefetch of the next visit; DESIGN.md section 4 "Round 4"), 0: round 3's batch-synchronous kernel.
+ *          Same walk, same per-pair arithmetic: bit-identical outputs (tests/test_gpu_parity.py::test_forward_kernels_are_identical).
  *   "fat_sort" (default 1): look-back sort passes over <= 2^20 items use 8192-item tiles staged through LDS (0: 2048-item tiles);
  *          "host_total" (default 1): capacity-path frames store their instance total into mapped pinned memory from the emission
  *          kernel (0: a device-to-host copy in the stream).  Speed only (tests/test_gpu_parity.py::test_radix_sort_is_stable_and_exact
