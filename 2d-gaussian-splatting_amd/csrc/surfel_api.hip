@@ -709,6 +709,7 @@ int64_t surfel_rasterize_forward(surfel_alloc_fn geom_alloc, void* geom_user, su
     ba.out_color = out_color; ba.out_others = out_others; ba.final_T = img.final_T; ba.n_contrib = img.n_contrib;
     ba.tile_map = img.tile_map; ba.map_flag = img.total + 2 * R_SLOTS + 1; ba.map_len = map_len;
     ba.stats = g_blend_stats;
+    ba.avg_list = (int)(R / ((int64_t)gx * gy));
     tm.begin();
     launch_blend_fwd(ba, s);
     STAGE_END(tm, ST_BLEND);
@@ -778,9 +779,14 @@ int surfel_rasterize_backward(surfel_alloc_fn scratch_alloc, void* scratch_user,
         // the scan kernel is launched beside the rows / quad kernel the tuner picked and all but one of them return at once (~4 us).
         // A rule, not a timed choice: the walks differ in summation order, and which bits a frame gets must follow from the frame alone.
         // (C5, 1.3e8 instances of which 4 % are staged: scan 3.19 vs 3.13 ms — no gain, hence the rule's upper bound on R.)
-        const bool scan_rule = opt_variant == 2 && g_opt_scan_large && !g_blend_stats;
-        bb.scan_rule = scan_rule ? 1 : 0;
-        if ((opt_variant == 2 || opt_variant == 4) && !g_blend_stats && g_opt_bwd_tune) {
+        // Where the host knows the count for certain — exact binning; a lazily counted frame reports its capacity, <= 2^20 — the size half
+        // of the rule is applied here and only ONE kernel is launched (an idle grid of a 4K frame's 32 k workgroups costs ~0.1 ms):
+        // 2^21 <= R < 2^26 -> the scan walk alone, R >= 2^26 -> rows / quad alone; below 2^21 both, and the device decides by footprint.
+        const bool auto_walk = opt_variant == 2 && g_opt_scan_large && !g_blend_stats;
+        const bool scan_only = auto_walk && R >= ((int64_t)1 << 21) && R < ((int64_t)1 << 26);
+        bb.scan_rule = (auto_walk && R < ((int64_t)1 << 21)) ? 1 : 0;
+        if (scan_only) bb.variant = 3;
+        if ((opt_variant == 2 || opt_variant == 4) && !scan_only && !g_blend_stats && g_opt_bwd_tune) {
             tl.lock();
             bb.variant = walk_tuner_pick(P, width, height, R, s, opt_variant == 4 ? 3 : 2, &tuner, &probe);
             if (probe >= 0) (void)hipEventRecord(tuner->e0[probe], s);

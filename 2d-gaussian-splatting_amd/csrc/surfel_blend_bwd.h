@@ -77,7 +77,8 @@ __device__ __forceinline__ bool device_picks_scan(const BlendBwdArgs& a) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { r += __shfl_xor(r, o); v += __shfl_xor(v, o); }
     const unsigned long long R = r;
-    return (R >= (1ull << 21) && R < (1ull << 26)) || R >= (unsigned long long)SCAN_MIN_INST_PER_SURFEL * v;
+    // (no gain on frames of >= 2^26 instances, whatever their footprints: C5, 1.3e8 instances of which 4 % are staged — scan 3.19 - 3.6 vs 3.13 ms)
+    return R < (1ull << 26) && (R >= (1ull << 21) || R >= (unsigned long long)SCAN_MIN_INST_PER_SURFEL * v);
 }
 
 __device__ __forceinline__ int block_max(int v, int* s_max) {

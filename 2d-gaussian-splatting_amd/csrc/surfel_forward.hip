@@ -412,7 +412,11 @@ static int g_fwd_pipe = 1;      // surfel_set_option("fwd_pipe", .): 1 pipelined
 void set_fwd_pipe(int v) { g_fwd_pipe = v != 0; }
 
 void launch_blend_fwd(const BlendFwdArgs& a, hipStream_t s) {
-    if (g_fwd_pipe) {
+    // Crowded frames (thousands of instances per tile of which a few per cent are ever staged: C5, 10 M surfels at 4K) end most tiles
+    // inside their second batch: the prefetch of a batch nobody walks and a barrier per 128 instead of 256 instances cost the pipelined
+    // kernel 17 % there (1.27 vs 1.08 ms) — such frames keep the batch-synchronous kernel.  Same bits either way.
+    const bool crowded = a.avg_list > 2048;
+    if (g_fwd_pipe && !crowded) {
         if (a.stats) hipLaunchKernelGGL(blend_fwd_pipe_kernel<true>, dim3(a.map_len), dim3(BLOCK), 0, s, a);
         else hipLaunchKernelGGL(blend_fwd_pipe_kernel<false>, dim3(a.map_len), dim3(BLOCK), 0, s, a);
         return;

@@ -27,6 +27,7 @@ struct BlendFwdArgs {
     float* out_color; float* out_others; float* final_T; uint32_t* n_contrib;
     const int* tile_map; const uint32_t* map_flag; int map_len;      // tile of every workgroup where map_flag[0] != 0 (tile_order_kernel; -1: none), xcd_tile order otherwise; the grid size
     unsigned long long* stats;   // optional [8]: [6] += (pixel, surfel) pairs composited (surfel_debug_set_blend_stats)
+    int avg_list;                // instances per tile where the host knows the count (exact binning path), else 0: picks the kernel (speed only)
 };
 
 struct BlendBwdArgs {
