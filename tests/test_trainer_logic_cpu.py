@@ -169,3 +169,34 @@ def test_early_gather_is_a_measured_choice(trainer):
     tr._eg_failed = False
     assert tr._eg_failed is False
 
+
+def test_early_gather_probe_keeps_every_rank_in_the_verdict(trainer, monkeypatch):
+    """a rank whose early colour gather failed during the start-up probe must keep the probe's state machine running —
+    the other ranks wait for it in the verdict's all-reduce — take the late form from then on, and vote "early = never", so that MAX
+    over the ranks turns every rank to the late form.  Events and the collective are faked (no GPU here)."""
+    import surfel_trainer as TR
+    tr, m, calls, opt = trainer
+    reduced = []
+
+    class FakeEvent:
+        t = 0.0
+
+        def __init__(self, enable_timing=False): self.stamp = None
+        def record(self): FakeEvent.t += 1.0; self.stamp = FakeEvent.t
+        def synchronize(self): pass
+        def elapsed_time(self, other): return other.stamp - self.stamp
+    monkeypatch.setattr(TR.torch.cuda, "Event", FakeEvent)
+    monkeypatch.setattr(TR.dist, "all_reduce", lambda t, op=None: reduced.append(t.clone()))
+    tr.early_gather, tr._eg_first, tr._eg_events, tr._eg_failed = "auto", None, [], False
+    tr.opt.densify_from_iter = 10 ** 9
+    took = []
+    for it in range(1, 3 + 2 * tr.EG_LEN + 2):
+        tr.iteration = it
+        if it == 5:      # the hook failed on this rank in the middle of the early window
+            tr._eg_failed = True
+        took.append(tr._probe_early_gather())
+    # warm-up (2 iterations) | early window: early until the failure, late after it | late window | verdict reached exactly once
+    assert took[:2] == [False, False] and took[2:4] == [True, True] and took[4:6] == [False, False]
+    assert len(reduced) == 1 and float(reduced[0][0]) > 1e37, reduced      # this rank's vote: the early form never wins
+    assert tr.early_gather is False and tr.early_gather_probe["choice"] == "late"
+
