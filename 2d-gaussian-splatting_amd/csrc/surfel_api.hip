@@ -259,7 +259,10 @@ int walk_tuner_pick(int P, int W, int H, int64_t R, hipStream_t s, int nwalks, W
         for (int v = 1; v < nwalks; v++) if (t->ns_per_inst[v] < t->ns_per_inst[best]) best = v;
         t->choice = kWalkVariant[best];
     }
-    const unsigned phase = t->calls++ % kTunePeriod;
+    // (two probes in every 32 calls until a verdict has stood for three periods, then two in every 256: a probe of the slower walk costs
+    // the step its difference — 60 us at C2 — and frames of one size and footprint octave rarely change sides)
+    const unsigned period = (t->choice >= 0 && t->calls >= 3 * kTunePeriod) ? 8 * kTunePeriod : kTunePeriod;
+    const unsigned phase = t->calls++ % period;
     if (phase >= kTuneFirst && phase < kTuneFirst + (unsigned)nwalks && !t->pending[phase - kTuneFirst]) {
         const int v = (int)(phase - kTuneFirst);
         if (!t->e0[v]) {
