@@ -29,8 +29,9 @@ def tile_row_instances():
     return (r[..., 1] - r[..., 0]).sum(1)
 
 
-IMG_HEAD_U2 = 64 + 1      # uint2 slots behind the tile ranges in the image buffer's zeroed head (csrc/surfel_api.hip: ImgState::carve):
-                          # 2 x 64 partial counters, the capacity path's instance total + the tile-map flag
+IMG_HEAD_U2 = 64 + 2      # uint2 slots behind the tile ranges in the image buffer's zeroed head (csrc/surfel_api.hip: ImgState::carve):
+                          # 2 x 64 partial counters, the capacity path's instance total + the tile-map flag, the checkpoint flag + a spare word
+                          # (behind the tile map, LAST: blend_bwd's list-splitting checkpoints, 17 KB per tile, frames of <= 4096 tiles)
 
 
 def image_layout(width, height):

@@ -69,9 +69,11 @@ def upload(arr):
 class Frame:
     """One scene's inputs in guarded memory + one forward / backward through the C ABI with guarded allocator callbacks."""
 
-    def __init__(self, lib, P, W, H, rad, seed=3):
+    def __init__(self, lib, P, W, H, rad, seed=3, opacity=None, **kw):
         self.lib, self.P, self.W, self.H = lib, P, W, H
-        sc = self.sc = synthetic.make_scene(P, W, H, seed=seed, px_radius=rad)
+        sc = self.sc = synthetic.make_scene(P, W, H, seed=seed, px_radius=rad, **kw)
+        if opacity is not None:
+            sc["opacities"] = np.full_like(sc["opacities"], opacity)
         self.d = {k: upload(np.ascontiguousarray(sc[k], np.float32)) for k in ("bg", "means3D", "opacities", "scales", "rotations", "shs", "viewmatrix", "projmatrix", "campos")}
         self.M = sc["shs"].shape[1]
         self.out_color, self.out_others, self.radii = guard_alloc(12 * W * H), guard_alloc(28 * W * H), guard_alloc(4 * P)
@@ -130,6 +132,19 @@ def main():
         big.backward(R, flags[variant])
         chk(hip.hipDeviceSynchronize(), "sync after the redo")
         print("overflow ok: capacity %d, exact count %d, granularity %d" % (cap, R, G), flush=True)
+        return
+    if sys.argv[1] == "split":
+        # blend_bwd list splitting: lists of ~700 faint instances per tile, every tile walked by two workgroups, the second one started from
+        # the forward's checkpoints — the last array of the image buffer, which ends at the end of its mapping
+        lib.surfel_set_option(b"fwd_pipe", int(sys.argv[2]))
+        lib.surfel_set_option(b"bwd_split", 2)
+        fr = Frame(lib, 60000, 160, 128, 6.0, seed=12, opacity=0.015, z_near=1.0, z_far=9.0)
+        for rep in range(3):
+            R = fr.forward(n.opt_tile_sort(2))
+            chk(hip.hipDeviceSynchronize(), "sync after forward")
+            fr.backward(R, 0)
+            chk(hip.hipDeviceSynchronize(), "sync after backward")
+            print("rep %d ok: R=%d binning=%d granularity=%d" % (rep, R, lib.surfel_debug_last_binning(), G), flush=True)
         return
     pipe, variant = int(sys.argv[1]), int(sys.argv[2])
     P, W, H, rad = (int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5]), float(sys.argv[6])) if len(sys.argv) > 6 else (30000, 400, 304, 4.0)

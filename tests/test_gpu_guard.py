@@ -30,3 +30,11 @@ def test_backward_of_an_overflowed_lazy_frame_touches_nothing(variant):
     """the backward of a lazily counted frame that REALLY overflowed its capacity, before the count is collected,
     with the gradient records at the end of their mapping; then the reported overflow and the redo."""
     assert "overflow ok" in _run("overflow", variant)
+
+
+@pytest.mark.parametrize("pipe", [1, 0])
+def test_list_splitting_stays_inside_the_image_buffer(pipe):
+    """blend_bwd list splitting: the forward's checkpoints (last array of the image buffer) written by either blend_fwd kernel and read
+    by the second workgroup of every tile, with unmapped pages right behind them"""
+    out = _run("split", pipe)
+    assert out.count(" ok: R=") == 3, out

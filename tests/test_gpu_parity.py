@@ -47,7 +47,10 @@ def _check_binning(run, R, radii):
     assert diff.mean() <= 5e-3, "radii mismatch fraction %.6f" % diff.mean()
     if diff.any():
         both = diff & (got > 0) & (radii > 0)
-        assert np.abs(got[both].astype(np.int64) - radii[both]).max(initial=0) <= 1
+        # (a radius of tens of thousands of pixels — a disc that all but touches the camera plane, seen on trained states — carries the
+        # fp32 error of its ill-conditioned projection: 2.5e-4 relative beyond 4096 px; its rect is the whole screen either way)
+        allow = np.where(radii[both] > 4096, np.ceil(2.5e-4 * radii[both]), 1)
+        assert (np.abs(got[both].astype(np.int64) - radii[both]) <= allow).all()
     # The device emits a (tile, surfel) instance only where the surfel's alpha>=1/255 bbox reaches the tile, so its
     # instance count is a subset of the reference rect count the oracle reports.
     assert run.R <= R + 8 * int(diff.sum()), (run.R, R)
@@ -239,7 +242,12 @@ def test_trained_state_parity():
     del tr, model
     import diff_surfel_rasterization as dsr
     dsr.set_grad_arena(None)
-    run = HipRun(a).forward()
+    lib = n.load()
+    assert lib.surfel_set_option(b"bwd_split", 2) == 0      # (this frame's image buffer carries the list-splitting checkpoints)
+    try:
+        run = HipRun(a).forward()
+    finally:
+        lib.surfel_set_option(b"bwd_split", 0)
     dk = run.depths()
     o64, o32 = Oracle("f64"), Oracle("f32")
     R, col, oth, radii, st = oracle_forward(o64, a, depth_key=dk)
@@ -260,9 +268,13 @@ def test_trained_state_parity():
     rg = np.random.default_rng(9)
     gC = rg.normal(size=col.shape).astype(np.float32); gO = rg.normal(size=oth.shape).astype(np.float32)
     og, og32 = o64.rasterize_backward(st, gC, gO), o32.rasterize_backward(st32, gC, gO)
-    for walk, flag in (("rows", n.OPT_BWD_ROWS), ("quad", n.OPT_BWD_QUAD), ("scan", n.OPT_BWD_SCAN), ("auto", 0)):
+    for walk, flag in (("rows", n.OPT_BWD_ROWS), ("quad", n.OPT_BWD_QUAD), ("scan", n.OPT_BWD_SCAN), ("auto", 0), ("split", 0)):
         run.debug = flag
-        g = run.backward(gC, gO)
+        lib.surfel_set_option(b"bwd_split", 2 if walk == "split" else 0)      # split: two workgroups per tile deeper than 320 (here: the centre tiles)
+        try:
+            g = run.backward(gC, gO)
+        finally:
+            lib.surfel_set_option(b"bwd_split", 0)
         for k, ref, r32 in [("means3D", og.dL_dmeans3D, og32.dL_dmeans3D), ("scales", og.dL_dscales, og32.dL_dscales), ("rots", og.dL_drots, og32.dL_drots),
                             ("opacity", og.dL_dopacity, og32.dL_dopacity), ("sh", og.dL_dsh, og32.dL_dsh), ("means2D", og.dL_dmean2D, og32.dL_dmean2D)]:
             x = g[k].reshape(ref.shape)
@@ -793,6 +805,71 @@ def test_scan_walk_matches_the_oracle_and_the_other_walks(kind):
             fs = frac_close(x.reshape(ref.shape), ref, 1e-4 * sc_ + 1e-12, G_RTOL)
             fr = frac_close(y.reshape(ref.shape), ref, 1e-4 * sc_ + 1e-12, G_RTOL)
             assert fs >= fr - 5e-4, "%s: dL/d%s vs oracle: scan %.5f, rows %.5f" % (kind, k, fs, fr)
+
+
+@pytest.mark.parametrize("kind", ["long_lists", "crowded", "huge_faint", "saturating", "C1"])
+@pytest.mark.parametrize("pipe", [1, 0])
+def test_list_splitting_matches_the_unsplit_walk(kind, pipe):
+    """blend_bwd list splitting (csrc/surfel_blend_bwd.h: split_start): tiles whose deepest composited position exceeds 320 are walked
+    by TWO workgroups of the per-row walk, the second one started at list position 256 from the state either blend_fwd kernel
+    checkpointed there.  The start value of the suffix sum is a difference of forward sums instead of a running sum, so the bits
+    differ from the unsplit walk where a tile is split — and ONLY there; the result must (a) be reproducible, (b) agree with the
+    unsplit rows walk to fp32 summation noise (the scan walk's bars), (c) meet the oracle as well as the unsplit walk does."""
+    import surfel_native as n
+    import synthetic
+    import diff_surfel_rasterization as dsr
+    from oracle.surfel_oracle import Oracle
+    lib = n.load()
+    if kind == "long_lists":
+        sc = synthetic.make_scene(60000, 160, 128, seed=12, px_radius=6.0, z_near=1.0, z_far=9.0)
+        sc["opacities"] = np.full_like(sc["opacities"], 0.015)
+    else:
+        sc = _walk_scene(kind)
+    a = scene_args(sc)
+    rng = np.random.default_rng(8)
+    gC = rng.normal(size=(3, a["H"], a["W"])).astype(np.float32); gO = rng.normal(size=(7, a["H"], a["W"])).astype(np.float32)
+    res = {}
+    try:
+        assert lib.surfel_set_option(b"fwd_pipe", pipe) == 0 and lib.surfel_set_option(b"bwd_split", 2) == 0
+        run = HipRun(a).forward()
+        W, H = a["W"], a["H"]
+        gx, gy = (W + 15) // 16, (H + 15) // 16
+        off = dsr.image_layout(W, H)[3]
+        last = run.ia.last()[off:off + 4 * W * H].view(run.torch.int32).view(H, W)
+        pad = run.torch.zeros((gy * 16, gx * 16), dtype=run.torch.int32, device=last.device)
+        pad[:H, :W] = last
+        n_split = int((pad.view(gy, 16, gx, 16).amax(dim=(1, 3)) > 320).sum().item())
+        run.debug = n.OPT_BWD_ROWS
+        res["rows"] = run.backward(gC, gO)
+        for name in ("split", "split2"):
+            run.debug = 0
+            res[name] = run.backward(gC, gO)
+    finally:
+        lib.surfel_set_option(b"bwd_split", 0)
+        lib.surfel_set_option(b"fwd_pipe", 1)
+    assert n_split > 0 or kind != "long_lists", "long_lists: no tile deeper than 320"
+    assert n_split == 0 or kind != "saturating", "%s: %d tiles deeper than 320" % (kind, n_split)
+    o = Oracle("f64")
+    R, col, oth, radii, st = oracle_forward(o, a, depth_key=run.depths())
+    og = o.rasterize_backward(st, gC, gO)
+    refs = dict(means3D=og.dL_dmeans3D, opacity=og.dL_dopacity, sh=og.dL_dsh, means2D=og.dL_dmean2D, scales=og.dL_dscales, rots=og.dL_drots)
+    for k in res["rows"]:
+        x, y = res["split"][k], res["rows"][k]
+        assert np.isfinite(x).all(), k
+        assert np.array_equal(x, res["split2"][k]), "split walk not reproducible: %s" % k
+        if n_split == 0:
+            assert np.array_equal(x, y), "%s: no tile is split, dL/d%s must be the unsplit walk's" % (kind, k)
+            continue
+        scale = np.abs(y).mean() + 1e-30
+        f = frac_close(x, y, 1e-5 * scale, 1e-3)
+        cs = cosine(x, y)
+        assert f >= 0.999 and cs >= 0.999999, "%s: dL/d%s split vs unsplit: %.5f of elements, cosine %.8f" % (kind, k, f, cs)
+        if k in refs:
+            ref = refs[k]
+            sc_ = np.abs(ref).mean() + 1e-30
+            fs = frac_close(x.reshape(ref.shape), ref, 1e-4 * sc_ + 1e-12, G_RTOL)
+            fr = frac_close(y.reshape(ref.shape), ref, 1e-4 * sc_ + 1e-12, G_RTOL)
+            assert fs >= fr - 5e-4, "%s: dL/d%s vs oracle: split %.5f, unsplit %.5f" % (kind, k, fs, fr)
 
 
 @pytest.mark.parametrize("kind", ["plain", "needles", "huge", "tiny", "opaque_faint", "huge_faint"])
