@@ -421,6 +421,21 @@ int surfel_debug_walk_choice(int width, int height) {
 }
 int surfel_debug_last_binning(void) { return g_last_binning; }
 int surfel_debug_capacity_evictions(void) { return g_cap_evictions; }
+
+int surfel_debug_image_layout(int width, int height, int64_t* out) {      // host arithmetic only: no device is touched
+    if (width <= 0 || height <= 0 || !out) return fail(SURFEL_E_INVALID, "bad arguments");
+    size_t total = 0;
+    ImgState::carve(nullptr, width, height, &total);
+    char* const base = reinterpret_cast<char*>(static_cast<uintptr_t>(1) << 40);      // (a carve over a fictitious base: only differences are used)
+    const ImgState im = ImgState::carve(base, width, height, nullptr);
+    out[0] = (int64_t)total;
+    out[1] = reinterpret_cast<char*>(im.final_T) - base;
+    out[2] = reinterpret_cast<char*>(im.n_contrib) - base;
+    out[3] = reinterpret_cast<char*>(im.tile_map) - base;
+    out[4] = im.ckpt ? reinterpret_cast<char*>(im.ckpt) - base : -1;
+    out[5] = reinterpret_cast<char*>(im.ckpt_flag) - base;
+    return 0;
+}
 int surfel_debug_set_blend_stats(void* dev_u64x8) { g_blend_stats = static_cast<unsigned long long*>(dev_u64x8); return 0; }
 
 int surfel_collect_stage_ms(float* sum_ms, int* count, int cap) {

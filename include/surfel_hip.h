@@ -257,6 +257,12 @@ int surfel_debug_last_binning(void);
  * make room for another one.  A dropped size costs its next frame the exact path and a host wait — speed only. */
 int surfel_debug_capacity_evictions(void);
 
+/* Debug: byte offsets inside the image buffer of a width x height frame under the current options (host arithmetic, no device needed):
+ * out[0] total size, [1] final_T / M1 / M2 planes, [2] last / median contributor planes, [3] tile map, [4] list-splitting checkpoints
+ * ("bwd_split"; -1: none), [5] the word that says whether the forward wrote checkpoints.  The tile ranges start at offset 0.  For the
+ * white-box tests and statistics scripts that read the buffer (diff_surfel_rasterization.image_layout mirrors it). */
+int surfel_debug_image_layout(int width, int height, int64_t* out);
+
 /* Debug: the walk the "bwd_tune" probes currently favour for frames of this size on the current device (the most used entry of
  * that size) — 0 per-row, 1 per-quad, -1 not decided yet (fewer than two timed calls have completed). */
 int surfel_debug_walk_choice(int width, int height);
