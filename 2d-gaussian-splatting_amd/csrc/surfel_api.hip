@@ -822,7 +822,12 @@ int surfel_rasterize_backward(surfel_alloc_fn scratch_alloc, void* scratch_user,
         // (wide footprints, few tiles: every tile resident at once, the launch as long as the longest list): two workgroups per tile of
         // the per-row walk, the second one started from the forward's checkpoint.  bwd_split = 2 splits whatever the frame (tests).
         bb.ckpt = img.ckpt; bb.ckpt_flag = img.ckpt_flag;
-        if (img.ckpt && opt_variant == 2 && !g_blend_stats && R < ((int64_t)1 << 21)) bb.split = g_bwd_split == 2 ? 2 : (bb.scan_rule ? 1 : 0);
+#ifdef BLEND_TRACE
+        const bool counters_on = false;      // (the trace build records per-workgroup times only: split launches are traced as well)
+#else
+        const bool counters_on = g_blend_stats != nullptr;
+#endif
+        if (img.ckpt && opt_variant == 2 && !counters_on && R < ((int64_t)1 << 21)) bb.split = g_bwd_split == 2 ? 2 : (bb.scan_rule ? 1 : 0);
         if (bb.split == 2) bb.variant = 0;
         if ((opt_variant == 2 || opt_variant == 4) && !scan_only && bb.split != 2 && !g_blend_stats && g_opt_bwd_tune) {
             tl.lock();

@@ -194,10 +194,13 @@ __device__ __forceinline__ void pair_gradients(Pixel& p, const Hit& h, const flo
 // ---------------------------------------------------------------------------------------------
 // blend_bwd, rows variant
 // ---------------------------------------------------------------------------------------------
-// SPLIT (round 4): TWO workgroups per tile.  Blocks [0, map_len) walk list positions [1, SPLIT_AT] of the tiles whose deepest
-// composited position exceeds SPLIT_MIN, starting from the forward's checkpoint (surfel_blend_bwd.h: split_start); blocks
-// [map_len, 2 map_len) walk the rest — (SPLIT_AT, maxc] of those tiles, the whole list of the others.  The lower halves come first
-// in the grid: with the tile map's longest-first order behind them the dispatcher sees the work items longest first.  An
+// SPLIT (round 4): TWO workgroups per tile, blocks 2 i and 2 i + 1 for entry i of the tile map.  The odd block walks list positions
+// [1, SPLIT_AT] of a tile whose deepest composited position exceeds SPLIT_MIN, starting from the forward's checkpoint
+// (surfel_blend_bwd.h: split_start), and returns at once otherwise; the even block walks the rest — (SPLIT_AT, maxc] of such a tile, the
+// whole list of any other.  Both halves of a tile are neighbours in the grid, so with the tile map's longest-first order the dispatcher
+// starts BOTH halves of the heaviest tiles first and the work items that have to wait for a slot are the short ones (the first version
+// put all lower halves in front: 781 of them took the slots and the upper halves of the heaviest tiles started at 60 - 180 us —
+// profiles/r04_wg_trace.md section 5).  An
 // object-centred frame (~1 000 non-empty tiles, all resident at once, each a serial chain of up to 570 positions) lasts as long
 // as its longest chain: the split halves it (profiles/r04_wg_trace.md).  Summation order differs from the unsplit walk in the
 // start value of X only; which frames are split follows from the frame alone (BlendBwdArgs::split).
@@ -223,8 +226,8 @@ __global__ void __launch_bounds__(BLOCK, ROWS_WAVES) blend_bwd_rows_kernel(Blend
 #ifdef BLEND_TRACE
     const unsigned long long trace_t0 = wall_clock64();
 #endif
-    const bool lower = SPLIT && (int)blockIdx.x < a.map_len;
-    const int tile = block_tile(a.tile_map, a.map_flag, SPLIT && !lower ? (int)blockIdx.x - a.map_len : (int)blockIdx.x, a.gx * a.gy);
+    const bool lower = SPLIT && (blockIdx.x & 1u);
+    const int tile = block_tile(a.tile_map, a.map_flag, SPLIT ? (int)(blockIdx.x >> 1) : (int)blockIdx.x, a.gx * a.gy);
     if (tile < 0) return;
     const bool ckpt_ok = SPLIT && a.ckpt && a.ckpt_flag[0] == 1u;      // the forward of THIS image buffer kept checkpoints
     if (lower && (!ckpt_ok || (int)(a.ranges[tile].y - a.ranges[tile].x) <= SPLIT_MIN)) return;
@@ -402,9 +405,9 @@ __global__ void __launch_bounds__(BLOCK, ROWS_WAVES) blend_bwd_rows_kernel(Blend
     }
 #ifdef BLEND_TRACE
     #ifdef ROWS_TIMING
-    if (STATS && !lower) trace_wg(a.stats, 65536, trace_t0, tile, maxc, tm_stage, tm_walk, tm_bar + tm_flush, tm_nvis);
+    if (STATS) trace_wg(a.stats, 65536, trace_t0, tile, top - lo, tm_stage, tm_walk, tm_bar + tm_flush, tm_nvis);
 #else
-    if (STATS && !lower) trace_wg(a.stats, 65536, trace_t0, tile, maxc);
+    if (STATS) trace_wg(a.stats, 65536, trace_t0, tile, top - lo);      // (slot = blockIdx: both halves of a split tile are recorded, each with the positions it walked)
 #endif
 #endif
 #ifdef ROWS_TIMING

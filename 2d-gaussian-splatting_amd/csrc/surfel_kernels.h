@@ -44,7 +44,7 @@ struct BlendBwdArgs {
     const float* depths;   // [P] view depths (the sort key's source)
     int variant;      // 0: per-DPP-row walk, 1: per-wave (8x8 quad) walk, 2: both launched, the device picks from the frame's totals (0 / 1 / 2 bit-identical); 3: scan walk
     const float* ckpt; const uint32_t* ckpt_flag;      // the forward's checkpoints (BlendFwdArgs) and the word that says they exist; NULL: no splitting
-    int split;        // 1: the rows kernel is launched with TWO workgroups per tile; the second walks list positions [1, SPLIT_AT] of tiles deeper than SPLIT_MIN
+    int split;        // 1: the rows kernel is launched with TWO workgroups per tile; blocks 2 i / 2 i + 1 for map entry i; the odd one walks list positions [1, SPLIT_AT] of tiles deeper than SPLIT_MIN
     int scan_rule;    // 1: the scan kernel AND the rows / quad kernel selected by `variant` are launched; the device decides from `totals` which one runs (surfel_blend_bwd.h: device_picks_scan)
     const uint32_t* totals;      // [2 * R_SLOTS] partial sums written by preprocess: tile instances | visible surfels
     const uint32_t* n_dev; uint32_t n_cap;      // capacity path: the frame's instance total on the device and the record capacity (= num_rendered).  n_dev[0] > n_cap:
