@@ -818,9 +818,9 @@ int surfel_rasterize_backward(surfel_alloc_fn scratch_alloc, void* scratch_user,
         const bool scan_only = auto_walk && R >= ((int64_t)1 << 21) && R < ((int64_t)1 << 26);
         bb.scan_rule = (auto_walk && R < ((int64_t)1 << 21)) ? 1 : 0;
         if (scan_only) bb.variant = 3;
-        // List splitting (surfel_common.h: SPLIT_AT) takes the place of the scan walk on the small frames the device rule gives to it
-        // (wide footprints, few tiles: every tile resident at once, the launch as long as the longest list): two workgroups per tile of
-        // the per-row walk, the second one started from the forward's checkpoint.  bwd_split = 2 splits whatever the frame (tests).
+        // List splitting (surfel_common.h: SPLIT_AT; option bwd_split, off by default — measured at parity with the scan walk): on the
+        // small frames the device rule would give to the scan walk (wide footprints, few tiles) the per-row walk runs two workgroups per
+        // long tile, the second one started from the forward's checkpoint.  bwd_split = 2 splits whatever the frame (tests).
         bb.ckpt = img.ckpt; bb.ckpt_flag = img.ckpt_flag;
 #ifdef BLEND_TRACE
         const bool counters_on = false;      // (the trace build records per-workgroup times only: split launches are traced as well)
