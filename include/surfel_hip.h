@@ -197,6 +197,12 @@ int surfel_debug_sort_pairs(surfel_alloc_fn scratch_alloc, void* scratch_user, u
  *          (tests/test_gpu_parity.py::test_list_splitting_matches_the_unsplit_walk).  2: split on every frame below 2^21 instances (tests).
  *          The option sizes the image buffer; a backward that finds no checkpoints in its image buffer (device flag set by the forward)
  *          walks unsplit, whatever the option says by then.
+ *          PRECISION: the second workgroup's start value holds the distortion term as a difference of the forward's own sums M1, M2 — a
+ *          variance-like form whose large terms cancel: ~1.3e-6 x (the distortion gradient) absolute.  At parity while the distortion
+ *          gradient is of the order of the colour gradient (every GPU test); NOT with the reference's DTU settings (lambda_dist = 1000: the
+ *          distortion gradient is thousands of times the colour gradient) — there the checkpoints must carry sums centred on the first
+ *          instance's depth map value, which restores parity at any ratio (tests/test_split_recurrence_cpu.py shows both).  Not a default
+ *          before that.
  *   "fat_sort" (default 1): look-back sort passes over <= 2^20 items use 8192-item tiles staged through LDS (0: 2048-item tiles);
  *          "host_total" (default 1): capacity-path frames store their instance total into mapped pinned memory from the emission
  *          kernel (0: a device-to-host copy in the stream).  Speed only (tests/test_gpu_parity.py::test_radix_sort_is_stable_and_exact

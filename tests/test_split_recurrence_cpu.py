@@ -1,4 +1,5 @@
-"""CPU: the arithmetic a list-splitting blend-backward would rest on (DESIGN.md section 8 "Next" #1; not built yet).
+"""CPU: the arithmetic the list-splitting blend-backward rests on (csrc/surfel_blend_bwd.h: split_start, option bwd_split; and the
+segment decomposition DESIGN.md section 8 "Next" #1 proposes: one checkpoint per 128 positions).
 
 The backward walks a pixel's composited list back to front with two scalars of state (csrc/surfel_backward.hip: pair_gradients):
     T_k = T_final / prod_{i >= k} (1 - alpha_i)                      transmittance in front of instance k
@@ -100,3 +101,80 @@ def test_split_walk_matches_the_sequential_walk(seed, n, split, alpha_hi):
     for k in range(n - 1, split - 1, -1):
         T_div = np.float32(T_div / (np.float32(1) - alpha[k]))
     assert abs(float(Ts) - float(Ts64)) <= abs(float(T_div) - float(Ts64)) + 1e-6 * float(Ts64)
+
+
+def _segments(seed, n, seg, alpha_hi, gscale, centered):
+    """(fraction within tolerance of the sequential fp32 walk, of the segmented fp32 walk, the fp64 identity's max error / mean|ref|)"""
+    rng = np.random.default_rng(seed)
+    alpha = rng.uniform(1.0 / 255.0, alpha_hi, n).astype(F)
+    c = rng.uniform(0, 1, (n, 3)).astype(F); nrm = rng.normal(size=(n, 3)).astype(F)
+    d = rng.uniform(0.5, 9.0, n).astype(F)
+    mm = (F(100.0 / 99.8) - F(100.0 / 99.8 * 0.2) / d).astype(F)
+    g = (rng.normal(size=3).astype(F), F(rng.normal()), F(rng.normal()), rng.normal(size=3).astype(F), F(abs(rng.normal()) * gscale), rng.uniform(0, 1, 3).astype(F))
+
+    def run(prec):
+        _Prec.t = prec
+        P = prec
+        cast = lambda x: np.asarray(x).astype(P) if isinstance(x, np.ndarray) else P(x)
+        al, cc, dd, nn, mmm = cast(alpha), cast(c), cast(d), cast(nrm), cast(mm)
+        gg = tuple(cast(x) for x in g)
+        gC_, gD_, gA_, gN_, gdist_, bg_ = gg
+        pre = forward(al, cc, dd, nn, mmm)
+        fin = pre[-1]
+        Tf, Cf, Df, Nf, M1f, M2f = fin
+        # the CENTRED running sums a forward could keep beside M1, M2: D1 = sum w (m - m0), D2 = sum w (m - m0)^2, m0 = the first instance's m
+        m0 = mmm[0]; T = P(1); D1 = P(0); D2 = P(0); cen = []
+        for a, mi in zip(al, mmm):
+            w = P(a * T); dl = P(mi - m0); D1 = P(D1 + dl * w); D2 = P(D2 + dl * dl * w); T = P(T * (P(1) - a)); cen.append((D1, D2))
+        D1f, D2f = cen[-1]
+        X_end = P(Tf * (bg_ @ gC_))
+        A = P(1) - Tf
+        seq = walk(al, cc, dd, nn, mmm, gg, fin, 0, n, Tf, X_end)
+        parts = []
+        for lo in range(0, n, seg):
+            hi = min(n, lo + seg)
+            if hi == n:
+                Ts, X_s = Tf, X_end
+            else:
+                Ts, Cs, Ds, Ns, M1s, M2s = pre[hi - 1]
+                if centered:      # A S2 - 2 M1 S1 + M2 S0 is invariant under m -> m - m0: the same form on sums a hundred times smaller
+                    D1s, D2s = cen[hi - 1]
+                    dist = A * (D2f - D2s) - P(2) * D1f * (D1f - D1s) + D2f * (Ts - Tf)
+                else:
+                    dist = A * (M2f - M2s) - P(2) * M1f * (M1f - M1s) + M2f * (Ts - Tf)
+                X_s = P(X_end + (Cf - Cs) @ gC_ + (Df - Ds) * gD_ + (Nf - Ns) @ gN_ + gA_ * (Ts - Tf) + gdist_ * dist)
+            parts.append(walk(al, cc, dd, nn, mmm, gg, fin, lo, hi, Ts, X_s))
+        return seq, np.concatenate(parts)
+    try:
+        ref, seg64 = run(np.float64)
+        seq, got = run(np.float32)
+    finally:
+        _Prec.t = np.float32
+    tol = 1e-4 * np.abs(ref).mean() + 2e-3 * np.abs(ref)
+    return (np.abs(seq - ref) <= tol).mean(), (np.abs(got - ref) <= tol).mean(), np.abs(seg64 - ref).max() / np.abs(ref).mean()
+
+
+CASES = [(5, 571, 128, 0.03), (6, 700, 128, 0.015), (7, 1619, 128, 0.01), (8, 300, 64, 0.2), (1, 700, 256, 0.02)]
+
+
+@pytest.mark.parametrize("seed,n,seg,alpha_hi", CASES)
+@pytest.mark.parametrize("gscale", [1.0, 100.0, 3000.0])
+def test_segments_from_per_segment_checkpoints(seed, n, seg, alpha_hi, gscale):
+    """The list cut into segments of `seg` positions, EVERY segment but the last started from the forward's checkpoint behind it (each
+    independently: the decomposition a backward over segments instead of tiles would use; the start error does not accumulate — each X_s
+    is ONE difference of forward sums).  gscale = the distortion gradient relative to the others: 1 in the GPU parity tests (N(0,1)
+    upstream gradients), ~3.75 lambda_dist in training — thousands with the reference's DTU settings (lambda_dist = 1000).
+
+    The distortion part of X_s is a variance-like form, A S2 - 2 M1 S1 + M2 S0, whose large terms cancel.  From differences of the forward's
+    OWN sums M1, M2 (what `split_start` does today) the cancellation costs ~1.3e-6 g_dist absolute: invisible at gscale 1, 35 - 65 % of
+    the elements out of tolerance on deep lists at gscale >= 100.  The form is invariant under m -> m - m0, so two more forward sums,
+    centred on the first instance's m, give the same start value from terms a hundred times smaller: parity at every gscale.  That
+    is why `bwd_split` may not become a default before the checkpoints carry the centred sums (include/surfel_hip.h)."""
+    f_seq, f_cen, id_err = _segments(seed, n, seg, alpha_hi, gscale, True)
+    assert id_err < 1e-9
+    assert f_cen >= 0.97 and f_cen >= f_seq - 0.03, (f_seq, f_cen)
+    f_seq2, f_plain, id_err2 = _segments(seed, n, seg, alpha_hi, gscale, False)
+    assert id_err2 < 1e-9 and f_seq2 == f_seq
+    if gscale <= 1.0:
+        assert f_plain >= 0.97, f_plain          # the regime of the GPU tests: the committed formulation is at parity
+    assert f_plain <= f_cen + 0.01               # ... and never better than the centred one
