@@ -27,7 +27,6 @@ void* g_colour_hook_user = nullptr;
 int g_opt_pbwd_coop = -1;  // surfel_set_option("pbwd_coop", .): record gather of preprocess_bwd — -1 by rule (R >= 6 P and R >= 2^25), 0 per thread, 1 wave-cooperative
 int g_opt_host_total = 1;  // surfel_set_option("host_total", .): capacity path — 1: bin_emit_kernel stores the instance total into mapped pinned memory, 0: D2H copy kernel (measurement)
 int g_opt_scan_large = 1;  // surfel_set_option("scan_large", .): auto lets the device rule hand frames to the scan walk (2^21 <= R < 2^26 instances, or >= 6 instances per emitting surfel)
-int g_bwd_split = 0;       // surfel_set_option("bwd_split", .): blend_bwd list splitting — 0 off (default: no checkpoints in the image buffer), 1 where the device rule says, 2 every frame below 2^21 instances
 int g_opt_bwd_tune = 1;    // surfel_set_option("bwd_tune", .): auto = timed probes (1) or the device-side rule alone (0)
 unsigned long long* g_blend_stats = nullptr;   // surfel_debug_set_blend_stats
 thread_local int64_t g_last_R = -1; thread_local int g_last_W = 0, g_last_H = 0;   // auto heuristic (speed only; results identical; a stale
@@ -128,25 +127,17 @@ struct BinState {    // per-instance state ("binningBuffer"); point_list is alwa
 };
 
 struct ImgState {    // per-pixel / per-tile state ("imgBuffer")
-    uint2* ranges; uint32_t* total; float* final_T; uint32_t* n_contrib; int* tile_map; float* ckpt; uint32_t* ckpt_flag;
-    static bool wants_ckpt(int W, int H) {      // a pure function of the frame size and the process-wide option: forward and backward carve alike
-        const size_t tiles = (size_t)((W + TILE - 1) / TILE) * ((H + TILE - 1) / TILE);
-        return g_bwd_split != 0 && tiles <= (size_t)SPLIT_MAX_TILES;
-    }
+    uint2* ranges; uint32_t* total; float* final_T; uint32_t* n_contrib; int* tile_map;
     static ImgState carve(void* base, int W, int H, size_t* total) {
         Carver c(base); ImgState im;
         const size_t tiles = (size_t)((W + TILE - 1) / TILE) * ((H + TILE - 1) / TILE);
         // [tiles] ranges + R_SLOTS partial instance totals + R_SLOTS partial visible-surfel counts + the instance total of the capacity
-        // path | the tile-map flag + the checkpoint flag | a spare word (zeroed together)
+        // path | the tile-map flag | two spare words (zeroed together)
         im.ranges = c.take<uint2>(tiles + R_SLOTS + 2);
         im.total = reinterpret_cast<uint32_t*>(im.ranges + tiles);
-        im.ckpt_flag = im.total + 2 * R_SLOTS + 2;
         im.final_T = c.take<float>((size_t)3 * W * H);
         im.n_contrib = c.take<uint32_t>((size_t)2 * W * H);
         im.tile_map = c.take<int>((size_t)tile_map_len((W + TILE - 1) / TILE, (H + TILE - 1) / TILE));      // blend workgroup -> tile (tile_order_kernel)
-        // LAST (every offset above is what it was without it): blend_bwd's list-splitting checkpoints, written by blend_fwd (surfel_common.h)
-        im.ckpt = wants_ckpt(W, H) ? c.take<float>(tiles * (size_t)(CKPT_F * BLOCK)) : nullptr;
-        if (!base) im.ckpt = nullptr;
         if (total) *total = c.size();
         return im;
     }
@@ -398,7 +389,6 @@ int surfel_set_option(const char* name, int value) {
     if (name && std::strcmp(name, "host_total") == 0) { g_opt_host_total = value != 0; return 0; }
     if (name && std::strcmp(name, "pbwd_coop") == 0) { g_opt_pbwd_coop = value < 0 ? -1 : (value != 0); return 0; }
     if (name && std::strcmp(name, "bwd_variant") == 0) { g_opt_bwd_variant = value < 0 ? 0 : (value > 4 ? 4 : value); return 0; }
-    if (name && std::strcmp(name, "bwd_split") == 0) { g_bwd_split = value < 0 ? 0 : (value > 2 ? 2 : value); return 0; }
     if (name && std::strcmp(name, "bwd_tune") == 0) { g_opt_bwd_tune = value != 0; return 0; }
     if (name && std::strcmp(name, "capacity_binning") == 0) { g_opt_capacity = value != 0; return 0; }
     if (name && std::strcmp(name, "tile_order") == 0) { g_opt_tile_order = value < 0 ? 0 : (value > 2 ? 2 : value); return 0; }
@@ -432,8 +422,6 @@ int surfel_debug_image_layout(int width, int height, int64_t* out) {      // hos
     out[1] = reinterpret_cast<char*>(im.final_T) - base;
     out[2] = reinterpret_cast<char*>(im.n_contrib) - base;
     out[3] = reinterpret_cast<char*>(im.tile_map) - base;
-    out[4] = im.ckpt ? reinterpret_cast<char*>(im.ckpt) - base : -1;
-    out[5] = reinterpret_cast<char*>(im.ckpt_flag) - base;
     return 0;
 }
 int surfel_debug_set_blend_stats(void* dev_u64x8) { g_blend_stats = static_cast<unsigned long long*>(dev_u64x8); return 0; }
@@ -642,7 +630,6 @@ int64_t surfel_rasterize_forward(surfel_alloc_fn geom_alloc, void* geom_user, su
             ba.out_color = out_color; ba.out_others = out_others; ba.final_T = img.final_T; ba.n_contrib = img.n_contrib;
             ba.tile_map = img.tile_map; ba.map_flag = img.total + 2 * R_SLOTS + 1; ba.map_len = map_len;
             ba.stats = g_blend_stats;
-            if (cap < ((int64_t)1 << 22)) { ba.ckpt = img.ckpt; ba.ckpt_flag = img.ckpt_flag; }      // (blend_bwd splits lists below 2^21 instances only; the capacity bounds the count from above)
             tm.begin();
             launch_blend_fwd(ba, s);
             STAGE_END(tm, ST_BLEND);
@@ -741,7 +728,6 @@ int64_t surfel_rasterize_forward(surfel_alloc_fn geom_alloc, void* geom_user, su
     ba.tile_map = img.tile_map; ba.map_flag = img.total + 2 * R_SLOTS + 1; ba.map_len = map_len;
     ba.stats = g_blend_stats;
     ba.avg_list = (int)(R / ((int64_t)gx * gy));
-    if (R < ((int64_t)1 << 21)) { ba.ckpt = img.ckpt; ba.ckpt_flag = img.ckpt_flag; }
     tm.begin();
     launch_blend_fwd(ba, s);
     STAGE_END(tm, ST_BLEND);
@@ -818,18 +804,7 @@ int surfel_rasterize_backward(surfel_alloc_fn scratch_alloc, void* scratch_user,
         const bool scan_only = auto_walk && R >= ((int64_t)1 << 21) && R < ((int64_t)1 << 26);
         bb.scan_rule = (auto_walk && R < ((int64_t)1 << 21)) ? 1 : 0;
         if (scan_only) bb.variant = 3;
-        // List splitting (surfel_common.h: SPLIT_AT; option bwd_split, off by default — measured at parity with the scan walk): on the
-        // small frames the device rule would give to the scan walk (wide footprints, few tiles) the per-row walk runs two workgroups per
-        // long tile, the second one started from the forward's checkpoint.  bwd_split = 2 splits whatever the frame (tests).
-        bb.ckpt = img.ckpt; bb.ckpt_flag = img.ckpt_flag;
-#ifdef BLEND_TRACE
-        const bool counters_on = false;      // (the trace build records per-workgroup times only: split launches are traced as well)
-#else
-        const bool counters_on = g_blend_stats != nullptr;
-#endif
-        if (img.ckpt && opt_variant == 2 && !counters_on && R < ((int64_t)1 << 21)) bb.split = g_bwd_split == 2 ? 2 : (bb.scan_rule ? 1 : 0);
-        if (bb.split == 2) bb.variant = 0;
-        if ((opt_variant == 2 || opt_variant == 4) && !scan_only && bb.split != 2 && !g_blend_stats && g_opt_bwd_tune) {
+        if ((opt_variant == 2 || opt_variant == 4) && !scan_only && !g_blend_stats && g_opt_bwd_tune) {
             tl.lock();
             bb.variant = walk_tuner_pick(P, width, height, R, s, opt_variant == 4 ? 3 : 2, &tuner, &probe);
             if (probe >= 0) (void)hipEventRecord(tuner->e0[probe], s);

@@ -194,17 +194,7 @@ __device__ __forceinline__ void pair_gradients(Pixel& p, const Hit& h, const flo
 // ---------------------------------------------------------------------------------------------
 // blend_bwd, rows variant
 // ---------------------------------------------------------------------------------------------
-// SPLIT (round 4): TWO workgroups per tile, blocks 2 i and 2 i + 1 for entry i of the tile map.  The odd block walks list positions
-// [1, SPLIT_AT] of a tile whose deepest composited position exceeds SPLIT_MIN, starting from the forward's checkpoint
-// (surfel_blend_bwd.h: split_start), and returns at once otherwise; the even block walks the rest — (SPLIT_AT, maxc] of such a tile, the
-// whole list of any other.  Both halves of a tile are neighbours in the grid, so with the tile map's longest-first order the dispatcher
-// starts BOTH halves of the heaviest tiles first and the work items that have to wait for a slot are the short ones (the first version
-// put all lower halves in front: 781 of them took the slots and the upper halves of the heaviest tiles started at 60 - 180 us —
-// profiles/r04_wg_trace.md section 5).  An
-// object-centred frame (~1 000 non-empty tiles, all resident at once, each a serial chain of up to 570 positions) lasts as long
-// as its longest chain: the split halves it (profiles/r04_wg_trace.md).  Summation order differs from the unsplit walk in the
-// start value of X only; which frames are split follows from the frame alone (BlendBwdArgs::split).
-template <bool STATS, bool SPLIT = false>
+template <bool STATS>
 __global__ void __launch_bounds__(BLOCK, ROWS_WAVES) blend_bwd_rows_kernel(BlendBwdArgs a) {
     __shared__ float4 s_rec[BS * 5];                          // 10 KB: q0-q4 of the staged instances
     __shared__ float4 s_slot[NSLOT * 5];                      // 21.25 KB: row totals, one 80-B slot per (instance, sub-tile)
@@ -213,12 +203,8 @@ __global__ void __launch_bounds__(BLOCK, ROWS_WAVES) blend_bwd_rows_kernel(Blend
     __shared__ uint32_t s_wtot[BS / 64];                      // slots of each staging wave's 64 instances
     __shared__ int s_rowlast[16];                             // per row: the largest `last` of its 16 pixels
     __shared__ int s_max;
-    if (SPLIT) {
-        if (a.split == 1 && !device_picks_scan(a)) return;      // (the frames the scan walk used to take: wide footprints, few tiles)
-    } else {
-        if (a.variant == 2 && !auto_picks_rows(a)) return;
-        if ((a.scan_rule || a.split == 1) && device_picks_scan(a)) return;
-    }
+    if (a.variant == 2 && !auto_picks_rows(a)) return;
+    if (a.scan_rule && device_picks_scan(a)) return;
     if (frame_overflowed(a.n_dev, a.n_cap)) return;
 #ifdef ROWS_TIMING
     const long long tm_start = __builtin_readcyclecounter();
@@ -226,11 +212,8 @@ __global__ void __launch_bounds__(BLOCK, ROWS_WAVES) blend_bwd_rows_kernel(Blend
 #ifdef BLEND_TRACE
     const unsigned long long trace_t0 = wall_clock64();
 #endif
-    const bool lower = SPLIT && (blockIdx.x & 1u);
-    const int tile = block_tile(a.tile_map, a.map_flag, SPLIT ? (int)(blockIdx.x >> 1) : (int)blockIdx.x, a.gx * a.gy);
+    const int tile = block_tile(a.tile_map, a.map_flag, (int)blockIdx.x, a.gx * a.gy);
     if (tile < 0) return;
-    const bool ckpt_ok = SPLIT && a.ckpt && a.ckpt_flag[0] == 1u;      // the forward of THIS image buffer kept checkpoints
-    if (lower && (!ckpt_ok || (int)(a.ranges[tile].y - a.ranges[tile].x) <= SPLIT_MIN)) return;
     const int tx = tile % a.gx, ty = tile / a.gx;
     int lx, ly, sub;
     thread_pixel(threadIdx.x, lx, ly, sub);
@@ -246,10 +229,6 @@ __global__ void __launch_bounds__(BLOCK, ROWS_WAVES) blend_bwd_rows_kernel(Blend
         if ((threadIdx.x & 15) == 0) s_rowlast[srow] = m;
     }
     const int maxc = block_max(px.last, &s_max);              // (its barriers also publish s_rowlast)
-    const bool split = ckpt_ok && maxc > SPLIT_MIN;
-    if (lower && !split) return;
-    const int top = lower ? SPLIT_AT : maxc, lo = (split && !lower) ? SPLIT_AT : 0;      // this workgroup walks positions (lo, top]
-    if (lower) split_start(px, a.ckpt, tile);
 
     // which value of the row total this lane stores (row_reduce20): lane t of quad q holds value 4t + {0,2,1,3}[q] of z[t]
     const int t4 = lane & 3, quad = (lane >> 2) & 3;
@@ -267,8 +246,8 @@ __global__ void __launch_bounds__(BLOCK, ROWS_WAVES) blend_bwd_rows_kernel(Blend
 #endif
     float pf_touch = 0.f;                     // landing register of the prefetch touches (never read)
     uint32_t pf_id = 0;
-    for (int hi = top; hi > lo; hi -= BS) {
-        const int mb = min(BS, hi - lo);
+    for (int hi = maxc; hi > 0; hi -= BS) {
+        const int mb = min(BS, hi);
         asm volatile("s_waitcnt vmcnt(0)" : "+v"(pf_touch) :: "memory");      // the previous touch has landed: pf_touch may be rewritten
         __syncthreads();                      // previous batch fully flushed
         if (wave < BS / 64) {
@@ -298,15 +277,15 @@ __global__ void __launch_bounds__(BLOCK, ROWS_WAVES) blend_bwd_rows_kernel(Blend
                 const unsigned long long b = __ballot((ovr >> s) & 1u);
                 if (lane == 0) s_rmask[s][wave] = b;
             }
-        } else if (hi - lo > BS) {
+        } else if (hi > BS) {
             // waves 2-3 have nothing to stage: they fetch the NEXT batch's ids, and after the barrier (while everybody walks)
             // pull those records towards this XCD's L2 with one dword load each, so that the gathers of the next staging pass
             // overlap this batch's arithmetic instead of forming one burst with every other workgroup's
             const int t = (int)threadIdx.x - BS;
-            if (t < min(BS, hi - lo - BS)) pf_id = a.point_list[range.x + (hi - BS - t) - 1];
+            if (t < min(BS, hi - BS)) pf_id = a.point_list[range.x + (hi - BS - t) - 1];
         }
         __syncthreads();
-        if (wave >= BS / 64 && hi - lo > BS && (int)threadIdx.x - BS < min(BS, hi - lo - BS)) {
+        if (wave >= BS / 64 && hi > BS && (int)threadIdx.x - BS < min(BS, hi - BS)) {
             const float* ptr = a.rec + (size_t)pf_id * REC_F;
             asm volatile("global_load_dword %0, %1, off" : "+v"(pf_touch) : "v"(ptr) : "memory");
         }
@@ -405,9 +384,9 @@ __global__ void __launch_bounds__(BLOCK, ROWS_WAVES) blend_bwd_rows_kernel(Blend
     }
 #ifdef BLEND_TRACE
     #ifdef ROWS_TIMING
-    if (STATS) trace_wg(a.stats, 65536, trace_t0, tile, top - lo, tm_stage, tm_walk, tm_bar + tm_flush, tm_nvis);
+    if (STATS) trace_wg(a.stats, 65536, trace_t0, tile, maxc, tm_stage, tm_walk, tm_bar + tm_flush, tm_nvis);
 #else
-    if (STATS) trace_wg(a.stats, 65536, trace_t0, tile, top - lo);      // (slot = blockIdx: both halves of a split tile are recorded, each with the positions it walked)
+    if (STATS) trace_wg(a.stats, 65536, trace_t0, tile, maxc);
 #endif
 #endif
 #ifdef ROWS_TIMING
@@ -417,7 +396,7 @@ __global__ void __launch_bounds__(BLOCK, ROWS_WAVES) blend_bwd_rows_kernel(Blend
         atomicAdd(&a.stats[7], (unsigned long long)tm_bar);
     }
 #endif
-    if (!lower) finish_tail(a, range, maxc, tile, tx, ty);
+    finish_tail(a, range, maxc, tile, tx, ty);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -541,11 +520,7 @@ __global__ void __launch_bounds__(BLOCK) blend_bwd_quad_kernel(BlendBwdArgs a) {
 void launch_blend_bwd(const BlendBwdArgs& a, hipStream_t s) {
     const dim3 grid(a.map_len), block(BLOCK);
     if (a.variant == 3) { launch_blend_bwd_scan(a, s); return; }
-    if (a.split) {      // two workgroups per tile; split == 1: only where the device rule says so (the kernels below then return at once)
-        if (a.stats) hipLaunchKernelGGL((blend_bwd_rows_kernel<true, true>), dim3(2 * a.map_len), block, 0, s, a);
-        else hipLaunchKernelGGL((blend_bwd_rows_kernel<false, true>), dim3(2 * a.map_len), block, 0, s, a);
-        if (a.split == 2) return;
-    } else if (a.scan_rule) launch_blend_bwd_scan(a, s);      // (returns at once unless the device rule picks it; the kernels below do the opposite)
+    if (a.scan_rule) launch_blend_bwd_scan(a, s);      // (returns at once unless the device rule picks it; the kernels below do the opposite)
     if (a.variant != 1) {
         if (a.stats) hipLaunchKernelGGL(blend_bwd_rows_kernel<true>, grid, block, 0, s, a);
         else hipLaunchKernelGGL(blend_bwd_rows_kernel<false>, grid, block, 0, s, a);

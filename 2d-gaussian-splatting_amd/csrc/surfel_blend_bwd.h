@@ -81,31 +81,6 @@ __device__ __forceinline__ bool device_picks_scan(const BlendBwdArgs& a) {
     return R < (1ull << 26) && (R >= (1ull << 21) || R >= (unsigned long long)SCAN_MIN_INST_PER_SURFEL * v);
 }
 
-// List splitting (surfel_common.h: SPLIT_AT): the state a pixel's walk has when it arrives at list position SPLIT_AT from behind,
-// without walking the positions behind it.  T is the forward's checkpoint; the suffix sum X_s = T_f bg.gC + sum_{i > s} w_i u_i follows
-// from the forward's sums, because every term of u_i is (a per-pixel constant) x (a per-pair quantity the forward accumulates):
-//     sum w c = C_f - C_s,  sum w d = D_f - D_s,  sum w n = N_f - N_s,  sum w = T_s - T_f,  sum w m = M1_f - M1_s,  sum w m^2 = M2_f - M2_s.
-// (Differences of fp32 sums: the absolute error is that of the sequential walk's own running sum — tests/test_split_recurrence_cpu.py.)
-// A pixel whose last contributor lies at or before SPLIT_AT keeps load_pixel's start: nothing behind SPLIT_AT touched it.
-__device__ __forceinline__ void split_start(Pixel& p, const float* __restrict__ ckpt, int tile) {
-    if (p.last <= SPLIT_AT) return;
-    const float* c = ckpt + (size_t)tile * (CKPT_F * BLOCK) + threadIdx.x;
-    const float Ts = c[0];
-    const float dT = Ts - p.T;                                     // sum of the weights behind the split
-    const float dC0 = c[10 * BLOCK] - c[1 * BLOCK], dC1 = c[11 * BLOCK] - c[2 * BLOCK], dC2 = c[12 * BLOCK] - c[3 * BLOCK];
-    const float dD = c[13 * BLOCK] - c[4 * BLOCK];
-    const float dN0 = c[14 * BLOCK] - c[5 * BLOCK], dN1 = c[15 * BLOCK] - c[6 * BLOCK], dN2 = c[16 * BLOCK] - c[7 * BLOCK];
-    const float dM1 = p.fM1 - c[8 * BLOCK], dM2 = p.fM2 - c[9 * BLOCK];
-    float x = p.X;
-    x = FMA(p.gC0, dC0, x); x = FMA(p.gC1, dC1, x); x = FMA(p.gC2, dC2, x);
-    x = FMA(p.g_depth, dD, x);
-    x = FMA(p.gN0, dN0, x); x = FMA(p.gN1, dN1, x); x = FMA(p.gN2, dN2, x);
-    x = FMA(p.g_alpha, dT, x);
-    x = FMA(p.g_dist, FMA(p.final_A, dM2, FMA(-2.f * p.fM1, dM1, p.fM2 * dT)), x);
-    p.X = x;
-    p.T = Ts;
-}
-
 __device__ __forceinline__ int block_max(int v, int* s_max) {
     if (threadIdx.x == 0) *s_max = 0;
     __syncthreads();

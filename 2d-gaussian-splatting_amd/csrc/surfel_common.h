@@ -123,18 +123,6 @@ __device__ __forceinline__ void trace_wg(unsigned long long* stats, int slot_bas
 #define TRACE_TM(acc)
 #endif
 
-// ---- blend_bwd list splitting (round 4) ----------------------------------------------------------------------------------------
-// On frames with few work items (an object-centred 800x800 frame: ~1 000 non-empty tiles, all resident from t = 0) the backward lasts as
-// long as its longest tile's serial walk (profiles/r04_wg_trace.md).  With option bwd_split the forward leaves, for every tile whose
-// list is longer than SPLIT_AT, each pixel's PREFIX state behind list position SPLIT_AT and its final sums; a second workgroup of the
-// backward can then start in the middle of the list: T from the checkpoint, the suffix sum X from differences of forward sums
-// (surfel_blend_bwd.h: split_start; the arithmetic is tests/test_split_recurrence_cpu.py).  Exact and tested — and worth only 3 % on the
-// frames it was built for, whose tiles already fill every resident slot (r04_wg_trace.md section 5): off by default.
-constexpr int SPLIT_AT = 256;            // list position behind which the forward checkpoints a pixel's state
-constexpr int SPLIT_MIN = 320;           // tiles whose deepest composited position exceeds this are walked by two workgroups
-constexpr int SPLIT_MAX_TILES = 4096;    // frames with more tiles are throughput-bound anyway: no checkpoint buffer (17 KB per tile)
-constexpr int CKPT_F = 17;               // floats per pixel: [0] T [1..3] C [4] D [5..7] N [8] M1 [9] M2 behind SPLIT_AT | [10..12] C [13] D [14..16] N at the end
-
 struct Rect { int x0, y0, x1, y1; };
 
 __device__ __forceinline__ Rect tile_rect(float px, float py, int r, int gx, int gy) {

@@ -13,21 +13,6 @@ namespace surfel {
 // blends FOUR different instances per pass of the loop body, and a small surfel occupies issue slots only where
 // it can contribute.  Per-pixel order is the staged (depth) order, so results equal the whole-tile walk.
 // ---------------------------------------------------------------------------------------------
-// blend_bwd's list-splitting checkpoints (surfel_common.h: SPLIT_AT): the pixel's running sums behind list position SPLIT_AT, and its
-// final raw sums (the colour output has the background folded in, and re-deriving the sum from it would round) — [tile][k][thread]
-__device__ __forceinline__ void store_ckpt_prefix(float* ckpt, int tile, float T, float C0, float C1, float C2, float D,
-                                                  float N0, float N1, float N2, float M1, float M2) {
-    unsigned t = threadIdx.x;
-    asm volatile("" : "+v"(t));      // (the address is computed HERE: hoisted out of the caller's loop it occupies registers through the walk — 96 -> 101 VGPRs, a wave per SIMD)
-    float* c = ckpt + (size_t)__builtin_amdgcn_readfirstlane(tile) * (CKPT_F * BLOCK) + t;
-    c[0 * BLOCK] = T; c[1 * BLOCK] = C0; c[2 * BLOCK] = C1; c[3 * BLOCK] = C2; c[4 * BLOCK] = D;
-    c[5 * BLOCK] = N0; c[6 * BLOCK] = N1; c[7 * BLOCK] = N2; c[8 * BLOCK] = M1; c[9 * BLOCK] = M2;
-}
-__device__ __forceinline__ void store_ckpt_final(float* ckpt, int tile, float C0, float C1, float C2, float D, float N0, float N1, float N2) {
-    float* c = ckpt + (size_t)tile * (CKPT_F * BLOCK) + threadIdx.x;
-    c[10 * BLOCK] = C0; c[11 * BLOCK] = C1; c[12 * BLOCK] = C2; c[13 * BLOCK] = D; c[14 * BLOCK] = N0; c[15 * BLOCK] = N1; c[16 * BLOCK] = N2;
-}
-
 constexpr int MW = 8;             // 32-bit mask words per staged batch of 256
 constexpr int MSTRIDE = MW + 2;   // + zero sentinel word, padded so each sub-tile's words start 8-B aligned
 
@@ -39,7 +24,6 @@ __global__ void __launch_bounds__(BLOCK) blend_fwd_kernel(BlendFwdArgs a) {
     const unsigned long long trace_t0 = wall_clock64();
     long long ttm_t = __builtin_readcyclecounter(), ttm_stage = 0, ttm_walk = 0, ttm_bar = 0, ttm_it = 0, ttm_s0 = 0, ttm_s1 = 0, ttm_s2 = 0;
 #endif
-    if (a.ckpt && blockIdx.x == 0 && threadIdx.x == 0) *a.ckpt_flag = 1u;      // this frame's image buffer carries checkpoints
     const int tile = block_tile(a.tile_map, a.map_flag, blockIdx.x, a.gx * a.gy);      // (tile_order_kernel: XCD-contiguous runs on uniform frames, longest lists first otherwise)
     if (tile < 0) return;
     const int tx = tile % a.gx, ty = tile / a.gx;
@@ -143,8 +127,6 @@ __global__ void __launch_bounds__(BLOCK) blend_fwd_kernel(BlendFwdArgs a) {
             if (cur == 0u && widx < nw - 1) { widx++; cur = next; next = mrow[widx + 1]; }
         }
         TRACE_TM(ttm_walk)
-        static_assert(SPLIT_AT == BLOCK, "the checkpoint sits behind this kernel's first batch");
-        if (base == 0 && n > SPLIT_AT && a.ckpt) store_ckpt_prefix(a.ckpt, tile, T, C0, C1, C2, D, N0, N1, N2, M1, M2);
     }
 #ifdef BLEND_TRACE
     if (STATS) trace_wg(a.stats, 0, trace_t0, tile, n, (ttm_s0 << 40) | (ttm_s1 << 20) | ttm_s2, ttm_walk, (ttm_stage << 24) | ttm_bar, ttm_it);
@@ -154,7 +136,6 @@ __global__ void __launch_bounds__(BLOCK) blend_fwd_kernel(BlendFwdArgs a) {
         for (int o = 32; o > 0; o >>= 1) npairs += __shfl_xor(npairs, o);
         if (lane == 0) atomicAdd(&a.stats[6], (unsigned long long)npairs);
     }
-    if (n > SPLIT_AT && a.ckpt) store_ckpt_final(a.ckpt, tile, C0, C1, C2, D, N0, N1, N2);
     if (inside) {
         const size_t HW = (size_t)a.H * a.W;
         const size_t pix = (size_t)pyi * a.W + pxi;
@@ -235,7 +216,6 @@ __global__ void __launch_bounds__(BLOCK) blend_fwd_pipe_kernel(BlendFwdArgs a) {
     const unsigned long long trace_t0 = wall_clock64();
     long long ttm_t = __builtin_readcyclecounter(), ttm_stage = 0, ttm_walk = 0, ttm_bar = 0, ttm_it = 0;
 #endif
-    if (a.ckpt && blockIdx.x == 0 && threadIdx.x == 0) *a.ckpt_flag = 1u;
     const int tile = block_tile(a.tile_map, a.map_flag, blockIdx.x, a.gx * a.gy);
     if (tile < 0) return;
     const int tx = tile % a.gx, ty = tile / a.gx;
@@ -307,8 +287,6 @@ __global__ void __launch_bounds__(BLOCK) blend_fwd_pipe_kernel(BlendFwdArgs a) {
         TRACE_TM(ttm_bar)
         for (int base = 0, buf = 0; base < n; base += NB, buf ^= 1) {
             const bool more = base + NB < n;
-            static_assert(SPLIT_AT % NB == 0, "the checkpoint sits on a batch boundary");
-            if (base == SPLIT_AT && a.ckpt) store_ckpt_prefix(a.ckpt, tile, T, C0, C1, C2, D, N0, N1, N2, M1, M2);      // (n > SPLIT_AT, and somebody is still blending)
             if (more) {      // next batch's records (their ids landed with this batch's records), and the ids of the batch behind it
                 issue(base + NB, buf ^ 1);
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -414,7 +392,6 @@ __global__ void __launch_bounds__(BLOCK) blend_fwd_pipe_kernel(BlendFwdArgs a) {
         for (int o = 32; o > 0; o >>= 1) npairs += __shfl_xor(npairs, o);
         if (lane == 0) atomicAdd(&a.stats[6], (unsigned long long)npairs);
     }
-    if (n > SPLIT_AT && a.ckpt) store_ckpt_final(a.ckpt, tile, C0, C1, C2, D, N0, N1, N2);
     if (inside) {
         const size_t HW = (size_t)a.H * a.W;
         const size_t pix = (size_t)pyi * a.W + pxi;

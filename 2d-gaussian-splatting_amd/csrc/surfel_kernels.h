@@ -28,8 +28,6 @@ struct BlendFwdArgs {
     const int* tile_map; const uint32_t* map_flag; int map_len;      // tile of every workgroup where map_flag[0] != 0 (tile_order_kernel; -1: none), xcd_tile order otherwise; the grid size
     unsigned long long* stats;   // optional [8]: [6] += (pixel, surfel) pairs composited (surfel_debug_set_blend_stats)
     int avg_list;                // instances per tile where the host knows the count (exact binning path), else 0: picks the kernel (speed only)
-    float* ckpt;                 // [tiles][CKPT_F][256] per-pixel checkpoints for blend_bwd's list splitting, or NULL (surfel_common.h)
-    uint32_t* ckpt_flag;         // device word (zeroed with the frame's head): set to 1 by the forward when it maintains `ckpt`
 };
 
 struct BlendBwdArgs {
@@ -43,8 +41,6 @@ struct BlendBwdArgs {
     uint8_t* has_rec;      // with cut: [P] zeroed by the caller; set for every surfel that gets at least one record (preprocess_bwd skips the others)
     const float* depths;   // [P] view depths (the sort key's source)
     int variant;      // 0: per-DPP-row walk, 1: per-wave (8x8 quad) walk, 2: both launched, the device picks from the frame's totals (0 / 1 / 2 bit-identical); 3: scan walk
-    const float* ckpt; const uint32_t* ckpt_flag;      // the forward's checkpoints (BlendFwdArgs) and the word that says they exist; NULL: no splitting
-    int split;        // 1: the rows kernel is launched with TWO workgroups per tile; blocks 2 i / 2 i + 1 for map entry i; the odd one walks list positions [1, SPLIT_AT] of tiles deeper than SPLIT_MIN
     int scan_rule;    // 1: the scan kernel AND the rows / quad kernel selected by `variant` are launched; the device decides from `totals` which one runs (surfel_blend_bwd.h: device_picks_scan)
     const uint32_t* totals;      // [2 * R_SLOTS] partial sums written by preprocess: tile instances | visible surfels
     const uint32_t* n_dev; uint32_t n_cap;      // capacity path: the frame's instance total on the device and the record capacity (= num_rendered).  n_dev[0] > n_cap:

@@ -186,23 +186,6 @@ int surfel_debug_sort_pairs(surfel_alloc_fn scratch_alloc, void* scratch_user, u
  *   "fwd_pipe" (default 1): blend forward kernel — 1: software-pipelined staging (LDS-DMA of the next batch's whole records under the
  *          walk, per-row byte lists, LDS prefetch of the next visit; DESIGN.md section 4 "Round 4"), 0: round 3's batch-synchronous kernel.
  *          Same walk, same per-pair arithmetic: bit-identical outputs (tests/test_gpu_parity.py::test_forward_kernels_are_identical).
- *   "bwd_split" (default 0): blend-backward LIST SPLITTING (round 4; measured at parity with the scan walk, hence off — DESIGN.md section 4).
- *          != 0: frames of <= 4096 tiles get per-pixel checkpoints at the end of their image buffer (17 KB per tile; written by blend_fwd
- *          for tiles whose list is longer than 256: the running sums behind list position 256 and the final raw sums).  1: under
- *          bwd_variant = auto, on frames below 2^21 tile instances that the device rule would hand to the scan walk (>= 6 instances per
- *          emitting surfel: object-centred / trained frames — few non-empty tiles, all resident at once, the launch as long as the longest
- *          list), the per-row walk is launched with TWO workgroups per tile instead: tiles whose deepest composited position exceeds 320
- *          are walked as (256, end] and [1, 256] concurrently, the second from the checkpoint.  A rule on the frame (bits follow from the
- *          frame alone); agrees with the unsplit walk to fp32 summation noise where a tile is split and bit for bit elsewhere
- *          (tests/test_gpu_parity.py::test_list_splitting_matches_the_unsplit_walk).  2: split on every frame below 2^21 instances (tests).
- *          The option sizes the image buffer; a backward that finds no checkpoints in its image buffer (device flag set by the forward)
- *          walks unsplit, whatever the option says by then.
- *          PRECISION: the second workgroup's start value holds the distortion term as a difference of the forward's own sums M1, M2 — a
- *          variance-like form whose large terms cancel: ~1.3e-6 x (the distortion gradient) absolute.  At parity while the distortion
- *          gradient is of the order of the colour gradient (every GPU test); NOT with the reference's DTU settings (lambda_dist = 1000: the
- *          distortion gradient is thousands of times the colour gradient) — there the checkpoints must carry sums centred on the first
- *          instance's depth map value, which restores parity at any ratio (tests/test_split_recurrence_cpu.py shows both).  Not a default
- *          before that.
  *   "fat_sort" (default 1): look-back sort passes over <= 2^20 items use 8192-item tiles staged through LDS (0: 2048-item tiles);
  *          "host_total" (default 1): capacity-path frames store their instance total into mapped pinned memory from the emission
  *          kernel (0: a device-to-host copy in the stream).  Speed only (tests/test_gpu_parity.py::test_radix_sort_is_stable_and_exact
@@ -264,9 +247,8 @@ int surfel_debug_last_binning(void);
 int surfel_debug_capacity_evictions(void);
 
 /* Debug: byte offsets inside the image buffer of a width x height frame under the current options (host arithmetic, no device needed):
- * out[0] total size, [1] final_T / M1 / M2 planes, [2] last / median contributor planes, [3] tile map, [4] list-splitting checkpoints
- * ("bwd_split"; -1: none), [5] the word that says whether the forward wrote checkpoints.  The tile ranges start at offset 0.  For the
- * white-box tests and statistics scripts that read the buffer (diff_surfel_rasterization.image_layout mirrors it). */
+ * out[0] total size, [1] final_T / M1 / M2 planes, [2] last / median contributor planes, [3] tile map.  The tile ranges start at
+ * offset 0.  For the white-box tests and statistics scripts that read the buffer (diff_surfel_rasterization.image_layout mirrors it). */
 int surfel_debug_image_layout(int width, int height, int64_t* out);
 
 /* Debug: the walk the "bwd_tune" probes currently favour for frames of this size on the current device (the most used entry of

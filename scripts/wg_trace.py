@@ -92,21 +92,6 @@ def main():
             out = summarise(raw[k], name)
             out["workload"] = wl
             print(json.dumps(out), flush=True)
-        if "--split" in sys.argv:      # SURFEL_OPTIONS=bwd_split=2: odd blocks are the lower halves ([1, 256] from the checkpoint), even blocks the upper halves / unsplit tiles
-            W, H = TRAINED_PRESETS[wl]["res"] if wl in TRAINED_PRESETS else synthetic.CONFIGS[wl][1:3]
-            gx, gy = (W + 15) // 16, (H + 15) // 16
-            map_len = 32 * ((((gx + 3) // 4) * gy + 7) // 8)
-            base = raw[1][:, 0][raw[1][:, 1] > 0].astype(np.int64).min()
-            for nm, part in (("lower halves", raw[1][1:2 * map_len:2]), ("upper halves and unsplit tiles", raw[1][0:2 * map_len:2])):
-                d = part[(part[:, 1] > 0) & ((part[:, 3] >> 32) > 0)].astype(np.int64)
-                if d.shape[0] == 0:
-                    continue
-                s0, e0, nn = (d[:, 0] - base) * 0.01, (d[:, 1] - base) * 0.01, d[:, 3] >> 32
-                print(json.dumps({"workload": wl, "part": nm, "workgroups": int(d.shape[0]), "positions_p50_max": [int(np.median(nn)), int(nn.max())],
-                                  "start_us_p50_p90_max": [round(float(np.percentile(s0, q)), 1) for q in (50, 90, 100)],
-                                  "dur_us_p50_p90_max": [round(float(np.percentile(e0 - s0, q)), 1) for q in (50, 90, 100)],
-                                  "end_us_p50_max": [round(float(np.percentile(e0, q)), 1) for q in (50, 100)],
-                                  "ns_per_position_p50": round(float(np.median(1e3 * (e0 - s0) / np.maximum(1, nn))), 1)}), flush=True)
         del tr
         import diff_surfel_rasterization as dsr
         dsr.set_grad_arena(None)

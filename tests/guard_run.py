@@ -133,16 +133,15 @@ def main():
         chk(hip.hipDeviceSynchronize(), "sync after the redo")
         print("overflow ok: capacity %d, exact count %d, granularity %d" % (cap, R, G), flush=True)
         return
-    if sys.argv[1] == "split":
-        # blend_bwd list splitting: lists of ~700 faint instances per tile, every tile walked by two workgroups, the second one started from
-        # the forward's checkpoints — the last array of the image buffer, which ends at the end of its mapping
+    if sys.argv[1] == "long":
+        # lists of ~700 faint instances per tile (several staged batches per tile, the prefetch of the batch behind the last one, the
+        # records of the deepest positions): forward kernel argv[2], backward walk argv[3]
         lib.surfel_set_option(b"fwd_pipe", int(sys.argv[2]))
-        lib.surfel_set_option(b"bwd_split", 2)
         fr = Frame(lib, 60000, 160, 128, 6.0, seed=12, opacity=0.015, z_near=1.0, z_far=9.0)
         for rep in range(3):
             R = fr.forward(n.opt_tile_sort(2))
             chk(hip.hipDeviceSynchronize(), "sync after forward")
-            fr.backward(R, 0)
+            fr.backward(R, flags[int(sys.argv[3])])
             chk(hip.hipDeviceSynchronize(), "sync after backward")
             print("rep %d ok: R=%d binning=%d granularity=%d" % (rep, R, lib.surfel_debug_last_binning(), G), flush=True)
         return

@@ -153,26 +153,17 @@ def test_surfel_options_environment_hook():
 
 def test_image_layout_mirror_matches_the_library():
     """diff_surfel_rasterization.image_layout (what the white-box GPU tests and scripts/tile_lists.py read the image buffer with) against
-    ImgState::carve itself, with and without the list-splitting checkpoints at the buffer's end."""
+    ImgState::carve itself."""
     import ctypes
     import surfel_native
     import diff_surfel_rasterization as dsr
     lib = surfel_native.load()
     lib.surfel_debug_image_layout.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_int64)]
     out = (ctypes.c_int64 * 6)()
-    try:
-        for split in (0, 1):
-            assert lib.surfel_set_option(b"bwd_split", split) == 0
-            for W, H in [(1, 1), (16, 16), (72, 56), (800, 800), (800, 600), (1600, 1060), (1920, 1080), (3840, 2160), (1023, 1025)]:
-                assert lib.surfel_debug_image_layout(W, H, out) == 0
-                gx, gy, final_T, n_contrib, tile_map = dsr.image_layout(W, H)
-                assert (out[1], out[2], out[3]) == (final_T, n_contrib, tile_map), (W, H, list(out))
-                assert out[5] == (gx * gy + 64) * 8 + 8 and out[5] + 4 <= final_T      # behind the tile-map flag, inside the zeroed head
-                tiles = gx * gy
-                if split and tiles <= 4096:
-                    assert out[4] > tile_map and out[0] >= out[4] + tiles * 17 * 256 * 4 and out[0] - (out[4] + tiles * 17 * 256 * 4) < 256
-                else:
-                    assert out[4] == -1 and out[0] < tile_map + 4 * 32 * (tiles // 8 + 64) + 256
-        assert lib.surfel_debug_image_layout(0, 4, out) < 0
-    finally:
-        lib.surfel_set_option(b"bwd_split", 0)
+    for W, H in [(1, 1), (16, 16), (72, 56), (800, 800), (800, 600), (1600, 1060), (1920, 1080), (3840, 2160), (1023, 1025)]:
+        assert lib.surfel_debug_image_layout(W, H, out) == 0
+        gx, gy, final_T, n_contrib, tile_map = dsr.image_layout(W, H)
+        assert (out[1], out[2], out[3]) == (final_T, n_contrib, tile_map), (W, H, list(out))
+        tiles = gx * gy
+        assert tile_map < out[0] < tile_map + 4 * 32 * (tiles // 8 + 64) + 256
+    assert lib.surfel_debug_image_layout(0, 4, out) < 0

@@ -32,9 +32,9 @@ def test_backward_of_an_overflowed_lazy_frame_touches_nothing(variant):
     assert "overflow ok" in _run("overflow", variant)
 
 
-@pytest.mark.parametrize("pipe", [1, 0])
-def test_list_splitting_stays_inside_the_image_buffer(pipe):
-    """blend_bwd list splitting: the forward's checkpoints (last array of the image buffer) written by either blend_fwd kernel and read
-    by the second workgroup of every tile, with unmapped pages right behind them"""
-    out = _run("split", pipe)
+@pytest.mark.parametrize("pipe,variant", [(1, 0), (0, 3), (1, 3)])
+def test_long_lists_stay_inside_their_buffers(pipe, variant):
+    """lists of ~700 faint instances per tile: several staged batches per tile in both blend directions, the prefetch of the batch
+    behind a tile's last one, with unmapped pages right behind every buffer"""
+    out = _run("long", pipe, variant)
     assert out.count(" ok: R=") == 3, out

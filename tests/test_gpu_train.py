@@ -981,8 +981,8 @@ def test_view_parallel_step_rehearsed_on_rccl_with_early_gather():
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("ratio,white", [(0.3, False), (1.0, True)])
-def test_whole_training_iterations_match_the_oracle_chain(ratio, white):
+@pytest.mark.parametrize("ratio,white,lam_dist", [(0.3, False, 100.0), (1.0, True, 1000.0), (1.0, False, 1000.0)])
+def test_whole_training_iterations_match_the_oracle_chain(ratio, white, lam_dist):
     """Three complete training iterations (train.py:54-138) of the HIP trainer against the same iterations composed from the CPU
     oracles, every stage in fp64: oracle rasterizer forward -> L1 + SSIM and allmap post-processing + regularisers
     (oracle/train_oracle.py, pinned to the reference's own Python) -> oracle rasterizer backward -> the reference's Adam set-up
@@ -1006,7 +1006,8 @@ def test_whole_training_iterations_match_the_oracle_chain(ratio, white):
     m.spatial_lr_scale = 2.0
     raw0 = {k: m._pv[k].detach().cpu().numpy().astype(np.float64).copy() for k in ("xyz", "opacity", "scaling", "rotation")}
     sh0 = m._pv["sh"].detach().cpu().numpy().astype(np.float64).reshape(P, 16, 3).copy()
-    opt = TR.optimization_params(lambda_dist=100.0, lambda_normal=0.05, dist_from_iter=0, normal_from_iter=0, densify_from_iter=10 ** 9,
+    # (lam_dist = 1000, depth_ratio = 1: the reference's DTU configuration, /root/reference/scripts/dtu_eval.py:23)
+    opt = TR.optimization_params(lambda_dist=lam_dist, lambda_normal=0.05, dist_from_iter=0, normal_from_iter=0, densify_from_iter=10 ** 9,
                                  opacity_reset_interval=10 ** 9)
     tr = TR.Trainer(m, cams, opt, TR.pipeline_params(depth_ratio=ratio), white_background=white)
     hip_scalars = []

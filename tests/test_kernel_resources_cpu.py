@@ -15,8 +15,7 @@ sys.path.insert(0, os.path.join(REPO, "scripts"))
 LIMITS = {
     "blend_fwd_pipe_kernel<false>": (96, 32 * 1024),           # 5 waves / SIMD, 5 workgroups / CU
     "blend_fwd_kernel<false>": (96, 32 * 1024),
-    "blend_bwd_rows_kernel<false, false>": (96, 32 * 1024),
-    "blend_bwd_rows_kernel<false, true>": (96, 32 * 1024),     # the list-splitting instance
+    "blend_bwd_rows_kernel<false>": (96, 32 * 1024),
     "blend_bwd_quad_kernel<false>": (96, 32 * 1024),
     "blend_bwd_scan_kernel<false>": (168, 160 * 1024 // 3),    # 3 waves / SIMD, 3 workgroups / CU
 }
