@@ -9,7 +9,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "lib", "libsurfel_hip.so")
-SOURCES = ["surfel_preprocess.hip", "surfel_forward.hip", "surfel_backward.hip", "surfel_backward_scan.hip", "surfel_sort.hip", "surfel_api.hip", "knn.hip",
+SOURCES = ["surfel_preprocess.hip", "surfel_forward.hip", "surfel_backward.hip", "surfel_backward_scan.hip", "surfel_sort.hip", "surfel_api.hip", "knn.hip", "box_probe.hip",
            "train_loss.hip", "train_post.hip", "train_fused.hip", "train_optim.hip", "train_api.hip"]
 # blend kernels: packed-f32 VALU (SLP) costs ~1.6x a scalar op on gfx950 plus the v_movs that pair the operands
 # surfel_backward.hip spells every fused multiply-add out (FMA macro) and is compiled with contraction off, so its kernel variants

@@ -238,6 +238,13 @@ def main():
     PRIME = 15      # set-up iterations before the contract's W warm-up steps: allocator high-water marks, binning-path heuristic, clocks
     for _ in range(PRIME):
         tr.step()
+    probe = None
+    if rank == 0:      # what this box sustains, in this process, right before the timed window (helpers_bench.box_probe)
+        try:
+            from helpers_bench import box_probe
+            probe = box_probe(dev)
+        except Exception as e:      # noqa: BLE001 — an extra must not cost the run its headline
+            probe = {"error": repr(e)}
     tr.pipe.debug = 3       # HIP events around the dominant kernel only (blend_bwd), resolved after the timed region, no sync
     tr.time_exchange = world > 1     # N > 1: events around the stream waits on the collectives -> exposed exchange time
 
@@ -319,7 +326,9 @@ def main():
         roof = roofline_object(per_kernel, args.workload, P, V, R, Rs, W, H, n_pass)
         out = {"metric": "train iters/sec (full iteration: rasterizer fwd+bwd, L1+SSIM, normal+dist regularisers, Adam) + fwd Msplats/s @1080p",
                "value": round(iters_per_s, 3), "unit": "train-iters/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-               "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "strong" if bands else "weak", "vs_baseline": None,
+               "ms_per_step": round(ms_per_step, 4),
+               "ms_per_step_normalised": (round(ms_per_step / probe["slowdown_vs_reference_box"], 4) if probe and "slowdown_vs_reference_box" in probe else None),
+               "box_probe": probe, "higher_is_better": True, "scaling": "strong" if bands else "weak", "vs_baseline": None,
                "dtype": "f32", "data": "synthetic",
                "config": {"workload": (trained_info["workload"] + "; steady-state iteration, every loss term on") if trained_info else
                                       "%s-synthetic: %d random surfels, %dx%d, sh_degree 3, %d target views rendered from the unperturbed "

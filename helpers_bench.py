@@ -309,6 +309,65 @@ def trained_leg(dev, preset="trained", steps=30, warmup=5, state=None):
     return out
 
 
+# Reference box of `ms_per_step_normalised`: the probe values of a FAST box of the pool (round 5's calibration run,
+# profiles/r05_box_probe_calibration.json) and the split of the C2 step by what bounds its kernels (profiles/r04_C2_kernel_stats.csv:
+# blend fwd + bwd = issue-bound, binning + loss + small launches = latency-bound, Adam + preprocess fwd / bwd = HBM-bound).
+BOX_REF = {"valu_Ginst_per_s": 772.0, "sort_512k_us": 52.8, "hbm_copy_GBps": 5313.0, "launch_us": 2.46}
+STEP_SPLIT = {"valu": 0.48, "latency": 0.27, "hbm": 0.25}
+
+
+def box_probe(dev):
+    """What THIS box sustains, measured before the timed window: HBM copy GB/s, the cost of a dependent launch boundary,
+    the wave-instruction rate and shader clock of independent v_fma_f32 streams (include/surfel_hip.h: surfel_debug_box_probe), and a
+    fixed 0.5 M-pair tile sort (two look-back passes of the product's own sort on 12-bit keys: the latency-bound stage that stretched
+    26 - 29 % on round 4's driver box).  `slowdown_vs_reference_box` = the factor by which a C2 step is expected to be longer on this
+    box than on the reference box, from the three classes of kernels the step consists of (STEP_SPLIT)."""
+    import ctypes as C
+    import torch
+    import surfel_native as n
+    lib = n.load()
+    scratch = torch.zeros(1 << 17, dtype=torch.uint8, device=dev)
+    out = (C.c_float * 8)()
+    s = n.current_stream_ptr(dev)
+    res = {}
+    with torch.cuda.device(dev):
+        for _ in range(2):      # (first call: code upload)
+            rc = lib.surfel_debug_box_probe(n.ptr(scratch), scratch.numel(), out, s)
+        if rc != 0:
+            return {"error": n.last_error()}
+        res.update({"launch_us": round(out[0], 3), "valu_Ginst_per_s": round(out[1], 1), "valu_Ginst_per_s_in_kernel_span": round(out[5], 1),
+                    "shader_clock_GHz_under_fma_grid": round(out[2], 3), "fma_cycles_per_wave_inst_per_simd": round(out[4], 3)})
+        # the fixed sort: 512 Ki (key, value) pairs, 12-bit keys (an 800x800 frame's tile ids), the product's own passes
+        N = 1 << 19
+        g = torch.Generator(device="cpu").manual_seed(1)
+        keys0 = torch.randint(0, 2500, (N,), generator=g, dtype=torch.int32).to(dev)
+        vals0 = torch.arange(N, dtype=torch.int32, device=dev)
+        alloc = n.TorchAllocator(dev)
+        times = []
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        for k in range(12):
+            keys, vals = keys0.clone(), vals0.clone()
+            e0.record()
+            rc = lib.surfel_debug_sort_pairs(alloc.cb, None, n.ptr(keys), n.ptr(vals), N, 0, 12, s)
+            e1.record()
+            torch.cuda.synchronize()
+            if rc != 0:
+                return {"error": n.last_error()}
+            if k >= 2:
+                times.append(e0.elapsed_time(e1) * 1e3)
+        res["sort_512k_us"] = round(float(np.median(times)), 2)
+        assert bool((keys[1:] >= keys[:-1]).all())
+    cp = copy_bandwidth(dev, mbytes=512, iters=8)
+    res["hbm_copy_GBps"] = cp["GBps_read_plus_write"]
+    r = BOX_REF
+    res["reference_box"] = dict(r)
+    res["slowdown_vs_reference_box"] = round(STEP_SPLIT["valu"] * r["valu_Ginst_per_s"] / max(res["valu_Ginst_per_s"], 1e-3)
+                                             + STEP_SPLIT["latency"] * res["sort_512k_us"] / r["sort_512k_us"]
+                                             + STEP_SPLIT["hbm"] * r["hbm_copy_GBps"] / max(res["hbm_copy_GBps"], 1e-3), 4)
+    res["step_split_assumed"] = dict(STEP_SPLIT)
+    return res
+
+
 def copy_bandwidth(dev, mbytes=1024, iters=10):
     """Same-run HBM copy probe (SURVEY 8d): device-to-device copy of a buffer far larger than the 256 MB Infinity Cache;
     GB/s counts bytes read + written."""

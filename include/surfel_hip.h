@@ -251,6 +251,14 @@ int surfel_debug_capacity_evictions(void);
  * offset 0.  For the white-box tests and statistics scripts that read the buffer (diff_surfel_rasterization.image_layout mirrors it). */
 int surfel_debug_image_layout(int width, int height, int64_t* out);
 
+/* Debug / bench: what THIS GPU sustains, independent of the product's kernels (csrc/box_probe.hip) — 256 dependent empty launches, and a
+ * grid of independent v_fma_f32 streams at 8 waves per SIMD timed with events on `stream` (the call synchronises).  scratch: >= 128 KiB of
+ * device memory.  out[0] us per dependent launch boundary, [1] G wave-instructions / s of the FMA grid (whole chip, by events), [2] shader
+ * clock that grid sustained in GHz (s_memtime ticks per 100 MHz s_memrealtime tick), [3] ms of the FMA grid, [4] shader cycles per
+ * wave-instruction per SIMD over the grid's own span (nominal 2), [5] G wave-instructions / s over that span.  bench.py prints them as `box_probe` so that runs on different boxes of a pool can
+ * be compared.  No reference counterpart. */
+int surfel_debug_box_probe(void* scratch, int64_t scratch_bytes, float* out6, void* stream);
+
 /* Debug: the walk the "bwd_tune" probes currently favour for frames of this size on the current device (the most used entry of
  * that size) — 0 per-row, 1 per-quad, -1 not decided yet (fewer than two timed calls have completed). */
 int surfel_debug_walk_choice(int width, int height);

@@ -6,6 +6,7 @@
 #   fetch/   --pmc FETCH_SIZE   (own pass: FETCH_SIZE takes 3 of the 4 TCC slots)
 #   write/   --pmc WRITE_SIZE   (own pass)
 #   sq/      --pmc SQ_* issue/wait counters
+#   grbm/    --pmc GRBM_GUI_ACTIVE (+ that pass's own kernel trace) -> effective clock per kernel
 #   sq2/     (full only) lanes enabled per VALU instruction, wait breakdown
 # PMC passes never combine with sys/hip/hsa trace domains (only --kernel-trace is implied by rocprofv3 itself).
 # The blend-backward walk is FORCED (SURFEL_OPTIONS=bwd_variant=<walk>,bwd_tune=0; default rows) in every pass: with the tuner on,
@@ -30,6 +31,8 @@ timeout 200 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -o p --
 timeout 200 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/write -o p -- python $ROOT/bench.py $SHORT > $OUT/bench_write.log 2>&1
 timeout 200 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_INST_ANY SQ_LDS_BANK_CONFLICT \
     --output-format csv -d $OUT/sq -o p -- python $ROOT/bench.py $SHORT > $OUT/bench_sq.log 2>&1
+# effective shader clock per kernel: GRBM_GUI_ACTIVE / kernel wall time (MI355X_MICROARCH.md "DVFS give-back"); its kernel trace stays
+timeout 200 rocprofv3 --pmc GRBM_GUI_ACTIVE --output-format csv -d $OUT/grbm -o p -- python $ROOT/bench.py $SHORT > $OUT/bench_grbm.log 2>&1
 if [ "$MODE" = "full" ]; then
 # lanes enabled per VALU instruction (the hardware's VALUUtilization; EXEC-enabled lanes, not lanes doing useful work: see
 # profiles/r02_blend_bwd_variants.md) + wait breakdown

@@ -49,6 +49,38 @@ def pmc_means(d):
     return {k: dict({c: sum(v) / len(v) for c, v in cs.items()}, launches=max(len(v) for v in cs.values())) for k, cs in acc.items()}
 
 
+def eff_clock(d):
+    """{kernel: (mean GRBM_GUI_ACTIVE per launch, mean duration ns, GHz)} from the grbm pass: busy cycles of the graphics clock domain
+    per dispatch / the dispatch's wall time = the shader clock the kernel actually ran at (MI355X_MICROARCH.md "DVFS give-back").
+    rocprofv3 reports the counter summed over the 8 XCDs (every XCD's GRBM counts while any of the dispatch is in flight): a ratio
+    above 4 cycles per ns is divided by 8 and flagged."""
+    f = one(os.path.join(d, "**", "*counter_collection.csv"))
+    if not f:
+        return {}
+    rows = list(csv.DictReader(open(f)))
+    dur = {}
+    if rows and "Start_Timestamp" in rows[0] and "End_Timestamp" in rows[0]:
+        for r in rows:
+            dur[r["Dispatch_Id"]] = float(r["End_Timestamp"]) - float(r["Start_Timestamp"])
+    else:
+        kt = one(os.path.join(d, "**", "*kernel_trace.csv"))
+        if kt:
+            for r in csv.DictReader(open(kt)):
+                dur[r.get("Dispatch_Id", r.get("Correlation_Id"))] = float(r["End_Timestamp"]) - float(r["Start_Timestamp"])
+    acc = collections.defaultdict(list)
+    for r in rows:
+        if r["Counter_Name"] != "GRBM_GUI_ACTIVE" or r["Dispatch_Id"] not in dur or dur[r["Dispatch_Id"]] <= 0:
+            continue
+        acc[short(r["Kernel_Name"])].append((float(r["Counter_Value"]), dur[r["Dispatch_Id"]]))
+    out = {}
+    for k, v in acc.items():
+        v = v[len(v) // 4:] if len(v) >= 8 else v      # (drop the cold first quarter)
+        c, t = sum(x[0] for x in v) / len(v), sum(x[1] for x in v) / len(v)
+        ghz = c / t
+        out[k] = {"GRBM_GUI_ACTIVE": c, "grbm_pass_duration_ns": t, "xcd_summed": ghz > 4.0, "eff_clock_GHz": round(ghz / 8.0 if ghz > 4.0 else ghz, 3)}
+    return out
+
+
 def main():
     tag = sys.argv[1]
     wl = sys.argv[2] if len(sys.argv) > 2 else "C2"
@@ -79,6 +111,8 @@ def main():
     for sub in ("fetch", "write", "sq", "sq2"):
         for k, cs in pmc_means(os.path.join(src, sub)).items():
             merged[k].update(cs)
+    for k, cs in eff_clock(os.path.join(src, "grbm")).items():
+        merged[k].update(cs)
     ours = ("rs_", "os_", "scan_", "tile_", "ssim_", "post_", "adam_", "loss_", "densify_", "activate_", "reduce_", "bin_", "train_loss_")
     merged = {k: v for k, v in merged.items() if k in STAGE_OF or k.startswith(ours) or "knn" in k}
     traffic = {}

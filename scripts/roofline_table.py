@@ -17,14 +17,18 @@ for k, c in pmc.items():
     us = float(st["AverageNs"]) / 1e3
     gbs = c["HBM_bytes_per_launch"] / (us * 1e-6) / 1e9
     valu = c.get("SQ_INSTS_VALU", 0.0) / (us * 1e-6) / 1e9
-    rows.append((float(st["TotalDurationNs"]), base, int(st["Calls"]), us, c["HBM_bytes_per_launch"] / 1e6, gbs, gbs / 8000.0, valu, valu / 1228.9))
+    clk = c.get("eff_clock_GHz")
+    # VALU issue against the clock the kernel actually sustained: 1024 SIMDs x clk / 2 cycles per wave64 fp32 instruction
+    fv_sus = (valu / (1024 * clk / 2.0)) if clk else None
+    rows.append((float(st["TotalDurationNs"]), base, int(st["Calls"]), us, c["HBM_bytes_per_launch"] / 1e6, gbs, gbs / 8000.0, valu, valu / 1228.9, clk, fv_sus))
 rows.sort(reverse=True)
 out = ["# Per-kernel roofline, %s / %s (MI355X: HBM 8 000 GB/s, fp32 VALU issue 1 228.9 G wave-inst/s)" % (tag, wl), "",
-       "| kernel | launches | avg µs | HBM MB / launch | GB/s | frac of HBM peak | VALU G wave-inst/s | frac of VALU peak | bound |",
-       "|---|---|---|---|---|---|---|---|---|"]
-for _, k, n, us, mb, gbs, fh, valu, fv in rows:
+       "eff_clock_GHz = GRBM_GUI_ACTIVE / kernel wall time (own --pmc pass); 'of sustained' = VALU rate / (1024 SIMDs x eff clock / 2).", "",
+       "| kernel | launches | avg µs | HBM MB / launch | GB/s | frac of HBM peak | VALU G wave-inst/s | frac of VALU peak (2.4 GHz) | eff_clock_GHz | frac of VALU issue at the sustained clock | bound |",
+       "|---|---|---|---|---|---|---|---|---|---|---|"]
+for _, k, n, us, mb, gbs, fh, valu, fv, clk, fvs in rows:
     bound = "HBM" if fh >= 0.4 and fh >= fv else ("VALU issue" if fv >= 0.3 else "latency / launch")
-    out.append("| `%s` | %d | %.1f | %.1f | %.0f | %.2f | %.0f | %.2f | %s |" % (k, n, us, mb, gbs, fh, valu, fv, bound))
+    out.append("| `%s` | %d | %.1f | %.1f | %.0f | %.2f | %.0f | %.2f | %s | %s | %s |" % (k, n, us, mb, gbs, fh, valu, fv, "%.2f" % clk if clk else "-", "%.2f" % fvs if fvs else "-", bound))
 path = os.path.join(REPO, "profiles", "%s_%s_roofline.md" % (tag, wl))
 open(path, "w").write("\n".join(out) + "\n")
 print("\n".join(out))

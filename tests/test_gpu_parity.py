@@ -26,7 +26,8 @@ IMG_ATOL, IMG_RTOL, IMG_FRAC = 1e-4, 1e-4, 0.999
 LARGE_SORT_DEFAULT = 2          # surfel_set_option("large_sort") default of the library (profiles/r02_large_sort.md)
 G_RTOL, G_FRAC, G_COS = 2e-3, 0.999, 0.9999
 GOLDEN_IMG_FRAC, GOLDEN_G_FRAC, GOLDEN_G_COS = 0.9995, 0.997, 0.99999      # test_golden_fixture: measured 1.00000 / 1.00000 / 1.0000000 on every tensor (512 surfels, 64x48)
-DIST_G_FRAC = 0.97         # test_distortion_dominated_gradients / test_dtu_gradient_regime_parity: the absolute floor; the binding bar is the fp32 CPU run of the oracle
+DIST_G_FRAC = {1000.0: 0.995, 30000.0: 0.96}      # test_distortion_dominated_gradients: floors = the measured minima (0.99733 / 0.96570, C1 scan) - 0.3 / 0.6 %; the fp32 CPU run of the oracle scores 0.99617 / 0.94700 there
+DTU_G_FRAC = 0.993         # test_dtu_gradient_regime_parity: measured 0.99634 (means3D, scan) ... 0.99997 (sh); fp32 CPU run 0.99420 ... 0.99992
 TRAINED_G_FRAC = 0.992     # test_trained_state_parity: measured 0.99565 (means3D) ... 0.99963 (sh) on every walk, the fp32 CPU run of the oracle 0.99510 ... 0.99959
 
 
@@ -322,7 +323,7 @@ def test_dtu_gradient_regime_parity():
           (P, run.R, np.round(scalars.cpu().numpy(), 5).tolist(), ratio, float(np.abs(gO[2:5]).mean() / np.abs(gC).mean())))
     assert ratio > 300.0      # the regime: the distortion gradient dominates the colour gradient by orders of magnitude
     og, og32 = o64.rasterize_backward(st, gC, gO), o32.rasterize_backward(st32, gC, gO)
-    _walk_table("DTU", run, gC, gO, og, og32, DIST_G_FRAC)
+    _walk_table("DTU", run, gC, gO, og, og32, DTU_G_FRAC)
 
 
 def test_config_c5_stress():
@@ -882,7 +883,7 @@ def test_distortion_dominated_gradients(kind, gscale):
             fr, f32 = frac_close(x, ref, 1e-4 * scale, G_RTOL), frac_close(r32, ref, 1e-4 * scale, G_RTOL)
             cs, cs32 = cosine(x, ref), cosine(r32, ref)
             print("g_dist x%g %s %s %s: frac hip %.5f cpu-fp32 %.5f | cosine hip %.7f cpu-fp32 %.7f" % (gscale, kind, walk, k, fr, f32, cs, cs32))
-            assert fr >= DIST_G_FRAC and fr >= f32 - 0.005, "%s %s %s: hip %.5f, cpu-fp32 %.5f" % (kind, walk, k, fr, f32)
+            assert fr >= DIST_G_FRAC[gscale] and fr >= f32 - 0.005, "%s %s %s: hip %.5f, cpu-fp32 %.5f" % (kind, walk, k, fr, f32)
             assert cs >= 0.9999 or cs >= cs32 - 1e-4, "%s %s %s cosine hip %.7f, cpu-fp32 %.7f" % (kind, walk, k, cs, cs32)
 
 
