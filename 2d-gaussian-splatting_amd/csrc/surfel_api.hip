@@ -27,6 +27,7 @@ void* g_colour_hook_user = nullptr;
 int g_opt_pbwd_coop = -1;  // surfel_set_option("pbwd_coop", .): record gather of preprocess_bwd — -1 by rule (R >= 6 P and R >= 2^25), 0 per thread, 1 wave-cooperative
 int g_opt_host_total = 1;  // surfel_set_option("host_total", .): capacity path — 1: bin_emit_kernel stores the instance total into mapped pinned memory, 0: D2H copy kernel (measurement)
 int g_opt_scan_large = 1;  // surfel_set_option("scan_large", .): auto lets the device rule hand frames to the scan walk (2^21 <= R < 2^26 instances, or >= 6 instances per emitting surfel)
+int g_opt_stream = 1;      // surfel_set_option("tile_stream", .): blend_fwd leaves the tile stream for blend_bwd (surfel_common.h); 0: blend_bwd gathers
 int g_opt_bwd_tune = 1;    // surfel_set_option("bwd_tune", .): auto = timed probes (1) or the device-side rule alone (0)
 unsigned long long* g_blend_stats = nullptr;   // surfel_debug_set_blend_stats
 thread_local int64_t g_last_R = -1; thread_local int g_last_W = 0, g_last_H = 0;   // auto heuristic (speed only; results identical; a stale
@@ -113,12 +114,20 @@ struct GeomState {   // per-surfel state ("geomBuffer")
 
 struct BinState {    // per-instance state ("binningBuffer"); point_list is always at a fixed offset
     uint32_t* point_list; uint32_t* vals_alt; uint32_t* keys_a; uint32_t* keys_b; char* sort_temp; size_t sort_temp_bytes;
-    static BinState carve(void* base, size_t R, size_t sort_bytes, size_t* total) {
+    float4* strm_rec = nullptr; uint32_t* strm_mask = nullptr;      // the tile stream (surfel_common.h), or NULL
+    static bool wants_stream(size_t R) { return g_opt_stream != 0 && R > 0 && (long long)R <= STRM_MAX_R; }
+    // stream: the forward's decision (wants_stream of ITS capacity); the backward never carves it — it is called with the exact count
+    // where the forward carved with a capacity, and finds the stream through the registry below
+    static BinState carve(void* base, size_t R, size_t sort_bytes, size_t* total, bool stream = false) {
         Carver c(base); BinState b;
         b.point_list = c.take<uint32_t>(R);
         b.vals_alt = c.take<uint32_t>(R);
         b.keys_a = c.take<uint32_t>(R);
         b.keys_b = c.take<uint32_t>(R);
+        if (stream) {
+            b.strm_rec = c.take<float4>(R * STRM_Q);
+            b.strm_mask = c.take<uint32_t>(R);
+        }
         b.sort_temp = c.take<char>(sort_bytes);
         b.sort_temp_bytes = sort_bytes;
         if (total) *total = c.size();
@@ -142,6 +151,27 @@ struct ImgState {    // per-pixel / per-tile state ("imgBuffer")
         return im;
     }
 };
+
+// Which binning buffers hold a tile stream (surfel_common.h), and where.  The forward decides (option, capacity, blend kernel) and
+// registers every binning buffer it fills — with a stream or without; the backward, handed the same buffer later (possibly on autograd's
+// worker thread, possibly after other forwards), looks it up and stages from the stream if it finds one.  A buffer the registry no
+// longer knows (more than kStreamRegs forwards in between) is gathered by surfel id: always valid, same bits.  An address can only
+// be re-registered after its previous frame's buffers were freed, i.e. when no backward of that frame can come any more.
+struct StreamReg { const void* bin = nullptr; const float4* rec = nullptr; const uint32_t* mask = nullptr; };
+constexpr int kStreamRegs = 64;
+StreamReg g_stream_regs[kStreamRegs];
+unsigned g_stream_next = 0;
+std::mutex g_stream_mu;
+void stream_register(const void* bin, const float4* rec, const uint32_t* mask) {
+    std::lock_guard<std::mutex> lk(g_stream_mu);
+    for (auto& r : g_stream_regs) if (r.bin == bin) { r.rec = rec; r.mask = mask; return; }
+    g_stream_regs[g_stream_next++ % kStreamRegs] = StreamReg{bin, rec, mask};
+}
+bool stream_lookup(const void* bin, const float4** rec, const uint32_t** mask) {
+    std::lock_guard<std::mutex> lk(g_stream_mu);
+    for (auto& r : g_stream_regs) if (r.bin == bin && r.rec) { *rec = r.rec; *mask = r.mask; return true; }
+    return false;
+}
 
 // Stage timing on the caller's stream with HIP events.
 //   mode 1 (debug): synchronise + hipGetLastError after every stage (the reference's `debug` flag).
@@ -390,6 +420,7 @@ int surfel_set_option(const char* name, int value) {
     if (name && std::strcmp(name, "pbwd_coop") == 0) { g_opt_pbwd_coop = value < 0 ? -1 : (value != 0); return 0; }
     if (name && std::strcmp(name, "bwd_variant") == 0) { g_opt_bwd_variant = value < 0 ? 0 : (value > 4 ? 4 : value); return 0; }
     if (name && std::strcmp(name, "bwd_tune") == 0) { g_opt_bwd_tune = value != 0; return 0; }
+    if (name && std::strcmp(name, "tile_stream") == 0) { g_opt_stream = value != 0; return 0; }
     if (name && std::strcmp(name, "capacity_binning") == 0) { g_opt_capacity = value != 0; return 0; }
     if (name && std::strcmp(name, "tile_order") == 0) { g_opt_tile_order = value < 0 ? 0 : (value > 2 ? 2 : value); return 0; }
     return fail(SURFEL_E_INVALID, "unknown option");
@@ -582,10 +613,11 @@ int64_t surfel_rasterize_forward(surfel_alloc_fn geom_alloc, void* geom_user, su
         if (cap > 0) {      // the binning buffers exist before preprocess runs: it clears the tile sort's head on the way
             const size_t sort_bytes = capacity_sort_scratch_bytes((size_t)cap, end_bit);
             size_t bin_bytes = 0;
-            BinState::carve(nullptr, (size_t)cap, sort_bytes, &bin_bytes);
+            const bool strm = BinState::wants_stream((size_t)cap);
+            BinState::carve(nullptr, (size_t)cap, sort_bytes, &bin_bytes, strm);
             void* bin_base = binning_alloc(binning_user, bin_bytes);
             if (!bin_base) return fail(SURFEL_E_ALLOC, "binning buffer allocation failed");
-            bin = BinState::carve(bin_base, (size_t)cap, sort_bytes, nullptr);
+            bin = BinState::carve(bin_base, (size_t)cap, sort_bytes, nullptr, strm);
             pa.zero_c = reinterpret_cast<uint32_t*>(bin.sort_temp); pa.zero_c_words = (uint32_t)bin_emit_head_words();
             pa.block_totals = geom.offsets;      // (the scan output of the exact path: free here)
         }
@@ -630,6 +662,8 @@ int64_t surfel_rasterize_forward(surfel_alloc_fn geom_alloc, void* geom_user, su
             ba.out_color = out_color; ba.out_others = out_others; ba.final_T = img.final_T; ba.n_contrib = img.n_contrib;
             ba.tile_map = img.tile_map; ba.map_flag = img.total + 2 * R_SLOTS + 1; ba.map_len = map_len;
             ba.stats = g_blend_stats;
+            ba.strm_rec = bin.strm_rec; ba.strm_mask = bin.strm_mask;
+            stream_register(bin.point_list, launch_blend_fwd_writes_stream(ba) ? bin.strm_rec : nullptr, bin.strm_mask);
             tm.begin();
             launch_blend_fwd(ba, s);
             STAGE_END(tm, ST_BLEND);
@@ -650,6 +684,9 @@ int64_t surfel_rasterize_forward(surfel_alloc_fn geom_alloc, void* geom_user, su
                 if (ce->boost < 2) ce->boost++;
                 ce->last_overflow = ce->frames;
                 HIP_TRY(hipMemsetAsync(img.ranges, 0, sizeof(uint2) * (size_t)gx * gy, s));
+                // (the capacity path's device total is not this frame's count any more — the exact path leaves 0 there, so that
+                // the backward's overflow guard compares nothing stale; the tile-map flag goes with it, run_tile_order decides again below)
+                HIP_TRY(hipMemsetAsync(img.total + 2 * R_SLOTS, 0, 2 * sizeof(uint32_t), s));
             }
         }
         if (!blended) {
@@ -678,10 +715,11 @@ int64_t surfel_rasterize_forward(surfel_alloc_fn geom_alloc, void* geom_user, su
 
             const size_t sort_bytes = radix_sort_scratch_bytes((size_t)R);
             size_t bin_bytes = 0;
-            BinState::carve(nullptr, (size_t)R, sort_bytes, &bin_bytes);
+            const bool strm = BinState::wants_stream((size_t)R);
+            BinState::carve(nullptr, (size_t)R, sort_bytes, &bin_bytes, strm);
             void* bin_base = binning_alloc(binning_user, bin_bytes > 0 ? bin_bytes : 256);
             if (!bin_base) return fail(SURFEL_E_ALLOC, "binning buffer allocation failed");
-            bin = BinState::carve(bin_base, (size_t)R, sort_bytes, nullptr);
+            bin = BinState::carve(bin_base, (size_t)R, sort_bytes, nullptr, strm);
             if (R > 0) {
                 // (3) stable sort on the tile-id bits only: depth order inside every tile is preserved.  The value buffers
                 // are assigned so that the ping-pong ends in bin.point_list.
@@ -728,6 +766,8 @@ int64_t surfel_rasterize_forward(surfel_alloc_fn geom_alloc, void* geom_user, su
     ba.tile_map = img.tile_map; ba.map_flag = img.total + 2 * R_SLOTS + 1; ba.map_len = map_len;
     ba.stats = g_blend_stats;
     ba.avg_list = (int)(R / ((int64_t)gx * gy));
+    ba.strm_rec = bin.strm_rec; ba.strm_mask = bin.strm_mask;
+    stream_register(bin.point_list, launch_blend_fwd_writes_stream(ba) ? bin.strm_rec : nullptr, bin.strm_mask);
     tm.begin();
     launch_blend_fwd(ba, s);
     STAGE_END(tm, ST_BLEND);
@@ -786,6 +826,7 @@ int surfel_rasterize_backward(surfel_alloc_fn scratch_alloc, void* scratch_user,
     bb.grec = grec; bb.cut = cut; bb.has_rec = has_rec; bb.depths = geom.depths; bb.variant = opt_variant; bb.stats = g_blend_stats; bb.totals = img.total;
     // num_rendered of a lazily counted frame is its CAPACITY: if the frame's real total (on the device since bin_emit_kernel; 0 on the
     // exact path) exceeds it, the lists are truncated and the first-instance slots run past `grec` — the kernels below return at once
+    if (!(debug_in & SURFEL_OPT_BWD_GATHER) && g_opt_stream) (void)stream_lookup(binning_buffer, &bb.strm_rec, &bb.strm_mask);      // (stays NULL: the walks gather)
     bb.n_dev = img.total + 2 * R_SLOTS; bb.n_cap = (uint32_t)(R < 0xffffffffll ? R : 0xffffffffll);
     if (R > 0) {
         WalkTuner* tuner = nullptr;

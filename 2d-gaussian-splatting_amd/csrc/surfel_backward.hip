@@ -45,7 +45,7 @@ constexpr int NVP = 20;   // 18 gradient values per instance, padded to 20 for t
 #define ROWS_RSHIFT 8
 #endif
 #ifndef ROWS_WAVES
-#define ROWS_WAVES 5
+#define ROWS_WAVES 4      // 128 VGPRs (the stream pieces of the next batch ride across the flush); 4 -> 5 workgroups per CU measured 0 % (profiles/r02_blend_bwd_variants.md)
 #endif
 constexpr int RSHIFT = ROWS_RSHIFT;
 constexpr int RSLOTS = 1 << RSHIFT;   // rows variant: (instance, sub-tile) slots per round
@@ -194,7 +194,17 @@ __device__ __forceinline__ void pair_gradients(Pixel& p, const Hit& h, const flo
 // ---------------------------------------------------------------------------------------------
 // blend_bwd, rows variant
 // ---------------------------------------------------------------------------------------------
-template <bool STATS>
+// Round 5 (what the forward got in round 4, profiles/r04_wg_trace.md section 5b):
+//   * staging from the forward's TILE STREAM (surfel_common.h) where the frame has one: all 256 threads read the batch's 10 KB of
+//     records and its footprint bits as contiguous 16-B pieces — requested before the previous batch's last flush, consumed behind it —
+//     instead of ids -> 112-B gather -> footprint test; the gather path stays for frames without a stream (same bits);
+//   * the walk: every row expands its 128-bit instance mask ONCE per batch into a byte list (the row's 16 lanes take one mask byte
+//     each, DPP prefix sum); a round's visits are a contiguous run of that list, the loop is a counted loop over the wave's longest
+//     run (no find-first-set / clear / word refill / votes per visit).
+// Per-pair arithmetic, slot assignment and the flush's summation tree are unchanged: rows / quad stay bit-identical.
+constexpr int LROW = BS + 4;      // bytes per row list, padded to whole words
+
+template <bool STATS, bool STREAM>
 __global__ void __launch_bounds__(BLOCK, ROWS_WAVES) blend_bwd_rows_kernel(BlendBwdArgs a) {
     __shared__ float4 s_rec[BS * 5];                          // 10 KB: q0-q4 of the staged instances
     __shared__ float4 s_slot[NSLOT * 5];                      // 21.25 KB: row totals, one 80-B slot per (instance, sub-tile)
@@ -202,16 +212,11 @@ __global__ void __launch_bounds__(BLOCK, ROWS_WAVES) blend_bwd_rows_kernel(Blend
     __shared__ unsigned long long s_rmask[16][BS / 64];       // per row: the staged instances that reach its sub-tile
     __shared__ uint32_t s_wtot[BS / 64];                      // slots of each staging wave's 64 instances
     __shared__ int s_rowlast[16];                             // per row: the largest `last` of its 16 pixels
+    __shared__ __attribute__((aligned(4))) uint8_t s_list[16][LROW];      // per row: staged indices of the instances on its list, back to front
     __shared__ int s_max;
     if (a.variant == 2 && !auto_picks_rows(a)) return;
     if (a.scan_rule && device_picks_scan(a)) return;
     if (frame_overflowed(a.n_dev, a.n_cap)) return;
-#ifdef ROWS_TIMING
-    const long long tm_start = __builtin_readcyclecounter();
-#endif
-#ifdef BLEND_TRACE
-    const unsigned long long trace_t0 = wall_clock64();
-#endif
     const int tile = block_tile(a.tile_map, a.map_flag, (int)blockIdx.x, a.gx * a.gy);
     if (tile < 0) return;
     const int tx = tile % a.gx, ty = tile / a.gx;
@@ -220,47 +225,84 @@ __global__ void __launch_bounds__(BLOCK, ROWS_WAVES) blend_bwd_rows_kernel(Blend
     (void)sub;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int srow = threadIdx.x >> 4;                        // this lane's DPP row among the tile's 16 = its sub-tile's bit
+    const int i16 = threadIdx.x & 15;
     const uint32_t below = (1u << srow) - 1u;
     const uint2 range = a.ranges[tile];
     Pixel px = load_pixel(a, tx * TILE + lx, ty * TILE + ly);
     {   // a row never visits an instance behind the last contributor of all its pixels
         int m = px.last;
         m = max(m, __shfl_xor(m, 1)); m = max(m, __shfl_xor(m, 2)); m = max(m, __shfl_xor(m, 4)); m = max(m, __shfl_xor(m, 8));
-        if ((threadIdx.x & 15) == 0) s_rowlast[srow] = m;
+        if (i16 == 0) s_rowlast[srow] = m;
     }
+    for (int k = i16; k < LROW / 4; k += 16) reinterpret_cast<uint32_t*>(&s_list[srow][0])[k] = 0u;      // (bytes past a list's end are read as indices: any valid one will do)
     const int maxc = block_max(px.last, &s_max);              // (its barriers also publish s_rowlast)
 
     // which value of the row total this lane stores (row_reduce20): lane t of quad q holds value 4t + {0,2,1,3}[q] of z[t]
     const int t4 = lane & 3, quad = (lane >> 2) & 3;
     const int pq = ((quad & 1) << 1) | (quad >> 1);
     float* const s_slotf = reinterpret_cast<float*>(s_slot);
+    uint8_t* const lrow = &s_list[srow][0];
 
-    // -DROWS_TIMING (diagnostic build, see DESIGN.md "blend_bwd"): the instrumented kernel accumulates s_memtime ticks per phase
-    // of every wave instead of the lane counters — stats[5] staging (kernel start / batch top -> first round, barrier waits
-    // included), [6] walk, [7] wait at the barrier after the walk, [4] flush, [2] wave visits (scripts/bwd_ab.py: rows_raw).
-#ifdef ROWS_TIMING
-    long long tm_stage = 0, tm_walk = 0, tm_bar = 0, tm_flush = 0, tm_nvis = 0, tm_t = tm_start;
-#define TM(acc) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); const long long t_ = __builtin_readcyclecounter(); acc += t_ - tm_t; tm_t = t_; }
-#else
-#define TM(acc)
-#endif
-    float pf_touch = 0.f;                     // landing register of the prefetch touches (never read)
-    uint32_t pf_id = 0;
+    // STREAM: the host found the forward's tile stream for this frame (surfel_api.hip: stream_lookup)
+    constexpr bool strm_on = STREAM;
+    const float4* __restrict__ strm = a.strm_rec;
+    const uint32_t* __restrict__ smask = a.strm_mask;
+    float pf_touch = 0.f;                     // gather path: landing register of the prefetch touches (never read)
+    uint32_t pf_id = 0;                       // gather path: an id of the next batch (waves 2-3); stream path: the id behind pm (large frames)
+    float4 pv0 = make_float4(0.f, 0.f, 0.f, 0.f), pv1 = pv0, pv2 = pv0;      // this thread's pieces of the NEXT batch
+    uint32_t pm = 0u;                                                        // ... and (threads 0 .. 127) an instance's footprint bits
+    auto fetch = [&](int hi_n) {      // the batch of list positions (hi_n - mbn, hi_n]: ascending positions = ascending stream entries
+        const int mbn = min(BS, hi_n), np = STRM_Q * mbn;
+        const size_t g0 = (size_t)range.x + (size_t)(hi_n - mbn);
+        const float4* __restrict__ src = strm + g0 * STRM_Q;
+        if ((int)threadIdx.x < np) pv0 = src[threadIdx.x];
+        if ((int)threadIdx.x + BLOCK < np) pv1 = src[threadIdx.x + BLOCK];
+        if ((int)threadIdx.x + 2 * BLOCK < np) pv2 = src[threadIdx.x + 2 * BLOCK];
+        if ((int)threadIdx.x < mbn) {
+            pm = smask[g0 + (size_t)(mbn - 1 - (int)threadIdx.x)];
+            if (a.has_rec) pf_id = a.point_list[g0 + (size_t)(mbn - 1 - (int)threadIdx.x)];      // (large frames: the surfel that gets a record, for its "has a record" byte)
+        }
+    };
+    if (strm_on && maxc > 0) fetch(maxc);
+
     for (int hi = maxc; hi > 0; hi -= BS) {
         const int mb = min(BS, hi);
-        asm volatile("s_waitcnt vmcnt(0)" : "+v"(pf_touch) :: "memory");      // the previous touch has landed: pf_touch may be rewritten
+        if (!strm_on) asm volatile("s_waitcnt vmcnt(0)" : "+v"(pf_touch) :: "memory");      // the previous touch has landed: pf_touch may be rewritten
         __syncthreads();                      // previous batch fully flushed
-        if (wave < BS / 64) {
-            unsigned ovr = 0;
+        unsigned ovr = 0;
+        if (strm_on) {
+            // pieces -> s_rec.  Stream entry jj (ascending position) is staged instance t = mb - 1 - jj (t = 0: the deepest position)
+            const int np = STRM_Q * mb;
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                const int p = (int)threadIdx.x + BLOCK * k;
+                const int jj = (p * 13108) >> 16;       // p / 5 for p < 640
+                if (p < np) s_rec[(mb - 1 - jj) * 5 + (p - 5 * jj)] = k == 0 ? pv0 : (k == 1 ? pv1 : pv2);
+            }
+            if ((int)threadIdx.x < mb) {
+                ovr = pm & 0xffffu;
+                if (a.has_rec) a.has_rec[pf_id] = 1;      // every staged instance gets a record (finish_tail)
+            }
+        } else if (wave < BS / 64) {
             if ((int)threadIdx.x < mb) {
                 const int pos = hi - (int)threadIdx.x;
                 const uint32_t id = a.point_list[range.x + pos - 1];
                 const float4* __restrict__ src = reinterpret_cast<const float4*>(a.rec + (size_t)id * REC_F);
-                if (a.has_rec) a.has_rec[id] = 1;      // every staged instance gets a record (finish_tail)
+                if (a.has_rec) a.has_rec[id] = 1;
                 const float4 v0 = src[0], v1 = src[1], v2 = src[2], v3 = src[3], v4 = src[4], v5 = src[5], v6 = src[6];
                 s_rec[threadIdx.x * 5 + 0] = v0; s_rec[threadIdx.x * 5 + 1] = v1; s_rec[threadIdx.x * 5 + 2] = v2;
                 s_rec[threadIdx.x * 5 + 3] = v3; s_rec[threadIdx.x * 5 + 4] = v4;
                 ovr = subtile_overlap_rows(make_foot(v2, v5, v6), tx * TILE, ty * TILE);
+            }
+        } else if (hi > BS) {
+            // gather path, waves 2-3: fetch the NEXT batch's ids, and after the barrier (while everybody walks) pull those records
+            // towards this XCD's L2 with one dword load each, so that the next gather overlaps this batch's arithmetic
+            const int t = (int)threadIdx.x - BS;
+            if (t < min(BS, hi - BS)) pf_id = a.point_list[range.x + (hi - BS - t) - 1];
+        }
+        if (wave < BS / 64) {
+            if ((int)threadIdx.x < mb) {
+                const int pos = hi - (int)threadIdx.x;
                 unsigned live = 0;
 #pragma unroll
                 for (int s = 0; s < 16; s++) live |= (pos <= s_rowlast[s]) ? (1u << s) : 0u;
@@ -277,15 +319,9 @@ __global__ void __launch_bounds__(BLOCK, ROWS_WAVES) blend_bwd_rows_kernel(Blend
                 const unsigned long long b = __ballot((ovr >> s) & 1u);
                 if (lane == 0) s_rmask[s][wave] = b;
             }
-        } else if (hi > BS) {
-            // waves 2-3 have nothing to stage: they fetch the NEXT batch's ids, and after the barrier (while everybody walks)
-            // pull those records towards this XCD's L2 with one dword load each, so that the gathers of the next staging pass
-            // overlap this batch's arithmetic instead of forming one burst with every other workgroup's
-            const int t = (int)threadIdx.x - BS;
-            if (t < min(BS, hi - BS)) pf_id = a.point_list[range.x + (hi - BS - t) - 1];
         }
         __syncthreads();
-        if (wave >= BS / 64 && hi > BS && (int)threadIdx.x - BS < min(BS, hi - BS)) {
+        if (!strm_on && wave >= BS / 64 && hi > BS && (int)threadIdx.x - BS < min(BS, hi - BS)) {
             const float* ptr = a.rec + (size_t)pf_id * REC_F;
             asm volatile("global_load_dword %0, %1, off" : "+v"(pf_touch) : "v"(ptr) : "memory");
         }
@@ -297,56 +333,72 @@ __global__ void __launch_bounds__(BLOCK, ROWS_WAVES) blend_bwd_rows_kernel(Blend
         const int rnd0 = min((int)(s_info[lane] >> 16) >> RSHIFT, nrounds - 1);
         const int rnd1 = min(((int)(s_info[64 + lane] >> 16) + off1) >> RSHIFT, nrounds - 1);
         const unsigned long long c0 = s_rmask[srow][0], c1 = s_rmask[srow][1];
-        TM(tm_stage)
+        {   // the row's byte list: lane i16 expands mask byte i16 (instances 8 i16 .. 8 i16 + 7) behind an exclusive prefix over the row
+            const uint32_t wsel = (i16 & 8) ? ((i16 & 4) ? (uint32_t)(c1 >> 32) : (uint32_t)c1) : ((i16 & 4) ? (uint32_t)(c0 >> 32) : (uint32_t)c0);
+            const uint32_t byte = (wsel >> (8 * (i16 & 3))) & 0xffu;
+            int off = __popc(byte), t;
+            t = __builtin_amdgcn_update_dpp(0, off, 0x111, 0xf, 0xf, true); off += t;      // row_shr:1
+            t = __builtin_amdgcn_update_dpp(0, off, 0x112, 0xf, 0xf, true); off += t;      // row_shr:2
+            t = __builtin_amdgcn_update_dpp(0, off, 0x114, 0xf, 0xf, true); off += t;      // row_shr:4
+            t = __builtin_amdgcn_update_dpp(0, off, 0x118, 0xf, 0xf, true); off += t;      // row_shr:8
+            off -= __popc(byte);
+#pragma unroll
+            for (int k = 0; k < 8; k++)
+                if ((byte >> k) & 1u) lrow[off + __popc(byte & ((1u << k) - 1u))] = (uint8_t)(8 * i16 + k);
+        }
+        int lpos = 0;                                         // list entries of this row consumed by the rounds so far
+        unsigned long long cum0 = 0ull, cum1 = 0ull;          // instances of rounds <= r
         for (int r = 0; r < nrounds; r++) {
             const unsigned long long m0 = __ballot((lane < mb) & (rnd0 == r)), m1 = __ballot((64 + lane < mb) & (rnd1 == r));
-            // ---- walk: every row visits, in list order, its instances of round r.  (No software prefetch of the next record:
-            // the VALU pipe is the bound and other waves cover the LDS latency — the pipelined form cost 22 VGPRs and 5 %.)
-            unsigned long long cur = c0 & m0, nxt = c1 & m1;
-            int wbase = 0;
-            if (cur == 0ull) { cur = nxt; nxt = 0ull; wbase = 64; }
-            for (;;) {
-                if (cur == 0ull) { cur = nxt; nxt = 0ull; wbase = 64; }
-                const bool actc = cur != 0ull;
-                if (!__any(actc)) break;
-                const int jc = wbase + __builtin_ctzll(cur | (1ull << 63));
-                if (actc) cur &= cur - 1ull;
-                const uint32_t infoc = s_info[jc];
-                const float4 c_q0 = s_rec[jc * 5 + 0], c_q1 = s_rec[jc * 5 + 1], c_q2 = s_rec[jc * 5 + 2], c_q3 = s_rec[jc * 5 + 3], c_q4 = s_rec[jc * 5 + 4];
-                // current visit
-                Hit h;
-                const int pos = hi - jc;      // 1-based position in the tile's list
-                const bool ok = pair_hit(px, c_q0, c_q1, c_q2, pos, h) & actc;
-                float gv[NVP], z[5];
-                pair_gradients(px, h, c_q3, c_q4, ok, pos, gv);
-                row_reduce20(gv, z);
-#ifdef ROWS_TIMING
-                tm_nvis++;
-#elif defined(BLEND_TRACE)
-                // (per-workgroup times only: the per-visit counters would dominate them)
-#else
-                if (STATS) {
-                    const unsigned long long okb = __ballot(ok), ab = __ballot(actc);
-                    if (lane == 0) {
-                        atomicAdd(&a.stats[0], 64ull); atomicAdd(&a.stats[1], (unsigned long long)__popcll(okb));
-                        atomicAdd(&a.stats[2], 1ull); atomicAdd(&a.stats[3], (unsigned long long)(__popcll(ab) >> 4));
-                        const int hitrows = ((okb & 0xffffull) != 0) + (((okb >> 16) & 0xffffull) != 0) + (((okb >> 32) & 0xffffull) != 0) + ((okb >> 48) != 0);
-                        atomicAdd(&a.stats[4], (unsigned long long)hitrows);
+            cum0 |= m0; cum1 |= m1;
+            // ---- walk: every row visits, in list order, its instances of round r — a contiguous run of its byte list (an instance's
+            // round grows with its staged index)
+            const int lend = __popcll(c0 & cum0) + __popcll(c1 & cum1);
+            const int len = lend - lpos;
+            const int niter = max(max(__builtin_amdgcn_readlane(len, 0), __builtin_amdgcn_readlane(len, 16)),
+                                  max(__builtin_amdgcn_readlane(len, 32), __builtin_amdgcn_readlane(len, 48)));
+            if (niter > 0) {
+                // (No read-ahead of the next visit's record: measured in round 5 with the forward's scheme — next record in registers, loop
+                // unrolled by two with the roles swapped — it buys nothing where this walk is the default (C2: 0.1988 vs 0.1991 ms, four
+                // waves per SIMD cover the LDS latency) and 1 - 2 % on the frames the scan walk takes anyway, for 21 registers.)
+                for (int v = 0; v < niter; v++) {
+                    const bool actc = v < len;
+                    const int jc = (int)lrow[lpos + v];      // (past a shorter row's run: allocated, a valid index — the visit is masked)
+                    const uint32_t infoc = s_info[jc];
+                    const float4 c_q0 = s_rec[jc * 5 + 0], c_q1 = s_rec[jc * 5 + 1], c_q2 = s_rec[jc * 5 + 2], c_q3 = s_rec[jc * 5 + 3], c_q4 = s_rec[jc * 5 + 4];
+                    Hit h;
+                    const int pos = hi - jc;      // 1-based position in the tile's list
+                    const bool ok = pair_hit(px, c_q0, c_q1, c_q2, pos, h) & actc;
+                    float gv[NVP], z[5];
+                    pair_gradients(px, h, c_q3, c_q4, ok, pos, gv);
+                    row_reduce20(gv, z);
+                    if (STATS) {
+                        const unsigned long long okb = __ballot(ok), ab = __ballot(actc);
+                        if (lane == 0) {
+                            atomicAdd(&a.stats[0], 64ull); atomicAdd(&a.stats[1], (unsigned long long)__popcll(okb));
+                            atomicAdd(&a.stats[2], 1ull); atomicAdd(&a.stats[3], (unsigned long long)(__popcll(ab) >> 4));
+                            const int hitrows = ((okb & 0xffffull) != 0) + (((okb >> 16) & 0xffffull) != 0) + (((okb >> 32) & 0xffffull) != 0) + ((okb >> 48) != 0);
+                            atomicAdd(&a.stats[4], (unsigned long long)hitrows);
+                        }
+                    }
+                    if (actc) {
+                        const int E = (int)(infoc >> 16) + (jc >= 64 ? off1 : 0);
+                        const int slot = (E & (RSLOTS - 1)) + __popc(infoc & below);
+                        float* sp = s_slotf + slot * NVP;
+                        const float val = t4 == 0 ? z[0] : (t4 == 1 ? z[1] : (t4 == 2 ? z[2] : z[3]));
+                        sp[4 * t4 + pq] = val;
+                        if (t4 == 0) sp[16 + pq] = z[4];
                     }
                 }
-#endif
-                if (actc) {
-                    const int E = (int)(infoc >> 16) + (jc >= 64 ? off1 : 0);
-                    const int slot = (E & (RSLOTS - 1)) + __popc(infoc & below);
-                    float* sp = s_slotf + slot * NVP;
-                    const float v = t4 == 0 ? z[0] : (t4 == 1 ? z[1] : (t4 == 2 ? z[2] : z[3]));
-                    sp[4 * t4 + pq] = v;
-                    if (t4 == 0) sp[16 + pq] = z[4];
-                }
             }
-            TM(tm_walk)
+            lpos = lend;
             __syncthreads();
-            TM(tm_bar)
+            // the next batch's stream pieces: requested here, in front of the batch's last flush, consumed behind it
+            if (strm_on && r == nrounds - 1 && hi > BS) fetch(hi - BS);
+            else {      // (no request: tell the compiler the prefetch registers hold nothing from here on — otherwise they stay allocated through every walk)
+                asm volatile("" : "=v"(pv0.x), "=v"(pv0.y), "=v"(pv0.z), "=v"(pv0.w), "=v"(pv1.x), "=v"(pv1.y), "=v"(pv1.z), "=v"(pv1.w));
+                asm volatile("" : "=v"(pv2.x), "=v"(pv2.y), "=v"(pv2.z), "=v"(pv2.w), "=v"(pm), "=v"(pf_id));
+            }
             // ---- flush round r: its instances are a contiguous run of the staged list.  One thread per (instance, float4 of its
             // record): the instance's slots are added in the fixed order ((r0+r1)+(r2+r3)) per wave, waves 0..3 — the summation
             // tree of the quad variant, so both variants give the same bits.
@@ -379,23 +431,8 @@ __global__ void __launch_bounds__(BLOCK, ROWS_WAVES) blend_bwd_rows_kernel(Blend
                 }
             }
             __syncthreads();                  // slots reusable
-            TM(tm_flush)
         }
     }
-#ifdef BLEND_TRACE
-    #ifdef ROWS_TIMING
-    if (STATS) trace_wg(a.stats, 65536, trace_t0, tile, maxc, tm_stage, tm_walk, tm_bar + tm_flush, tm_nvis);
-#else
-    if (STATS) trace_wg(a.stats, 65536, trace_t0, tile, maxc);
-#endif
-#endif
-#ifdef ROWS_TIMING
-    if (STATS && lane == 0) {
-        atomicAdd(&a.stats[2], (unsigned long long)tm_nvis); atomicAdd(&a.stats[4], (unsigned long long)tm_flush);
-        atomicAdd(&a.stats[5], (unsigned long long)tm_stage); atomicAdd(&a.stats[6], (unsigned long long)tm_walk);
-        atomicAdd(&a.stats[7], (unsigned long long)tm_bar);
-    }
-#endif
     finish_tail(a, range, maxc, tile, tx, ty);
 }
 
@@ -522,8 +559,9 @@ void launch_blend_bwd(const BlendBwdArgs& a, hipStream_t s) {
     if (a.variant == 3) { launch_blend_bwd_scan(a, s); return; }
     if (a.scan_rule) launch_blend_bwd_scan(a, s);      // (returns at once unless the device rule picks it; the kernels below do the opposite)
     if (a.variant != 1) {
-        if (a.stats) hipLaunchKernelGGL(blend_bwd_rows_kernel<true>, grid, block, 0, s, a);
-        else hipLaunchKernelGGL(blend_bwd_rows_kernel<false>, grid, block, 0, s, a);
+        const bool st = a.strm_rec != nullptr;
+        if (a.stats) { if (st) hipLaunchKernelGGL((blend_bwd_rows_kernel<true, true>), grid, block, 0, s, a); else hipLaunchKernelGGL((blend_bwd_rows_kernel<true, false>), grid, block, 0, s, a); }
+        else { if (st) hipLaunchKernelGGL((blend_bwd_rows_kernel<false, true>), grid, block, 0, s, a); else hipLaunchKernelGGL((blend_bwd_rows_kernel<false, false>), grid, block, 0, s, a); }
     }
     if (a.variant != 0) {
         if (a.stats) hipLaunchKernelGGL(blend_bwd_quad_kernel<true>, grid, block, 0, s, a);

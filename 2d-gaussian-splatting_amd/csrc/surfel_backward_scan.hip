@@ -68,21 +68,10 @@ constexpr int STATE_SCRATCH = 49;      // float4s: 16 steps x 16 B + 64 lanes x 
 // conflict on every read of every step: 16.2 M of the kernel's LDS conflict cycles per launch at C2 against 1.4 M for the rows walk
 // (profiles/r03gscan_C2_pmc.json).  One float4 of padding per row moves the rows 4 banks apart.
 constexpr int PIX_ROW = 16 * 3 + 1, STATE_ROW = 16 + 1;
-// -DSCAN_TIMING (diagnostic build): the instrumented kernel accumulates shader-clock ticks per phase of every wave instead of the lane
-// counters — stats[0] staging + lists, [1] walk, [2] wait at the barrier behind the walk, [3] flush, [4] wait behind the flush,
-// [5] record write, [6] whole kernel, [7] waves (scripts/bwd_ab.py prints them as scan_raw).
-#ifdef SCAN_TIMING
-// (no vmcnt wait: the next batch's record loads and the gradient-record stores stay in flight across the phases, as in the production kernel)
-#define TM(acc) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); const long long t_ = __builtin_readcyclecounter(); acc += t_ - tm_t; tm_t = t_; }
-#define LANE_STATS false
-#else
-#define TM(acc)
-#define LANE_STATS STATS
-#endif
 #ifndef SCAN_MIN_WG
 #define SCAN_MIN_WG 3
 #endif
-template <bool STATS>
+template <bool STATS, bool STREAM>
 __global__ void __launch_bounds__(BLOCK, SCAN_MIN_WG) blend_bwd_scan_kernel(BlendBwdArgs a) {
     __shared__ float4 s_rec[SB * 5];                          // 10 KB: q0-q4 of the staged instances
     __shared__ float4 s_slot[BLOCK * 5];                      // 20 KB: the round's partial records, one per walking lane
@@ -94,14 +83,6 @@ __global__ void __launch_bounds__(BLOCK, SCAN_MIN_WG) blend_bwd_scan_kernel(Blen
     __shared__ uint32_t s_cmm[SB];                            // per staged instance: first | last << 8 round it takes part in
     __shared__ int s_rowlast[16];
     __shared__ int s_max;
-#ifdef SCAN_PAD_LDS      // occupancy experiment: SCAN_PAD_LDS bytes of unused LDS
-    __shared__ char s_pad[SCAN_PAD_LDS];
-    if (a.W < 0) s_pad[threadIdx.x] = 1;
-#endif
-#ifdef SCAN_TIMING
-    const long long tm_start = __builtin_readcyclecounter();
-    long long tm_stage = 0, tm_walk = 0, tm_bar1 = 0, tm_flush = 0, tm_bar2 = 0, tm_rec = 0, tm_bar0 = 0, tm_lists = 0, tm_t = tm_start;
-#endif
     const int tid = threadIdx.x;
     if (a.scan_rule && a.variant != 3 && !device_picks_scan(a)) return;
     if (frame_overflowed(a.n_dev, a.n_cap)) return;
@@ -138,14 +119,34 @@ __global__ void __launch_bounds__(BLOCK, SCAN_MIN_WG) blend_bwd_scan_kernel(Blen
     const int ft = tid & (SB - 1), fh = tid >> 7;
     float4 f0 = make_float4(0.f, 0.f, 0.f, 0.f), f1 = f0, f2 = f0;
 
-    // Software-pipelined staging: the records of batch b+1 are loaded into registers while batch b is walked (every thread holds
-    // half a record: (instance li, half hf) — hf 0: q0 q1 q3 q4, hf 1: q2 q5 q6 and the footprint test), the surfel ids one batch
-    // further ahead; the gradient records of batch b are stored at the top of batch b+1, BEHIND the consumption of the prefetched
-    // registers (gfx9 counts loads and stores in one vmcnt: a wait for the loads would otherwise wait for the stores as well).
+    // Software-pipelined staging: what batch b+1 needs is loaded into registers while batch b is walked; the gradient records of
+    // batch b are stored at the top of batch b+1, BEHIND the consumption of the prefetched registers (gfx9 counts loads and stores in
+    // one vmcnt: a wait for the loads would otherwise wait for the stores as well).
+    //   * frames with a TILE STREAM (surfel_common.h; round 5): every thread holds up to three contiguous 16-B pieces of the batch's
+    //     10 KB of stream records, the threads of the upper half also an instance's footprint bits — no ids, no gather, no footprint test;
+    //   * frames without one: half a 112-B record per thread ((instance ft, half fh) — fh 0: q0 q1 q3 q4, fh 1: q2 q5 q6 and the
+    //     footprint test), the surfel ids one batch further ahead.
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
     float4 pa = zero4, pb = zero4, pc = zero4, pd = zero4;
     uint32_t nid = 0;
-    {
+    constexpr bool strm_on = STREAM;      // the host found the forward's tile stream for this frame (surfel_api.hip: stream_lookup)
+    const float4* __restrict__ strm = a.strm_rec;
+    const uint32_t* __restrict__ smask = a.strm_mask;
+    auto fetch = [&](int hi_n) {      // the batch of list positions (hi_n - mbn, hi_n]: pa pb pc = pieces tid, tid + 256, tid + 512; nid = footprint bits
+        const int mbn = min(SB, hi_n), np = STRM_Q * mbn;
+        const size_t g0 = (size_t)range.x + (size_t)(hi_n - mbn);
+        const float4* __restrict__ src = strm + g0 * STRM_Q;
+        if (tid < np) pa = src[tid];
+        if (tid + BLOCK < np) pb = src[tid + BLOCK];
+        if (tid + 2 * BLOCK < np) pc = src[tid + 2 * BLOCK];
+        if (ft < mbn) {      // upper half: the instance's footprint bits; lower half (large frames): its surfel, for the "has a record" byte
+            if (fh == 1) nid = smask[g0 + (size_t)(mbn - 1 - ft)];
+            else if (a.has_rec) nid = a.point_list[g0 + (size_t)(mbn - 1 - ft)];
+        }
+    };
+    if (strm_on) {
+        if (maxc > 0) fetch(maxc);
+    } else {
         const float4* __restrict__ recq = reinterpret_cast<const float4*>(a.rec);
         if (ft < min(SB, maxc)) {
             const uint32_t id = a.point_list[range.x + (maxc - ft) - 1];
@@ -161,7 +162,26 @@ __global__ void __launch_bounds__(BLOCK, SCAN_MIN_WG) blend_bwd_scan_kernel(Blen
         const int mb = min(SB, hi);
         __syncthreads();                      // previous batch written out: s_rec / s_list / s_rank reusable
         unsigned ovr = 0;
-        if (ft < mb) {
+        if (strm_on) {
+            // pieces -> s_rec: stream entry jj (ascending position) is staged instance mb - 1 - jj (0 = the deepest position)
+            const int np = STRM_Q * mb;
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                const int p = tid + BLOCK * k;
+                const int jj = (p * 13108) >> 16;       // p / 5 for p < 640
+                if (p < np) s_rec[(mb - 1 - jj) * 5 + (p - 5 * jj)] = k == 0 ? pa : (k == 1 ? pb : pc);
+            }
+            if (ft < mb) {
+                if (fh == 1) {
+                    ovr = nid & 0xffffu;
+                    const int pos = hi - ft;
+                    unsigned live = 0;            // a sub-tile never meets an instance behind the last contributor of all its pixels
+#pragma unroll
+                    for (int s = 0; s < 16; s++) live |= (pos <= s_rowlast[s]) ? (1u << s) : 0u;
+                    ovr &= live;
+                } else if (a.has_rec) a.has_rec[nid] = 1;      // every staged instance gets a record (finish_tail)
+            }
+        } else if (ft < mb) {
             if (fh == 0) { s_rec[ft * 5 + 0] = pa; s_rec[ft * 5 + 1] = pb; s_rec[ft * 5 + 3] = pc; s_rec[ft * 5 + 4] = pd; }
             else {
                 s_rec[ft * 5 + 2] = pa;
@@ -173,17 +193,15 @@ __global__ void __launch_bounds__(BLOCK, SCAN_MIN_WG) blend_bwd_scan_kernel(Blen
                 ovr &= live;
             }
         }
-#ifdef SCAN_TIMING
-        asm volatile("" :: "v"(ovr));
-        TM(tm_rec)      // top barrier + the wait for the prefetched records + LDS writes + footprint test
-#endif
         if (pend) {                           // the previous batch's gradient records
             float4* __restrict__ dst = reinterpret_cast<float4*>(a.grec + pend_slot * GREC_F);
             if (fh == 0) { dst[0] = f0; dst[1] = f1; dst[2] = f2; }
             else { dst[3] = f0; dst[4] = f1; }
         }
         f0 = zero4; f1 = zero4; f2 = zero4;
-        if (hi - SB > 0) {                    // next batch's records, and the ids of the one behind it
+        if (strm_on) {
+            if (hi - SB > 0) fetch(hi - SB);
+        } else if (hi - SB > 0) {             // next batch's records, and the ids of the one behind it
             const float4* __restrict__ recq = reinterpret_cast<const float4*>(a.rec);
             if (ft < min(SB, hi - SB)) {
                 const float4* __restrict__ src = recq + (size_t)nid * REC_Q;
@@ -199,9 +217,7 @@ __global__ void __launch_bounds__(BLOCK, SCAN_MIN_WG) blend_bwd_scan_kernel(Blen
                 if (lane == 0) s_bal[s][wave - 2] = b;
             }
         }
-        TM(tm_stage)
         __syncthreads();
-        TM(tm_bar0)
         if (fh == 1) {                        // (the threads that hold the footprints)
             // rank of this instance on every list it is on = instances ahead of it (staged order = back to front) on that list
             uint32_t rk[4] = {~0u, ~0u, ~0u, ~0u};
@@ -229,7 +245,6 @@ __global__ void __launch_bounds__(BLOCK, SCAN_MIN_WG) blend_bwd_scan_kernel(Blen
         const uint32_t fcm = s_cmm[ft];
         const int fcmin = (int)(fcm & 255u), fcmax = (int)(fcm >> 8);
 
-        TM(tm_lists)
         for (int c = 0; c < nrounds; c++) {
             const int idx = c * CH + i16;
             const bool valid = idx < n_row;
@@ -285,7 +300,7 @@ __global__ void __launch_bounds__(BLOCK, SCAN_MIN_WG) blend_bwd_scan_kernel(Blen
                     const float Xb = S.y + row_scan_add_excl(wu);             // suffix sum behind this lane's instance
                     const float dL_dalpha = ok ? FMA(T, u, -(Xb * i1a)) : 0.f;
                     swr[p * 2] = make_float2(T, Xb + wu);
-                    if (LANE_STATS) {
+                    if (STATS) {
                         const unsigned long long okb = __ballot(ok), vb = __ballot(valid);
                         if (lane == 0) {
                             atomicAdd(&a.stats[0], 64ull); atomicAdd(&a.stats[1], (unsigned long long)__popcll(okb));
@@ -320,9 +335,7 @@ __global__ void __launch_bounds__(BLOCK, SCAN_MIN_WG) blend_bwd_scan_kernel(Blen
                 s_slot[tid * 5 + 3] = make_float4(g[12], g[13], g[14], g[15]);
                 s_slot[tid * 5 + 4] = make_float4(g[16], g[17], 0.f, 0.f);
             }
-            TM(tm_walk)
             __syncthreads();
-            TM(tm_bar1)
             // ---- flush round c: the slot of (sub-tile s, lane r & 15) belongs to the instance of rank r = 16 c + lane on list s.
             // Fixed order: rounds ascending, sub-tiles ascending inside a round.
             if (ft < mb && c >= fcmin && c <= fcmax) {
@@ -340,35 +353,25 @@ __global__ void __launch_bounds__(BLOCK, SCAN_MIN_WG) blend_bwd_scan_kernel(Blen
                     }
                 }
             }
-            TM(tm_flush)
             __syncthreads();                  // slots reusable
-            TM(tm_bar2)
         }
         // ---- the batch's gradient records: every staged instance gets one (zeros if no pixel took it)
         pend = ft < mb;
         if (pend) pend_slot = grec_slot(s_rec[ft * 5 + 4], tx, ty);
-        TM(tm_lists)
     }
     if (pend) {
         float4* __restrict__ dst = reinterpret_cast<float4*>(a.grec + pend_slot * GREC_F);
         if (fh == 0) { dst[0] = f0; dst[1] = f1; dst[2] = f2; }
         else { dst[3] = f0; dst[4] = f1; }
     }
-#ifdef SCAN_TIMING
-    if (STATS && lane == 0) {
-        atomicAdd(&a.stats[0], (unsigned long long)tm_stage); atomicAdd(&a.stats[1], (unsigned long long)tm_walk);
-        atomicAdd(&a.stats[2], (unsigned long long)tm_bar1); atomicAdd(&a.stats[3], (unsigned long long)tm_flush);
-        atomicAdd(&a.stats[4], (unsigned long long)(tm_bar2 + tm_bar0 + tm_lists)); atomicAdd(&a.stats[5], (unsigned long long)tm_rec);
-        atomicAdd(&a.stats[6], (unsigned long long)(__builtin_readcyclecounter() - tm_start)); atomicAdd(&a.stats[7], 1ull);
-    }
-#endif
     finish_tail(a, range, maxc, tile, tx, ty);
 }
 
 void launch_blend_bwd_scan(const BlendBwdArgs& a, hipStream_t s) {
     const dim3 grid(a.map_len), block(BLOCK);
-    if (a.stats) hipLaunchKernelGGL(blend_bwd_scan_kernel<true>, grid, block, 0, s, a);
-    else hipLaunchKernelGGL(blend_bwd_scan_kernel<false>, grid, block, 0, s, a);
+    const bool st = a.strm_rec != nullptr;
+    if (a.stats) { if (st) hipLaunchKernelGGL((blend_bwd_scan_kernel<true, true>), grid, block, 0, s, a); else hipLaunchKernelGGL((blend_bwd_scan_kernel<true, false>), grid, block, 0, s, a); }
+    else { if (st) hipLaunchKernelGGL((blend_bwd_scan_kernel<false, true>), grid, block, 0, s, a); else hipLaunchKernelGGL((blend_bwd_scan_kernel<false, false>), grid, block, 0, s, a); }
 }
 
 }  // namespace surfel

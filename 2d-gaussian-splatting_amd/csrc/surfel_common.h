@@ -123,6 +123,26 @@ __device__ __forceinline__ void trace_wg(unsigned long long* stats, int slot_bas
 #define TRACE_TM(acc)
 #endif
 
+// ---- the tile stream (round 5) ---------------------------------------------------------------------------------------------------
+// blend_bwd used to stage a batch as blend_fwd does: surfel ids of the list -> 112-B record gather (two DEPENDENT global round trips,
+// 64 cache lines per load instruction, every line fetched up to seven times) -> exact footprint test of every instance against the
+// tile's 16 sub-tiles (~150 instructions per staged instance) — 28 % of a scan-walk wave's life on a trained frame
+// (profiles/r04_wg_trace.md section 4), and the backward has no LDS left for the forward's remedy (a second record buffer filled by DMA).
+// But the forward HAS all of it in LDS at the moment it walks a batch: the whole records and the footprint bits.  It now leaves them
+// behind in list order — 80 B (q0-q4) + 4 B (the 16 sub-tile bits, in the backward's row order) per staged list position, written
+// once, coalesced, by the wave that fetched them — and the backward's staging becomes ONE contiguous, dependency-free read per batch,
+// prefetched a batch ahead.  The blend kernels run at < 0.1 of the HBM roofline and are bound by issue and latency: this trades
+// bytes (164 B per staged instance, about what the gather fetched) for both.  Only positions the forward walked have entries — exactly
+// the positions (<= a tile's deepest contributor) the backward stages.  Frames above 2^24 instances (C5: 11 GB of stream for 4 % staged
+// positions) and the batch-synchronous forward kernel write none: the two words the forward leaves in the image buffer say where the
+// stream is, 0 = nowhere, and the backward gathers as before — same bits either way (tests/test_gpu_parity.py::test_tile_stream_*).
+constexpr int STRM_Q = 5;                          // float4s per stream record (q0-q4 of the 112-B surfel record)
+constexpr long long STRM_MAX_R = 1ll << 24;        // largest binning capacity that gets a stream
+// sub-tile bits in `sub` order (4 * by + bx, blend_fwd) -> row order (bit 4 w + r <-> DPP row r of wave w, blend_bwd): swap index bits 1, 2
+__device__ __forceinline__ unsigned subtile_bits_to_rows(unsigned m) {
+    return (m & 0xC3C3u) | ((m & 0x0C0Cu) << 2) | ((m & 0x3030u) >> 2);
+}
+
 struct Rect { int x0, y0, x1, y1; };
 
 __device__ __forceinline__ Rect tile_rect(float px, float py, int r, int gx, int gy) {

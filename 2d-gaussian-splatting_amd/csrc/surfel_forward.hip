@@ -205,7 +205,7 @@ __device__ __forceinline__ unsigned subtile_overlap_half(const Foot& f, int tile
 
 static_assert(REC_Q == 7, "the DMA's piece -> record arithmetic assumes 112-B records");
 template <bool STATS>
-__global__ void __launch_bounds__(BLOCK) blend_fwd_pipe_kernel(BlendFwdArgs a) {
+__global__ void __launch_bounds__(BLOCK, 5) blend_fwd_pipe_kernel(BlendFwdArgs a) {
     __shared__ float4 s_rec[2][NB][REC_Q];             // 28 KB: the whole 112-B records of two batches, [buffer][instance][quarter]
     __shared__ __attribute__((aligned(16))) uint32_t s_mask[2][16 * PMSTRIDE];     // [buffer][sub-tile][word]
     __shared__ int s_alldone[2][4];
@@ -225,7 +225,8 @@ __global__ void __launch_bounds__(BLOCK) blend_fwd_pipe_kernel(BlendFwdArgs a) {
     const int pxi = tx * TILE + lx, pyi = ty * TILE + ly;
     const bool inside = pxi < a.W && pyi < a.H;
     const float pxf = (float)pxi, pyf = (float)pyi;
-    const uint2 range = a.ranges[tile];
+    const uint2 range_v = a.ranges[tile];
+    const uint2 range = make_uint2(__builtin_amdgcn_readfirstlane(range_v.x), __builtin_amdgcn_readfirstlane(range_v.y));      // (uniform: kept in SGPRs)
     const int n = (int)(range.y - range.x);
 
     bool done = !inside;
@@ -259,11 +260,32 @@ __global__ void __launch_bounds__(BLOCK) blend_fwd_pipe_kernel(BlendFwdArgs a) {
     auto masks = [&](int base, int buf) {
         unsigned ov = 0;
         const int j = 32 * wave + (lane & 31), half = lane >> 5;
+        // the tile stream (surfel_common.h): what blend_bwd will need of these 32 instances, left behind in list order by the wave that
+        // holds it — 2.5 KB of records as three coalesced 16-B stores per lane (read from LDS here, under the footprint arithmetic, stored
+        // behind it), and the 16 footprint bits per instance
+        const int first = base + 32 * wave;                                  // list position (0-based) of this wave's first instance
+        const int npc = STRM_Q * min(32, n - first);                         // 16-B pieces this wave owes the stream
         if (base + j < n) ov = subtile_overlap_half(make_foot(s_rec[buf][j][2], s_rec[buf][j][5], s_rec[buf][j][6]), tx * TILE, ty * TILE, half);
 #pragma unroll
         for (int k = 0; k < 8; k++) {
             const unsigned long long b = __ballot((ov >> k) & 1u);
             if (lane == 0) { s_mask[buf][k * PMSTRIDE + wave] = (uint32_t)b; s_mask[buf][(8 + k) * PMSTRIDE + wave] = (uint32_t)(b >> 32); }
+        }
+        if (a.strm_rec) {
+            const unsigned other = (unsigned)__shfl_xor((int)ov, 32);      // the other half of the tile
+            // (addresses computed HERE, from a lane id the compiler cannot see through: hoisted out of the batch loop they occupy registers
+            // through the walk)
+            unsigned ln = (unsigned)lane;
+            asm volatile("" : "+v"(ln));
+            const unsigned rx = __builtin_amdgcn_readfirstlane(range.x);
+            if (ln < 32u && first + (int)ln < n) a.strm_mask[(size_t)rx + (size_t)(first + (int)ln)] = subtile_bits_to_rows(ov | (other << 8));
+            float4* __restrict__ dst = a.strm_rec + ((size_t)rx + (size_t)first) * STRM_Q + ln;
+            const float4* src = &s_rec[buf][32 * wave][0];
+            const int p0 = (int)ln, p1 = (int)ln + 64, p2 = (int)ln + 128;           // piece p = quarter p % 5 of instance p / 5
+            const int j0 = (p0 * 13108) >> 16, j1 = (p1 * 13108) >> 16, j2 = (p2 * 13108) >> 16;      // p / 5 (exact below 65536 / 4)
+            if (p0 < npc) dst[0] = src[REC_Q * j0 + (p0 - STRM_Q * j0)];
+            if (p1 < npc) dst[64] = src[REC_Q * j1 + (p1 - STRM_Q * j1)];
+            if (p2 < npc) dst[128] = src[REC_Q * j2 + (p2 - STRM_Q * j2)];
         }
     };
     const unsigned ids_base = __builtin_amdgcn_readfirstlane(lds_offset(&s_ids[wave][0]));
@@ -392,9 +414,16 @@ __global__ void __launch_bounds__(BLOCK) blend_fwd_pipe_kernel(BlendFwdArgs a) {
         for (int o = 32; o > 0; o >>= 1) npairs += __shfl_xor(npairs, o);
         if (lane == 0) atomicAdd(&a.stats[6], (unsigned long long)npairs);
     }
-    if (inside) {
+    // (the pixel's coordinates are derived again here, from a thread id the compiler cannot see through: kept from the top of the kernel
+    // they occupy two registers through the walk — the 97th and 98th)
+    unsigned tid_e = threadIdx.x;
+    asm volatile("" : "+v"(tid_e));
+    int lx_e, ly_e, sub_e;
+    thread_pixel((int)tid_e, lx_e, ly_e, sub_e);
+    const int pxe = tx * TILE + lx_e, pye = ty * TILE + ly_e;
+    if (pxe < a.W && pye < a.H) {
         const size_t HW = (size_t)a.H * a.W;
-        const size_t pix = (size_t)pyi * a.W + pxi;
+        const size_t pix = (size_t)pye * a.W + pxe;
         a.final_T[pix] = T; a.final_T[HW + pix] = M1; a.final_T[2 * HW + pix] = M2;
         a.n_contrib[pix] = last; a.n_contrib[HW + pix] = medc;
         a.out_color[pix] = C0 + T * a.bg[0];
@@ -410,6 +439,8 @@ __global__ void __launch_bounds__(BLOCK) blend_fwd_pipe_kernel(BlendFwdArgs a) {
 
 static int g_fwd_pipe = 1;      // surfel_set_option("fwd_pipe", .): 1 pipelined staging (default), 0 the batch-synchronous kernel
 void set_fwd_pipe(int v) { g_fwd_pipe = v != 0; }
+
+bool launch_blend_fwd_writes_stream(const BlendFwdArgs& a) { return a.strm_rec != nullptr && g_fwd_pipe && !(a.avg_list > 2048); }
 
 void launch_blend_fwd(const BlendFwdArgs& a, hipStream_t s) {
     // Crowded frames (thousands of instances per tile of which a few per cent are ever staged: C5, 10 M surfels at 4K) end most tiles

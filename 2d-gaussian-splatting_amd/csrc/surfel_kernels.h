@@ -28,6 +28,8 @@ struct BlendFwdArgs {
     const int* tile_map; const uint32_t* map_flag; int map_len;      // tile of every workgroup where map_flag[0] != 0 (tile_order_kernel; -1: none), xcd_tile order otherwise; the grid size
     unsigned long long* stats;   // optional [8]: [6] += (pixel, surfel) pairs composited (surfel_debug_set_blend_stats)
     int avg_list;                // instances per tile where the host knows the count (exact binning path), else 0: picks the kernel (speed only)
+    // the TILE STREAM (surfel_common.h): per list position the 80-B blend record + the 16 sub-tile footprint bits, in list order, for blend_bwd
+    float4* strm_rec; uint32_t* strm_mask;      // [R][5] | [R], or NULL: none is written
 };
 
 struct BlendBwdArgs {
@@ -41,6 +43,7 @@ struct BlendBwdArgs {
     uint8_t* has_rec;      // with cut: [P] zeroed by the caller; set for every surfel that gets at least one record (preprocess_bwd skips the others)
     const float* depths;   // [P] view depths (the sort key's source)
     int variant;      // 0: per-DPP-row walk, 1: per-wave (8x8 quad) walk, 2: both launched, the device picks from the frame's totals (0 / 1 / 2 bit-identical); 3: scan walk
+    const float4* strm_rec; const uint32_t* strm_mask;      // the forward's tile stream (BlendFwdArgs), or NULL: the staging gathers the records by surfel id
     int scan_rule;    // 1: the scan kernel AND the rows / quad kernel selected by `variant` are launched; the device decides from `totals` which one runs (surfel_blend_bwd.h: device_picks_scan)
     const uint32_t* totals;      // [2 * R_SLOTS] partial sums written by preprocess: tile instances | visible surfels
     const uint32_t* n_dev; uint32_t n_cap;      // capacity path: the frame's instance total on the device and the record capacity (= num_rendered).  n_dev[0] > n_cap:
@@ -72,6 +75,7 @@ int tile_map_len(int gx, int gy);
 // verdict: optional device-visible word that receives 1 (uniform frame) / 2 (uneven lists)
 void launch_tile_order(const uint2* ranges, int gx, int gy, int* map, uint32_t* map_flag /* zeroed */, int force, uint32_t* verdict, hipStream_t s);
 void launch_blend_fwd(const BlendFwdArgs& a, hipStream_t s);
+bool launch_blend_fwd_writes_stream(const BlendFwdArgs& a);      // does the kernel launch_blend_fwd picks for `a` write the tile stream (a.strm_rec given)?
 void set_fwd_pipe(int v);             // 1 (default): software-pipelined staging (LDS-DMA of the next batch under the walk), 0: batch-synchronous kernel
 void launch_mark_visible(int P, const float* means3D, const float* vm, uint8_t* present, hipStream_t s);
 void launch_blend_bwd(const BlendBwdArgs& a, hipStream_t s);

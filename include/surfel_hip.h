@@ -50,6 +50,7 @@ extern "C" {
 #define SURFEL_OPT_ZERO_RECORDS   (1 << 18)            /* backward: zero records behind a tile's saturation point (default: R < 2^21); bit-identical to the cuts */
 #define SURFEL_OPT_TILE_ORDER(m)  ((((m) + 1) & 3) << 19)  /* forward: "tile_order" = m (0, 1, 2) for this call (the matching backward follows the forward) */
 #define SURFEL_OPT_LAZY_COUNT     (1 << 21)            /* forward: do not wait for the instance count (see surfel_forward_count) */
+#define SURFEL_OPT_BWD_GATHER     (1 << 22)            /* backward: ignore the forward's tile stream ("tile_stream") and gather the records by surfel id; bit-identical */
 #define SURFEL_OPT_BWD_SCAN       (1 << 15)            /* backward: scan walk ("bwd_variant" = 3) for this call; deterministic, NOT bit-identical to rows / quad */
 
 /* Allocator callback: return a device pointer to `bytes` bytes, 256-byte aligned, valid until the

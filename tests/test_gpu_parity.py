@@ -794,6 +794,55 @@ def test_forward_kernels_are_identical(kind):
             assert np.array_equal(out[0][4][k], other[4][k]), "%s: dL/d%s differs" % (kind, k)
 
 
+@pytest.mark.parametrize("kind", ["plain", "needles", "huge", "grazing", "huge_faint", "crowded", "saturating", "C1", "clustered", "long_lists"])
+def test_tile_stream_is_staging_only(kind):
+    """The TILE STREAM (csrc/surfel_common.h; round 5): blend_fwd leaves, per list position it walked, the 80-B blend record and the 16
+    footprint bits in list order; blend_bwd (rows and scan walks) stages a batch from that contiguous stream instead of ids -> 112-B
+    gather -> footprint test.  It only changes how a batch reaches LDS: for every walk the gradients with the stream are BIT-IDENTICAL
+    to the gradients of the gathering staging (per call: SURFEL_OPT_BWD_GATHER; process-wide: "tile_stream" = 0 — the forward then
+    writes none and the backward finds the two offset words zero), on the exact and on the capacity binning path, and for a forward
+    by the batch-synchronous kernel (which writes no stream)."""
+    import surfel_native as n
+    import synthetic
+    lib = n.load()
+    if kind == "clustered":
+        sc = _clustered_scene()
+    elif kind == "long_lists":      # ~700 instances per tile: six batches of 128, the last one partial
+        sc = synthetic.make_scene(60000, 160, 128, seed=12, px_radius=6.0, z_near=1.0, z_far=9.0)
+        sc["opacities"] = np.full_like(sc["opacities"], 0.015)
+    else:
+        sc = _walk_scene(kind)
+    a = scene_args(sc)
+    rng = np.random.default_rng(19)
+    gC = rng.normal(size=(3, a["H"], a["W"])).astype(np.float32); gO = rng.normal(size=(7, a["H"], a["W"])).astype(np.float32)
+    walks = (("rows", n.OPT_BWD_ROWS), ("scan", n.OPT_BWD_SCAN), ("auto", 0))
+    res = {}
+    try:
+        for tag, stream, pipe in (("stream", 1, 1), ("stream_again", 1, 1), ("off", 0, 1), ("old_forward", 1, 0)):
+            assert lib.surfel_set_option(b"tile_stream", stream) == 0 and lib.surfel_set_option(b"fwd_pipe", pipe) == 0
+            run = HipRun(a, debug=n.OPT_EXACT_BINNING if tag == "stream" else 0).forward()      # (the later forwards of this size take the capacity path)
+            res[tag + "_binning"] = lib.surfel_debug_last_binning()
+            for w, flag in walks:
+                run.debug = flag
+                res[(tag, w)] = run.backward(gC, gO)
+                run.debug = 0
+                if tag == "stream":
+                    run.debug = flag | n.OPT_BWD_GATHER
+                    res[("gather", w)] = run.backward(gC, gO)
+    finally:
+        lib.surfel_set_option(b"tile_stream", 1)
+        lib.surfel_set_option(b"fwd_pipe", 1)
+    assert res["stream_binning"] == 0      # (the later forwards take the capacity path where the frame qualifies for it: crowded tiles do not)
+    assert res["stream_again_binning"] in (1, 2) or kind in ("huge_faint", "long_lists", "crowded", "saturating"), res["stream_again_binning"]
+    for w, _ in walks:
+        ref = res[("stream", w)]
+        for k in ref:
+            assert np.isfinite(ref[k]).all(), (w, k)
+        for tag in ("gather", "stream_again", "off", "old_forward"):
+            for k in ref:
+                assert np.array_equal(ref[k], res[(tag, w)][k]), "%s, %s walk: dL/d%s with the tile stream differs from '%s'" % (kind, w, k, tag)
+
+
 def _walk_scene(kind, seed=31):
     import synthetic
     if kind == "C1":

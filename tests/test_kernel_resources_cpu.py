@@ -15,9 +15,11 @@ sys.path.insert(0, os.path.join(REPO, "scripts"))
 LIMITS = {
     "blend_fwd_pipe_kernel<false>": (96, 32 * 1024),           # 5 waves / SIMD, 5 workgroups / CU
     "blend_fwd_kernel<false>": (96, 32 * 1024),
-    "blend_bwd_rows_kernel<false>": (96, 32 * 1024),
+    "blend_bwd_rows_kernel<false, true>": (128, 40 * 1024),    # 4 waves / SIMD, 4 workgroups / CU (5 measured no faster); staging from the tile stream
+    "blend_bwd_rows_kernel<false, false>": (128, 40 * 1024),   # ... staging by gather
     "blend_bwd_quad_kernel<false>": (96, 32 * 1024),
-    "blend_bwd_scan_kernel<false>": (168, 160 * 1024 // 3),    # 3 waves / SIMD, 3 workgroups / CU
+    "blend_bwd_scan_kernel<false, true>": (168, 160 * 1024 // 3),    # 3 waves / SIMD, 3 workgroups / CU
+    "blend_bwd_scan_kernel<false, false>": (168, 160 * 1024 // 3),
 }
 
 
