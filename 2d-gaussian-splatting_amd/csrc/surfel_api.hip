@@ -21,14 +21,10 @@ namespace {
 thread_local std::string g_err;
 int g_opt_cull = 1;        // surfel_set_option("cull", .)
 int g_opt_tile_sort = 1;   // surfel_set_option("tile_depth_sort", .): 0 never, 1 auto (by last frame's R / tiles), 2 always
-int g_opt_bwd_variant = 2; // surfel_set_option("bwd_variant", .): 0 per-row walk, 1 per-quad walk, 2 auto (0 / 1 / 2 bit-identical), 3 scan walk, 4 auto over all three
+int g_opt_bwd_variant = 2; // surfel_set_option("bwd_variant", .): 0 per-row walk, 1 per-quad walk (0 / 1 bit-identical), 2 auto = rows or scan by the device rule, 3 scan walk
 surfel_hook_fn g_colour_hook = nullptr;   // surfel_set_backward_hook
 void* g_colour_hook_user = nullptr;
-int g_opt_pbwd_coop = -1;  // surfel_set_option("pbwd_coop", .): record gather of preprocess_bwd — -1 by rule (R >= 6 P and R >= 2^25), 0 per thread, 1 wave-cooperative
-int g_opt_host_total = 1;  // surfel_set_option("host_total", .): capacity path — 1: bin_emit_kernel stores the instance total into mapped pinned memory, 0: D2H copy kernel (measurement)
-int g_opt_scan_large = 1;  // surfel_set_option("scan_large", .): auto lets the device rule hand frames to the scan walk (2^21 <= R < 2^26 instances, or >= 6 instances per emitting surfel)
 int g_opt_stream = 1;      // surfel_set_option("tile_stream", .): blend_fwd leaves the tile stream for blend_bwd (surfel_common.h); 0: blend_bwd gathers
-int g_opt_bwd_tune = 1;    // surfel_set_option("bwd_tune", .): auto = timed probes (1) or the device-side rule alone (0)
 unsigned long long* g_blend_stats = nullptr;   // surfel_debug_set_blend_stats
 thread_local int64_t g_last_R = -1; thread_local int g_last_W = 0, g_last_H = 0;   // auto heuristic (speed only; results identical; a stale
                                                                                     // value from another device / stream only costs one slower frame)
@@ -223,90 +219,6 @@ struct StageTimer {
         if (_e) return fail(SURFEL_E_HIP, kStageNames[st], (hipError_t)_e);                \
     } while (0)
 
-// Online choice of the blend_bwd walk (bwd_variant = 2, the default).  The two walks are bit-identical, so the choice only
-// changes speed, and which one is faster depends on footprint statistics that no cheap formula captured: the same instances per
-// surfel gave rows -8 % on one C4 frame and +10 % on another (profiles/r02_blend_bwd_variants.md).  So it is measured: per
-// (device, width, height, octave of tile instances per surfel), two backward calls out of every kTunePeriod are timed with HIP
-// events on the launch stream — one per walk, never the first two calls of an entry (cold code and caches); the events are polled
-// by later calls, never synchronised — and the walk with the lower time per tile instance (running mean over probes) is launched
-// alone until the next probe.  Until both walks have been timed, and while the stream is being
-// captured into a graph, both kernels are launched and the device-side rule (R <= 4 V) picks.
-struct WalkTuner {
-    int dev = -1, W = 0, H = 0, octave = 0, nwalks = 2;
-    unsigned calls = 0;
-    int choice = -1;
-    float ns_per_inst[3] = {0.f, 0.f, 0.f};
-    bool have[3] = {false, false, false}, pending[3] = {false, false, false};
-    int64_t pend_R[3] = {0, 0, 0};
-    hipEvent_t e0[3] = {nullptr, nullptr, nullptr}, e1[3] = {nullptr, nullptr, nullptr};
-};
-constexpr int kTuners = 8;
-constexpr unsigned kTunePeriod = 32;
-constexpr unsigned kTuneFirst = 2;      // phase of the first probe
-constexpr int kWalkVariant[3] = {0, 1, 3};      // probe slot -> BlendBwdArgs::variant (rows, quad, scan)
-WalkTuner g_tuners[kTuners];
-unsigned g_tuner_next = 0;
-std::mutex g_tuner_mu;
-
-// returns the variant to launch (0 rows, 1 quad, 3 scan, 2 rows + quad with the device rule); *probe = the slot being timed by this
-// call, or -1.  nwalks = 2: rows / quad (bit-identical, "bwd_variant" 2); 3: the scan walk competes as well ("bwd_variant" 4).
-int walk_octave(int P, int64_t R) {
-    int o = 0;
-    for (int64_t x = R / (P > 0 ? P : 1); x > 1 && o < 15; x >>= 1) o++;
-    return o;
-}
-int walk_tuner_pick(int P, int W, int H, int64_t R, hipStream_t s, int nwalks, WalkTuner** out, int* probe) {
-    *out = nullptr; *probe = -1;
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess) return 2;
-    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-    if (hipStreamIsCapturing(s, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) return 2;
-    WalkTuner* t = nullptr;
-    const int octave = walk_octave(P, R);
-    for (auto& c : g_tuners) if (c.dev == dev && c.W == W && c.H == H && c.octave == octave && c.nwalks == nwalks) { t = &c; break; }
-    if (!t) {
-        t = &g_tuners[g_tuner_next++ % kTuners];
-        for (int v = 0; v < 3; v++) {
-            if (t->pending[v]) (void)hipEventSynchronize(t->e1[v]);        // an evicted entry: its events are about to be reused
-            // events belong to the device they were created on: an entry that moves to another device gets fresh ones
-            if (t->dev != dev && t->e0[v]) { (void)hipEventDestroy(t->e0[v]); (void)hipEventDestroy(t->e1[v]); t->e0[v] = t->e1[v] = nullptr; }
-            t->pending[v] = false; t->have[v] = false; t->ns_per_inst[v] = 0.f;
-        }
-        t->dev = dev; t->W = W; t->H = H; t->octave = octave; t->nwalks = nwalks; t->calls = 0; t->choice = -1;
-    }
-    for (int v = 0; v < nwalks; v++) {
-        if (!t->pending[v] || hipEventQuery(t->e1[v]) != hipSuccess) continue;
-        float ms = 0.f;
-        if (hipEventElapsedTime(&ms, t->e0[v], t->e1[v]) == hipSuccess && t->pend_R[v] > 0) {
-            const float x = 1e6f * ms / (float)t->pend_R[v];
-            t->ns_per_inst[v] = t->have[v] ? 0.5f * (t->ns_per_inst[v] + x) : x;
-            t->have[v] = true;
-        }
-        t->pending[v] = false;
-    }
-    bool all = true;
-    for (int v = 0; v < nwalks; v++) all = all && t->have[v];
-    if (all) {
-        int best = 0;
-        for (int v = 1; v < nwalks; v++) if (t->ns_per_inst[v] < t->ns_per_inst[best]) best = v;
-        t->choice = kWalkVariant[best];
-    }
-    // (two probes in every 32 calls until a verdict has stood for three periods, then two in every 256: a probe of the slower walk costs
-    // the step its difference — 60 us at C2 — and frames of one size and footprint octave rarely change sides)
-    const unsigned period = (t->choice >= 0 && t->calls >= 3 * kTunePeriod) ? 8 * kTunePeriod : kTunePeriod;
-    const unsigned phase = t->calls++ % period;
-    if (phase >= kTuneFirst && phase < kTuneFirst + (unsigned)nwalks && !t->pending[phase - kTuneFirst]) {
-        const int v = (int)(phase - kTuneFirst);
-        if (!t->e0[v]) {
-            if (hipEventCreate(&t->e0[v]) != hipSuccess) { t->e0[v] = nullptr; return t->choice >= 0 ? t->choice : 2; }
-            if (hipEventCreate(&t->e1[v]) != hipSuccess) { (void)hipEventDestroy(t->e0[v]); t->e0[v] = t->e1[v] = nullptr; return t->choice >= 0 ? t->choice : 2; }
-        }
-        *out = t; *probe = v;
-        return kWalkVariant[v];
-    }
-    return t->choice >= 0 ? t->choice : 2;
-}
-
 // One event + one pinned read-back buffer per (host thread, device): a thread that rasterizes on a second GPU gets its own pair
 // instead of recording an event created on another device.
 constexpr int kMaxDevices = 32;
@@ -413,13 +325,8 @@ int surfel_set_option(const char* name, int value) {
     if (name && std::strcmp(name, "cull") == 0) { g_opt_cull = value ? 1 : 0; return 0; }
     if (name && std::strcmp(name, "tile_depth_sort") == 0) { g_opt_tile_sort = value < 0 ? 0 : (value > 2 ? 2 : value); return 0; }
     if (name && std::strcmp(name, "large_sort") == 0) { set_large_sort_impl(value); return 0; }
-    if (name && std::strcmp(name, "fat_sort") == 0) { set_fat_sort(value); return 0; }
     if (name && std::strcmp(name, "fwd_pipe") == 0) { set_fwd_pipe(value); return 0; }
-    if (name && std::strcmp(name, "scan_large") == 0) { g_opt_scan_large = value != 0; return 0; }
-    if (name && std::strcmp(name, "host_total") == 0) { g_opt_host_total = value != 0; return 0; }
-    if (name && std::strcmp(name, "pbwd_coop") == 0) { g_opt_pbwd_coop = value < 0 ? -1 : (value != 0); return 0; }
-    if (name && std::strcmp(name, "bwd_variant") == 0) { g_opt_bwd_variant = value < 0 ? 0 : (value > 4 ? 4 : value); return 0; }
-    if (name && std::strcmp(name, "bwd_tune") == 0) { g_opt_bwd_tune = value != 0; return 0; }
+    if (name && std::strcmp(name, "bwd_variant") == 0) { g_opt_bwd_variant = value < 0 ? 0 : (value > 3 ? 3 : value); return 0; }
     if (name && std::strcmp(name, "tile_stream") == 0) { g_opt_stream = value != 0; return 0; }
     if (name && std::strcmp(name, "capacity_binning") == 0) { g_opt_capacity = value != 0; return 0; }
     if (name && std::strcmp(name, "tile_order") == 0) { g_opt_tile_order = value < 0 ? 0 : (value > 2 ? 2 : value); return 0; }
@@ -431,15 +338,6 @@ int surfel_set_backward_hook(surfel_hook_fn colour_ready, void* user) {
     return 0;
 }
 
-int surfel_debug_walk_choice(int width, int height) {
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess) return -1;
-    std::lock_guard<std::mutex> lk(g_tuner_mu);
-    int choice = -1;
-    unsigned best = 0;
-    for (auto& c : g_tuners) if (c.dev == dev && c.W == width && c.H == height && c.calls >= best) { best = c.calls; choice = c.choice; }
-    return choice;
-}
 int surfel_debug_last_binning(void) { return g_last_binning; }
 int surfel_debug_capacity_evictions(void) { return g_cap_evictions; }
 
@@ -629,7 +527,7 @@ int64_t surfel_rasterize_forward(surfel_alloc_fn geom_alloc, void* geom_user, su
         uint32_t* hR = pinned_u32();
         hipEvent_t evR = r_event();
         if (!hR || !evR) return fail(SURFEL_E_HIP, "pinned buffer / event creation failed");
-        const bool host_total = cap > 0 && g_opt_host_total;      // capacity path: bin_emit_kernel stores the total into the mapped pinned buffer itself — no copy kernel
+        const bool host_total = cap > 0;      // capacity path: bin_emit_kernel stores the total into the mapped pinned buffer itself — no copy kernel
         if (!host_total) {
             HIP_TRY(hipMemcpyAsync(hR, img.total, sizeof(uint32_t) * R_SLOTS, hipMemcpyDeviceToHost, s));
             HIP_TRY(hipEventRecord(evR, s));
@@ -788,7 +686,7 @@ int surfel_rasterize_backward(surfel_alloc_fn scratch_alloc, void* scratch_user,
     (void)tan_fovx; (void)tan_fovy; (void)colors_precomp;
     g_stage_n = 0;
     const int debug_in = debug;
-    const int opt_variant = (debug & SURFEL_OPT_BWD_SCAN) ? 3 : ((debug & SURFEL_OPT_BWD_QUAD) ? 1 : ((debug & SURFEL_OPT_BWD_ROWS) ? 0 : g_opt_bwd_variant));   // 2 = auto
+    const int opt_variant = (debug & SURFEL_OPT_BWD_SCAN) ? 3 : ((debug & SURFEL_OPT_BWD_QUAD) ? 1 : ((debug & SURFEL_OPT_BWD_ROWS) ? 0 : g_opt_bwd_variant));   // 0 rows, 1 quad, 2 auto, 3 scan
     debug &= 0xff;
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (P == 0) return 0;
@@ -829,41 +727,31 @@ int surfel_rasterize_backward(surfel_alloc_fn scratch_alloc, void* scratch_user,
     if (!(debug_in & SURFEL_OPT_BWD_GATHER) && g_opt_stream) (void)stream_lookup(binning_buffer, &bb.strm_rec, &bb.strm_mask);      // (stays NULL: the walks gather)
     bb.n_dev = img.total + 2 * R_SLOTS; bb.n_cap = (uint32_t)(R < 0xffffffffll ? R : 0xffffffffll);
     if (R > 0) {
-        WalkTuner* tuner = nullptr;
-        int probe = -1;
-        std::unique_lock<std::mutex> tl(g_tuner_mu, std::defer_lock);
-        if (opt_variant == 4) bb.variant = 2;      // (no verdict yet, stats mode, tuning off: rows + quad with the device rule)
-        // The scan walk takes the frames whose footprints span many tiles and the large ones — decided ON THE DEVICE from the frame's
-        // totals (surfel_blend_bwd.h: device_picks_scan; the host of a lazily counted frame knows neither R nor the emitting surfels):
-        // the scan kernel is launched beside the rows / quad kernel the tuner picked and all but one of them return at once (~4 us).
-        // A rule, not a timed choice: the walks differ in summation order, and which bits a frame gets must follow from the frame alone.
-        // (C5, 1.3e8 instances of which 4 % are staged: scan 3.19 vs 3.13 ms — no gain, hence the rule's upper bound on R.)
+        // auto: rows or scan.  The scan walk takes the frames whose footprints span many tiles and the large ones — decided ON THE DEVICE
+        // from the frame's totals (surfel_blend_bwd.h: device_picks_scan; the host of a lazily counted frame knows neither R nor the
+        // emitting surfels): both kernels are launched and the workgroups of one of them return at once (~4 us).  A rule, not a timed
+        // choice: the walks differ in summation order, and which bits a frame gets must follow from the frame alone.
         // Where the host knows the count for certain — exact binning; a lazily counted frame reports its capacity, <= 2^20 — the size half
         // of the rule is applied here and only ONE kernel is launched (an idle grid of a 4K frame's 32 k workgroups costs ~0.1 ms):
-        // 2^21 <= R < 2^26 -> the scan walk alone, R >= 2^26 -> rows / quad alone; below 2^21 both, and the device decides by footprint.
-        const bool auto_walk = opt_variant == 2 && g_opt_scan_large && !g_blend_stats;
-        const bool scan_only = auto_walk && R >= ((int64_t)1 << 21) && R < ((int64_t)1 << 26);
-        bb.scan_rule = (auto_walk && R < ((int64_t)1 << 21)) ? 1 : 0;
-        if (scan_only) bb.variant = 3;
-        if ((opt_variant == 2 || opt_variant == 4) && !scan_only && !g_blend_stats && g_opt_bwd_tune) {
-            tl.lock();
-            bb.variant = walk_tuner_pick(P, width, height, R, s, opt_variant == 4 ? 3 : 2, &tuner, &probe);
-            if (probe >= 0) (void)hipEventRecord(tuner->e0[probe], s);
+        // 2^21 <= R < 2^26 -> the scan walk alone, R >= 2^26 -> rows alone (C5: 1.3e8 instances of which 4 % are staged — scan 3.19 vs
+        // 3.13 ms); below 2^21 both, and the device decides by footprint.  (The per-quad walk, bit-identical to rows, is launched only
+        // on request: it never won on a frame the rule would give it — profiles/r04_bench_n1_full.json blend_bwd_ms_by_walk.)
+        const bool auto_walk = opt_variant == 2;
+        bb.variant = auto_walk ? 0 : opt_variant;
+        if (auto_walk && !g_blend_stats) {
+            if (R >= ((int64_t)1 << 21)) bb.variant = R < ((int64_t)1 << 26) ? 3 : 0;
+            else bb.scan_rule = 1;
         }
         tm.begin(ST_BBWD);
         launch_blend_bwd(bb, s);
         STAGE_END(tm, ST_BBWD);
-        if (probe >= 0) {
-            tuner->pending[probe] = hipEventRecord(tuner->e1[probe], s) == hipSuccess;
-            tuner->pend_R[probe] = R;
-        }
     }
 
     PreprocessBwdArgs pb{};
     pb.P = P; pb.D = D; pb.M = M; pb.W = width; pb.H = height; pb.scale_modifier = scale_modifier;
     // record gather: per thread, or by the wave when a surfel holds many records AND the records (80 B each) overflow the 256 MB
     // Infinity Cache (measured: the cooperative form wins at C5 only, and loses 30 - 85 % on small frames); bit-identical sums
-    pb.coop = (debug_in & SURFEL_OPT_PBWD_COOP) ? 1 : ((debug_in & SURFEL_OPT_PBWD_THREAD) ? 0 : (g_opt_pbwd_coop >= 0 ? g_opt_pbwd_coop : ((R >= (int64_t)6 * P && R >= ((int64_t)32 << 20)) ? 1 : 0)));
+    pb.coop = (debug_in & SURFEL_OPT_PBWD_COOP) ? 1 : ((debug_in & SURFEL_OPT_PBWD_THREAD) ? 0 : ((R >= (int64_t)6 * P && R >= ((int64_t)32 << 20)) ? 1 : 0));
     pb.means3D = means3D; pb.radii = radii; pb.shs = shs; pb.clamped = geom.clamped; pb.scales = scales; pb.rotations = rotations;
     pb.transMat_precomp = transMat_precomp; pb.viewmatrix = viewmatrix; pb.projmatrix = projmatrix; pb.campos = cam_pos;
     pb.rec = geom.rec; pb.tiles_touched = geom.tiles_touched; pb.grec = grec; pb.cut = cut; pb.has_rec = has_rec; pb.depths = geom.depths; pb.gx = gx;

@@ -12,7 +12,7 @@
 //                   adds an instance's slots in the tree order ((r0+r1)+(r2+r3)) per wave, waves 0..3.
 //   quad          : a wave (8x8 pixels) walks the instances its quad overlaps, one per visit, wave-wide reduction
 //                   (38 DPP adds + 5 permlane swaps), per-wave LDS partials.  Round 1's kernel; the faster walk on wide footprints.
-// Which of the two runs is decided by the caller (surfel_api.hip: timed probes, `bwd_tune`) or, for variant 2, on the device.
+// Which of the two runs is the caller's choice (BlendBwdArgs::variant); rows is the product's walk, quad the reference it is held to.
 // A third walk with another structure (lanes = instances, DPP row scans; not bit-identical to these two) lives in
 // surfel_backward_scan.hip.  What happens to the instances behind a tile's saturation point: surfel_blend_bwd.h (finish_tail).
 // Semantics: oracle/surfel_oracle.c stages 4-5 (restating the absent diff-surfel-rasterization).
@@ -214,7 +214,6 @@ __global__ void __launch_bounds__(BLOCK, ROWS_WAVES) blend_bwd_rows_kernel(Blend
     __shared__ int s_rowlast[16];                             // per row: the largest `last` of its 16 pixels
     __shared__ __attribute__((aligned(4))) uint8_t s_list[16][LROW];      // per row: staged indices of the instances on its list, back to front
     __shared__ int s_max;
-    if (a.variant == 2 && !auto_picks_rows(a)) return;
     if (a.scan_rule && device_picks_scan(a)) return;
     if (frame_overflowed(a.n_dev, a.n_cap)) return;
     const int tile = block_tile(a.tile_map, a.map_flag, (int)blockIdx.x, a.gx * a.gy);
@@ -447,7 +446,6 @@ __global__ void __launch_bounds__(BLOCK) blend_bwd_quad_kernel(BlendBwdArgs a) {
     __shared__ unsigned long long s_qmask[4][4];     // [quad][staging wave] overlap bitmasks of the staged batch
     __shared__ int s_quadlast[4];                    // per quad (= wave): the largest `last` of its 64 pixels
     __shared__ int s_max;
-    if (a.variant == 2 && auto_picks_rows(a)) return;
     if (a.scan_rule && device_picks_scan(a)) return;
     if (frame_overflowed(a.n_dev, a.n_cap)) return;
     const int tile = block_tile(a.tile_map, a.map_flag, blockIdx.x, a.gx * a.gy);
@@ -557,13 +555,12 @@ __global__ void __launch_bounds__(BLOCK) blend_bwd_quad_kernel(BlendBwdArgs a) {
 void launch_blend_bwd(const BlendBwdArgs& a, hipStream_t s) {
     const dim3 grid(a.map_len), block(BLOCK);
     if (a.variant == 3) { launch_blend_bwd_scan(a, s); return; }
-    if (a.scan_rule) launch_blend_bwd_scan(a, s);      // (returns at once unless the device rule picks it; the kernels below do the opposite)
-    if (a.variant != 1) {
+    if (a.scan_rule) launch_blend_bwd_scan(a, s);      // (returns at once unless the device rule picks it; the kernel below does the opposite)
+    if (a.variant == 0) {
         const bool st = a.strm_rec != nullptr;
         if (a.stats) { if (st) hipLaunchKernelGGL((blend_bwd_rows_kernel<true, true>), grid, block, 0, s, a); else hipLaunchKernelGGL((blend_bwd_rows_kernel<true, false>), grid, block, 0, s, a); }
         else { if (st) hipLaunchKernelGGL((blend_bwd_rows_kernel<false, true>), grid, block, 0, s, a); else hipLaunchKernelGGL((blend_bwd_rows_kernel<false, false>), grid, block, 0, s, a); }
-    }
-    if (a.variant != 0) {
+    } else {
         if (a.stats) hipLaunchKernelGGL(blend_bwd_quad_kernel<true>, grid, block, 0, s, a);
         else hipLaunchKernelGGL(blend_bwd_quad_kernel<false>, grid, block, 0, s, a);
     }

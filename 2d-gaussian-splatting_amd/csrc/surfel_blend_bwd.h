@@ -52,18 +52,6 @@ __device__ __forceinline__ size_t grec_slot(const float4 q4, int tx, int ty) {
     return (size_t)basei + (size_t)((ty - y0) * rw + (tx - x0));
 }
 
-// variant == 2: both kernels are launched and each decides on the device, from the frame's totals, whether it is the one to run.
-// Small footprints (few tile instances per emitting surfel) favour the per-row walk — it wastes fewer lanes; on wide footprints
-// the per-quad walk's cheaper visit wins (profiles/r02_blend_bwd_variants.md).  Every workgroup reaches the same verdict.
-constexpr int AUTO_ROWS_MAX_INST_PER_SURFEL = 4;
-__device__ __forceinline__ bool auto_picks_rows(const BlendBwdArgs& a) {
-    const int lane = threadIdx.x & 63;
-    uint32_t r = a.totals[lane], v = a.totals[R_SLOTS + lane];
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { r += __shfl_xor(r, o); v += __shfl_xor(v, o); }
-    return (unsigned long long)r <= (unsigned long long)AUTO_ROWS_MAX_INST_PER_SURFEL * v;
-}
-
 // BlendBwdArgs::scan_rule: the scan walk (surfel_backward_scan.hip) and ONE of rows / quad are launched, and every workgroup of both
 // decides from the frame's totals which of the two runs — deterministic from the frame alone (the walks differ in summation order:
 // which bits a frame gets must not depend on timing or history).  Scan wins where a surfel's footprint spans many tiles — trained

@@ -102,27 +102,6 @@ __device__ __forceinline__ bool frame_overflowed(const uint32_t* __restrict__ n_
 #endif
 }
 
-// -DBLEND_TRACE (diagnostic build, scripts/wg_trace.py): the instrumented blend kernels leave, per workgroup, [start, end] in 100 MHz
-// ticks, the hardware ids (HW_ID | XCC_ID << 32) and (tile | list length << 32) behind the 16 counters of the stats buffer.
-#ifdef BLEND_TRACE
-constexpr int TRACE_W = 8;      // u64 words per workgroup
-__device__ __forceinline__ void trace_wg(unsigned long long* stats, int slot_base, unsigned long long t0, int tile, int n,
-                                         long long c_stage = 0, long long c_walk = 0, long long c_bar = 0, long long iters = 0) {
-    if (threadIdx.x == 0) {      // (the phase cycles are wave 0's)
-        unsigned hw, xcc;
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-        unsigned long long* d = stats + 16 + TRACE_W * (size_t)(slot_base + blockIdx.x);
-        d[0] = t0; d[1] = wall_clock64(); d[2] = (unsigned long long)hw | ((unsigned long long)xcc << 32);
-        d[3] = (unsigned long long)(unsigned)tile | ((unsigned long long)(unsigned)n << 32);
-        d[4] = (unsigned long long)c_stage; d[5] = (unsigned long long)c_walk; d[6] = (unsigned long long)c_bar; d[7] = (unsigned long long)iters;
-    }
-}
-#define TRACE_TM(acc) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); const long long t_ = __builtin_readcyclecounter(); acc += t_ - ttm_t; ttm_t = t_; }
-#else
-#define TRACE_TM(acc)
-#endif
-
 // ---- the tile stream (round 5) ---------------------------------------------------------------------------------------------------
 // blend_bwd used to stage a batch as blend_fwd does: surfel ids of the list -> 112-B record gather (two DEPENDENT global round trips,
 // 64 cache lines per load instruction, every line fetched up to seven times) -> exact footprint test of every instance against the

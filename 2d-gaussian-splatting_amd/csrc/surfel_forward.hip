@@ -20,10 +20,6 @@ template <bool STATS>
 __global__ void __launch_bounds__(BLOCK) blend_fwd_kernel(BlendFwdArgs a) {
     __shared__ float4 s_rec[BLOCK * 5];
     __shared__ __attribute__((aligned(8))) uint32_t s_mask[16 * MSTRIDE];    // [sub-tile][word]
-#ifdef BLEND_TRACE
-    const unsigned long long trace_t0 = wall_clock64();
-    long long ttm_t = __builtin_readcyclecounter(), ttm_stage = 0, ttm_walk = 0, ttm_bar = 0, ttm_it = 0, ttm_s0 = 0, ttm_s1 = 0, ttm_s2 = 0;
-#endif
     const int tile = block_tile(a.tile_map, a.map_flag, blockIdx.x, a.gx * a.gy);      // (tile_order_kernel: XCD-contiguous runs on uniform frames, longest lists first otherwise)
     if (tile < 0) return;
     const int tx = tile % a.gx, ty = tile / a.gx;
@@ -47,28 +43,15 @@ __global__ void __launch_bounds__(BLOCK) blend_fwd_kernel(BlendFwdArgs a) {
 
     for (int base = 0; base < n; base += BLOCK) {
         if (__syncthreads_count(done) == BLOCK) break;
-        TRACE_TM(ttm_bar)
         const int m = min(BLOCK, n - base);
         unsigned ov = 0;
         if ((int)threadIdx.x < m) {
             const uint32_t id = a.point_list[range.x + base + threadIdx.x];
-#ifdef BLEND_TRACE
-            asm volatile("" :: "v"(id));
-            TRACE_TM(ttm_s0)
-#endif
             const float4* __restrict__ src = reinterpret_cast<const float4*>(a.rec + (size_t)id * REC_F);
             const float4 v0 = src[0], v1 = src[1], v2 = src[2], v3 = src[3], v4 = src[4], v5 = src[5], v6 = src[6];
-#ifdef BLEND_TRACE
-            asm volatile("" :: "v"(v0.x), "v"(v1.x), "v"(v2.x), "v"(v3.x), "v"(v4.x), "v"(v5.x), "v"(v6.x));
-            TRACE_TM(ttm_s1)
-#endif
             s_rec[threadIdx.x * 5 + 0] = v0; s_rec[threadIdx.x * 5 + 1] = v1; s_rec[threadIdx.x * 5 + 2] = v2;
             s_rec[threadIdx.x * 5 + 3] = v3; s_rec[threadIdx.x * 5 + 4] = v4;
             ov = subtile_overlap(make_foot(v2, v5, v6), tx * TILE, ty * TILE);
-#ifdef BLEND_TRACE
-            asm volatile("" :: "v"(ov));
-            TRACE_TM(ttm_s2)
-#endif
         }
         // per-sub-tile bitmasks of the 64 instances this staging wave holds (words 2*wave, 2*wave+1)
 #pragma unroll
@@ -76,9 +59,7 @@ __global__ void __launch_bounds__(BLOCK) blend_fwd_kernel(BlendFwdArgs a) {
             const unsigned long long b = __ballot((ov >> s) & 1u);
             if (lane == 0) *reinterpret_cast<unsigned long long*>(&s_mask[s * MSTRIDE + 2 * wave]) = b;
         }
-        TRACE_TM(ttm_stage)
         __syncthreads();
-        TRACE_TM(ttm_bar)
         const int nw = (m + 31) >> 5;                 // mask words in use
         // row walk state: cur = unvisited instances of word widx, next = word widx+1 (prefetched)
         int widx = 0;
@@ -89,9 +70,6 @@ __global__ void __launch_bounds__(BLOCK) blend_fwd_kernel(BlendFwdArgs a) {
         }
         for (;;) {
             if (!__any((cur != 0u) | (widx < nw - 1))) break;
-#ifdef BLEND_TRACE
-            ttm_it++;
-#endif
             const bool act = cur != 0u;
             const int j = (widx << 5) + __builtin_ctz(cur | 0x80000000u);
             cur &= cur - 1u;
@@ -126,11 +104,7 @@ __global__ void __launch_bounds__(BLOCK) blend_fwd_kernel(BlendFwdArgs a) {
             }
             if (cur == 0u && widx < nw - 1) { widx++; cur = next; next = mrow[widx + 1]; }
         }
-        TRACE_TM(ttm_walk)
     }
-#ifdef BLEND_TRACE
-    if (STATS) trace_wg(a.stats, 0, trace_t0, tile, n, (ttm_s0 << 40) | (ttm_s1 << 20) | ttm_s2, ttm_walk, (ttm_stage << 24) | ttm_bar, ttm_it);
-#endif
     if (STATS) {      // stats[6] += composited pairs (the backward's stats[1] must count the same set)
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) npairs += __shfl_xor(npairs, o);
@@ -155,7 +129,7 @@ __global__ void __launch_bounds__(BLOCK) blend_fwd_kernel(BlendFwdArgs a) {
 // ---------------------------------------------------------------------------------------------
 // blend_fwd, software-pipelined staging ("pipe", the default; round 4).
 //
-// What the per-workgroup trace of the kernel above showed (scripts/wg_trace.py, profiles/r04_wg_trace.md): on a trained frame the
+// What the per-workgroup trace of the kernel above showed (profiles/r04_wg_trace.md): on a trained frame the
 // slowest tile spends 41 % of its life STAGING — surfel ids -> 112-B record gather (two dependent global round trips per batch,
 // issued by every resident workgroup at the same moment: the CU's fetch path, ~11 B/clk, is the bound) -> footprint test -> masks
 // -> barrier — and only then walks; its VALU sits idle meanwhile (0.23 of the issue peak over the launch), and nothing else is
@@ -212,10 +186,6 @@ __global__ void __launch_bounds__(BLOCK, 5) blend_fwd_pipe_kernel(BlendFwdArgs a
     __shared__ uint32_t s_list[4][4][NB / 4 + 1];      // 2.1 KB: per wave and DPP row, the staged indices (bytes) of the row's visits of this batch
     __shared__ uint32_t s_ids[4][32];                  // per wave, the surfel ids of its 32 instances of the batch after next (DMA as well:
                                                        // a load hipcc tracks would make it wait for vmcnt(0) — i.e. for the record DMA — at its next use)
-#ifdef BLEND_TRACE
-    const unsigned long long trace_t0 = wall_clock64();
-    long long ttm_t = __builtin_readcyclecounter(), ttm_stage = 0, ttm_walk = 0, ttm_bar = 0, ttm_it = 0;
-#endif
     const int tile = block_tile(a.tile_map, a.map_flag, blockIdx.x, a.gx * a.gy);
     if (tile < 0) return;
     const int tx = tile % a.gx, ty = tile / a.gx;
@@ -304,9 +274,7 @@ __global__ void __launch_bounds__(BLOCK, 5) blend_fwd_pipe_kernel(BlendFwdArgs a
         issue_ids(NB);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         masks(0, 0);
-        TRACE_TM(ttm_stage)
         __syncthreads();
-        TRACE_TM(ttm_bar)
         for (int base = 0, buf = 0; base < n; base += NB, buf ^= 1) {
             const bool more = base + NB < n;
             if (more) {      // next batch's records (their ids landed with this batch's records), and the ids of the batch behind it
@@ -356,9 +324,6 @@ __global__ void __launch_bounds__(BLOCK, 5) blend_fwd_pipe_kernel(BlendFwdArgs a
 #pragma unroll
                     for (int k = 0; k < 4; k++) {
                         if (i + k >= niter) break;
-#ifdef BLEND_TRACE
-                        ttm_it++;
-#endif
                         const bool act = i + k < len;
                         // the next visit's record: on its way while this one is computed
                         const int jn = (int)(k < 3 ? (jw >> (8 * (k + 1))) & 0xffu : jw_next & 0xffu);
@@ -392,23 +357,17 @@ __global__ void __launch_bounds__(BLOCK, 5) blend_fwd_pipe_kernel(BlendFwdArgs a
                     if (__all(done)) break;
                 }
             }
-            TRACE_TM(ttm_walk)
             if (more) {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's own DMA of the next batch
                 masks(base + NB, buf ^ 1);
             }
             const int wave_done = __all(done) ? 1 : 0;      // (evaluated by the whole wave, not under the lane-0 branch)
             if (lane == 0) s_alldone[buf][wave] = wave_done;
-            TRACE_TM(ttm_stage)
             __syncthreads();
-            TRACE_TM(ttm_bar)
             if ((s_alldone[buf][0] & s_alldone[buf][1] & s_alldone[buf][2] & s_alldone[buf][3]) != 0) break;
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (a DMA issued for a batch that saturation made unnecessary must land before the LDS is handed back)
     }
-#ifdef BLEND_TRACE
-    if (STATS) trace_wg(a.stats, 0, trace_t0, tile, n, ttm_stage, ttm_walk, ttm_bar, ttm_it);
-#endif
     if (STATS) {
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) npairs += __shfl_xor(npairs, o);

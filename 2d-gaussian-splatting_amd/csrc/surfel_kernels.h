@@ -42,7 +42,7 @@ struct BlendBwdArgs {
     uint2* cut;       // [tiles] (depth bits, surfel index + 1) of the last instance of every tile that has a record, or NULL: every instance gets a record (surfel_blend_bwd.h: finish_tail)
     uint8_t* has_rec;      // with cut: [P] zeroed by the caller; set for every surfel that gets at least one record (preprocess_bwd skips the others)
     const float* depths;   // [P] view depths (the sort key's source)
-    int variant;      // 0: per-DPP-row walk, 1: per-wave (8x8 quad) walk, 2: both launched, the device picks from the frame's totals (0 / 1 / 2 bit-identical); 3: scan walk
+    int variant;      // 0: per-DPP-row walk, 1: per-wave (8x8 quad) walk (0 / 1 bit-identical), 3: scan walk
     const float4* strm_rec; const uint32_t* strm_mask;      // the forward's tile stream (BlendFwdArgs), or NULL: the staging gathers the records by surfel id
     int scan_rule;    // 1: the scan kernel AND the rows / quad kernel selected by `variant` are launched; the device decides from `totals` which one runs (surfel_blend_bwd.h: device_picks_scan)
     const uint32_t* totals;      // [2 * R_SLOTS] partial sums written by preprocess: tile instances | visible surfels
@@ -88,7 +88,6 @@ void launch_knn(int P, const float* points, float* out, void* scratch, size_t sc
 size_t knn_scratch_bytes(int P);
 size_t radix_sort_scratch_bytes(size_t n);
 void set_large_sort_impl(int v);      // for n > 2^20 — 0: three launches per pass (own), 1: rocprim::radix_sort_pairs, 2: auto (default)
-void set_fat_sort(int v);             // look-back passes (<= 2^20 items): 1 (default) 8192-item tiles staged through LDS, 0 2048-item tiles
 int radix_sort_passes(size_t n, int begin_bit, int end_bit);
 int radix_sort_result_buffer(size_t n, int begin_bit, int end_bit);
 int radix_sort_pairs_u32(uint32_t* keys_a, uint32_t* vals_a, uint32_t* keys_b, uint32_t* vals_b, size_t n, int begin_bit, int end_bit,

@@ -298,8 +298,6 @@ __global__ void __launch_bounds__(RS_THREADS) os_pass_kernel(const uint32_t* __r
 // 32 items = one 128-B line, written by consecutive lanes; and the look-back chain is a quarter as long.
 constexpr int FT_THREADS = 1024, FT_IPT = 8, FT_TILE = FT_THREADS * FT_IPT, FT_WAVES = FT_THREADS / 64;
 constexpr int FT_LB = 32;      // look-back window: at most 128 tiles exist, all resident and publishing at about the same moment
-int g_fat_sort = 1;
-void set_fat_sort(int v) { g_fat_sort = v != 0; }
 static inline uint32_t ft_nblocks(size_t n) { return (uint32_t)((n + FT_TILE - 1) / FT_TILE); }
 
 __global__ void __launch_bounds__(FT_THREADS) os_pass_fat_kernel(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ vals,
@@ -654,12 +652,8 @@ int radix_sort_pairs_u32(uint32_t* keys_a, uint32_t* vals_a, uint32_t* keys_b, u
         const uint32_t mask = (1u << nb) - 1u;
         const uint32_t* kin = cur ? keys_b : keys_a; const uint32_t* vin = cur ? vals_b : vals_a;
         uint32_t* kout = cur ? keys_a : keys_b; uint32_t* vout = cur ? vals_a : vals_b;
-        if (g_fat_sort)
-            hipLaunchKernelGGL(os_pass_fat_kernel, dim3(ft_nblocks(n)), dim3(FT_THREADS), 0, s, kin, vin, kout, vout, (uint32_t)n, bit, mask,
-                               ghist + p * RS_RADIX, status + (size_t)p * nblocks * RS_RADIX, ticket + p, (const uint32_t*)nullptr, 1);
-        else
-            hipLaunchKernelGGL(os_pass_kernel<true>, dim3(nblocks), dim3(RS_THREADS), 0, s, kin, vin, kout, vout, (uint32_t)n, bit, mask,
-                               ghist + p * RS_RADIX, status + (size_t)p * nblocks * RS_RADIX, ticket + p, nblocks, (const uint32_t*)nullptr, 1);
+        hipLaunchKernelGGL(os_pass_fat_kernel, dim3(ft_nblocks(n)), dim3(FT_THREADS), 0, s, kin, vin, kout, vout, (uint32_t)n, bit, mask,
+                           ghist + p * RS_RADIX, status + (size_t)p * nblocks * RS_RADIX, ticket + p, (const uint32_t*)nullptr, 1);
         cur ^= 1;
     }
     return cur;
@@ -757,12 +751,8 @@ int radix_sort_pairs_u32_devn(uint32_t* keys_a, uint32_t* vals_a, uint32_t* keys
         const uint32_t mask = (1u << nb) - 1u;
         const uint32_t* kin = cur ? keys_b : keys_a; const uint32_t* vin = cur ? vals_b : vals_a;
         uint32_t* kout = cur ? keys_a : keys_b; uint32_t* vout = cur ? vals_a : vals_b;
-        if (g_fat_sort)
-            hipLaunchKernelGGL(os_pass_fat_kernel, dim3(ft_nblocks(cap)), dim3(FT_THREADS), 0, s, kin, vin, kout, vout, (uint32_t)cap, bit, mask,
-                               ghist + (size_t)p * RS_RADIX * BE_HSTRIDE, status + (size_t)p * nblocks * RS_RADIX, ticket + p, n_dev, BE_HSTRIDE);
-        else
-            hipLaunchKernelGGL(os_pass_kernel<true>, dim3(nblocks), dim3(RS_THREADS), 0, s, kin, vin, kout, vout, (uint32_t)cap, bit, mask,
-                               ghist + (size_t)p * RS_RADIX * BE_HSTRIDE, status + (size_t)p * nblocks * RS_RADIX, ticket + p, nblocks, n_dev, BE_HSTRIDE);
+        hipLaunchKernelGGL(os_pass_fat_kernel, dim3(ft_nblocks(cap)), dim3(FT_THREADS), 0, s, kin, vin, kout, vout, (uint32_t)cap, bit, mask,
+                           ghist + (size_t)p * RS_RADIX * BE_HSTRIDE, status + (size_t)p * nblocks * RS_RADIX, ticket + p, n_dev, BE_HSTRIDE);
         cur ^= 1;
     }
     return cur;

@@ -257,6 +257,10 @@ def main():
     for _ in range(args.warmup):
         tr.step()
     fence()
+    if world == 1 and hasattr(tr, "_rng") and hasattr(tr, "_stack"):
+        # the timed window sees the SAME views in every run of this command (the views of a capture differ 2-3x in instance count): the
+        # rocprofv3 passes of scripts/profile_gpu.sh and the bench legs then time and count the same frames
+        tr._rng.seed(20260922); tr._stack = []
     loss_first = float(tr.last["loss"])
     surfel_native.collect_stage_times()     # drop warm-up events
     tr.exchange_events = []

@@ -124,6 +124,8 @@ def time_trainer(tr, steps, warmup, prime=15, workload=None):
     retimed = False
     for attempt in range(2):
         host = []
+        if hasattr(tr, "_rng") and hasattr(tr, "_stack"):      # the same views as `python bench.py --workload <this leg>` times (bench.py)
+            tr._rng.seed(20260922); tr._stack = []
         t0 = time.perf_counter()
         for _ in range(steps):
             h0 = time.perf_counter()

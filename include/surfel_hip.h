@@ -43,7 +43,7 @@ extern "C" {
 #define SURFEL_OPT_TILE_SORT(m)   ((((m) + 1) & 3) << 9)   /* forward: "tile_depth_sort" = m (0, 1, 2) for this call */
 #define SURFEL_OPT_BWD_QUAD       (1 << 11)            /* backward: per-quad walk ("bwd_variant" = 1) for this call */
 #define SURFEL_OPT_BWD_ROWS       (1 << 12)            /* backward: per-row walk ("bwd_variant" = 0) for this call */
-#define SURFEL_OPT_PBWD_COOP      (1 << 13)            /* backward: wave-cooperative gather of the gradient records (default: R >= 6 P and R >= 2^25) */
+#define SURFEL_OPT_PBWD_COOP      (1 << 13)            /* backward: wave-cooperative gather of the gradient records in the per-surfel kernel (default: by rule, R >= 6 P and R >= 2^25) */
 #define SURFEL_OPT_PBWD_THREAD    (1 << 14)            /* backward: per-thread gather of the gradient records */
 #define SURFEL_OPT_EXACT_BINNING  (1 << 16)            /* forward: "capacity_binning" = 0 for this call (binning buffers sized after a host wait for the instance count) */
 #define SURFEL_OPT_TILE_CUTS      (1 << 17)            /* backward: no gradient records behind a tile's saturation point, preprocess_bwd tests the tile cuts (default: R >= 2^21) */
@@ -146,61 +146,30 @@ const char* surfel_stage_name(int stage);
 int surfel_debug_sort_pairs(surfel_alloc_fn scratch_alloc, void* scratch_user, uint32_t* keys, uint32_t* vals, int64_t n,
                             int begin_bit, int end_bit, void* stream);
 
-/* Process-wide tuning / test switches; returns 0, or SURFEL_E_INVALID for an unknown name.
- *   "cull" (default 1): 0 disables every exact-preserving cull (tile emission restricted to the surfel's
- *          alpha>=1/255 footprint, per-quad / per-sub-tile instance masks) so the blend kernels visit every
- *          (pixel, surfel) pair of the reference's tile rectangles.  Results are bit-identical either way —
- *          that is what tests/test_gpu_parity.py::test_culling_is_exact checks.
- *   "tile_depth_sort" (default 1 = auto): binning path — 2: always order every tile's instance run by depth in LDS after an
- *          index-order emission (no P-sized depth sort; fastest for small / medium frames), 0: always depth-presort the surfels
- *          (large frames), 1: choose by the previous frame's instances per tile.  Results are bit-identical
- *          (tests/test_gpu_parity.py::test_binning_paths_are_identical).
- *   "large_sort": sorts of more than 2^20 items (the P-sized depth sort and the R-sized tile sort of large frames) — 0: the library's
- *          three-launches-per-pass radix sort, 1: rocprim::radix_sort_pairs, 2 (default): rocPRIM for key fields of <= 16 bits and for
- *          >= 4 M items, the library's passes otherwise (profiles/r02_large_sort.md).  Both stable: identical results
- *          (tests/test_gpu_parity.py::test_radix_sort_is_stable_and_exact runs both).
- *   "bwd_variant" (default 2 = auto): blend-backward walk — 0: every DPP row of 16 lanes (a 4x4-pixel sub-tile) walks its own
- *          instance list, row totals gathered through private LDS slots; 1: every wave (8x8 pixels) walks one list (round 1's
- *          kernel).  Same per-pair arithmetic and the same summation tree: gradients are bit-identical
- *          (tests/test_gpu_parity.py::test_backward_variants_are_identical), so the choice between these two only ever changes
- *          speed.  Under auto ("scan_large", default 1) the scan walk (3) is launched beside the rows / quad kernel and the DEVICE
- *          decides from the frame's totals which one runs: frames with >= 6 tile instances per emitting surfel (trained / wide-footprint
- *          frames: -13 % / -5 %) or with 2^21 <= R < 2^26 tile instances (-7 % at 8 M instances) take walk 3, the other kernel returns at
- *          once — a rule on the frame, so the bits of a frame follow from the frame alone.
- *          3: the scan walk (surfel_backward_scan.hip: lanes are instances, DPP row scans carry the per-pixel recurrences, gradients
- *          accumulate in registers) — deterministic, but a different summation order: agrees with rows / quad to fp32 summation noise,
- *          not bit for bit; 7 % faster than both on frames of several million instances, at parity around 2 M, 11 % slower on
- *          0.5 M instances of small random footprints (profiles/r03_blend_bwd_scan.md).  4: auto over all three walks by the same timed probes — fastest, but which bits a frame
- *          gets then depends on the probes' verdict.
- *   "bwd_tune" (default 1): how auto chooses.  1: per (device, width, height, octave of tile instances per surfel), two backward
- *          calls in every 32 are timed with HIP events on the launch stream (one per walk; polled later, never synchronised) and
- *          the faster walk per tile instance is launched alone in between; 0: both kernels are launched every call and the device decides from the frame's
- *          totals (rows iff tile instances <= 4 x emitting surfels) — also what happens before both walks have been timed and
- *          while the stream is being captured into a graph.
- *   "tile_order" (default 0): which tile every blend workgroup takes.  1: workgroup b -> XCD b % 8 walks a contiguous run of tiles
- *          (neighbouring tiles share surfel records in that XCD's L2) — right for frames whose tiles hold similar lists; 2: groups of
- *          4 adjacent tiles, longest lists first, dealt round-robin over the XCDs — right for object-centred / trained frames, where a
- *          few hundred tiles hold the long lists (the trained leg's blend kernels ran at 0.25 of the VALU issue peak
- *          with order 1: the XCDs owning the image's middle rows did the work, the heaviest tiles finished alone); 0: decided per
- *          frame on the device from the lists (busiest XCD > 1.15x its share, or a list > 4 average lists -> 2).  Scheduling only:
- *          results are bit-identical (tests/test_gpu_parity.py::test_tile_order_is_scheduling_only).
- *   "fwd_pipe" (default 1): blend forward kernel — 1: software-pipelined staging (LDS-DMA of the next batch's whole records under the
- *          walk, per-row byte lists, LDS prefetch of the next visit; DESIGN.md section 4 "Round 4"), 0: round 3's batch-synchronous kernel.
- *          Same walk, same per-pair arithmetic: bit-identical outputs (tests/test_gpu_parity.py::test_forward_kernels_are_identical).
- *   "fat_sort" (default 1): look-back sort passes over <= 2^20 items use 8192-item tiles staged through LDS (0: 2048-item tiles);
- *          "host_total" (default 1): capacity-path frames store their instance total into mapped pinned memory from the emission
- *          kernel (0: a device-to-host copy in the stream).  Speed only (tests/test_gpu_parity.py::test_radix_sort_is_stable_and_exact
- *          runs both tile sizes).
- *   "pbwd_coop" (default -1): record gather of the per-surfel backward — -1: by rule (wave-cooperative where R >= 6 P and R >= 2^25,
- *          per thread otherwise; measured again in round 3: the cooperative form loses 15 % at C2H and 25 % at C4), 0 / 1: forced.
- *          Bit-identical either way (tests/test_gpu_parity.py::test_record_gather_variants_are_identical).
- *   "capacity_binning" (default 1): frames on the per-tile-depth-sort path with <= 2^20 tile instances size their binning buffers
- *          from the largest instance count recent frames of the same size produced (+ 1/8 head room) instead of waiting for this
- *          frame's count in the middle of the forward: scan, emission and the tile sort's histograms run as ONE kernel right behind
- *          preprocess, the sort passes and the tile ranges read the count from the device, and the host looks at the count only once
- *          the whole forward is enqueued.  A frame that overflows its capacity is redone with exact sizes (surfel_debug_last_binning
- *          reports 2).  Results are bit-identical either way (tests/test_gpu_parity.py::test_capacity_binning_is_identical); the
- *          returned instance count is always the exact one.
+/* Process-wide defaults of the eight switches below; returns 0, or SURFEL_E_INVALID for an unknown name.  None of them changes a result
+ * bit except where stated; each default is the measured best, the other settings exist for the tests that prove the
+ * identity and for A / B runs of an unmodified caller (SURFEL_OPTIONS="name=value,..." in the environment of surfel_native.py).
+ *   "cull"             1   exact footprint culling: tile emission restricted to the surfel's alpha >= 1/255 footprint, per-sub-tile
+ *                          instance masks.  0: every (pixel, surfel) pair of the reference's tile rectangles is visited.
+ *   "tile_depth_sort"  1   binning path — 2: surfel-order emission, then every tile orders its run by depth in LDS (small / medium frames);
+ *                          0: depth-presorted emission (large frames); 1: by the previous frame's instances per tile.
+ *   "capacity_binning" 1   per-tile-sort frames of <= 2^20 instances size their binning buffers from the largest count recent frames of that
+ *                          size produced (+ 1/8) and never wait for this frame's count inside the forward; a frame that overflows is redone
+ *                          with exact sizes (surfel_debug_last_binning() == 2).  The returned count is always exact.
+ *   "large_sort"       2   sorts of > 2^20 items — 0: the library's three-launches-per-pass radix sort, 1: rocprim::radix_sort_pairs,
+ *                          2: rocPRIM for key fields <= 16 bits and >= 4 M items, own passes otherwise.  Both stable.
+ *   "tile_order"       0   which tile a blend workgroup takes — 1: XCD-contiguous runs, 2: longest lists first, dealt over the XCDs,
+ *                          0: decided per frame on the device from the lists.  Scheduling only.
+ *   "fwd_pipe"         1   blend forward with LDS-DMA double-buffered staging (0: the batch-synchronous kernel it is held bit-identical to).
+ *   "tile_stream"      1   blend_fwd leaves, per list position it walked, the 80-B blend record and the 16 footprint bits in list order
+ *                          (84 B x capacity of binning buffer, frames of <= 2^24 instances); blend_bwd stages from that contiguous stream
+ *                          instead of surfel ids -> 112-B gather -> footprint test.  0: none is written, the backward gathers.
+ *   "bwd_variant"      2   blend-backward walk — 0 per-row (every DPP row of 16 lanes = a 4x4-pixel sub-tile walks its own list),
+ *                          1 per-quad (round 1's kernel: the reference the per-row walk is held bit-identical to), 3 scan (lanes are
+ *                          instances, DPP row scans carry the per-pixel recurrences: deterministic, agrees with 0 / 1 to fp32 summation
+ *                          noise, NOT bit for bit), 2 auto: 0 or 3 by a rule on the frame alone — 3 iff the frame holds >= 6 tile
+ *                          instances per emitting surfel or 2^21 <= R < 2^26 instances (decided on the device where the host does not
+ *                          know the count) — so the bits of a frame follow from the frame, never from timing or history.
  * Threading: the library keeps one pinned read-back buffer and one event per (host thread, device); calls are not re-entrant
  * per thread, and the intended layout is one process per GPU (torch.distributed.run).  Stage-timing events recorded with
  * debug >= 2 are kept until surfel_collect_stage_ms() (at most 8192 pairs; older ones are dropped). */
@@ -259,10 +228,6 @@ int surfel_debug_image_layout(int width, int height, int64_t* out);
  * wave-instruction per SIMD over the grid's own span (nominal 2), [5] G wave-instructions / s over that span.  bench.py prints them as `box_probe` so that runs on different boxes of a pool can
  * be compared.  No reference counterpart. */
 int surfel_debug_box_probe(void* scratch, int64_t scratch_bytes, float* out6, void* stream);
-
-/* Debug: the walk the "bwd_tune" probes currently favour for frames of this size on the current device (the most used entry of
- * that size) — 0 per-row, 1 per-quad, -1 not decided yet (fewer than two timed calls have completed). */
-int surfel_debug_walk_choice(int width, int height);
 
 #ifdef __cplusplus
 }

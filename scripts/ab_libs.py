@@ -24,7 +24,7 @@ def main():
                 name, _, spec = arm.partition("=")
                 tag, _, opts = spec.partition(":")
                 env = dict(os.environ)
-                if tag:
+                if tag and tag != "-":
                     env["SURFEL_LIB"] = os.path.join(REPO, "2d-gaussian-splatting_amd", "lib", "libsurfel_hip_%s.so" % tag)
                 if opts:
                     env["SURFEL_OPTIONS"] = opts

@@ -4,7 +4,7 @@
 
     python scripts/ab_stage.py trained,garden,C2 fwd_pipe=0 fwd_pipe=1 [--steps 30] [--reps 2]
 
-Each setting is a comma-separated list of name=value pairs for surfel_set_option ("bwd_variant=3,bwd_tune=0").  Settings alternate
+Each setting is a comma-separated list of name=value pairs for surfel_set_option ("bwd_variant=3,tile_stream=0").  Settings alternate
 (A B A B ...) so that clock drift hits both alike.  GPU only; prints one JSON line per workload.
 """
 import json

@@ -10,9 +10,9 @@ STATE=""
 case $WL in trained|garden) STATE="--state /tmp/state_$WL.ply"; timeout 120 python $ROOT/bench.py --workload $WL $STATE --quick --steps 2 --warmup 1 > $OUT/make_state.log 2>&1;; esac
 for tag in A B; do
   if [ $tag = A ]; then OPT=$A; else OPT=$B; fi
-  SURFEL_OPTIONS="bwd_tune=0,$OPT" timeout 120 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY \
+  SURFEL_OPTIONS="$OPT" timeout 120 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY \
       --output-format csv -d $OUT/$tag -o p -- python $ROOT/bench.py --workload $WL $STATE --steps 8 --warmup 2 --quick > $OUT/bench_$tag.log 2>&1
-  SURFEL_OPTIONS="bwd_tune=0,$OPT" timeout 120 rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_INST_CYCLES_SALU SQ_INSTS_SMEM SQ_INSTS_BRANCH SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT \
+  SURFEL_OPTIONS="$OPT" timeout 120 rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_INST_CYCLES_SALU SQ_INSTS_SMEM SQ_INSTS_BRANCH SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT \
       --output-format csv -d $OUT/${tag}2 -o p -- python $ROOT/bench.py --workload $WL $STATE --steps 8 --warmup 2 --quick > $OUT/bench_${tag}2.log 2>&1
 done
 cd $ROOT

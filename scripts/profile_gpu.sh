@@ -9,9 +9,8 @@
 #   grbm/    --pmc GRBM_GUI_ACTIVE (+ that pass's own kernel trace) -> effective clock per kernel
 #   sq2/     (full only) lanes enabled per VALU instruction, wait breakdown
 # PMC passes never combine with sys/hip/hsa trace domains (only --kernel-trace is implied by rocprofv3 itself).
-# The blend-backward walk is FORCED (SURFEL_OPTIONS=bwd_variant=<walk>,bwd_tune=0; default rows) in every pass: with the tuner on,
-# probe launches of the other walks and the both-kernels fallback dilute the per-launch means, and separate passes may pick
-# different walks.  Trained workloads (trained / garden) are trained once and cached in /tmp.
+# The blend-backward walk is FORCED (SURFEL_OPTIONS=bwd_variant=<walk>; default rows) in every pass: under auto the kernel the device
+# rule does not pick is launched as well and returns at once, which dilutes its per-launch means.  Trained workloads (trained / garden) are trained once and cached in /tmp.
 # scripts/profile_summary.py then condenses these into profiles/.
 TAG=${1:-r03}
 WL=${2:-C2}
@@ -21,12 +20,13 @@ ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/prof_${TAG}_$WL
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-export SURFEL_OPTIONS="bwd_variant=$WALK,bwd_tune=0"
+export SURFEL_OPTIONS="bwd_variant=$WALK"
 echo "$WALK" > $OUT/walk.txt
 STATE=""
 case $WL in trained|garden) STATE="--state /tmp/state_$WL.ply"; timeout 200 python $ROOT/bench.py --workload $WL $STATE --quick --steps 2 --warmup 1 > $OUT/bench_make_state.log 2>&1;; esac
 timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -o kt -- python $ROOT/bench.py --workload $WL $STATE --quick > $OUT/bench_kt.log 2>&1
-SHORT="--workload $WL $STATE --steps 8 --warmup 2 --quick"
+# (the PMC passes time the same views as the bench leg of this workload: same steps / warm-up, the window reseeds its view order)
+case $WL in trained) SHORT="--workload $WL $STATE --steps 30 --warmup 5 --quick";; garden|C4|C2H) SHORT="--workload $WL $STATE --steps 20 --warmup 5 --quick";; *) SHORT="--workload $WL $STATE --steps 20 --warmup 5 --quick";; esac
 timeout 200 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -o p -- python $ROOT/bench.py $SHORT > $OUT/bench_fetch.log 2>&1
 timeout 200 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/write -o p -- python $ROOT/bench.py $SHORT > $OUT/bench_write.log 2>&1
 timeout 200 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_INST_ANY SQ_LDS_BANK_CONFLICT \

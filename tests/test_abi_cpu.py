@@ -145,7 +145,7 @@ def test_surfel_options_environment_hook():
     import subprocess
     import sys
     code = "import sys; sys.path.insert(0, %r); import surfel_native as n; n.load(); print('loaded')" % os.path.join(REPO, "2d-gaussian-splatting_amd")
-    ok = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, SURFEL_OPTIONS="bwd_variant=1, bwd_tune=0,cull=1"), capture_output=True, text=True)
+    ok = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, SURFEL_OPTIONS="bwd_variant=1, tile_stream=0,cull=1"), capture_output=True, text=True)
     assert ok.returncode == 0 and "loaded" in ok.stdout, ok.stderr[-2000:]
     bad = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, SURFEL_OPTIONS="no_such_option=1"), capture_output=True, text=True)
     assert bad.returncode != 0 and "no_such_option" in bad.stderr

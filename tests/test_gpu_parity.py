@@ -1058,35 +1058,31 @@ def test_backward_hook_splits_off_the_colour_gradients():
         assert calls == [1] and all(np.array_equal(ref[k], again[k], equal_nan=True) for k in ref)
 
 
-def test_walk_tuner_settles_and_keeps_the_bits():
-    """"bwd_tune": with bwd_variant = auto the library times one call per walk out of every 64 and then launches the faster walk
-    alone.  The gradients of every call — probes, the both-kernels fallback before a verdict, the settled choice — are the bits of
-    the forced walks, and a verdict exists after a handful of calls; with "bwd_tune" = 0 the device-side rule alone decides."""
-    import torch
+@pytest.mark.parametrize("kind,expect", [("small_footprints", "rows"), ("wide_footprints", "scan")])
+def test_auto_walk_follows_the_device_rule(kind, expect):
+    """bwd_variant = auto: the rows walk and the scan walk are both launched and the DEVICE decides from the frame's own totals which one
+    runs (>= 6 tile instances per emitting surfel -> scan; csrc/surfel_blend_bwd.h: device_picks_scan) — no timed probes, no history:
+    the gradients of every auto call are the bits of the walk the rule names, call after call, on the exact and the capacity path."""
     import surfel_native as n
     lib = n.load()
-    sc = _scene((6000, 208, 144), seed=5)          # a frame size no other test uses: this test owns its tuner entry
+    sc = _scene((6000, 208, 144), seed=5) if kind == "small_footprints" else _scene((3000, 208, 144), seed=5, px_radius=14.0)
     a = scene_args(sc)
     rng = np.random.default_rng(2)
     gC = rng.normal(size=(3, a["H"], a["W"])).astype(np.float32); gO = rng.normal(size=(7, a["H"], a["W"])).astype(np.float32)
     run = HipRun(a).forward()
-    run.debug = n.OPT_BWD_ROWS
-    ref = run.backward(gC, gO)
-    run.debug = 0
-    assert lib.surfel_debug_walk_choice(a["W"], a["H"]) == -1
-    try:
-        for it in range(8):
-            g = run.backward(gC, gO)
-            torch.cuda.synchronize()
-            for k in ref:
-                assert np.array_equal(ref[k], g[k]), (it, k)
-        assert lib.surfel_debug_walk_choice(a["W"], a["H"]) in (0, 1)
-        assert lib.surfel_set_option(b"bwd_tune", 0) == 0
+    vis = int((run.radii > 0).sum().item())
+    print("%s: %d instances, %d emitting surfels (%.1f per surfel)" % (kind, run.R, vis, run.R / max(1, vis)))
+    assert (run.R >= 6 * vis) == (expect == "scan")
+    refs = {}
+    for w, flag in (("rows", n.OPT_BWD_ROWS), ("scan", n.OPT_BWD_SCAN)):
+        run.debug = flag
+        refs[w] = run.backward(gC, gO)
+    assert any(not np.array_equal(refs["rows"][k], refs["scan"][k]) for k in refs["rows"])      # (the two walks do differ in their bits)
+    for it in range(4):
+        run = HipRun(a).forward()      # (later forwards of this size take the capacity path)
         g = run.backward(gC, gO)
-        for k in ref:
-            assert np.array_equal(ref[k], g[k]), k
-    finally:
-        lib.surfel_set_option(b"bwd_tune", 1)
+        for k in g:
+            assert np.array_equal(refs[expect][k], g[k]), (it, k, lib.surfel_debug_last_binning())
 
 
 def test_blend_stats_counters():
@@ -1120,7 +1116,7 @@ def test_blend_stats_counters():
                                     (611_573, (0, 12)), (3_000_001, (0, 32)), (5_000_000, (0, 15)), (2_000_003, (7, 8)), (2_000_003, (5, 5)),
                                     (4097, (31, 32)), (4097, (0, 0)), (8191, (0, 32)), (8193, (0, 12)), (40_000, (0, 12)), (1_048_576, (0, 13))])
 def test_radix_sort_is_stable_and_exact(n, bits):
-    """The one-launch-per-pass radix sort (decoupled look-back; 8192-item tiles staged through LDS and the 2048-item form) against
+    """The one-launch-per-pass radix sort (decoupled look-back, 8192-item tiles staged through LDS) against
     numpy's stable argsort, incl. heavy duplicates; 1-bit and empty key fields (the order is then the input order); large inputs
     also through rocprim::radix_sort_pairs."""
     import torch
@@ -1129,12 +1125,11 @@ def test_radix_sort_is_stable_and_exact(n, bits):
     dev = torch.device("cuda:0")
     rng = np.random.default_rng(n)
     lo, hi = bits
-    # large inputs: the library's own passes and rocprim::radix_sort_pairs (3: rocPRIM at every size); small ones: both tile sizes (4: thin)
-    impls = (0, 1) if n > (1 << 20) else (0, 4, 3)
+    # large inputs: the library's own passes and rocprim::radix_sort_pairs; small ones: the look-back passes and rocPRIM (3: rocPRIM at every size)
+    impls = (0, 1) if n > (1 << 20) else (0, 3)
     for trial in [(t, i) for i in impls for t in range(3)]:
         trial, impl = trial
-        assert lib.surfel_set_option(b"fat_sort", 0 if impl == 4 else 1) == 0
-        assert lib.surfel_set_option(b"large_sort", 0 if impl == 4 else impl) == 0
+        assert lib.surfel_set_option(b"large_sort", impl) == 0
         if trial == 0:
             keys = rng.integers(0, 2 ** 32, n, dtype=np.uint64).astype(np.uint32)
         elif trial == 1:   # few distinct keys: long same-digit runs, every tie must keep input order
@@ -1152,7 +1147,6 @@ def test_radix_sort_is_stable_and_exact(n, bits):
         assert np.array_equal(v.cpu().numpy().view(np.uint32), vals[order]), "trial %d impl %d: order differs" % (trial, impl)
         assert np.array_equal(k.cpu().numpy().view(np.uint32), keys[order])
     lib.surfel_set_option(b"large_sort", LARGE_SORT_DEFAULT)
-    lib.surfel_set_option(b"fat_sort", 1)
 
 
 def test_grad_arena_is_zero_copy_and_identical():
