@@ -329,7 +329,7 @@ def box_probe(dev):
     import surfel_native as n
     lib = n.load()
     scratch = torch.zeros(1 << 17, dtype=torch.uint8, device=dev)
-    out = (C.c_float * 8)()
+    out = (C.c_float * 12)()
     s = n.current_stream_ptr(dev)
     res = {}
     with torch.cuda.device(dev):
@@ -338,7 +338,11 @@ def box_probe(dev):
         if rc != 0:
             return {"error": n.last_error()}
         res.update({"launch_us": round(out[0], 3), "valu_Ginst_per_s": round(out[1], 1), "valu_Ginst_per_s_in_kernel_span": round(out[5], 1),
-                    "shader_clock_GHz_under_fma_grid": round(out[2], 3), "fma_cycles_per_wave_inst_per_simd": round(out[4], 3)})
+                    "shader_clock_GHz_under_fma_grid": round(out[2], 3), "fma_cycles_per_wave_inst_per_simd": round(out[4], 3),
+                    "add_cycles_per_wave_inst_per_simd": round(out[6], 3), "pk_fma_cycles_per_wave_inst_per_simd": round(out[7], 3),
+                    "blend_mix_Mvisits_per_s": round(out[8], 1),
+                    "note": "4 waves per SIMD of independent chains; one fp32 wave64 instruction per ~4 shader cycles per SIMD (a 16-lane pipe), "
+                            "i.e. the chip's non-packed fp32 issue peak is 1024 SIMDs x clock / 4 — half of the 157.3 TFLOP/s / 128 figure, which needs v_pk_fma_f32"})
         # the fixed sort: 512 Ki (key, value) pairs, 12-bit keys (an 800x800 frame's tile ids), the product's own passes
         N = 1 << 19
         g = torch.Generator(device="cpu").manual_seed(1)

@@ -222,12 +222,14 @@ int surfel_debug_capacity_evictions(void);
 int surfel_debug_image_layout(int width, int height, int64_t* out);
 
 /* Debug / bench: what THIS GPU sustains, independent of the product's kernels (csrc/box_probe.hip) — 256 dependent empty launches, and a
- * grid of independent v_fma_f32 streams at 8 waves per SIMD timed with events on `stream` (the call synchronises).  scratch: >= 128 KiB of
+ * grid of independent v_fma_f32 streams at 4 waves per SIMD timed with events on `stream` (the call synchronises).  scratch: >= 128 KiB of
  * device memory.  out[0] us per dependent launch boundary, [1] G wave-instructions / s of the FMA grid (whole chip, by events), [2] shader
  * clock that grid sustained in GHz (s_memtime ticks per 100 MHz s_memrealtime tick), [3] ms of the FMA grid, [4] shader cycles per
- * wave-instruction per SIMD over the grid's own span (nominal 2), [5] G wave-instructions / s over that span.  bench.py prints them as `box_probe` so that runs on different boxes of a pool can
+ * wave-instruction per SIMD over the grid's own span, [5] G wave-instructions / s over that span, [6] / [7] the cycles figure of [4] for grids
+ * of v_add_f32 and of v_pk_fma_f32 (two FMAs per lane and instruction), [8] M wave-visits / s of a frozen stand-in for a blend-backward
+ * visit (LDS reads + ~100 fp32 multiply-adds + transcendentals + selects + a 38-DPP reduction) at 4 workgroups per CU.  bench.py prints them as `box_probe` so that runs on different boxes of a pool can
  * be compared.  No reference counterpart. */
-int surfel_debug_box_probe(void* scratch, int64_t scratch_bytes, float* out6, void* stream);
+int surfel_debug_box_probe(void* scratch, int64_t scratch_bytes, float* out9, void* stream);
 
 #ifdef __cplusplus
 }

@@ -17,7 +17,9 @@ for k, c in pmc.items():
     us = float(st["AverageNs"]) / 1e3
     gbs = c["HBM_bytes_per_launch"] / (us * 1e-6) / 1e9
     valu = c.get("SQ_INSTS_VALU", 0.0) / (us * 1e-6) / 1e9
-    clk = c.get("eff_clock_GHz")
+    # (GRBM_GUI_ACTIVE also counts the dispatch's ramp before / after the kernel's own timestamps: a few thousand cycles, i.e. the ratio is
+    # only meaningful for kernels that run for tens of microseconds)
+    clk = c.get("eff_clock_GHz") if us >= 30.0 else None
     # VALU issue against the clock the kernel actually sustained: 1024 SIMDs x clk / 2 cycles per wave64 fp32 instruction
     fv_sus = (valu / (1024 * clk / 2.0)) if clk else None
     rows.append((float(st["TotalDurationNs"]), base, int(st["Calls"]), us, c["HBM_bytes_per_launch"] / 1e6, gbs, gbs / 8000.0, valu, valu / 1228.9, clk, fv_sus))
