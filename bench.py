@@ -328,6 +328,12 @@ def main():
         iters_per_s = (1 if bands else world) * args.steps / dt
         per_kernel = {k: v[0] / v[1] for k, v in stages.items()}
         roof = roofline_object(per_kernel, args.workload, P, V, R, Rs, W, H, n_pass)
+        if roof and roof.get("valu_issue") and probe and probe.get("valu_Ginst_per_s_in_kernel_span"):
+            # against what THIS box's VALUs issue on independent v_fma_f32 streams (box_probe), not the 157.3 TFLOP/s / 128 yardstick that
+            # non-packed fp32 code cannot reach
+            vi = roof["valu_issue"]
+            vi["fma_ceiling_this_box_Ginst_per_s"] = probe["valu_Ginst_per_s_in_kernel_span"]
+            vi["frac_of_fma_ceiling_this_box"] = round(vi["achieved_Ginst_per_s"] / probe["valu_Ginst_per_s_in_kernel_span"], 4)
         out = {"metric": "train iters/sec (full iteration: rasterizer fwd+bwd, L1+SSIM, normal+dist regularisers, Adam) + fwd Msplats/s @1080p",
                "value": round(iters_per_s, 3), "unit": "train-iters/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": round(ms_per_step, 4),

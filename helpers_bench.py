@@ -311,19 +311,22 @@ def trained_leg(dev, preset="trained", steps=30, warmup=5, state=None):
     return out
 
 
-# Reference box of `ms_per_step_normalised`: the probe values of a FAST box of the pool (round 5's calibration run,
-# profiles/r05_box_probe_calibration.json) and the split of the C2 step by what bounds its kernels (profiles/r04_C2_kernel_stats.csv:
-# blend fwd + bwd = issue-bound, binning + loss + small launches = latency-bound, Adam + preprocess fwd / bwd = HBM-bound).
-BOX_REF = {"valu_Ginst_per_s": 772.0, "sort_512k_us": 52.8, "hbm_copy_GBps": 5313.0, "launch_us": 2.46}
-STEP_SPLIT = {"valu": 0.48, "latency": 0.27, "hbm": 0.25}
+# Reference box of `ms_per_step_normalised`: the probe values of ONE box of the pool (round 5's calibration run on the final probe code,
+# profiles/r05_box_probe_calibration.json: C2 step 0.6032 ms there) and the split of the C2 step by what bounds its kernels
+# (profiles/r05_C2_roofline.md: blend fwd + bwd = issue-bound, binning + loss + small launches = latency-bound, Adam + preprocess
+# fwd / bwd = HBM-bound).  The blend share is scaled by the frozen blend-like mix kernel, not by the pure FMA stream: boxes that differ
+# by 30 % on v_fma_f32 (526 ... 779 G wave-inst/s measured in one afternoon) differ by 4 % on the step.
+BOX_REF = {"blend_mix_Mvisits_per_s": 3857.0, "sort_512k_us": 53.4, "hbm_copy_GBps": 5319.0, "launch_us": 2.45, "valu_Ginst_per_s": 735.0}
+STEP_SPLIT = {"blend": 0.48, "latency": 0.27, "hbm": 0.25}
 
 
 def box_probe(dev):
     """What THIS box sustains, measured before the timed window: HBM copy GB/s, the cost of a dependent launch boundary,
     the wave-instruction rate and shader clock of independent v_fma_f32 streams (include/surfel_hip.h: surfel_debug_box_probe), and a
     fixed 0.5 M-pair tile sort (two look-back passes of the product's own sort on 12-bit keys: the latency-bound stage that stretched
-    26 - 29 % on round 4's driver box).  `slowdown_vs_reference_box` = the factor by which a C2 step is expected to be longer on this
-    box than on the reference box, from the three classes of kernels the step consists of (STEP_SPLIT)."""
+    26 - 29 % on round 4's driver box), a frozen blend-like instruction-mix kernel.  `slowdown_vs_reference_box` = the factor by which a C2
+    step is expected to be longer on this box than on the reference box, from the three classes of kernels the step consists of
+    (STEP_SPLIT); a first-order model — the raw probe values are printed so that a reader can weigh them differently."""
     import ctypes as C
     import torch
     import surfel_native as n
@@ -367,7 +370,7 @@ def box_probe(dev):
     res["hbm_copy_GBps"] = cp["GBps_read_plus_write"]
     r = BOX_REF
     res["reference_box"] = dict(r)
-    res["slowdown_vs_reference_box"] = round(STEP_SPLIT["valu"] * r["valu_Ginst_per_s"] / max(res["valu_Ginst_per_s"], 1e-3)
+    res["slowdown_vs_reference_box"] = round(STEP_SPLIT["blend"] * r["blend_mix_Mvisits_per_s"] / max(res["blend_mix_Mvisits_per_s"], 1e-3)
                                              + STEP_SPLIT["latency"] * res["sort_512k_us"] / r["sort_512k_us"]
                                              + STEP_SPLIT["hbm"] * r["hbm_copy_GBps"] / max(res["hbm_copy_GBps"], 1e-3), 4)
     res["step_split_assumed"] = dict(STEP_SPLIT)
