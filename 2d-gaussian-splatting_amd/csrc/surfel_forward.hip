@@ -231,8 +231,8 @@ __global__ void __launch_bounds__(BLOCK, 5) blend_fwd_pipe_kernel(BlendFwdArgs a
         unsigned ov = 0;
         const int j = 32 * wave + (lane & 31), half = lane >> 5;
         // the tile stream (surfel_common.h): what blend_bwd will need of these 32 instances, left behind in list order by the wave that
-        // holds it — 2.5 KB of records as three coalesced 16-B stores per lane (read from LDS here, under the footprint arithmetic, stored
-        // behind it), and the 16 footprint bits per instance
+        // holds it — 2.5 KB of records as three coalesced 16-B stores per lane (read from LDS behind the ballots: pieces requested earlier —
+        // under the footprint arithmetic or under the ballots — measured the same or cost a wave per SIMD), and the 16 footprint bits per instance
         const int first = base + 32 * wave;                                  // list position (0-based) of this wave's first instance
         const int npc = STRM_Q * min(32, n - first);                         // 16-B pieces this wave owes the stream
         if (base + j < n) ov = subtile_overlap_half(make_foot(s_rec[buf][j][2], s_rec[buf][j][5], s_rec[buf][j][6]), tx * TILE, ty * TILE, half);
