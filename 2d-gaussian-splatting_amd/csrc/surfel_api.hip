@@ -137,7 +137,7 @@ struct ImgState {    // per-pixel / per-tile state ("imgBuffer")
         Carver c(base); ImgState im;
         const size_t tiles = (size_t)((W + TILE - 1) / TILE) * ((H + TILE - 1) / TILE);
         // [tiles] ranges + R_SLOTS partial instance totals + R_SLOTS partial visible-surfel counts + the instance total of the capacity
-        // path | the tile-map flag | two spare words (zeroed together)
+        // path | the tile-map flag | the frame's backward walk (blend_fwd) | a spare word (zeroed together)
         im.ranges = c.take<uint2>(tiles + R_SLOTS + 2);
         im.total = reinterpret_cast<uint32_t*>(im.ranges + tiles);
         im.final_T = c.take<float>((size_t)3 * W * H);
@@ -560,7 +560,7 @@ int64_t surfel_rasterize_forward(surfel_alloc_fn geom_alloc, void* geom_user, su
             ba.out_color = out_color; ba.out_others = out_others; ba.final_T = img.final_T; ba.n_contrib = img.n_contrib;
             ba.tile_map = img.tile_map; ba.map_flag = img.total + 2 * R_SLOTS + 1; ba.map_len = map_len;
             ba.stats = g_blend_stats;
-            ba.strm_rec = bin.strm_rec; ba.strm_mask = bin.strm_mask;
+            ba.strm_rec = bin.strm_rec; ba.strm_mask = bin.strm_mask; ba.totals = img.total; ba.walk_word = img.total + 2 * R_SLOTS + 2;
             stream_register(bin.point_list, launch_blend_fwd_writes_stream(ba) ? bin.strm_rec : nullptr, bin.strm_mask);
             tm.begin();
             launch_blend_fwd(ba, s);
@@ -664,7 +664,7 @@ int64_t surfel_rasterize_forward(surfel_alloc_fn geom_alloc, void* geom_user, su
     ba.tile_map = img.tile_map; ba.map_flag = img.total + 2 * R_SLOTS + 1; ba.map_len = map_len;
     ba.stats = g_blend_stats;
     ba.avg_list = (int)(R / ((int64_t)gx * gy));
-    ba.strm_rec = bin.strm_rec; ba.strm_mask = bin.strm_mask;
+    ba.strm_rec = bin.strm_rec; ba.strm_mask = bin.strm_mask; ba.totals = img.total; ba.walk_word = img.total + 2 * R_SLOTS + 2;
     stream_register(bin.point_list, launch_blend_fwd_writes_stream(ba) ? bin.strm_rec : nullptr, bin.strm_mask);
     tm.begin();
     launch_blend_fwd(ba, s);
@@ -721,7 +721,7 @@ int surfel_rasterize_backward(surfel_alloc_fn scratch_alloc, void* scratch_user,
     bb.ranges = img.ranges; bb.point_list = bin.point_list; bb.rec = geom.rec; bb.bg = background;
     bb.final_T = img.final_T; bb.n_contrib = img.n_contrib; bb.dL_dpix = dL_dout_color; bb.dL_dothers = dL_dout_others;
     bb.tile_map = img.tile_map; bb.map_flag = img.total + 2 * R_SLOTS + 1; bb.map_len = tile_map_len(gx, gy);      // the forward's tile order (its lists are the backward's lists)
-    bb.grec = grec; bb.cut = cut; bb.has_rec = has_rec; bb.depths = geom.depths; bb.variant = opt_variant; bb.stats = g_blend_stats; bb.totals = img.total;
+    bb.grec = grec; bb.cut = cut; bb.has_rec = has_rec; bb.depths = geom.depths; bb.variant = opt_variant; bb.stats = g_blend_stats; bb.walk_word = img.total + 2 * R_SLOTS + 2;
     // num_rendered of a lazily counted frame is its CAPACITY: if the frame's real total (on the device since bin_emit_kernel; 0 on the
     // exact path) exceeds it, the lists are truncated and the first-instance slots run past `grec` — the kernels below return at once
     if (!(debug_in & SURFEL_OPT_BWD_GATHER) && g_opt_stream) (void)stream_lookup(binning_buffer, &bb.strm_rec, &bb.strm_mask);      // (stays NULL: the walks gather)

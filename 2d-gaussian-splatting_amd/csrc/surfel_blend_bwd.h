@@ -52,22 +52,9 @@ __device__ __forceinline__ size_t grec_slot(const float4 q4, int tx, int ty) {
     return (size_t)basei + (size_t)((ty - y0) * rw + (tx - x0));
 }
 
-// BlendBwdArgs::scan_rule: the scan walk (surfel_backward_scan.hip) and ONE of rows / quad are launched, and every workgroup of both
-// decides from the frame's totals which of the two runs — deterministic from the frame alone (the walks differ in summation order:
-// which bits a frame gets must not depend on timing or history).  Scan wins where a surfel's footprint spans many tiles — trained
-// frames: 9 instances per emitting surfel, -9 % against rows; C2H: 10.8, -3 ... -6 % — and on large frames (2^21 <= R < 2^26: C4,
-// garden -7 %); small random footprints (C2: 2.2 instances per surfel) stay with rows (scan +11 % there).  profiles/r03_blend_bwd_scan.md,
-// BENCH_r03.json blend_bwd_ms_by_walk.
-constexpr unsigned SCAN_MIN_INST_PER_SURFEL = 6;
-__device__ __forceinline__ bool device_picks_scan(const BlendBwdArgs& a) {
-    const int lane = threadIdx.x & 63;
-    uint32_t r = a.totals[lane], v = a.totals[R_SLOTS + lane];
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { r += __shfl_xor(r, o); v += __shfl_xor(v, o); }
-    const unsigned long long R = r;
-    // (no gain on frames of >= 2^26 instances, whatever their footprints: C5, 1.3e8 instances of which 4 % are staged — scan 3.19 - 3.6 vs 3.13 ms)
-    return R < (1ull << 26) && (R >= (1ull << 21) || R >= (unsigned long long)SCAN_MIN_INST_PER_SURFEL * v);
-}
+// BlendBwdArgs::scan_rule: the scan kernel and the rows kernel are both launched and every workgroup of both looks the frame's walk up
+// in the word blend_fwd left (surfel_common.h: frame_walk) — the workgroups of the other kernel return at once.
+__device__ __forceinline__ bool device_picks_scan(const BlendBwdArgs& a) { return a.walk_word[0] == WALK_SCAN; }
 
 __device__ __forceinline__ int block_max(int v, int* s_max) {
     if (threadIdx.x == 0) *s_max = 0;

@@ -122,6 +122,24 @@ __device__ __forceinline__ unsigned subtile_bits_to_rows(unsigned m) {
     return (m & 0xC3C3u) | ((m & 0x0C0Cu) << 2) | ((m & 0x3030u) >> 2);
 }
 
+// Which blend-backward walk a frame takes under "bwd_variant" = auto — a rule on the frame's own totals, so that the bits of a frame
+// follow from the frame alone (the walks differ in summation order).  The scan walk (surfel_backward_scan.hip) wins where a surfel's
+// footprint spans many tiles — trained frames: 9 instances per emitting surfel, -9 % against rows; C2H: 10.8, -3 ... -6 % — and on large
+// frames (2^21 <= R < 2^26: C4, garden -7 %; C5, 1.3e8 instances of which 4 % are staged: no gain); small random footprints (C2: 2.2
+// instances per surfel) stay with the per-row walk (scan +11 % there).  Evaluated ONCE per frame, by the first wave of blend_fwd, and
+// left in a word of the image buffer's head: the backward's two grids each read that word (round 5: every workgroup of both grids used
+// to sum the 128 partial counters itself, in front of its first load).
+constexpr unsigned SCAN_MIN_INST_PER_SURFEL = 6;
+constexpr uint32_t WALK_ROWS = 1u, WALK_SCAN = 2u;
+__device__ __forceinline__ uint32_t frame_walk(const uint32_t* __restrict__ totals /* [2 * R_SLOTS]: tile instances | emitting surfels */) {
+    const int lane = threadIdx.x & 63;
+    uint32_t r = totals[lane], v = totals[R_SLOTS + lane];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { r += __shfl_xor(r, o); v += __shfl_xor(v, o); }
+    const unsigned long long R = r;
+    return (R < (1ull << 26) && (R >= (1ull << 21) || R >= (unsigned long long)SCAN_MIN_INST_PER_SURFEL * v)) ? WALK_SCAN : WALK_ROWS;
+}
+
 struct Rect { int x0, y0, x1, y1; };
 
 __device__ __forceinline__ Rect tile_rect(float px, float py, int r, int gx, int gy) {

@@ -20,6 +20,7 @@ template <bool STATS>
 __global__ void __launch_bounds__(BLOCK) blend_fwd_kernel(BlendFwdArgs a) {
     __shared__ float4 s_rec[BLOCK * 5];
     __shared__ __attribute__((aligned(8))) uint32_t s_mask[16 * MSTRIDE];    // [sub-tile][word]
+    if (blockIdx.x == 0 && threadIdx.x < 64) { const uint32_t w = frame_walk(a.totals); if (threadIdx.x == 0) a.walk_word[0] = w; }      // the frame's backward walk, decided once
     const int tile = block_tile(a.tile_map, a.map_flag, blockIdx.x, a.gx * a.gy);      // (tile_order_kernel: XCD-contiguous runs on uniform frames, longest lists first otherwise)
     if (tile < 0) return;
     const int tx = tile % a.gx, ty = tile / a.gx;
@@ -186,6 +187,7 @@ __global__ void __launch_bounds__(BLOCK, 5) blend_fwd_pipe_kernel(BlendFwdArgs a
     __shared__ uint32_t s_list[4][4][NB / 4 + 1];      // 2.1 KB: per wave and DPP row, the staged indices (bytes) of the row's visits of this batch
     __shared__ uint32_t s_ids[4][32];                  // per wave, the surfel ids of its 32 instances of the batch after next (DMA as well:
                                                        // a load hipcc tracks would make it wait for vmcnt(0) — i.e. for the record DMA — at its next use)
+    if (blockIdx.x == 0 && threadIdx.x < 64) { const uint32_t w = frame_walk(a.totals); if (threadIdx.x == 0) a.walk_word[0] = w; }      // the frame's backward walk, decided once
     const int tile = block_tile(a.tile_map, a.map_flag, blockIdx.x, a.gx * a.gy);
     if (tile < 0) return;
     const int tx = tile % a.gx, ty = tile / a.gx;

@@ -30,6 +30,7 @@ struct BlendFwdArgs {
     int avg_list;                // instances per tile where the host knows the count (exact binning path), else 0: picks the kernel (speed only)
     // the TILE STREAM (surfel_common.h): per list position the 80-B blend record + the 16 sub-tile footprint bits, in list order, for blend_bwd
     float4* strm_rec; uint32_t* strm_mask;      // [R][5] | [R], or NULL: none is written
+    const uint32_t* totals; uint32_t* walk_word;      // [2 * R_SLOTS] partial sums written by preprocess (tile instances | visible surfels) -> the frame's backward walk (surfel_common.h: frame_walk)
 };
 
 struct BlendBwdArgs {
@@ -44,8 +45,8 @@ struct BlendBwdArgs {
     const float* depths;   // [P] view depths (the sort key's source)
     int variant;      // 0: per-DPP-row walk, 1: per-wave (8x8 quad) walk (0 / 1 bit-identical), 3: scan walk
     const float4* strm_rec; const uint32_t* strm_mask;      // the forward's tile stream (BlendFwdArgs), or NULL: the staging gathers the records by surfel id
-    int scan_rule;    // 1: the scan kernel AND the rows / quad kernel selected by `variant` are launched; the device decides from `totals` which one runs (surfel_blend_bwd.h: device_picks_scan)
-    const uint32_t* totals;      // [2 * R_SLOTS] partial sums written by preprocess: tile instances | visible surfels
+    int scan_rule;    // 1: the scan kernel AND the rows / quad kernel selected by `variant` are launched; the device looks up which one runs (surfel_blend_bwd.h: device_picks_scan)
+    const uint32_t* walk_word;   // the word blend_fwd left: WALK_ROWS / WALK_SCAN (surfel_common.h: frame_walk)
     const uint32_t* n_dev; uint32_t n_cap;      // capacity path: the frame's instance total on the device and the record capacity (= num_rendered).  n_dev[0] > n_cap:
                                                 // a lazily counted frame that overflowed — its lists are truncated, the caller redoes it: every backward kernel returns at once
     unsigned long long* stats;   // optional [4]: lane slots issued, useful (pixel, surfel) lanes, wave visits, row / quad visits

@@ -30,7 +30,7 @@ def tile_row_instances():
 
 
 IMG_HEAD_U2 = 64 + 2      # uint2 slots behind the tile ranges in the image buffer's zeroed head (csrc/surfel_api.hip: ImgState::carve):
-                          # 2 x 64 partial counters, the capacity path's instance total + the tile-map flag, two spare words
+                          # 2 x 64 partial counters, the capacity path's instance total + the tile-map flag, the frame's backward walk + a spare word
 
 
 def image_layout(width, height):
