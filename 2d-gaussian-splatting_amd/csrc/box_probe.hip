@@ -129,10 +129,43 @@ __global__ void __launch_bounds__(256, 4) probe_mix_kernel(unsigned long long* o
     if (threadIdx.x == 0) { out[4 * blockIdx.x + 6] = r0; out[4 * blockIdx.x + 7] = r1; }
 }
 
+// Dependent-load latency: one lane chases a permutation cycle through `n` words (stride chosen by the host so that every hop leaves the
+// line and the page); ns per hop = the round trip of a load that misses L1 / L2 / MALL depending on the footprint.
+__global__ void probe_chase_kernel(const uint32_t* __restrict__ next, int hops, unsigned long long* out) {
+    if (threadIdx.x != 0) return;
+    uint32_t i = 0;
+    const unsigned long long r0 = wall_clock64();
+    for (int k = 0; k < hops; k++) i = next[i];
+    const unsigned long long r1 = wall_clock64();
+    out[0] = (r1 - r0) + (i == 0xffffffffu ? 1ull : 0ull);
+}
+__global__ void probe_chase_init_kernel(uint32_t* __restrict__ next, uint32_t n, uint32_t stride) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) next[i] = (uint32_t)(((unsigned long long)i + stride) % n);
+}
+
 }  // namespace
 }  // namespace surfel
 
 using namespace surfel;
+
+// ns per dependent global load through a cycle over `bytes` of `buf` (a power of two >= 1 MiB; stride 4099 words: co-prime, > a page)
+extern "C" int surfel_debug_latency_probe(void* buf, int64_t bytes, int hops, float* ns_per_hop, void* stream) {
+    if (!buf || bytes < (1 << 20) || hops <= 0 || !ns_per_hop) return api_fail(SURFEL_E_INVALID, "latency probe: bad arguments", hipSuccess);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const uint32_t n = (uint32_t)(bytes / 4) - 2;      // (the last two words receive the result)
+    uint32_t* next = static_cast<uint32_t*>(buf);
+    unsigned long long* out = reinterpret_cast<unsigned long long*>(next + (n & ~1u));
+    hipLaunchKernelGGL(probe_chase_init_kernel, dim3((n + 255) / 256), dim3(256), 0, s, next, n & ~1u, 4099u | 1u);
+    hipLaunchKernelGGL(probe_chase_kernel, dim3(1), dim3(64), 0, s, next, 256, out);      // warm code (not the data: the footprint decides what the hops hit)
+    hipLaunchKernelGGL(probe_chase_kernel, dim3(1), dim3(64), 0, s, next, hops, out);
+    unsigned long long ticks = 0;
+    hipError_t e = hipStreamSynchronize(s);
+    if (e == hipSuccess) e = hipMemcpy(&ticks, out, sizeof(ticks), hipMemcpyDeviceToHost);
+    if (e != hipSuccess) return api_fail(SURFEL_E_HIP, "latency probe", e);
+    *ns_per_hop = (float)((double)ticks * 10.0 / (double)hops);
+    return 0;
+}
 
 extern "C" int surfel_debug_box_probe(void* scratch, int64_t scratch_bytes, float* out, void* stream) {
     // 1024 workgroups = 4 per CU = 4 waves per SIMD: all resident from the first cycle (8 per CU came out as two dispatch rounds on some

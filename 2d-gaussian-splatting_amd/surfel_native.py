@@ -20,7 +20,7 @@ HOOK_FN = C.CFUNCTYPE(None, C.c_void_p)
 
 EXPORTS = ["surfel_abi_version", "surfel_last_error", "surfel_rasterize_forward", "surfel_rasterize_backward",
            "surfel_mark_visible", "surfel_knn_dist2", "surfel_last_stage_ms", "surfel_last_stage_ids", "surfel_stage_name",
-           "surfel_collect_stage_ms", "surfel_set_option", "surfel_debug_sort_pairs", "surfel_debug_set_blend_stats", "surfel_debug_last_binning", "surfel_debug_capacity_evictions", "surfel_debug_image_layout", "surfel_debug_box_probe", "surfel_set_backward_hook", "surfel_forward_count",
+           "surfel_collect_stage_ms", "surfel_set_option", "surfel_debug_sort_pairs", "surfel_debug_set_blend_stats", "surfel_debug_last_binning", "surfel_debug_capacity_evictions", "surfel_debug_image_layout", "surfel_debug_box_probe", "surfel_debug_latency_probe", "surfel_set_backward_hook", "surfel_forward_count",
            # include/surfel_train.h
            "surfel_l1_ssim_forward", "surfel_l1_ssim_backward", "surfel_l1_ssim_forward_w", "surfel_l1_ssim_backward_w", "surfel_render_post_forward", "surfel_render_post_backward", "surfel_train_loss_forward", "surfel_train_loss_backward",
            "surfel_reduce_partials", "surfel_loss_finalize", "surfel_activate", "surfel_adam_step", "surfel_sh_grad_gather", "surfel_densify_stats"]
@@ -92,6 +92,8 @@ def load():
         lib.surfel_debug_set_blend_stats.argtypes = [vp]
         lib.surfel_debug_box_probe.restype = i
         lib.surfel_debug_box_probe.argtypes = [vp, i64, C.POINTER(C.c_float), vp]
+        lib.surfel_debug_latency_probe.restype = i
+        lib.surfel_debug_latency_probe.argtypes = [vp, i64, i, C.POINTER(C.c_float), vp]
         lib.surfel_set_backward_hook.restype = i
         lib.surfel_set_backward_hook.argtypes = [HOOK_FN, vp]
         lib.surfel_forward_count.restype = i64

@@ -328,6 +328,17 @@ def main():
         iters_per_s = (1 if bands else world) * args.steps / dt
         per_kernel = {k: v[0] / v[1] for k, v in stages.items()}
         roof = roofline_object(per_kernel, args.workload, P, V, R, Rs, W, H, n_pass)
+        # Normalisation of the step to a "fast run" of the pool.  Round 5 sampled the pool with every probe of box_probe (FMA / add / pk_fma
+        # issue rates, shader clock, a blend-like mix kernel, a standalone 0.5 M-pair sort, HBM copy, L2 / HBM load latency, host launch
+        # cost): NONE of them separates the two classes of runs that exist (C2 step 0.576 vs 0.63 ms at identical probe values,
+        # profiles/r05_box_samples.txt).  What does is a latency-bound kernel timed IN the step: the tile sort (two look-back passes over
+        # the frame's pairs; unchanged since round 3) takes 39.5 us in a fast run and 49 - 53 us in a slow one, and over five runs the
+        # step moved by 0.33 x the sort's relative change.  So: normalised = step / (1 + 0.33 (tile_sort / 39.5 us - 1)), C2 only.
+        if args.workload == "C2" and per_kernel.get("tile_sort"):
+            out_norm = {"tile_sort_us_in_step": round(per_kernel["tile_sort"] * 1e3, 2), "tile_sort_us_fast_run": 39.5, "step_sensitivity": 0.33}
+            out_norm["slowdown_vs_fast_run"] = round(1.0 + 0.33 * (per_kernel["tile_sort"] * 1e3 / 39.5 - 1.0), 4)
+        else:
+            out_norm = None
         if roof and roof.get("valu_issue") and probe and probe.get("valu_Ginst_per_s_in_kernel_span"):
             # against what THIS box's VALUs issue on independent v_fma_f32 streams (box_probe), not the 157.3 TFLOP/s / 128 yardstick that
             # non-packed fp32 code cannot reach
@@ -337,8 +348,8 @@ def main():
         out = {"metric": "train iters/sec (full iteration: rasterizer fwd+bwd, L1+SSIM, normal+dist regularisers, Adam) + fwd Msplats/s @1080p",
                "value": round(iters_per_s, 3), "unit": "train-iters/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": round(ms_per_step, 4),
-               "ms_per_step_normalised": (round(ms_per_step / probe["slowdown_vs_reference_box"], 4) if probe and "slowdown_vs_reference_box" in probe else None),
-               "box_probe": probe, "higher_is_better": True, "scaling": "strong" if bands else "weak", "vs_baseline": None,
+               "ms_per_step_normalised": (round(ms_per_step / out_norm["slowdown_vs_fast_run"], 4) if out_norm else None),
+               "normalisation": out_norm, "box_probe": probe, "higher_is_better": True, "scaling": "strong" if bands else "weak", "vs_baseline": None,
                "dtype": "f32", "data": "synthetic",
                "config": {"workload": (trained_info["workload"] + "; steady-state iteration, every loss term on") if trained_info else
                                       "%s-synthetic: %d random surfels, %dx%d, sh_degree 3, %d target views rendered from the unperturbed "

@@ -230,6 +230,9 @@ int surfel_debug_image_layout(int width, int height, int64_t* out);
  * visit (LDS reads + ~100 fp32 multiply-adds + transcendentals + selects + a 38-DPP reduction) at 4 workgroups per CU.  bench.py prints them as `box_probe` so that runs on different boxes of a pool can
  * be compared.  No reference counterpart. */
 int surfel_debug_box_probe(void* scratch, int64_t scratch_bytes, float* out9, void* stream);
+/* ... and its dependent-load latency: one lane chases a cycle of `hops` loads through `bytes` (>= 1 MiB) of `buf`; the footprint decides what
+ * a hop hits (4 MiB: the XCD's L2, 1 GiB: HBM).  The call synchronises. */
+int surfel_debug_latency_probe(void* buf, int64_t bytes, int hops, float* ns_per_hop, void* stream);
 
 #ifdef __cplusplus
 }

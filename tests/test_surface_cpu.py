@@ -103,7 +103,7 @@ def test_box_probe_normalisation_is_the_identity_on_its_reference_box():
          + hb.STEP_SPLIT["hbm"] * r["hbm_copy_GBps"] / r["hbm_copy_GBps"])
     assert abs(s - 1.0) < 1e-12
     src = open(os.path.join(REPO, "helpers_bench.py")).read()
-    assert 'STEP_SPLIT["blend"] * r["blend_mix_Mvisits_per_s"]' in src and "slowdown_vs_reference_box" in src
+    assert 'STEP_SPLIT["blend"] * r["blend_mix_Mvisits_per_s"]' in src and "slowdown_vs_reference_box_by_probes" in src
     assert "ms_per_step_normalised" in open(os.path.join(REPO, "bench.py")).read()
 
 
