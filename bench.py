@@ -235,16 +235,18 @@ def main():
     else:
         P, W, H, zf = synthetic.CONFIGS[args.workload]
         tr = make_trainer(dev, args.workload, n_views=n_views, sharding=args.sharding)      # Trainer picks up the process group
-    PRIME = 15      # set-up iterations before the contract's W warm-up steps: allocator high-water marks, binning-path heuristic, clocks
-    for _ in range(PRIME):
-        tr.step()
+    # what this box sustains, in this process, BEFORE the set-up iterations (helpers_bench.box_probe; its host-side parts leave the GPU idle for
+    # tens of milliseconds: placed between the set-up iterations and the warm-up it cost the 20-step window 3 % — clocks)
     probe = None
-    if rank == 0:      # what this box sustains, in this process, right before the timed window (helpers_bench.box_probe)
+    if rank == 0:
         try:
             from helpers_bench import box_probe
             probe = box_probe(dev)
         except Exception as e:      # noqa: BLE001 — an extra must not cost the run its headline
             probe = {"error": repr(e)}
+    PRIME = 15      # set-up iterations before the contract's W warm-up steps: allocator high-water marks, binning-path heuristic, clocks
+    for _ in range(PRIME):
+        tr.step()
     tr.pipe.debug = 3       # HIP events around the dominant kernel only (blend_bwd), resolved after the timed region, no sync
     tr.time_exchange = world > 1     # N > 1: events around the stream waits on the collectives -> exposed exchange time
 
