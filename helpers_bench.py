@@ -346,8 +346,10 @@ def box_probe(dev):
                     "shader_clock_GHz_under_fma_grid": round(out[2], 3), "fma_cycles_per_wave_inst_per_simd": round(out[4], 3),
                     "add_cycles_per_wave_inst_per_simd": round(out[6], 3), "pk_fma_cycles_per_wave_inst_per_simd": round(out[7], 3),
                     "blend_mix_Mvisits_per_s": round(out[8], 1),
-                    "note": "4 waves per SIMD of independent chains; one fp32 wave64 instruction per ~4 shader cycles per SIMD (a 16-lane pipe), "
-                            "i.e. the chip's non-packed fp32 issue peak is 1024 SIMDs x clock / 4 — half of the 157.3 TFLOP/s / 128 figure, which needs v_pk_fma_f32"})
+                    "note": "box-relative figures: 1024 workgroups of 4 waves, 8 FMAs + 3 scalar loop instructions per trip, span timing.  The instruction classes "
+                            "themselves are measured by scripts/issue_probe.hip (profiles/r05_issue_probe.md): 2.5 shader cycles per wave64 instruction per SIMD for "
+                            "fma / add / mul / mov / and, 4.3 for DPP / min / max / compare / select / shift / SGPR-operand forms, 8.2 transcendental; two waves per SIMD "
+                            "reach those rates: the non-packed fp32 ceiling is 1024 SIMDs x clock / 2.5"})
         # the fixed sort: 512 Ki (key, value) pairs, 12-bit keys (an 800x800 frame's tile ids), the product's own passes
         N = 1 << 19
         g = torch.Generator(device="cpu").manual_seed(1)

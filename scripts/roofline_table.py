@@ -26,9 +26,9 @@ for k, c in pmc.items():
 rows.sort(reverse=True)
 out = ["# Per-kernel roofline, %s / %s (MI355X: HBM 8 000 GB/s, fp32 VALU issue 1 228.9 G wave-inst/s)" % (tag, wl), "",
        "eff_clock_GHz = GRBM_GUI_ACTIVE / kernel wall time (own --pmc pass; kernels of >= 30 us only); 'of sustained' = VALU rate / (1024 SIMDs x eff clock / 2),",
-       "i.e. against the NOMINAL 2 cycles per wave64 fp32 instruction.  Independent v_fma_f32 streams at 4 waves per SIMD measure 2.9 - 4.2 cycles per",
-       "wave-instruction per SIMD on the boxes of the pool (bench.py: box_probe; 526 - 787 G wave-inst/s chip-wide): a kernel at 0.45 of the nominal",
-       "figure runs at 0.65 - 0.85 of what the VALUs of its box issue.", "",
+       "i.e. against the NOMINAL 2 cycles per wave64 fp32 instruction.  Measured per instruction kind (scripts/issue_probe.hip, profiles/r05_issue_probe.md):",
+       "fma / add / mul / mov / and 2.5 cycles, every DPP form, min / max, compares, selects, shifts and SGPR-operand forms 4.3, transcendentals 8.2 — a blend",
+       "kernel at 0.45 of the nominal figure runs at ~0.75 of what its own instruction mix can issue.", "",
        "| kernel | launches | avg µs | HBM MB / launch | GB/s | frac of HBM peak | VALU G wave-inst/s | frac of VALU peak (2.4 GHz) | eff_clock_GHz | frac of VALU issue at the sustained clock | bound |",
        "|---|---|---|---|---|---|---|---|---|---|---|"]
 for _, k, n, us, mb, gbs, fh, valu, fv, clk, fvs in rows:
