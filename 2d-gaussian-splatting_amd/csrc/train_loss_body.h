@@ -30,19 +30,48 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
-// LDS layout (42 KB at window 11 -> 3 workgroups / CU): the staged tile as float2 (x,y) with pitch XP, the horizontal moments as
-// float4 (E[x], E[y], E[x^2], E[y^2]) with pitch HZP + float (E[xy]).  Each thread slides the window over NE consecutive
-// elements held in registers (window 11: 4 outputs per 14 LDS reads instead of 44), horizontally then vertically.
+// LDS layout (27.6 KB at window 11 -> 5 workgroups / CU): the staged tile as float2 (x,y) with pitch XP; the horizontal moments as
+// float4 (E[x], E[y], E[x^2], E[y^2]) with pitch HZP + float (E[xy]) are written OVER it — every thread keeps its horizontal-pass
+// results in registers across the barrier that retires the staged tile.  Each thread slides the window over NE consecutive elements
+// held in registers (window 11: 4 outputs per 14 LDS reads instead of 44), horizontally then vertically.
+// (Round 5, scripts/loss_trace.hip: at 43 KB = 3 workgroups / CU a workgroup took 8.2 us for ~3.7 us of vector issue and the launch
+// was the sum of its workgroups' latencies over 768 slots.)
 constexpr int HZP = ST + 1;       // float4 pitch of the horizontal-pass result
+
+// Horizontal moments of NO consecutive outputs of one staged row: the (2 SR + 1)-tap window slid over NO + 2 SR elements.  The taps of
+// an output are accumulated in ascending order whatever NO is: same bits for every split of a row into items.
+template <int SR, int NO>
+__device__ __forceinline__ void hz_moments5(const float2* __restrict__ row, const SsimWin& win, float (&a)[NO], float (&b)[NO], float (&aa)[NO], float (&bb)[NO],
+                                            float (&ab)[NO]) {
+    constexpr int NEL = NO + 2 * SR, NW = 2 * SR + 1;
+    float xv[NEL], yv[NEL];
+    const float4* src = reinterpret_cast<const float4*>(row);
+#pragma unroll
+    for (int k = 0; k < NEL / 2; k++) { const float4 t = src[k]; xv[2 * k] = t.x; yv[2 * k] = t.y; xv[2 * k + 1] = t.z; yv[2 * k + 1] = t.w; }
+#pragma unroll
+    for (int j = 0; j < NO; j++) { a[j] = 0.f; b[j] = 0.f; aa[j] = 0.f; bb[j] = 0.f; ab[j] = 0.f; }
+#pragma unroll
+    for (int e = 0; e < NEL; e++) {
+        const float x = xv[e], y = yv[e], xx = x * x, yy = y * y, xy = x * y;
+#pragma unroll
+        for (int j = 0; j < NO; j++) {
+            const int k = e - j;
+            if (k >= 0 && k < NW) {
+                const float w = win.w[k];
+                a[j] += w * x; b[j] += w * y; aa[j] += w * xx; bb[j] += w * yy; ab[j] += w * xy;
+            }
+        }
+    }
+}
 
 template <int SR>
 __device__ __forceinline__ void ssim_fwd_body(char* smem, int vblock, int vgrid, int H, int W, const float* __restrict__ img, const float* __restrict__ gt,
                                                        float* __restrict__ dmaps, size_t map_stride, float* __restrict__ partials, SsimWin win) {
     SSIM_GEOMETRY(SR);
-    // LDS carve-up (the caller provides ssim_fwd_lds<SR>() bytes, 16-B aligned): hz4 | sxy | hz1 | red
+    // LDS carve-up (the caller provides ssim_fwd_lds<SR>() bytes, 16-B aligned): sxy, and over it after the horizontal pass hz4 | hz1 | red
+    float2* const sxy = reinterpret_cast<float2*>(smem);
     float4* const hz4 = reinterpret_cast<float4*>(smem);
-    float2* const sxy = reinterpret_cast<float2*>(smem + sizeof(float4) * SHALO * HZP);
-    float* const hz1 = reinterpret_cast<float*>(smem + sizeof(float4) * SHALO * HZP + sizeof(float2) * SHALO * XP);
+    float* const hz1 = reinterpret_cast<float*>(smem + sizeof(float4) * SHALO * HZP);
     float* const red = hz1 + SHALO * ST;
     const int tid = threadIdx.x;
     // workgroup b runs on XCD b % 8: every XCD gets a contiguous run of (plane, tile) so that neighbouring tiles' halos hit in
@@ -73,36 +102,36 @@ __device__ __forceinline__ void ssim_fwd_body(char* smem, int vblock, int vgrid,
         }
     }
     __syncthreads();
-    // horizontal pass: item = (row r of 42, group of 4 output columns)
-    for (int it = tid; it < SHALO * (ST / 4); it += 256) {
-        const int r = it >> 3, c0 = (it & 7) << 2;
-        float xv[NE], yv[NE];
-        const float4* src = reinterpret_cast<const float4*>(&sxy[r * XP + c0]);
+    // horizontal pass into registers.  Staged rows 0 .. 31: one item of 4 output columns per thread (256 items); the 2 SR rows behind
+    // them: items of 2 output columns (16 per row: 160 at window 11) — as 80 four-column items they were a second trip of the first
+    // 80 threads only, i.e. twice the work for the SIMDs that hold waves 0 and 1
+    const int r1 = tid >> 3, c1 = (tid & 7) << 2;
+    const int r2 = ST + (tid >> 4), c2 = (tid & 15) << 1;
+    const bool has2 = tid < 2 * SR * 16;
+    float a1[4], b1[4], aa1[4], bb1[4], ab1[4], a2[2], b2[2], aa2[2], bb2[2], ab2[2];
+    hz_moments5<SR, 4>(&sxy[r1 * XP + c1], win, a1, b1, aa1, bb1, ab1);
+    if (has2) hz_moments5<SR, 2>(&sxy[r2 * XP + c2], win, a2, b2, aa2, bb2, ab2);
+    const int c = tid & 31, g = tid >> 5;      // vertical pass: thread -> column c, output rows 4g .. 4g+3
+    float l1 = 0.f;                            // ... whose own pixels' L1 term is taken now: the staged tile is about to be overwritten
 #pragma unroll
-        for (int k = 0; k < NE / 2; k++) { const float4 t = src[k]; xv[2 * k] = t.x; yv[2 * k] = t.y; xv[2 * k + 1] = t.z; yv[2 * k + 1] = t.w; }
-        float a[4] = {0.f, 0.f, 0.f, 0.f}, b[4] = {0.f, 0.f, 0.f, 0.f}, aa[4] = {0.f, 0.f, 0.f, 0.f}, bb[4] = {0.f, 0.f, 0.f, 0.f},
-              ab[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < 4; j++) {
+        const float2 v = sxy[(4 * g + j + SR) * XP + c + SR];
+        if (y0 + 4 * g + j < H && x0 + c < W) l1 += fabsf(v.x - v.y);
+    }
+    __syncthreads();                           // the staged tile is dead: the moments go over it
 #pragma unroll
-        for (int e = 0; e < NE; e++) {
-            const float x = xv[e], y = yv[e], xx = x * x, yy = y * y, xy = x * y;
+    for (int j = 0; j < 4; j++) {
+        hz4[r1 * HZP + c1 + j] = make_float4(a1[j], b1[j], aa1[j], bb1[j]);
+        hz1[r1 * ST + c1 + j] = ab1[j];
+    }
+    if (has2) {
 #pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const int k = e - j;
-                if (k >= 0 && k < NW) {
-                    const float w = win.w[k];
-                    a[j] += w * x; b[j] += w * y; aa[j] += w * xx; bb[j] += w * yy; ab[j] += w * xy;
-                }
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            hz4[r * HZP + c0 + j] = make_float4(a[j], b[j], aa[j], bb[j]);
-            hz1[r * ST + c0 + j] = ab[j];
+        for (int j = 0; j < 2; j++) {
+            hz4[r2 * HZP + c2 + j] = make_float4(a2[j], b2[j], aa2[j], bb2[j]);
+            hz1[r2 * ST + c2 + j] = ab2[j];
         }
     }
     __syncthreads();
-    // vertical pass: thread -> column c, output rows 4g .. 4g+3
-    const int c = tid & 31, g = tid >> 5;
     float mu1[4] = {0.f, 0.f, 0.f, 0.f}, mu2[4] = {0.f, 0.f, 0.f, 0.f}, e11[4] = {0.f, 0.f, 0.f, 0.f}, e22[4] = {0.f, 0.f, 0.f, 0.f},
           e12[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -118,9 +147,13 @@ __device__ __forceinline__ void ssim_fwd_body(char* smem, int vblock, int vgrid,
             }
         }
     }
-    float l1 = 0.f, ss = 0.f;
+    float ss = 0.f;
 #pragma unroll
     for (int j = 0; j < 4; j++) {
+        // One rounding per operation as written, like the reference's tensor ops (loss_utils.py:46-61): under -ffp-contract=fast the
+        // compiler contracts "ss += A * B * iCD" or "x * y + z * w" one way or the other depending on the code AROUND them (seen in
+        // round 5: moving the L1 term out of this loop changed the bits of ss), and the fused and the plain launches must agree.
+#pragma clang fp contract(off)
         const int r = 4 * g + j;
         const int gy = y0 + r, gx = x0 + c;
         if (gy < H && gx < W) {
@@ -130,8 +163,6 @@ __device__ __forceinline__ void ssim_fwd_body(char* smem, int vblock, int vgrid,
             const float C = mu1_sq + mu2_sq + SSIM_C1, D = s1 + s2 + SSIM_C2;
             const float iCD = 1.f / (C * D);
             const float S = A * B * iCD;
-            const float2 v = sxy[(r + SR) * XP + c + SR];
-            l1 += fabsf(v.x - v.y);
             ss += S;
             if (dmaps) {
                 const size_t o = poff + (size_t)gy * W + gx;
@@ -152,16 +183,41 @@ __device__ __forceinline__ void ssim_fwd_body(char* smem, int vblock, int vgrid,
 }
 
 
+// the backward's horizontal pass: three maps, NO consecutive outputs of one staged row (taps in ascending order: hz_moments5)
+template <int SR, int NO>
+__device__ __forceinline__ void hz_moments3(const float2* __restrict__ row12, const float* __restrict__ row3, const SsimWin& win, float (&a)[NO], float (&b)[NO],
+                                            float (&d)[NO]) {
+    constexpr int NEL = NO + 2 * SR, NW = 2 * SR + 1;
+    float m1[NEL], m2[NEL], m3[NEL];
+    const float4* src = reinterpret_cast<const float4*>(row12);
+#pragma unroll
+    for (int k = 0; k < NEL / 2; k++) { const float4 t = src[k]; m1[2 * k] = t.x; m2[2 * k] = t.y; m1[2 * k + 1] = t.z; m2[2 * k + 1] = t.w; }
+    const float2* src3 = reinterpret_cast<const float2*>(row3);
+#pragma unroll
+    for (int k = 0; k < NEL / 2; k++) { const float2 t = src3[k]; m3[2 * k] = t.x; m3[2 * k + 1] = t.y; }
+#pragma unroll
+    for (int j = 0; j < NO; j++) { a[j] = 0.f; b[j] = 0.f; d[j] = 0.f; }
+#pragma unroll
+    for (int e = 0; e < NEL; e++) {
+#pragma unroll
+        for (int j = 0; j < NO; j++) {
+            const int k = e - j;
+            if (k >= 0 && k < NW) { const float w = win.w[k]; a[j] += w * m1[e]; b[j] += w * m2[e]; d[j] += w * m3[e]; }
+        }
+    }
+}
+
 template <int SR>
 __device__ __forceinline__ void ssim_bwd_body(char* smem, int vblock, int vgrid, int H, int W, const float* __restrict__ img, const float* __restrict__ gt,
                                                        const float* __restrict__ dmaps, size_t map_stride, float c_l1, float c_ssim,
                                                        const float* __restrict__ g_l1_dev, const float* __restrict__ g_ssim_dev,
                                                        float* __restrict__ grad_img, SsimWin win) {
     SSIM_GEOMETRY(SR);
-    // LDS carve-up (ssim_bwd_lds<SR>() bytes): hz (horizontal pass of (M1, M2, M3, -)) | s12 (M1, M2) | s3 (M3)
+    // LDS carve-up (ssim_bwd_lds<SR>() bytes): s12 (M1, M2) | s3 (M3), and over them after the horizontal pass hz = (M1, M2, M3, -) per
+    // element (the results wait in registers across the barrier, as in the forward body: 23 KB instead of 45)
     float4* const hz = reinterpret_cast<float4*>(smem);
-    float2* const s12 = reinterpret_cast<float2*>(smem + sizeof(float4) * SHALO * HZP);
-    float* const s3 = reinterpret_cast<float*>(smem + sizeof(float4) * SHALO * HZP + sizeof(float2) * SHALO * XP);
+    float2* const s12 = reinterpret_cast<float2*>(smem);
+    float* const s3 = reinterpret_cast<float*>(smem + sizeof(float2) * SHALO * XP);
     const int tid = threadIdx.x;
     // workgroup b runs on XCD b % 8: every XCD gets a contiguous run of (plane, tile) so that neighbouring tiles' halos hit in
     // one L2 instead of being fetched from HBM once per XCD
@@ -191,26 +247,19 @@ __device__ __forceinline__ void ssim_bwd_body(char* smem, int vblock, int vgrid,
         }
     }
     __syncthreads();
-    for (int it = tid; it < SHALO * (ST / 4); it += 256) {
-        const int r = it >> 3, c0 = (it & 7) << 2;
-        float m1[NE], m2[NE], m3[NE];
-        const float4* src = reinterpret_cast<const float4*>(&s12[r * XP + c0]);
+    // horizontal pass into registers: 4 output columns per thread for staged rows 0 .. 31, 2 per thread for the 2 SR rows behind (ssim_fwd_body)
+    const int r1 = tid >> 3, c1 = (tid & 7) << 2;
+    const int r2 = ST + (tid >> 4), c2 = (tid & 15) << 1;
+    const bool has2 = tid < 2 * SR * 16;
+    float a1[4], b1[4], d1[4], a2[2], b2[2], d2[2];
+    hz_moments3<SR, 4>(&s12[r1 * XP + c1], &s3[r1 * XP + c1], win, a1, b1, d1);
+    if (has2) hz_moments3<SR, 2>(&s12[r2 * XP + c2], &s3[r2 * XP + c2], win, a2, b2, d2);
+    __syncthreads();                           // the staged maps are dead: the horizontal pass goes over them
 #pragma unroll
-        for (int k = 0; k < NE / 2; k++) { const float4 t = src[k]; m1[2 * k] = t.x; m2[2 * k] = t.y; m1[2 * k + 1] = t.z; m2[2 * k + 1] = t.w; }
-        const float2* src3 = reinterpret_cast<const float2*>(&s3[r * XP + c0]);
+    for (int j = 0; j < 4; j++) hz[r1 * HZP + c1 + j] = make_float4(a1[j], b1[j], d1[j], 0.f);
+    if (has2) {
 #pragma unroll
-        for (int k = 0; k < NE / 2; k++) { const float2 t = src3[k]; m3[2 * k] = t.x; m3[2 * k + 1] = t.y; }
-        float a[4] = {0.f, 0.f, 0.f, 0.f}, b[4] = {0.f, 0.f, 0.f, 0.f}, d[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int e = 0; e < NE; e++) {
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const int k = e - j;
-                if (k >= 0 && k < NW) { const float w = win.w[k]; a[j] += w * m1[e]; b[j] += w * m2[e]; d[j] += w * m3[e]; }
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < 4; j++) hz[r * HZP + c0 + j] = make_float4(a[j], b[j], d[j], 0.f);
+        for (int j = 0; j < 2; j++) hz[r2 * HZP + c2 + j] = make_float4(a2[j], b2[j], d2[j], 0.f);
     }
     __syncthreads();
     const float k_l1 = c_l1 * (g_l1_dev ? g_l1_dev[0] : 1.f), k_ss = c_ssim * (g_ssim_dev ? g_ssim_dev[0] : 1.f);
@@ -233,7 +282,9 @@ __device__ __forceinline__ void ssim_bwd_body(char* smem, int vblock, int vgrid,
         const float xv = img[o], yv = gt[o];
         const float df = xv - yv;
         const float sgn = df > 0.f ? 1.f : (df < 0.f ? -1.f : 0.f);
-        grad_img[o] = k_l1 * sgn + k_ss * (a[j] + 2.f * xv * b[j] + yv * d[j]);
+        // (spelled out: "a * b + c * d" leaves the compiler two ways to contract, and it takes either depending on the code around it)
+        const float conv = __builtin_fmaf(yv, d[j], __builtin_fmaf(2.f * xv, b[j], a[j]));
+        grad_img[o] = __builtin_fmaf(k_ss, conv, k_l1 * sgn);
     }
 }
 
@@ -280,8 +331,13 @@ __device__ __forceinline__ void loss_finalize_body(float (*red)[16], const LossF
     }
 }
 
-template <int SR> constexpr size_t ssim_fwd_lds() { return sizeof(float4) * (ST + 2 * SR) * HZP + sizeof(float2) * (ST + 2 * SR) * (ST + 2 * SR + 4) + sizeof(float) * (ST + 2 * SR) * ST + 32; }
-template <int SR> constexpr size_t ssim_bwd_lds() { return sizeof(float4) * (ST + 2 * SR) * HZP + (sizeof(float2) + sizeof(float)) * (ST + 2 * SR) * (ST + 2 * SR + 4); }
+constexpr size_t lds_max(size_t a, size_t b) { return a > b ? a : b; }
+template <int SR> constexpr size_t ssim_fwd_lds() {
+    return lds_max(sizeof(float2) * (ST + 2 * SR) * (ST + 2 * SR + 4), sizeof(float4) * (ST + 2 * SR) * HZP + sizeof(float) * (ST + 2 * SR) * ST + 32);
+}
+template <int SR> constexpr size_t ssim_bwd_lds() {
+    return lds_max((sizeof(float2) + sizeof(float)) * (ST + 2 * SR) * (ST + 2 * SR + 4), sizeof(float4) * (ST + 2 * SR) * HZP);
+}
 
 }  // namespace lossk
 }  // namespace surfel
