@@ -24,7 +24,7 @@ constexpr int SR11 = 5;      // the reference's window_size = 11 (loss_utils.py:
 constexpr size_t cmax(size_t a, size_t b) { return a > b ? a : b; }
 
 // grid = [n_ssim SSIM workgroups, padded to a multiple of 8 so that the post-processing part keeps its XCD mapping | n_post workgroups]
-__global__ __launch_bounds__(256, 5) void train_loss_fwd_kernel(int n_ssim, int n_ssim_pad, int n_post, int H, int W, const float* __restrict__ img,
+__global__ __launch_bounds__(256) void train_loss_fwd_kernel(int n_ssim, int n_ssim_pad, int n_post, int H, int W, const float* __restrict__ img,
                                                              const float* __restrict__ gt, float* __restrict__ dmaps, size_t map_stride,
                                                              float* __restrict__ partials, lossk::SsimWin win, const float* __restrict__ allmap,
                                                              const float* __restrict__ cam, float ratio, float* __restrict__ maps,

@@ -110,6 +110,10 @@ __device__ __forceinline__ void ssim_fwd_body(char* smem, int vblock, int vgrid,
     const bool has2 = tid < 2 * SR * 16;
     float a1[4], b1[4], aa1[4], bb1[4], ab1[4], a2[2], b2[2], aa2[2], bb2[2], ab2[2];
     hz_moments5<SR, 4>(&sxy[r1 * XP + c1], win, a1, b1, aa1, bb1, ab1);
+    // The first item's results are pinned here: left alone, the compiler sinks its ~250 multiply-adds below the second item (towards
+    // the stores behind the barrier) and keeps BOTH items' inputs live — 25 registers and the fifth workgroup per CU.
+#pragma unroll
+    for (int j = 0; j < 4; j++) asm volatile("" : "+v"(a1[j]), "+v"(b1[j]), "+v"(aa1[j]), "+v"(bb1[j]), "+v"(ab1[j]));
     if (has2) hz_moments5<SR, 2>(&sxy[r2 * XP + c2], win, a2, b2, aa2, bb2, ab2);
     const int c = tid & 31, g = tid >> 5;      // vertical pass: thread -> column c, output rows 4g .. 4g+3
     float l1 = 0.f;                            // ... whose own pixels' L1 term is taken now: the staged tile is about to be overwritten
@@ -136,6 +140,10 @@ __device__ __forceinline__ void ssim_fwd_body(char* smem, int vblock, int vgrid,
           e12[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int e = 0; e < NE; e++) {
+        if (e == NE / 2) {      // the second half's 35 LDS values are requested behind the first half's arithmetic (all 70 in flight: spills at 96 registers)
+#pragma unroll
+            for (int j = 0; j < 4; j++) asm volatile("" : "+v"(mu1[j]), "+v"(mu2[j]), "+v"(e11[j]), "+v"(e22[j]), "+v"(e12[j]) :: "memory");
+        }
         const float4 h = hz4[(4 * g + e) * HZP + c];
         const float h1 = hz1[(4 * g + e) * ST + c];
 #pragma unroll
@@ -253,6 +261,8 @@ __device__ __forceinline__ void ssim_bwd_body(char* smem, int vblock, int vgrid,
     const bool has2 = tid < 2 * SR * 16;
     float a1[4], b1[4], d1[4], a2[2], b2[2], d2[2];
     hz_moments3<SR, 4>(&s12[r1 * XP + c1], &s3[r1 * XP + c1], win, a1, b1, d1);
+#pragma unroll
+    for (int j = 0; j < 4; j++) asm volatile("" : "+v"(a1[j]), "+v"(b1[j]), "+v"(d1[j]));      // (pinned: see ssim_fwd_body)
     if (has2) hz_moments3<SR, 2>(&s12[r2 * XP + c2], &s3[r2 * XP + c2], win, a2, b2, d2);
     __syncthreads();                           // the staged maps are dead: the horizontal pass goes over them
 #pragma unroll
@@ -267,6 +277,10 @@ __device__ __forceinline__ void ssim_bwd_body(char* smem, int vblock, int vgrid,
     float a[4] = {0.f, 0.f, 0.f, 0.f}, b[4] = {0.f, 0.f, 0.f, 0.f}, d[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int e = 0; e < NE; e++) {
+        if (e == NE / 2) {      // (second half of the LDS reads behind the first half's arithmetic: ssim_fwd_body)
+#pragma unroll
+            for (int j = 0; j < 4; j++) asm volatile("" : "+v"(a[j]), "+v"(b[j]), "+v"(d[j]) :: "memory");
+        }
         const float4 h = hz[(4 * g + e) * HZP + c];
 #pragma unroll
         for (int j = 0; j < 4; j++) {

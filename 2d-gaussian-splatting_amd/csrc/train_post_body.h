@@ -32,20 +32,29 @@ __device__ __forceinline__ float nan_to_num00(float x) {
 }
 __device__ __forceinline__ bool finite_f(float x) { return fabsf(x) <= FLT_MAX; }   // false for nan / inf
 
-__device__ __forceinline__ float surf_depth_at(const float* __restrict__ allmap, size_t HW, size_t o, float ratio) {
-    const float a0 = allmap[o], a1 = allmap[HW + o], a5 = allmap[5 * HW + o];
+// One rounding per operation as written in this file's per-pixel arithmetic (#pragma clang fp contract(off) in every function): the
+// expressions are full of "a * b + c * d" (cross products, ray directions, blends), which -ffp-contract=fast contracts one way or the
+// other depending on the code around them — and the fused and the plain launches, two inlinings of these bodies, must give the same
+// bits.  It is also what the reference's tensor ops do (utils/point_utils.py:6-36: separate multiplies, adds, torch.cross).
+__device__ __forceinline__ float surf_depth_of(float a0, float a1, float a5, float ratio) {
+#pragma clang fp contract(off)
     const float expd = nan_to_num00(a0 / a1);
     const float med = nan_to_num00(a5);
     return expd * (1.f - ratio) + ratio * med;
 }
+__device__ __forceinline__ float surf_depth_at(const float* __restrict__ allmap, size_t HW, size_t o, float ratio) {
+    return surf_depth_of(allmap[o], allmap[HW + o], allmap[5 * HW + o], ratio);
+}
 
 __device__ __forceinline__ void ray_dir(const Cam& c, int x, int y, float* d) {
+#pragma clang fp contract(off)
     const float fx = (float)x, fy = (float)y;
 #pragma unroll
     for (int j = 0; j < 3; j++) d[j] = fx * c.K[j] + fy * c.K[3 + j] + c.K[6 + j];
 }
 
 __device__ __forceinline__ void cross3(const float* a, const float* b, float* r) {
+#pragma clang fp contract(off)
     r[0] = a[1] * b[2] - a[2] * b[1];
     r[1] = a[2] * b[0] - a[0] * b[2];
     r[2] = a[0] * b[1] - a[1] * b[0];
@@ -60,6 +69,7 @@ __device__ __forceinline__ float wave_sum(float v) {
 // maps: 0 alpha | 1-3 rend_normal | 4 dist | 5 surf_depth | 6-8 surf_normal
 __device__ __forceinline__ void post_fwd_body(char* smem, int vblock, int vgrid, int H, int W, const float* __restrict__ allmap, const float* __restrict__ cam,
                                                        float ratio, float* __restrict__ maps, float* __restrict__ partials) {
+#pragma clang fp contract(off)
     constexpr int HB = PT + 2;   // 18
     float* const px = reinterpret_cast<float*>(smem);      // LDS carve-up (post_fwd_lds() bytes): px | py | pz | red
     float* const py = px + HB * HB;
@@ -73,27 +83,33 @@ __device__ __forceinline__ void post_fwd_body(char* smem, int vblock, int vgrid,
     const int tile = xcd_tile(vblock, vgrid);
     const int x0 = (tile % gxt) * PT, y0 = (tile / gxt) * PT;
     const size_t HW = (size_t)H * W;
+    // The thread's own pixel first: its six values are requested in front of the staging loop, so that the workgroup pays ONE global
+    // round trip instead of two (a workgroup is all latency: scripts/loss_trace.hip, 2.9 us for 256 pixels).
+    const int lx = tid & 15, ly = tid >> 4;
+    const int gx = x0 + lx, gy = y0 + ly;
+    const bool inside = gx < W && gy < H;
+    const size_t o = inside ? (size_t)gy * W + gx : 0;
+    float a0 = 0.f, alpha = 0.f, a5 = 0.f, dist = 0.f, nv[3] = {0.f, 0.f, 0.f};
+    if (inside) {
+        a0 = allmap[o]; alpha = allmap[HW + o]; a5 = allmap[5 * HW + o]; dist = allmap[6 * HW + o];
+        nv[0] = allmap[2 * HW + o]; nv[1] = allmap[3 * HW + o]; nv[2] = allmap[4 * HW + o];
+    }
     for (int i = tid; i < HB * HB; i += 256) {
         const int r = i / HB, cc = i - r * HB;
-        const int gy = y0 + r - 1, gx = x0 + cc - 1;
+        const int qy = y0 + r - 1, qx = x0 + cc - 1;
         float p[3] = {0.f, 0.f, 0.f};
-        if (gy >= 0 && gy < H && gx >= 0 && gx < W) {
-            const float sd = surf_depth_at(allmap, HW, (size_t)gy * W + gx, ratio);
+        if (qy >= 0 && qy < H && qx >= 0 && qx < W) {
+            const float sd = surf_depth_at(allmap, HW, (size_t)qy * W + qx, ratio);
             float d[3];
-            ray_dir(c, gx, gy, d);
+            ray_dir(c, qx, qy, d);
 #pragma unroll
             for (int j = 0; j < 3; j++) p[j] = sd * d[j] + c.o[j];
         }
         px[i] = p[0]; py[i] = p[1]; pz[i] = p[2];
     }
     __syncthreads();
-    const int lx = tid & 15, ly = tid >> 4;
-    const int gx = x0 + lx, gy = y0 + ly;
     float e_n = 0.f, e_d = 0.f;
-    if (gx < W && gy < H) {
-        const size_t o = (size_t)gy * W + gx;
-        const float alpha = allmap[HW + o];
-        const float nv[3] = {allmap[2 * HW + o], allmap[3 * HW + o], allmap[4 * HW + o]};
+    if (inside) {
         float rn[3];
 #pragma unroll
         for (int j = 0; j < 3; j++) rn[j] = c.A[3 * j] * nv[0] + c.A[3 * j + 1] * nv[1] + c.A[3 * j + 2] * nv[2];
@@ -109,8 +125,7 @@ __device__ __forceinline__ void post_fwd_body(char* smem, int vblock, int vgrid,
 #pragma unroll
             for (int j = 0; j < 3; j++) sn[j] = v[j] * inv * alpha;
         }
-        const float dist = allmap[6 * HW + o];
-        const float sd = surf_depth_at(allmap, HW, o, ratio);      // recomputed: recovering it from the staged point would lose bits
+        const float sd = surf_depth_of(a0, alpha, a5, ratio);      // recomputed: recovering it from the staged point would lose bits
         if (maps) {      // NULL: only the regulariser sums are wanted (the training loss: 36 B/pixel of stores saved)
             maps[o] = alpha;
             maps[HW + o] = rn[0]; maps[2 * HW + o] = rn[1]; maps[3 * HW + o] = rn[2];
@@ -137,8 +152,10 @@ __device__ __forceinline__ void post_fwd_body(char* smem, int vblock, int vgrid,
 __device__ __forceinline__ void post_bwd_body(char* smem, int vblock, int vgrid, int H, int W, const float* __restrict__ allmap, const float* __restrict__ cam,
                                                        float ratio, const float* __restrict__ gmaps, float c_normal, float c_dist,
                                                        const float* __restrict__ gscale_dev, float* __restrict__ gall) {
+#pragma clang fp contract(off)
     constexpr int HP = PT + 4;   // 20: points, 2-pixel halo
     constexpr int HD = PT + 2;   // 18: per-pixel normal gradients, 1-pixel halo
+    constexpr int ND = (HD * HD + 255) / 256;      // normal-gradient items per thread (2)
     // LDS carve-up (post_bwd_lds() bytes): px | py | pz | dd: d(loss)/d(dx vector) [0..2], d(loss)/d(dy vector) [3..5] of the pixel's
     // normal | sn_s: the pixel's surf_normal (unit normal * alpha) for the fused regulariser
     float* const px = reinterpret_cast<float*>(smem);
@@ -154,26 +171,51 @@ __device__ __forceinline__ void post_bwd_body(char* smem, int vblock, int vgrid,
     const size_t HW = (size_t)H * W;
     const float gs = gscale_dev ? gscale_dev[0] : 1.f;
     const float cn = c_normal * gs, cd = c_dist * gs;
+    // Everything the later phases read from global memory is requested HERE, in front of the staging loop: the workgroup then pays one
+    // global round trip instead of three dependent ones (staging -> barrier -> normals' alpha / rendered normal -> barrier -> the own
+    // pixel's depth channels; scripts/loss_trace.hip: 4.7 us per workgroup, all of it latency).
+    const int lx = tid & 15, ly = tid >> 4;
+    const int gx = x0 + lx, gy = y0 + ly;
+    const bool inside = gx < W && gy < H;
+    const size_t o = inside ? (size_t)gy * W + gx : 0;
+    float a0 = 0.f, a1 = 0.f, a5 = 0.f;
+    if (inside) { a0 = allmap[o]; a1 = allmap[HW + o]; a5 = allmap[5 * HW + o]; }
+    float alpha_d[ND], nv_d[ND][3];
+#pragma unroll
+    for (int k = 0; k < ND; k++) {
+        const int i = tid + 256 * k;
+        const int r = i / HD, cc = i - r * HD;
+        const int qy = y0 + r - 1, qx = x0 + cc - 1;
+        alpha_d[k] = 0.f; nv_d[k][0] = 0.f; nv_d[k][1] = 0.f; nv_d[k][2] = 0.f;
+        if (i < HD * HD && qx >= 1 && qx <= W - 2 && qy >= 1 && qy <= H - 2) {
+            const size_t q = (size_t)qy * W + qx;
+            alpha_d[k] = allmap[HW + q];
+            if (cn != 0.f) { nv_d[k][0] = allmap[2 * HW + q]; nv_d[k][1] = allmap[3 * HW + q]; nv_d[k][2] = allmap[4 * HW + q]; }
+        }
+    }
     for (int i = tid; i < HP * HP; i += 256) {
         const int r = i / HP, cc = i - r * HP;
-        const int gy = y0 + r - 2, gx = x0 + cc - 2;
+        const int qy = y0 + r - 2, qx = x0 + cc - 2;
         float p[3] = {0.f, 0.f, 0.f};
-        if (gy >= 0 && gy < H && gx >= 0 && gx < W) {
-            const float sd = surf_depth_at(allmap, HW, (size_t)gy * W + gx, ratio);
+        if (qy >= 0 && qy < H && qx >= 0 && qx < W) {
+            const float sd = surf_depth_at(allmap, HW, (size_t)qy * W + qx, ratio);
             float d[3];
-            ray_dir(c, gx, gy, d);
+            ray_dir(c, qx, qy, d);
 #pragma unroll
             for (int j = 0; j < 3; j++) p[j] = sd * d[j] + c.o[j];
         }
         px[i] = p[0]; py[i] = p[1]; pz[i] = p[2];
     }
     __syncthreads();
-    for (int i = tid; i < HD * HD; i += 256) {
+#pragma unroll
+    for (int k = 0; k < ND; k++) {
+        const int i = tid + 256 * k;
+        if (i >= HD * HD) break;
         const int r = i / HD, cc = i - r * HD;
-        const int gy = y0 + r - 1, gx = x0 + cc - 1;
+        const int qy = y0 + r - 1, qx = x0 + cc - 1;
         float ddx[3] = {0.f, 0.f, 0.f}, ddy[3] = {0.f, 0.f, 0.f}, sn[3] = {0.f, 0.f, 0.f};
-        if (gx >= 1 && gx <= W - 2 && gy >= 1 && gy <= H - 2) {       // interior pixel: has a finite-difference normal
-            const size_t o = (size_t)gy * W + gx;
+        if (qx >= 1 && qx <= W - 2 && qy >= 1 && qy <= H - 2) {       // interior pixel: has a finite-difference normal
+            const size_t og = (size_t)qy * W + qx;
             const int q = (r + 1) * HP + cc + 1;
             const float dxv[3] = {px[q + HP] - px[q - HP], py[q + HP] - py[q - HP], pz[q + HP] - pz[q - HP]};
             const float dyv[3] = {px[q + 1] - px[q - 1], py[q + 1] - py[q - 1], pz[q + 1] - pz[q - 1]};
@@ -182,12 +224,12 @@ __device__ __forceinline__ void post_bwd_body(char* smem, int vblock, int vgrid,
             const float len = sqrtf(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
             const float inv = 1.f / fmaxf(len, 1e-12f);
             const float u[3] = {v[0] * inv, v[1] * inv, v[2] * inv};
-            const float alpha = allmap[HW + o];
+            const float alpha = alpha_d[k];
             // upstream gradient w.r.t. surf_normal = u * alpha(detached)
             float g[3] = {0.f, 0.f, 0.f};
-            if (gmaps) { g[0] = gmaps[6 * HW + o]; g[1] = gmaps[7 * HW + o]; g[2] = gmaps[8 * HW + o]; }
+            if (gmaps) { g[0] = gmaps[6 * HW + og]; g[1] = gmaps[7 * HW + og]; g[2] = gmaps[8 * HW + og]; }
             if (cn != 0.f) {     // d/dsn of cn * (1 - rn . sn) = -cn * rn
-                const float nv[3] = {allmap[2 * HW + o], allmap[3 * HW + o], allmap[4 * HW + o]};
+                const float nv[3] = {nv_d[k][0], nv_d[k][1], nv_d[k][2]};
 #pragma unroll
                 for (int j = 0; j < 3; j++) g[j] -= cn * (c.A[3 * j] * nv[0] + c.A[3 * j + 1] * nv[1] + c.A[3 * j + 2] * nv[2]);
             }
@@ -210,10 +252,7 @@ __device__ __forceinline__ void post_bwd_body(char* smem, int vblock, int vgrid,
         for (int j = 0; j < 3; j++) { dd[j][i] = ddx[j]; dd[3 + j][i] = ddy[j]; sn_s[j][i] = sn[j]; }
     }
     __syncthreads();
-    const int lx = tid & 15, ly = tid >> 4;
-    const int gx = x0 + lx, gy = y0 + ly;
-    if (gx >= W || gy >= H) return;
-    const size_t o = (size_t)gy * W + gx;
+    if (!inside) return;
     const int q = (ly + 1) * HD + lx + 1;
     // points[y+1,x] receives +ddx of pixel (y,x) -> this pixel gathers +ddx from the row above, -ddx from the row below,
     // +ddy from the column to the left, -ddy from the column to the right (zeros where that pixel has no normal).
@@ -235,7 +274,6 @@ __device__ __forceinline__ void post_bwd_body(char* smem, int vblock, int vgrid,
 #pragma unroll
         for (int j = 0; j < 3; j++) g_rn[j] -= cn * sn_s[j][q];
     }
-    const float a0 = allmap[o], a1 = allmap[HW + o], a5 = allmap[5 * HW + o];
     const float e = a0 / a1;
     float ga0 = 0.f, ga1 = g_alpha, ga5 = 0.f;
     if (finite_f(e) && a1 != 0.f) {

@@ -22,7 +22,7 @@
 
 using namespace surfel;
 #ifndef MINW_F
-#define MINW_F 5      // __launch_bounds__(256, n) of the forward kernel — the register budget of n waves per SIMD (the product's: train_fused.hip)
+#define MINW_F 1      // -DMINW_F=n / -DMINW_B=n: __launch_bounds__(256, n) — the register budget of n waves per SIMD (the product: no bound)
 #endif
 #ifndef MINW_B
 #define MINW_B 1
