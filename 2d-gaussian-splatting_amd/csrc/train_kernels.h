@@ -34,6 +34,10 @@ void launch_activate(int P, const float* theta, float* act, hipStream_t s);
 void launch_adam(int P, float* theta, const float* grad, float* m, float* v, float* act, const float* lr, float beta1, float beta2, float eps,
                  float bc1, float bc2_sqrt, float grad_scale, int D, int N, const float* campos_all, const float* gcol_all, int parts,
                  hipStream_t s);
+// densify_stats + adam (SH block rebuilt from the colour gradients + geometry sections) as one launch; g2d == NULL: no statistics
+void launch_train_update(int P, float* theta, const float* grad, float* m, float* v, float* act, const float* lr, float beta1, float beta2,
+                         float eps, float bc1, float bc2_sqrt, float grad_scale, int D, int N, const float* campos_all, const float* gcol_all,
+                         const float* g2d, const int* radii, float* accum, float* denom, float* maxr, hipStream_t s);
 void launch_sh_grad_gather(int P, int D, int N, const float* means3D, const float* campos_all, const float* gcol_all, float* dL_dsh,
                            hipStream_t s);
 void launch_densify_stats(int P, const float* g2d, const int* radii, float* accum, float* denom, float* maxr, hipStream_t s);

@@ -49,10 +49,8 @@ __global__ __launch_bounds__(256) void adam_elem_kernel(size_t n_xyz, size_t n_a
 }
 
 // per-surfel sections behind activation functions; also refreshes the activated values
-__global__ __launch_bounds__(256) void adam_act_kernel(int P, float* __restrict__ theta, const float* __restrict__ grad, float* __restrict__ m,
-                                                       float* __restrict__ v, float* __restrict__ act, AdamK k) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= P) return;
+__device__ __forceinline__ void adam_act_surfel(int i, int P, float* __restrict__ theta, const float* __restrict__ grad, float* __restrict__ m,
+                                                float* __restrict__ v, float* __restrict__ act, const AdamK& k) {
     const size_t o_op = (size_t)3 * P, o_sc = (size_t)4 * P, o_rot = (size_t)6 * P;
 #pragma unroll
     for (int j = 0; j < 3; j++) {   // xyz (no activation): here rather than in a launch of its own
@@ -110,6 +108,13 @@ __global__ __launch_bounds__(256) void adam_act_kernel(int P, float* __restrict_
     }
 }
 
+__global__ __launch_bounds__(256) void adam_act_kernel(int P, float* __restrict__ theta, const float* __restrict__ grad, float* __restrict__ m,
+                                                       float* __restrict__ v, float* __restrict__ act, AdamK k) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P) return;
+    adam_act_surfel(i, P, theta, grad, m, v, act, k);
+}
+
 __global__ __launch_bounds__(256) void activate_kernel(int P, const float* __restrict__ theta, float* __restrict__ act) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= P) return;
@@ -126,16 +131,20 @@ __global__ __launch_bounds__(256) void activate_kernel(int P, const float* __res
     for (int j = 0; j < 4; j++) act[(size_t)3 * P + 4 * (size_t)i + j] = q[j] * inv;
 }
 
-__global__ __launch_bounds__(256) void densify_stats_kernel(int P, const float* __restrict__ g2d, const int* __restrict__ radii,
-                                                            float* __restrict__ accum, float* __restrict__ denom, float* __restrict__ maxr) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= P) return;
+__device__ __forceinline__ void densify_surfel(int i, const float* __restrict__ g2d, const int* __restrict__ radii, float* __restrict__ accum,
+                                               float* __restrict__ denom, float* __restrict__ maxr) {
     const int r = radii[i];
     if (r <= 0) return;
     const float gx = g2d[3 * (size_t)i], gy = g2d[3 * (size_t)i + 1], gz = g2d[3 * (size_t)i + 2];
     accum[i] += sqrtf(gx * gx + gy * gy + gz * gz);
     denom[i] += 1.f;
     maxr[i] = fmaxf(maxr[i], (float)r);
+}
+__global__ __launch_bounds__(256) void densify_stats_kernel(int P, const float* __restrict__ g2d, const int* __restrict__ radii,
+                                                            float* __restrict__ accum, float* __restrict__ denom, float* __restrict__ maxr) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P) return;
+    densify_surfel(i, g2d, radii, accum, denom, maxr);
 }
 
 // View-parallel training: dL/dSH of the summed loss is  sum_r basis(dir(mean, campos_r)) (x) g_r  with g_r = rank r's
@@ -228,7 +237,60 @@ __global__ __launch_bounds__(256) void adam_sh_kernel(int P, int D, int N, float
     }
 }
 
+// The whole update of an iteration in which nothing is rebuilt, as ONE launch (three before: densify_stats_kernel, adam_sh_kernel,
+// adam_act_kernel — two dependent launch boundaries of ~2.5 us each and a 5-us kernel that is all latency).  One workgroup = 64
+// surfels.  Before the barrier wave 0 rebuilds their SH gradients (reading the positions the forward saw), wave 1 adds their
+// densification statistics; behind it all waves run Adam over the 64 x 48 SH floats and the last wave the per-surfel sections (xyz moves
+// HERE: nobody else reads these 64 positions).  Same device functions as the three kernels: same bits
+// (tests/test_gpu_train.py::test_fused_update_equals_the_three_launches).
+__global__ __launch_bounds__(256) void train_update_kernel(int P, int D, int N, float* __restrict__ theta, const float* __restrict__ grad,
+                                                           float* __restrict__ m, float* __restrict__ v, float* __restrict__ act,
+                                                           const float* __restrict__ campos_all, const float* __restrict__ gcol_all,
+                                                           const float* __restrict__ g2d, const int* __restrict__ radii, float* __restrict__ accum,
+                                                           float* __restrict__ denom, float* __restrict__ maxr, AdamK k) {
+    __shared__ float s_g[64 * 49];
+    const int tid = threadIdx.x;
+    const int i0 = blockIdx.x * 64;
+    if (tid < 64) {
+        const int i = i0 + tid;
+        if (i < P) {
+            float acc[48];
+            sh_grad_rebuild(i, P, D, N, theta[3 * (size_t)i], theta[3 * (size_t)i + 1], theta[3 * (size_t)i + 2], campos_all, gcol_all, acc);
+#pragma unroll
+            for (int q = 0; q < 48; q++) s_g[tid * 49 + q] = acc[q] * k.grad_scale;
+        }
+    } else if (tid < 128 && g2d) {
+        const int i = i0 + tid - 64;
+        if (i < P) densify_surfel(i, g2d, radii, accum, denom, maxr);
+    }
+    __syncthreads();
+    {   // (the loop of adam_sh_kernel, statement for statement: the compiler's contraction of adam_update depends on the loop around it)
+        const int n = min(64, P - i0) * 48;
+        const size_t o = (size_t)10 * P + (size_t)48 * i0;
+        for (int e = tid; e < n; e += 256) {
+            const int sfl = e / 48, flat = e - sfl * 48;
+            float mi = m[o + e], vi = v[o + e];
+            theta[o + e] = adam_update(theta[o + e], s_g[sfl * 49 + flat], mi, vi, flat < 3 ? k.lr[1] : k.lr[2], k);
+            m[o + e] = mi; v[o + e] = vi;
+        }
+    }
+    if (tid >= 192) {      // the last wave: the per-surfel sections (its SH elements are the fewest: 48 x 64 = 12 x 256)
+        const int i = i0 + tid - 192;
+        if (i < P) adam_act_surfel(i, P, theta, grad, m, v, act, k);
+    }
+}
+
 }  // namespace
+
+void launch_train_update(int P, float* theta, const float* grad, float* m, float* v, float* act, const float* lr, float beta1, float beta2,
+                         float eps, float bc1, float bc2_sqrt, float grad_scale, int D, int N, const float* campos_all, const float* gcol_all,
+                         const float* g2d, const int* radii, float* accum, float* denom, float* maxr, hipStream_t s) {
+    AdamK k;
+    for (int i = 0; i < 6; i++) k.lr[i] = lr[i];
+    k.beta1 = beta1; k.beta2 = beta2; k.eps = eps; k.bc1 = bc1; k.bc2_sqrt = bc2_sqrt; k.grad_scale = grad_scale;
+    hipLaunchKernelGGL(train_update_kernel, dim3((P + 63) / 64), dim3(256), 0, s, P, D, N, theta, grad, m, v, act, campos_all, gcol_all, g2d, radii, accum,
+                       denom, maxr, k);
+}
 
 void launch_sh_grad_gather(int P, int D, int N, const float* means3D, const float* campos_all, const float* gcol_all, float* dL_dsh,
                            hipStream_t s) {

@@ -324,6 +324,25 @@ class GaussianModel:
         if rc < 0:
             raise RuntimeError("surfel_adam_step failed: %s" % _n.last_error())
 
+    def update_step(self, colour_grads, stats=None, grad_scale=1.0):
+        """add_densification_stats + optimizer_step(parts=3) as ONE launch (surfel_train_update) for the iterations in which nothing is
+        rebuilt between the two; same bits.  colour_grads as in optimizer_step (required: the SH block is rebuilt in the kernel);
+        stats = (dL/dmeans2D [P,3], radii [P] int32) or None."""
+        self.step_count += 1
+        lr = (C.c_float * 6)(*self.lr)
+        cam, gc = colour_grads[0].contiguous().float(), colour_grads[1].contiguous().float()
+        g = r = None
+        if stats is not None:
+            g, r = stats[0].contiguous().float(), stats[1].contiguous().to(torch.int32)
+        with torch.cuda.device(self.device):
+            rc = _n.load().surfel_train_update(self.P, _n.ptr(self.theta), _n.ptr(self.grad), _n.ptr(self.m), _n.ptr(self.v), _n.ptr(self.act),
+                                               lr, self.betas[0], self.betas[1], self.eps, self.step_count, float(grad_scale),
+                                               int(self.active_sh_degree), int(gc.shape[0]), _n.ptr(cam), _n.ptr(gc), _n.ptr(g), _n.ptr(r),
+                                               _n.ptr(self.xyz_gradient_accum), _n.ptr(self.denom), _n.ptr(self.max_radii2D),
+                                               _n.current_stream_ptr(self.device))
+        if rc < 0:
+            raise RuntimeError("surfel_train_update failed: %s" % _n.last_error())
+
     def exchange_gradients(self, campos_all, group=None):
         """View-parallel step: make self.grad the SUM over ranks of the per-view gradients with
           * ONE all-reduce of the contiguous geometry prefix (xyz, opacity, scaling, rotation: 40 B/surfel) and

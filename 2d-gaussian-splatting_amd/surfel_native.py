@@ -23,7 +23,7 @@ EXPORTS = ["surfel_abi_version", "surfel_last_error", "surfel_rasterize_forward"
            "surfel_collect_stage_ms", "surfel_set_option", "surfel_debug_sort_pairs", "surfel_debug_set_blend_stats", "surfel_debug_last_binning", "surfel_debug_capacity_evictions", "surfel_debug_image_layout", "surfel_debug_box_probe", "surfel_debug_latency_probe", "surfel_set_backward_hook", "surfel_forward_count",
            # include/surfel_train.h
            "surfel_l1_ssim_forward", "surfel_l1_ssim_backward", "surfel_l1_ssim_forward_w", "surfel_l1_ssim_backward_w", "surfel_render_post_forward", "surfel_render_post_backward", "surfel_train_loss_forward", "surfel_train_loss_backward",
-           "surfel_reduce_partials", "surfel_loss_finalize", "surfel_activate", "surfel_adam_step", "surfel_sh_grad_gather", "surfel_densify_stats"]
+           "surfel_reduce_partials", "surfel_loss_finalize", "surfel_activate", "surfel_adam_step", "surfel_train_update", "surfel_sh_grad_gather", "surfel_densify_stats"]
 
 # per-call option overrides carried in the upper bits of the `debug` argument (include/surfel_hip.h)
 OPT_NO_CULL = 1 << 8
@@ -114,6 +114,7 @@ def load():
                            ("surfel_loss_finalize", [vp, i, i, vp, i, i, f, f, f, vp, vp, vp]),
                            ("surfel_activate", [i, vp, vp, vp]),
                            ("surfel_adam_step", [i, vp, vp, vp, vp, vp, fp, f, f, f, i, f, i, i, vp, vp, i, vp]),
+                           ("surfel_train_update", [i, vp, vp, vp, vp, vp, fp, f, f, f, i, f, i, i, vp, vp, vp, vp, vp, vp, vp, vp]),
                            ("surfel_sh_grad_gather", [i, i, i, vp, vp, vp, vp, vp]),
                            ("surfel_densify_stats", [i, vp, vp, vp, vp, vp, vp])):
             fn = getattr(lib, name)

@@ -196,6 +196,7 @@ class Trainer:
         # fused SH path (default): the rasterizer's backward skips the 192 B/surfel SH gradients, the optimiser kernel rebuilds them
         # from the 12 B/surfel colour gradients.  Always on under view-parallel training (that is how the gradients are exchanged).
         self.fused_sh = self._exchange or os.environ.get("SURFEL_SH_FUSED", "1") != "0"
+        self.fused_update = os.environ.get("SURFEL_FUSED_UPDATE", "1") != "0"      # surfel_train_update (statistics + Adam in one launch)
         if model.grad is None:
             model.training_setup(self.opt)
         if self.world > 1:
@@ -354,7 +355,13 @@ class Trainer:
                 if self._async_exchange:
                     self._timed_wait(w_same)
                 self._rebalance_bands(cam)
-            if stats_live:
+            # statistics + optimiser step as ONE launch where nothing can come between them (single GPU, SH block rebuilt in the kernel,
+            # no densification / opacity reset this iteration): two launch boundaries and the statistics' latency-bound kernel fewer
+            one_launch = self.fused_update and self.fused_sh and not bands and not self._exchange and it < opt.iterations and not self._is_event_iteration(it)
+            if one_launch:
+                m.update_step((cam.camera_center[None], m.gcol[None]), stats=((g2d if manual else means2D.grad), radii) if stats_live else None)
+                rebuilt = True      # (nothing left to do below)
+            elif stats_live:
                 m.add_densification_stats(arena2d if bands else (g2d if manual else means2D.grad), radii=radii)
                 rebuilt = self._schedule_events(it, bands)
             if it < opt.iterations and not rebuilt:     # re-created parameters carry no gradient in the reference: no update

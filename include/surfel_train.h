@@ -16,6 +16,7 @@
  *                             torch.optim.Adam(eps=1e-15) over the six groups of :153-162, train.py:136-138
  *   surfel_activate           scene/gaussian_model.py:95-115 forward only (after (re)building the store)
  *   surfel_densify_stats      train.py:126-128 + scene/gaussian_model.py:405-407
+ *   surfel_train_update       the two above in one launch
  */
 #ifndef SURFEL_TRAIN_H
 #define SURFEL_TRAIN_H
@@ -149,6 +150,17 @@ int surfel_activate(int P, const float* theta, float* act, void* stream);
 int surfel_adam_step(int P, float* theta, const float* grad, float* m, float* v, float* act, const float* lr,
                      float beta1, float beta2, float eps, int t, float grad_scale,
                      int D, int N, const float* campos_all, const float* gcol_all, int parts, void* stream);
+
+/*
+ * surfel_densify_stats + surfel_adam_step(parts = 3, SH block rebuilt from the colour gradients) as ONE launch, for the iterations in
+ * which nothing is rebuilt between the two (train.py:126-138 without the densification branch): same results to the bit, two
+ * dependent launch boundaries and the statistics' all-latency kernel fewer.  dL_dmeans2D == NULL: no statistics (iterations behind
+ * densify_until_iter).  gcol_all / campos_all are required (N >= 1).
+ */
+int surfel_train_update(int P, float* theta, const float* grad, float* m, float* v, float* act, const float* lr,
+                        float beta1, float beta2, float eps, int t, float grad_scale,
+                        int D, int N, const float* campos_all, const float* gcol_all,
+                        const float* dL_dmeans2D, const int* radii, float* grad_accum, float* denom, float* max_radii, void* stream);
 
 /*
  * View-parallel training (new; the reference is single-GPU): the SH gradient of the summed loss rebuilt from every
