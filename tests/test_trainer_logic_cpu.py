@@ -26,6 +26,11 @@ class FakeModel:
     def optimizer_step(self, grad_scale=1.0, colour_grads=None, parts=3): self.log.append(("adam", grad_scale, colour_grads is not None, parts))
     def training_setup(self, opt): pass
 
+    def update_step(self, colour_grads, stats=None, grad_scale=1.0):      # statistics + Adam in one launch (surfel_train_update)
+        if stats is not None:
+            self.log.append(("stats",))
+        self.log.append(("adam", grad_scale, True, 3))
+
 
 @pytest.fixture()
 def trainer(monkeypatch):
