@@ -291,13 +291,15 @@ __global__ void __launch_bounds__(RS_THREADS) os_pass_kernel(const uint32_t* __r
 }
 
 // ---- the look-back pass for <= 2^20 items, fat tiles -------------------------------------------------------------------------
-// Same algorithm as os_pass_kernel<true>, 1024 threads x 8 items = 8192-item tiles, and the tile's items go through LDS in
+// Same algorithm as os_pass_kernel<true>, 1024-thread workgroups with 4096-item tiles (8192 until round 5), and the tile's items go through LDS in
 // tile-local sorted order before they are stored.  Measured on the thin (2048-item) pass at 0.5 M items (r03g_C2_kernel_stats):
 // 18.5 us for the 4-bit digit, 30.5 us for the 8-bit digit — the difference is the scatter: a thin tile holds 8 items per 8-bit
 // digit, stored by whichever lane ranked them (64 different lines per store instruction).  Here a digit's run in a tile is
-// 32 items = one 128-B line, written by consecutive lanes; and the look-back chain is a quarter as long.
-constexpr int FT_THREADS = 1024, FT_IPT = 8, FT_TILE = FT_THREADS * FT_IPT, FT_WAVES = FT_THREADS / 64;
-constexpr int FT_LB = 32;      // look-back window: at most 128 tiles exist, all resident and publishing at about the same moment
+// 16 items = 64 B, written by consecutive lanes; and the look-back chain is half as long.
+// (Round 5: 1024 x 4 = 4096-item tiles — 128 workgroups for an 800x800 frame's 0.5 M pairs instead of 64 — measured against 1024 x 8,
+// 1024 x 3, 1024 x 2, 768 x 4, 512 x 16, 512 x 8, 512 x 4: 36.4 us for the two passes against 39.0 / 38.2 / 42.7 / 38.3 / 41.0 / 37.5 / 45.1.)
+constexpr int FT_THREADS = 1024, FT_IPT = 4, FT_TILE = FT_THREADS * FT_IPT, FT_WAVES = FT_THREADS / 64;
+constexpr int FT_LB = 32;      // look-back window: at most 256 tiles exist, all resident and publishing at about the same moment
 static inline uint32_t ft_nblocks(size_t n) { return (uint32_t)((n + FT_TILE - 1) / FT_TILE); }
 
 __global__ void __launch_bounds__(FT_THREADS) os_pass_fat_kernel(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ vals,
