@@ -81,12 +81,14 @@ def roofline_object(per_kernel, workload, P, V, R, Rs, W, H, n_pass):
         n_inst = max([v.get("SQ_INSTS_VALU", 0.0) for k, v in pj.items() if k.startswith(dom)] or [0.0]) or None
         if n_inst:
             rate = n_inst / (per_kernel[dom] * 1e-3) / 1e9
-            # measured_ceiling: what independent v_fma_f32 streams reach on this chip with 8 waves / SIMD — 1.44 ns per
-            # wave-instruction per SIMD (scripts/ubench/valu_rate.hip, profiles/r02_valu_rate_ubench.txt) = 711 G/s over
-            # 1024 SIMDs; DPP adds / compares / selects run at 0.75x of that, v_exp / v_rcp at 0.35x
+            # measured_ceiling: what independent v_fma_f32 streams reach on this chip — 2.6 shader cycles per wave-instruction per SIMD at
+            # the 2.1 GHz such a grid sustains = 830 G/s over 1024 SIMDs (scripts/issue_probe.hip, profiles/r05_issue_probe.md: one
+            # workgroup per CU, slowest wave; rounds 2 - 4 quoted 711 from a probe with loop overhead).  The blend kernels' own mix (a
+            # quarter DPP adds at 4.3 cycles, compares / selects / min / max, transcendentals at 8.2) issues at 2.9 cycles per instruction:
+            # C2's blend_bwd sits at ~0.75 of the pure issue time of its own instructions (same file).
             valu = {"wave_insts_per_launch": int(n_inst), "achieved_Ginst_per_s": round(rate, 1), "peak_Ginst_per_s": 1228.9,
-                    "frac": round(rate / 1228.9, 4), "measured_ceiling_Ginst_per_s": 711.0,
-                    "frac_of_measured_ceiling": round(rate / 711.0, 4), "source": os.path.basename(pm)}
+                    "frac": round(rate / 1228.9, 4), "measured_ceiling_Ginst_per_s": 830.0,
+                    "frac_of_measured_ceiling": round(rate / 830.0, 4), "source": os.path.basename(pm)}
     except Exception:
         valu = None
     return {"bound": "hbm", "kernel": dom, "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -334,11 +336,12 @@ def main():
         # issue rates, shader clock, a blend-like mix kernel, a standalone 0.5 M-pair sort, HBM copy, L2 / HBM load latency, host launch
         # cost): NONE of them separates the two classes of runs that exist (C2 step 0.576 vs 0.63 ms at identical probe values,
         # profiles/r05_box_samples.txt).  What does is a latency-bound kernel timed IN the step: the tile sort (two look-back passes over
-        # the frame's pairs; unchanged since round 3) takes 39.5 us in a fast run and 49 - 53 us in a slow one, and over five runs the
-        # step moved by 0.33 x the sort's relative change.  So: normalised = step / (1 + 0.33 (tile_sort / 39.5 us - 1)), C2 only.
+        # the frame's pairs) took 39.5 us in a fast run and 49 - 53 us in a slow one, and over five runs the step moved by 0.33 x the
+        # sort's relative change.  So: normalised = step / (1 + 0.33 (tile_sort / fast - 1)), C2 only.  (fast = 36.5 us since the sort's
+        # tiles became 4096 items, late in round 5: 36.1 - 36.6 on fast-class runs.)
         if args.workload == "C2" and per_kernel.get("tile_sort"):
-            out_norm = {"tile_sort_us_in_step": round(per_kernel["tile_sort"] * 1e3, 2), "tile_sort_us_fast_run": 39.5, "step_sensitivity": 0.33}
-            out_norm["slowdown_vs_fast_run"] = round(1.0 + 0.33 * (per_kernel["tile_sort"] * 1e3 / 39.5 - 1.0), 4)
+            out_norm = {"tile_sort_us_in_step": round(per_kernel["tile_sort"] * 1e3, 2), "tile_sort_us_fast_run": 36.5, "step_sensitivity": 0.33}
+            out_norm["slowdown_vs_fast_run"] = round(1.0 + 0.33 * (per_kernel["tile_sort"] * 1e3 / 36.5 - 1.0), 4)
         else:
             out_norm = None
         if roof and roof.get("valu_issue") and probe and probe.get("valu_Ginst_per_s_in_kernel_span"):
