@@ -113,7 +113,7 @@ def main():
             merged[k].update(cs)
     for k, cs in eff_clock(os.path.join(src, "grbm")).items():
         merged[k].update(cs)
-    ours = ("rs_", "os_", "scan_", "tile_", "ssim_", "post_", "adam_", "loss_", "densify_", "activate_", "reduce_", "bin_", "train_loss_")
+    ours = ("rs_", "os_", "scan_", "tile_", "ssim_", "post_", "adam_", "loss_", "densify_", "activate_", "reduce_", "bin_", "train_loss_", "train_update_")
     merged = {k: v for k, v in merged.items() if k in STAGE_OF or k.startswith(ours) or "knn" in k}
     traffic = {}
     bwd_launches = -1
@@ -122,7 +122,7 @@ def main():
             cs["VALUUtilization_exec_lanes"] = round(cs["SQ_THREAD_CYCLES_VALU"] / (64.0 * cs["SQ_ACTIVE_INST_VALU"]), 4)
         if "FETCH_SIZE" in cs and "WRITE_SIZE" in cs:
             cs["HBM_bytes_per_launch"] = int(2 * cs["FETCH_SIZE"] * 1024 + cs["WRITE_SIZE"] * 1024)
-            if k in STAGE_OF or k.startswith(("ssim_", "post_", "adam_", "train_loss_")):
+            if k in STAGE_OF or k.startswith(("ssim_", "post_", "adam_", "train_loss_", "train_update_")):
                 st = STAGE_OF.get(k, k.replace("_kernel", ""))
                 # blend_bwd = the walk that ran most (rows | quad): the other kernel is launched for the tuner's probes and the
                 # pre-verdict calls, so its per-launch mean is a mix of full and idle launches — not a summand
