@@ -545,13 +545,17 @@ int64_t surfel_rasterize_forward(surfel_alloc_fn geom_alloc, void* geom_user, su
             if (host_total) HIP_TRY(hipEventRecord(evR, s));
             STAGE_END(tm, ST_EMIT);
             tm.begin();
-            const int wk = radix_sort_pairs_u32_devn(bin.keys_a, va, bin.keys_b, vb, (size_t)cap, end_bit, n_dev, bin.sort_temp, s);
+            // the tile ranges come out of the sort's last pass (its scatter knows every key boundary); frames of one tile have no pass
+            const bool fused_ranges = end_bit > 0;
+            const int wk = radix_sort_pairs_u32_devn(bin.keys_a, va, bin.keys_b, vb, (size_t)cap, end_bit, n_dev, bin.sort_temp, fused_ranges ? img.ranges : nullptr, s);
             STAGE_END(tm, ST_SORT);
+            if (!fused_ranges) {
+                tm.begin();
+                launch_tile_ranges_devn((size_t)cap, n_dev, wk ? bin.keys_b : bin.keys_a, img.ranges, s);
+                STAGE_END(tm, ST_RANGES);
+            }
             tm.begin();
-            launch_tile_ranges_devn((size_t)cap, n_dev, wk ? bin.keys_b : bin.keys_a, img.ranges, s);
-            STAGE_END(tm, ST_RANGES);
-            tm.begin();
-            launch_tile_depth_sort(gx * gy, ce->maxR, img.ranges, bin.point_list, geom.dkey_a, bin.vals_alt, bin.keys_a, bin.keys_b, s);
+            launch_tile_depth_sort(gx * gy, ce->maxR, img.ranges, bin.point_list, geom.dkey_a, bin.vals_alt, bin.keys_a, bin.keys_b, fused_ranges, s);
             STAGE_END(tm, ST_TSORT);
             run_tile_order(tile_ce, img.ranges, gx, gy, img.tile_map, img.total + 2 * R_SLOTS + 1, opt_tile_order, s);
             BlendFwdArgs ba{};
@@ -639,7 +643,7 @@ int64_t surfel_rasterize_forward(surfel_alloc_fn geom_alloc, void* geom_user, su
                 if (per_tile) {
                     // (4) every tile orders its run by (depth bits, surfel index); the ping-pong buffers of the tile sort are free now
                     tm.begin();
-                    launch_tile_depth_sort(gx * gy, R, img.ranges, bin.point_list, geom.dkey_a, bin.vals_alt, bin.keys_a, bin.keys_b, s);
+                    launch_tile_depth_sort(gx * gy, R, img.ranges, bin.point_list, geom.dkey_a, bin.vals_alt, bin.keys_a, bin.keys_b, false, s);
                     STAGE_END(tm, ST_TSORT);
                 }
             }

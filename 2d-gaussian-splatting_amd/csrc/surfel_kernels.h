@@ -95,8 +95,9 @@ int radix_sort_pairs_u32(uint32_t* keys_a, uint32_t* vals_a, uint32_t* keys_b, u
                          void* scratch, hipStream_t s, bool head_zeroed = false);
 size_t radix_sort_head_words(size_t n);       // words at the start of the sort scratch that must be zero (head_zeroed callers)
 size_t scan_scratch_words(size_t n);          // zeroed scratch of launch_scan_gather
-void launch_tile_depth_sort(int ntiles, int64_t R, const uint2* ranges, uint32_t* point_list, const uint32_t* depth_keys, uint32_t* tmp_ids,
-                            uint32_t* tmp_keys, uint32_t* tmp_rank, hipStream_t s);
+// decode: the ranges come from the sort's last pass (radix_sort_pairs_u32_devn) with complemented starts; the kernel turns them back
+void launch_tile_depth_sort(int ntiles, int64_t R, uint2* ranges, uint32_t* point_list, const uint32_t* depth_keys, uint32_t* tmp_ids,
+                            uint32_t* tmp_keys, uint32_t* tmp_rank, bool decode, hipStream_t s);
 void launch_scan_gather(const uint32_t* vals, const uint32_t* order, uint32_t* out, size_t n, void* zeroed_scratch, hipStream_t s);
 // capacity binning (surfel_sort.hip): scan + emission + tile-sort histograms in one launch, sort passes / ranges with the count on the device
 bool capacity_binning_ok(size_t cap, int end_bit);
@@ -105,8 +106,9 @@ size_t bin_emit_head_words();                 // words at the start of the capac
 void launch_bin_emit(int P, const uint32_t* tiles_touched, const uint32_t* rects, const uint32_t* block_totals, float* rec, uint32_t* keys, uint32_t* vals,
                      int gx, size_t cap, void* sort_scratch /* head zeroed */, int end_bit, uint32_t* n_out, uint32_t* n_host /* host-visible copy of the total, or NULL */,
                      hipStream_t s);
+// ranges != NULL (zeroed, one uint2 per key value): the last pass writes [first, last + 1) of every key, first as its complement
 int radix_sort_pairs_u32_devn(uint32_t* keys_a, uint32_t* vals_a, uint32_t* keys_b, uint32_t* vals_b, size_t cap, int end_bit, const uint32_t* n_dev,
-                              void* scratch, hipStream_t s);
+                              void* scratch, uint2* ranges, hipStream_t s);
 void launch_tile_ranges_devn(size_t cap, const uint32_t* n_dev, const uint32_t* keys, uint2* ranges, hipStream_t s);
 
 }  // namespace surfel

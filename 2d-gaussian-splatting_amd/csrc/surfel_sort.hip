@@ -306,7 +306,7 @@ __global__ void __launch_bounds__(FT_THREADS) os_pass_fat_kernel(const uint32_t*
                                                                  uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out, uint32_t n,
                                                                  int shift, uint32_t mask, const uint32_t* __restrict__ ghist,
                                                                  uint32_t* __restrict__ status, uint32_t* __restrict__ ticket,
-                                                                 const uint32_t* __restrict__ n_dev, int hstride) {
+                                                                 const uint32_t* __restrict__ n_dev, int hstride, uint2* __restrict__ ranges) {
     __shared__ uint32_t s_cnt[FT_WAVES][RS_RADIX];      // per-wave digit counts -> then per-wave tile-local offsets
     __shared__ uint2 s_item[FT_TILE];                   // (key, value) in tile-local sorted order
     __shared__ uint32_t s_gbase[RS_RADIX];              // global slot of a digit's first item of this tile, minus its tile-local slot
@@ -417,6 +417,17 @@ __global__ void __launch_bounds__(FT_THREADS) os_pass_fat_kernel(const uint32_t*
             const uint32_t dst = s_gbase[(kv.x >> shift) & mask] + q;
             keys_out[dst] = kv.x;
             vals_out[dst] = kv.y;
+            // Last pass of the capacity path (ranges != NULL; the keys are tile ids): the tile ranges come out of this scatter instead of
+            // a launch of their own.  The tile's items are in sorted order here; a neighbour with the same key has the same digit and is the
+            // global neighbour as well, so an item whose left (right) neighbour in the tile differs — or is missing — is the first (last)
+            // of its key in this tile's run.  A key's items can sit in two tiles' runs: min / max through atomics on zeroed words, the
+            // start kept as its complement (max of ~dst = min of dst); tile_depth_sort_kernel, the next launch, turns it back.
+            if (ranges) {
+                const bool first = q == 0u || s_item[q - 1].x != kv.x;
+                const bool last = q + 1u == items || s_item[q + 1].x != kv.x;
+                if (first) atomicMax(&ranges[kv.x].x, ~dst);
+                if (last) atomicMax(&ranges[kv.x].y, dst + 1u);
+            }
         }
     }
 }
@@ -564,11 +575,15 @@ __device__ __forceinline__ void tile_sort_regs(uint32_t n, uint32_t* __restrict_
 // TS_CAP = largest run sorted by the LDS network (8 B of LDS per key: 2048 -> 16 KB -> 10 workgroups / CU for frames whose tiles
 // are small; 4096 -> 32 KB otherwise).
 template <int TS_CAP>
-__global__ void __launch_bounds__(RS_THREADS) tile_depth_sort_kernel(const uint2* __restrict__ ranges, uint32_t* __restrict__ point_list,
+__global__ void __launch_bounds__(RS_THREADS) tile_depth_sort_kernel(uint2* __restrict__ ranges, uint32_t* __restrict__ point_list,
                                                                     const uint32_t* __restrict__ depth_keys, uint32_t* __restrict__ tmp_ids,
-                                                                    uint32_t* __restrict__ tmp_keys, uint32_t* __restrict__ tmp_rank) {
+                                                                    uint32_t* __restrict__ tmp_keys, uint32_t* __restrict__ tmp_rank, int decode) {
     __shared__ unsigned long long s[TS_CAP];       // 32 KB: (depth bits << 32) | surfel index
-    const uint2 rg = ranges[blockIdx.x];
+    uint2 rg = ranges[blockIdx.x];
+    if (decode && rg.y != 0u) {      // ranges left by the sort's last pass (os_pass_fat_kernel): the start is stored complemented
+        rg.x = ~rg.x;
+        if (threadIdx.x == 0) ranges[blockIdx.x].x = rg.x;
+    }
     const uint32_t n = rg.y - rg.x;
     if (n < 2u) return;
     uint32_t* __restrict__ pl = point_list + rg.x;
@@ -600,15 +615,15 @@ __global__ void __launch_bounds__(RS_THREADS) tile_depth_sort_kernel(const uint2
     for (uint32_t i = tid; i < n; i += RS_THREADS) pl[rank[i]] = ids[i];
 }
 
-void launch_tile_depth_sort(int ntiles, int64_t R, const uint2* ranges, uint32_t* point_list, const uint32_t* depth_keys, uint32_t* tmp_ids,
-                            uint32_t* tmp_keys, uint32_t* tmp_rank, hipStream_t st) {
+void launch_tile_depth_sort(int ntiles, int64_t R, uint2* ranges, uint32_t* point_list, const uint32_t* depth_keys, uint32_t* tmp_ids,
+                            uint32_t* tmp_keys, uint32_t* tmp_rank, bool decode, hipStream_t st) {
     if (ntiles <= 0) return;
     if (R <= (int64_t)256 * ntiles)
         hipLaunchKernelGGL(tile_depth_sort_kernel<2048>, dim3(ntiles), dim3(RS_THREADS), 0, st, ranges, point_list, depth_keys, tmp_ids, tmp_keys,
-                           tmp_rank);
+                           tmp_rank, decode ? 1 : 0);
     else
         hipLaunchKernelGGL(tile_depth_sort_kernel<4096>, dim3(ntiles), dim3(RS_THREADS), 0, st, ranges, point_list, depth_keys, tmp_ids, tmp_keys,
-                           tmp_rank);
+                           tmp_rank, decode ? 1 : 0);
 }
 
 // Sorts on key bits [begin_bit, end_bit).  Buffers ping-pong a -> b -> a ...; returns 0 if the result is in (keys_a, vals_a),
@@ -655,7 +670,7 @@ int radix_sort_pairs_u32(uint32_t* keys_a, uint32_t* vals_a, uint32_t* keys_b, u
         const uint32_t* kin = cur ? keys_b : keys_a; const uint32_t* vin = cur ? vals_b : vals_a;
         uint32_t* kout = cur ? keys_a : keys_b; uint32_t* vout = cur ? vals_a : vals_b;
         hipLaunchKernelGGL(os_pass_fat_kernel, dim3(ft_nblocks(n)), dim3(FT_THREADS), 0, s, kin, vin, kout, vout, (uint32_t)n, bit, mask,
-                           ghist + p * RS_RADIX, status + (size_t)p * nblocks * RS_RADIX, ticket + p, (const uint32_t*)nullptr, 1);
+                           ghist + p * RS_RADIX, status + (size_t)p * nblocks * RS_RADIX, ticket + p, (const uint32_t*)nullptr, 1, (uint2*)nullptr);
         cur ^= 1;
     }
     return cur;
@@ -739,7 +754,7 @@ __global__ void __launch_bounds__(BE_THREADS) bin_emit_kernel(int P, const uint3
 
 // tile sort of the capacity path: the look-back passes alone (histograms and state come from bin_emit_kernel); at most two passes
 int radix_sort_pairs_u32_devn(uint32_t* keys_a, uint32_t* vals_a, uint32_t* keys_b, uint32_t* vals_b, size_t cap, int end_bit, const uint32_t* n_dev,
-                              void* scratch, hipStream_t s) {
+                              void* scratch, uint2* ranges, hipStream_t s) {
     // scratch layout of the capacity path (u32 words): ghist[RS_MAX_PASSES][256] padded to BE_HSTRIDE | ticket (+pad to 64) | status
     const uint32_t nblocks = rs_nblocks(cap);
     const int passes = radix_sort_passes(cap, 0, end_bit);
@@ -754,7 +769,8 @@ int radix_sort_pairs_u32_devn(uint32_t* keys_a, uint32_t* vals_a, uint32_t* keys
         const uint32_t* kin = cur ? keys_b : keys_a; const uint32_t* vin = cur ? vals_b : vals_a;
         uint32_t* kout = cur ? keys_a : keys_b; uint32_t* vout = cur ? vals_a : vals_b;
         hipLaunchKernelGGL(os_pass_fat_kernel, dim3(ft_nblocks(cap)), dim3(FT_THREADS), 0, s, kin, vin, kout, vout, (uint32_t)cap, bit, mask,
-                           ghist + (size_t)p * RS_RADIX * BE_HSTRIDE, status + (size_t)p * nblocks * RS_RADIX, ticket + p, n_dev, BE_HSTRIDE);
+                           ghist + (size_t)p * RS_RADIX * BE_HSTRIDE, status + (size_t)p * nblocks * RS_RADIX, ticket + p, n_dev, BE_HSTRIDE,
+                           p == passes - 1 ? ranges : (uint2*)nullptr);      // (the last pass leaves the tile ranges behind, start complemented)
         cur ^= 1;
     }
     return cur;
