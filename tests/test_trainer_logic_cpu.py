@@ -30,6 +30,7 @@ class FakeModel:
         if stats is not None:
             self.log.append(("stats",))
         self.log.append(("adam", grad_scale, True, 3))
+        self.log.append(("one_launch",))
 
 
 @pytest.fixture()
@@ -95,6 +96,11 @@ def test_loop_schedules_match_reference(trainer):
         assert ("reset" in kinds) == (it < opt.densify_until_iter and it % opt.opacity_reset_interval == 0)   # train.py:134-135
         # re-created parameters carry no gradient in the reference -> no update on densification iterations, none on the last one
         assert ("adam" in kinds) == (it < opt.iterations and not densified)            # train.py:137-139
+        # statistics + update as one launch exactly where nothing can come between them: no densification, no opacity reset this iteration
+        reset = it < opt.densify_until_iter and it % opt.opacity_reset_interval == 0
+        assert ("one_launch" in kinds) == (it < opt.iterations and not densified and not reset)
+        if "one_launch" in kinds:
+            assert kinds.index("adam") > (kinds.index("stats") if "stats" in kinds else -1)
     # one view per iteration, sampled without replacement per epoch (train.py:64-67)
     views = [c[1] for _, cl in per_it for c in cl if c[0] == "raster"]
     for e in range(0, 60, 4):
