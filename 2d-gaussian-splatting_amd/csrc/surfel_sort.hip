@@ -580,9 +580,15 @@ __global__ void __launch_bounds__(RS_THREADS) tile_depth_sort_kernel(uint2* __re
                                                                     uint32_t* __restrict__ tmp_keys, uint32_t* __restrict__ tmp_rank, int decode) {
     __shared__ unsigned long long s[TS_CAP];       // 32 KB: (depth bits << 32) | surfel index
     uint2 rg = ranges[blockIdx.x];
-    if (decode && rg.y != 0u) {      // ranges left by the sort's last pass (os_pass_fat_kernel): the start is stored complemented
-        rg.x = ~rg.x;
-        if (threadIdx.x == 0) ranges[blockIdx.x].x = rg.x;
+    if (decode) {      // ranges left by the sort's last pass (os_pass_fat_kernel): the start is stored complemented
+        // every wave must HOLD the undecoded word before thread 0 overwrites it (a wave whose load landed after the store would complement
+        // the start twice): readfirstlane consumes the loaded value in front of the barrier, the barrier orders all loads before the store
+        rg.x = __builtin_amdgcn_readfirstlane(rg.x); rg.y = __builtin_amdgcn_readfirstlane(rg.y);
+        __syncthreads();
+        if (rg.y != 0u) {
+            rg.x = ~rg.x;
+            if (threadIdx.x == 0) ranges[blockIdx.x].x = rg.x;
+        }
     }
     const uint32_t n = rg.y - rg.x;
     if (n < 2u) return;

@@ -140,7 +140,7 @@ def capture_views(gt_model, cams, background, pipe=None):
 # ------------------------------------------------------------------------------------------------ the loop
 class Trainer:
     def __init__(self, model, cams, opt=None, pipe=None, white_background=False, extent=None, seed=0, sharding="views", first_iter=0,
-                 rehearse_exchange=False):
+                 rehearse_exchange=False, solo=False):
         """sharding (N > 1): "views" = every rank trains on its own view per step (default, BASELINE config 4); "bands" = all ranks
         render row bands of the SAME view (tile-band sharding, BASELINE config 5): every rank evaluates the loss on ITS band plus a
         32-row halo received from its two neighbours (surfel_losses.train_loss_band), back-propagates its own rows, and the
@@ -148,7 +148,9 @@ class Trainer:
         gradients; the camera is shared, so the SH gradients are rebuilt from the SUM of the colour gradients), no averaging.
         Band edges follow the previous frames' instances per tile row (re-balanced every `rebalance_every` iterations).
         rehearse_exchange: take the view-parallel step (schedule, collectives, split optimiser) even with a single rank — the
-        N > 1 code path run against the real backend on one GPU (tests/test_gpu_train.py, scripts/rccl_selfcheck.py)."""
+        N > 1 code path run against the real backend on one GPU (tests/test_gpu_train.py, scripts/rccl_selfcheck.py).
+        solo: ignore an initialised process group — this rank trains alone (bench.py: every rank prepares the same trained state by
+        itself, deterministically, before the timed view-parallel Trainer synchronises the replicas)."""
         if sharding not in ("views", "bands"):
             raise ValueError("sharding must be 'views' or 'bands'")
         self.sharding = sharding
@@ -158,7 +160,7 @@ class Trainer:
         self.white_background = white_background
         self.background = torch.tensor([1.0, 1.0, 1.0] if white_background else [0.0, 0.0, 0.0], dtype=torch.float32, device=model.device)
         self.extent = extent if extent is not None else cameras_extent(cams)
-        self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+        self.world = dist.get_world_size() if (not solo and dist.is_available() and dist.is_initialized()) else 1
         self.rank = dist.get_rank() if self.world > 1 else 0
         self.seed = seed
         self._rng = random.Random(seed)

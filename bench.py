@@ -171,10 +171,11 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--workload", default="C2", help="synthetic config name (synthetic.CONFIGS; C2 = BASELINE configs[1] shape, the headline), or a "
-                                                     "trained state: 'trained' (54 k surfels, 800x800) / 'garden' (>= 1 M surfels, 1600x1060: BASELINE configs[3]'s per-GPU shape)")
+    ap.add_argument("--workload", default="garden", help="'garden' (default, the headline: a TRAINED state of >= 2 M surfels at 1600x1060 = north_star's 1-GPU target shape, "
+                                                         "BASELINE configs[3]) / 'trained' (54 k surfels, 800x800), or a synthetic config name (synthetic.CONFIGS: C2 = BASELINE "
+                                                         "configs[1] shape, C4, C5, C2H)")
     ap.add_argument("--state", default=None, help="trained workloads: .ply cache of the trained model (loaded if present, written otherwise)")
-    ap.add_argument("--legs", default="C4,C2H,trained,garden", help="comma-separated side legs at N = 1 (any of C4, C2H, C3, trained, garden)")
+    ap.add_argument("--legs", default="C2,C4,C2H,trained,C5", help="comma-separated side legs at N = 1 (any of C2, C4, C2H, C3, C5, trained, garden)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-1080p", action="store_true")
     ap.add_argument("--no-raster-only", action="store_true")
@@ -227,7 +228,7 @@ def main():
         else:
             dist.init_process_group(backend)
 
-    from helpers_bench import TRAINED_PRESETS, make_trainer, trained_trainer
+    from helpers_bench import TRAINED_PRESETS, make_trainer, reseed_views, snapshot_for_cpu, trained_trainer, window_census
     n_views = max(8, world)
     trained_info = None
     if args.workload in TRAINED_PRESETS:
@@ -261,10 +262,10 @@ def main():
     for _ in range(args.warmup):
         tr.step()
     fence()
-    if world == 1 and hasattr(tr, "_rng") and hasattr(tr, "_stack"):
+    if world == 1:
         # the timed window sees the SAME views in every run of this command (the views of a capture differ 2-3x in instance count): the
-        # rocprofv3 passes of scripts/profile_gpu.sh and the bench legs then time and count the same frames
-        tr._rng.seed(20260922); tr._stack = []
+        # rocprofv3 passes of scripts/profile_gpu.sh, the census pass below and the bench legs then time and count the same frames
+        reseed_views(tr)
     loss_first = float(tr.last["loss"])
     surfel_native.collect_stage_times()     # drop warm-up events
     tr.exchange_events = []
@@ -303,25 +304,20 @@ def main():
         except Exception as e:      # noqa: BLE001
             coll_us = {"error": repr(e)}
     loss_last = float(tr.last["loss"])
-    # per-stage breakdown of the rasterizer: a second, untimed pass with every stage bracketed by events
-    # (bracketing all ~9 stages costs ~10 us each, which would perturb the timed region by ~9 % at this size)
-    tr.pipe.debug = 2
-    for _ in range(max(5, args.steps // 2)):
-        tr.step()
+    # per-stage breakdown of the rasterizer + the window's instance counts: a second, untimed pass over the SAME frames (same view order)
+    # with every stage bracketed by events (bracketing all ~9 stages costs ~10 us each: not inside the timed region) and R / Rs / V read
+    # back per frame -> the roofline's bytes and the kernel times belong to the same frames
+    stages, census = window_census(tr, args.steps, W, H)
     fence()
-    stages = surfel_native.collect_stage_times()
-    stages.update(dom_stage)
-    tr.pipe.debug = 0
+    stages.update(dom_stage)      # the dominant kernel's duration: the one measured inside the timed window
+    cpu_snapshot = snapshot_for_cpu(tr) if (rank == 0 and world == 1 and trained_info and not args.no_cpu_baseline) else None
     if world > 1:
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
-    # ---- workload statistics for the roofline (P, V, R, n_pass)
-    V = int((tr.last["radii"] > 0).sum().item())
-    import diff_surfel_rasterization
-    R = int(diff_surfel_rasterization.last_num_rendered)
-    Rs = diff_surfel_rasterization.staged_instances(W, H)
+    # ---- workload statistics for the roofline (P, V, R, n_pass): means over the window's frames
+    V, R, Rs = census["V"], census["R"], census["Rs"]
     tiles = ((W + 15) // 16) * ((H + 15) // 16)
     n_pass = -(-(32 + max(1, (tiles - 1).bit_length())) // 8)
 
@@ -332,18 +328,8 @@ def main():
         iters_per_s = (1 if bands else world) * args.steps / dt
         per_kernel = {k: v[0] / v[1] for k, v in stages.items()}
         roof = roofline_object(per_kernel, args.workload, P, V, R, Rs, W, H, n_pass)
-        # Normalisation of the step to a "fast run" of the pool.  Round 5 sampled the pool with every probe of box_probe (FMA / add / pk_fma
-        # issue rates, shader clock, a blend-like mix kernel, a standalone 0.5 M-pair sort, HBM copy, L2 / HBM load latency, host launch
-        # cost): NONE of them separates the two classes of runs that exist (C2 step 0.576 vs 0.63 ms at identical probe values,
-        # profiles/r05_box_samples.txt).  What does is a latency-bound kernel timed IN the step: the tile sort (two look-back passes over
-        # the frame's pairs) took 39.5 us in a fast run and 49 - 53 us in a slow one, and over five runs the step moved by 0.33 x the
-        # sort's relative change.  So: normalised = step / (1 + 0.33 (tile_sort / fast - 1)), C2 only.  (fast = 37.4 us since the sort's
-        # tiles became 4096 items and its last pass writes the tile ranges, late in round 5: 37.3 - 37.9 on fast-class runs.)
-        if args.workload == "C2" and per_kernel.get("tile_sort"):
-            out_norm = {"tile_sort_us_in_step": round(per_kernel["tile_sort"] * 1e3, 2), "tile_sort_us_fast_run": 37.4, "step_sensitivity": 0.33}
-            out_norm["slowdown_vs_fast_run"] = round(1.0 + 0.33 * (per_kernel["tile_sort"] * 1e3 / 37.4 - 1.0), 4)
-        else:
-            out_norm = None
+        if roof:
+            roof["window"] = census
         if roof and roof.get("valu_issue") and probe and probe.get("valu_Ginst_per_s_in_kernel_span"):
             # against what THIS box's VALUs issue on independent v_fma_f32 streams (box_probe), not the 157.3 TFLOP/s / 128 yardstick that
             # non-packed fp32 code cannot reach
@@ -352,16 +338,16 @@ def main():
             vi["frac_of_fma_ceiling_this_box"] = round(vi["achieved_Ginst_per_s"] / probe["valu_Ginst_per_s_in_kernel_span"], 4)
         out = {"metric": "train iters/sec (full iteration: rasterizer fwd+bwd, L1+SSIM, normal+dist regularisers, Adam) + fwd Msplats/s @1080p",
                "value": round(iters_per_s, 3), "unit": "train-iters/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-               "ms_per_step": round(ms_per_step, 4),
-               "ms_per_step_normalised": (round(ms_per_step / out_norm["slowdown_vs_fast_run"], 4) if out_norm else None),
-               "normalisation": out_norm, "box_probe": probe, "higher_is_better": True, "scaling": "strong" if bands else "weak", "vs_baseline": None,
+               "ms_per_step": round(ms_per_step, 4), "box_probe": probe, "higher_is_better": True, "scaling": "strong" if bands else "weak", "vs_baseline": None,
                "dtype": "f32", "data": "synthetic",
                "config": {"workload": (trained_info["workload"] + "; steady-state iteration, every loss term on") if trained_info else
                                       "%s-synthetic: %d random surfels, %dx%d, sh_degree 3, %d target views rendered from the unperturbed "
                                       "surfels, %s, lambda_dssim 0.2, lambda_normal 0.05, lambda_dist 1000, depth_ratio 1, "
                                       "Adam on 58 floats/surfel; %d set-up iterations before the warm-up" % (args.workload, P, W, H, n_views,
                                       "1 view/iteration split into row bands" if bands else "1 view/GPU/iteration", PRIME),
-                          "P": P, "visible": V, "instances_R": R, "instances_staged": Rs, "n_pass": n_pass, "tiles": tiles,
+                          "P": P, "image": "%dx%d" % (W, H), "visible_mean": round(V, 1), "instances_R_mean": round(R, 1), "instances_staged_mean": round(Rs, 1),
+                          "instances_R_range": [census["R_min"], census["R_max"]], "n_pass": n_pass, "tiles": tiles,
+                          "trained_state": trained_info,
                           "parallelism": ("tile-band sharding of one view over %d GPUs (image bands all-gathered, same gradient exchange)" % world) if bands
                           else ("view-parallel dp%d; per iteration 1 all-reduce of 40 B/surfel (geometry gradients) + 1 all-gather of "
                                 "12 B/surfel/rank (colour gradients -> SH gradients rebuilt locally)" % world)},
@@ -446,21 +432,16 @@ def main():
         out["legs"] = {}
         for leg in [x for x in args.legs.split(",") if x]:
             try:      # (a side leg must never cost the run its headline line)
+                if leg == args.workload:
+                    continue      # (the headline itself)
                 if leg in TRAINED_PRESETS:
                     out["legs"][leg] = trained_leg(dev, leg, steps=30 if leg == "trained" else 20, warmup=5)
+                elif leg == "C5":      # BASELINE configs[4]'s per-frame shape on ONE GPU: 10 M surfels, 3840x2160 (~15 ms per iteration)
+                    out["legs"][leg] = config_leg(dev, leg, steps=10, warmup=3, prime=5, walks=False)
                 else:
-                    out["legs"][leg] = config_leg(dev, leg, steps=30 if leg == "C2H" else 20, warmup=5)
+                    out["legs"][leg] = config_leg(dev, leg, steps=30 if leg in ("C2", "C2H") else 20, warmup=5)
             except Exception as e:      # noqa: BLE001
                 out["legs"][leg] = {"error": repr(e)}
-
-        # north_star's 1-GPU target shape (Mip-NeRF360 garden: BASELINE configs[3], scripts/m360_eval.py:40-46 / utils/camera_utils.py:25-33 of the
-        # reference) next to the C2 headline, at top level: the garden-sized trained state's full iteration
-        gl = out["legs"].get("garden")
-        if isinstance(gl, dict) and "ms_per_step" in gl:
-            out["headline_garden"] = {"metric": "train iters/sec, full iteration", "value": gl["iters_per_s"], "unit": "train-iters/s", "ms_per_step": gl["ms_per_step"],
-                                      "workload": gl.get("workload"), "P": gl.get("P"), "instances_R": gl.get("instances_R"), "instances_staged": gl.get("instances_staged"),
-                                      "roofline": gl.get("roofline"), "step_roofline": step_roofline(gl.get("kernels_ms"), gl["ms_per_step"], "garden", gl.get("P"), gl.get("visible"),
-                                                                                                   gl.get("instances_R"), gl.get("instances_staged"), 1600, 1060)}
 
     # ---- BASELINE configs[2] as a full train: the reference's 30 000-iteration schedule incl. densification and opacity resets
     if rank == 0 and world == 1 and not args.no_full_train:
@@ -476,7 +457,7 @@ def main():
         sys.path.insert(0, os.path.join(REPO, "tests"))
         from helpers_bench import cpu_baseline, cpu_dense_c1
         try:
-            out["cpu_baseline"] = cpu_baseline(args.workload)
+            out["cpu_baseline"] = cpu_baseline(args.workload, snapshot=cpu_snapshot)
         except Exception as e:      # noqa: BLE001
             out["cpu_baseline"] = {"error": repr(e)}
         try:

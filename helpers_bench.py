@@ -5,18 +5,40 @@ import time
 import numpy as np
 
 
-def fwd_1080p(dev, name="1080p_1M", iters=20, warmup=5):
+FWD_STAGES = ("preprocess_fwd", "scan", "emit_instances", "radix_sort", "tile_ranges", "blend_fwd")
+
+
+def fwd_roofline(P, R, Rs, W, H, ms):
+    """SURVEY 8d's B_fwd (preprocess 319 B/surfel + scan 8 B/surfel + 12 B/instance emitted + 24 B/instance/sort pass + 8 B/instance ranges
+    + 80 B per blended instance + 60 B/pixel) over the measured forward time, against the HBM peak.  `achieved` charges the blend stage
+    for the STAGED instances Rs (what a blend pass has to read); `survey_R` is the same with all R instances, as SURVEY 8d writes it."""
+    from bench import HBM_PEAK_GBS, algorithmic_bytes
+    tiles = ((W + 15) // 16) * ((H + 15) // 16)
+    n_pass = -(-(32 + max(1, (tiles - 1).bit_length())) // 8)
+    B = sum(algorithmic_bytes(k, P, P, R, W, H, n_pass, Rs) for k in FWD_STAGES)
+    B_R = sum(algorithmic_bytes(k, P, P, R, W, H, n_pass, None) for k in FWD_STAGES)
+    ach = B / (ms * 1e-3) / 1e9
+    return {"bound": "hbm", "stage": "forward (preprocess .. blend incl. sort)", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(ach / HBM_PEAK_GBS, 4), "algorithmic_bytes": int(B), "survey_R": {"algorithmic_bytes": int(B_R), "achieved": round(B_R / (ms * 1e-3) / 1e9, 1),
+                                                                                            "frac": round(B_R / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
+            "P": int(P), "instances_R": int(R), "instances_staged": int(Rs), "n_pass": n_pass, "tiles": tiles, "ms": round(ms, 4)}
+
+
+def _forward_only(dev, P, W, H, zf, iters, warmup):
+    """Median ms of the forward under no_grad (the renderer's inference call, render.py:57 of the reference: no backward follows, so the
+    forward leaves no tile stream behind), R and Rs of the frame."""
     import torch
     import synthetic
+    import diff_surfel_rasterization as dsr
     from diff_surfel_rasterization import GaussianRasterizationSettings, GaussianRasterizer
-    P, W, H, zf = synthetic.CONFIGS[name]
-    sc = synthetic.make_scene(P, W, H, seed=0, z_far=zf)
+    sc = synthetic.make_scene(int(P), W, H, seed=0, z_far=zf)
     t = lambda x: torch.as_tensor(np.ascontiguousarray(x)).to(dev)
     rs = GaussianRasterizationSettings(image_height=H, image_width=W, tanfovx=sc["tanfovx"], tanfovy=sc["tanfovy"], bg=t(sc["bg"]),
                                        scale_modifier=1.0, viewmatrix=t(sc["viewmatrix"]), projmatrix=t(sc["projmatrix"]),
                                        sh_degree=3, campos=t(sc["campos"]), prefiltered=False, debug=False)
     rast = GaussianRasterizer(raster_settings=rs)
     means3D, shs, opac, scales, rots = (t(sc[k]) for k in ("means3D", "shs", "opacities", "scales", "rotations"))
+    del sc
     means2D = torch.zeros_like(means3D)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     ms = []
@@ -29,28 +51,69 @@ def fwd_1080p(dev, name="1080p_1M", iters=20, warmup=5):
             torch.cuda.synchronize()
             if i >= warmup:
                 ms.append(e0.elapsed_time(e1))
-    import diff_surfel_rasterization
-    med = float(np.median(ms))
-    return {"workload": "%d surfels, %dx%d, forward only (preprocess..blend incl. sort)" % (P, W, H), "ms_median": round(med, 4),
-            "Msplats_per_s": round(P / (med * 1e-3) / 1e6, 2), "instances_R": int(diff_surfel_rasterization.last_num_rendered),
-            "Minst_per_s": round(diff_surfel_rasterization.last_num_rendered / (med * 1e-3) / 1e6, 2)}
+    R = int(dsr.last_num_rendered)
+    Rs = int(dsr.staged_instances(W, H))
+    del means3D, shs, opac, scales, rots, means2D, rast
+    torch.cuda.empty_cache()
+    return float(np.median(ms)), R, Rs
 
 
-def cpu_baseline(workload="C2"):
-    """Oracle fp32 port (oracle/surfel_oracle.c -DORACLE_F32, OpenMP) timed on the host: one fwd+bwd of the
-    same synthetic workload.  Reported beside the GPU figure; it is a baseline, not a target."""
+def fwd_1080p(dev, name="1080p_1M", iters=20, warmup=5):
+    import synthetic
+    P, W, H, zf = synthetic.CONFIGS[name]
+    med, R, Rs = _forward_only(dev, P, W, H, zf, iters, warmup)
+    return {"workload": "%d surfels, %dx%d, forward only (preprocess..blend incl. sort), no_grad" % (P, W, H), "ms_median": round(med, 4),
+            "Msplats_per_s": round(P / (med * 1e-3) / 1e6, 2), "instances_R": R, "instances_staged": Rs,
+            "Minst_per_s": round(R / (med * 1e-3) / 1e6, 2), "roofline": fwd_roofline(P, R, Rs, W, H, med)}
+
+
+CPU_THREADS = min(os.cpu_count() or 1, 32)      # BOTH CPU legs run on this many threads (the dense torch leg slows down beyond ~32)
+
+
+def _omp_threads(n):
+    """Thread count of the oracle's OpenMP regions (libgomp, the runtime oracle/liboracle_*.so links)."""
+    import ctypes
+    try:
+        ctypes.CDLL("libgomp.so.1").omp_set_num_threads(int(n))
+        return int(n)
+    except OSError:
+        return int(os.environ.get("OMP_NUM_THREADS", os.cpu_count() or 1))
+
+
+def snapshot_for_cpu(tr, view=0):
+    """Host copies of a Trainer's activated parameters and one of its cameras: the CPU baseline's sample of a trained workload."""
+    import math
+    m, cam = tr.model, tr.cams[view]
+    P = int(m.P)
+    f = lambda t: np.ascontiguousarray(t.detach().float().cpu().numpy())
+    return dict(P=P, W=int(cam.image_width), H=int(cam.image_height), means3D=f(m._pv["xyz"]), shs=f(m._pv["sh"].view(P, 16, 3)), opacities=f(m._av["opacity"]),
+                scales=f(m._av["scaling"]), rotations=f(m._av["rotation"]), viewmatrix=f(cam.world_view_transform), projmatrix=f(cam.full_proj_transform),
+                tanfovx=math.tan(cam.FoVx * 0.5), tanfovy=math.tan(cam.FoVy * 0.5), campos=f(cam.camera_center), bg=np.zeros(3, np.float32))
+
+
+def cpu_baseline(workload="C2", snapshot=None, budget_s=12.0):
+    """Oracle fp32 port (oracle/surfel_oracle.c -DORACLE_F32, OpenMP) timed on the host: rasterizer fwd+bwd passes of the headline
+    workload — the synthetic scene of a config name, or `snapshot` (snapshot_for_cpu: one view of the trained state the GPU leg
+    timed).  Reported beside the GPU figure; it is a baseline, not a target."""
     import synthetic
     from oracle.surfel_oracle import Oracle
-    sample = workload if workload in ("C1", "C2", "C3") else "C2"
-    P, W, H, zf = synthetic.CONFIGS[sample]
-    sc = synthetic.make_scene(P, W, H, seed=0, z_far=zf)
+    if snapshot is not None:
+        sc, P, W, H = snapshot, snapshot["P"], snapshot["W"], snapshot["H"]
+        sample = "%s: one view of the trained state" % workload
+    else:
+        name = workload if workload in synthetic.CONFIGS else "C2"
+        P, W, H, zf = synthetic.CONFIGS[name]
+        sc = synthetic.make_scene(P, W, H, seed=0, z_far=zf, px_radius=synthetic.PX_RADIUS.get(name))
+        sample = "%s-synthetic" % name
     o = Oracle("f32")
+    cores = _omp_threads(CPU_THREADS)
     rng = np.random.default_rng(0)
     gC = rng.normal(size=(3, H, W)).astype(np.float32); gO = rng.normal(size=(7, H, W)).astype(np.float32)
-    # bounded sample: whole fwd+bwd passes of the workload, repeated until ~10 s of CPU work (at most 20 passes)
+    # bounded sample: whole fwd+bwd passes of the workload, repeated until ~budget_s of CPU work (at most 20 passes)
     tf = tb = 0.0
     passes = 0
-    while passes < 20 and (tf + tb) < 10.0:
+    R = 0
+    while passes < 20 and (tf + tb) < budget_s:
         t0 = time.perf_counter()
         R, col, oth, radii, st = o.rasterize_forward(sc["bg"], sc["means3D"], None, sc["opacities"], sc["scales"], sc["rotations"], 1.0,
                                                      None, sc["viewmatrix"], sc["projmatrix"], sc["tanfovx"], sc["tanfovy"], H, W,
@@ -59,11 +122,10 @@ def cpu_baseline(workload="C2"):
         o.rasterize_backward(st, gC, gO)
         t2 = time.perf_counter()
         tf += t1 - t0; tb += t2 - t1; passes += 1
-    cores = int(os.environ.get("OMP_NUM_THREADS", os.cpu_count() or 1))
     return {"value": round(passes / (tf + tb), 4), "unit": "view-iters/s", "cores": cores, "kind": "port",
-            "sample": "%s-synthetic (%d surfels, %dx%d): %d rasterizer fwd+bwd passes of the fp32 OpenMP oracle port (the dominant part of "
-                      "an iteration; loss and Adam are NOT included, which favours the CPU figure), %.1f s of wall time; "
-                      "per pass fwd %.3f s, bwd %.3f s" % (sample, P, W, H, passes, tf + tb, tf / passes, tb / passes),
+            "sample": "%s (%d surfels, %dx%d, %d tile instances): %d rasterizer fwd+bwd passes of the fp32 OpenMP oracle port on %d threads (the dominant part "
+                      "of an iteration; loss and Adam are NOT included, which favours the CPU figure), %.1f s of wall time; "
+                      "per pass fwd %.3f s, bwd %.3f s" % (sample, P, W, H, int(R), passes, cores, tf + tb, tf / passes, tb / passes),
             "fwd_bwd_Msplats_per_s": round(P * passes / (tf + tb) / 1e6, 4)}
 
 
@@ -110,7 +172,38 @@ def _frozen_schedule(TR, regularizers=True):
                                   normal_from_iter=0 if regularizers else far, lambda_dist=1000.0, lambda_normal=0.05)
 
 
-def time_trainer(tr, steps, warmup, prime=15, workload=None):
+WINDOW_SEED = 20260922      # the view order of every timed window (bench legs, rocprofv3 passes): the same frames in every run of a command
+
+
+def reseed_views(tr, seed=WINDOW_SEED):
+    """Restart the Trainer's random view order (train.py:64-67's stack) from a fixed seed."""
+    if hasattr(tr, "_rng") and hasattr(tr, "_stack"):
+        tr._rng.seed(seed); tr._stack = []
+
+
+def window_census(tr, steps, W, H, seed=WINDOW_SEED):
+    """Replays the timed window's frames (same seed -> same views in the same order; the parameters have moved by `steps` Adam steps)
+    with every rasterizer stage bracketed by events, and sums per FRAME what the roofline needs: instances R, staged instances Rs,
+    visible surfels V.  Returns ({stage: (total_ms, launches)}, {"R": mean, "Rs": mean, "V": mean, "R_min": .., "R_max": ..}) — bytes and kernel times
+    of a leg then belong to the same frames (the views of a trained capture differ 2 - 3x in instance count)."""
+    import torch
+    import surfel_native
+    import diff_surfel_rasterization as dsr
+    surfel_native.collect_stage_times()
+    reseed_views(tr, seed)
+    tr.pipe.debug = 2
+    Rl, Rsl, Vl = [], [], []
+    for _ in range(steps):
+        tr.step()
+        torch.cuda.synchronize()
+        Rl.append(int(dsr.last_num_rendered)); Rsl.append(int(dsr.staged_instances(W, H))); Vl.append(int((tr.last["radii"] > 0).sum().item()))
+    st = surfel_native.collect_stage_times()
+    tr.pipe.debug = 0
+    n = float(len(Rl))
+    return st, {"R": sum(Rl) / n, "Rs": sum(Rsl) / n, "V": sum(Vl) / n, "R_min": min(Rl), "R_max": max(Rl), "frames": len(Rl)}
+
+
+def time_trainer(tr, steps, warmup, prime=15, workload=None, walks=True):
     """ms per full training iteration of an existing Trainer + the rasterizer's per-stage kernel times (second, untimed pass)."""
     import torch
     import surfel_native
@@ -124,8 +217,9 @@ def time_trainer(tr, steps, warmup, prime=15, workload=None):
     retimed = False
     for attempt in range(2):
         host = []
-        if hasattr(tr, "_rng") and hasattr(tr, "_stack"):      # the same views as `python bench.py --workload <this leg>` times (bench.py)
-            tr._rng.seed(20260922); tr._stack = []
+        reseed_views(tr)      # the same views as `python bench.py --workload <this leg>` times (bench.py)
+        surfel_native.collect_stage_times()
+        tr.pipe.debug = 3       # events around the dominant kernel (blend_bwd) only, resolved after the window
         t0 = time.perf_counter()
         for _ in range(steps):
             h0 = time.perf_counter()
@@ -133,6 +227,8 @@ def time_trainer(tr, steps, warmup, prime=15, workload=None):
             host.append(time.perf_counter() - h0)
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
+        tr.pipe.debug = 0
+        dom = surfel_native.collect_stage_times()
         # a single host stall (tens of ms: seen on boxes of the pool with unchanged kernel times and no allocation, GC run or overflow
         # inside the window) must not be reported as the leg's step time: the window is timed ONCE more and the repeat is flagged
         if attempt == 0 and max(host) > 20.0 * sorted(host)[len(host) // 2] and max(host) > 0.3 * dt:
@@ -148,17 +244,14 @@ def time_trainer(tr, steps, warmup, prime=15, workload=None):
              "host_ms_per_step_median": round(sorted(host)[len(host) // 2] * 1e3, 4), "host_ms_per_step_max": round(max(host) * 1e3, 4),
              "python_gc_collections_gen012": [g["collections"] - c for g, c in zip(gc.get_stats(), gc0)],
              "window_retimed_after_host_stall": retimed, "capacity_table_evictions": int(surfel_native.load().surfel_debug_capacity_evictions())}
-    surfel_native.collect_stage_times()
-    tr.pipe.debug = 2
-    for _ in range(max(5, steps // 2)):
-        tr.step()
-    torch.cuda.synchronize()
-    st = surfel_native.collect_stage_times()
-    tr.pipe.debug = 0
+    cam = tr.cams[0]
+    W, H = int(cam.image_width), int(cam.image_height)
+    st, cen = window_census(tr, steps, W, H)
+    st.update(dom)      # the dominant kernel's duration is the one measured INSIDE the timed window
     # both blend_bwd walks on this very state (the library default picks one per frame on the device): data for that choice
     ab, lanes = {}, {}
     lib = surfel_native.load()
-    for name, v in (("rows", 0), ("quad", 1), ("scan", 3)):
+    for name, v in ((("rows", 0), ("quad", 1), ("scan", 3)) if walks else ()):
         lib.surfel_set_option(b"bwd_variant", v)
         tr.pipe.debug = 2
         # every walk's window sees the SAME views in the same order (the views of a capture differ 2-3x in instance count: windows
@@ -187,23 +280,21 @@ def time_trainer(tr, steps, warmup, prime=15, workload=None):
         lanes[name] = {"useful_lane_frac": round(float(sv[1]) / max(1.0, float(sv[0])), 4), "wave_visits": int(sv[2]), "useful_pairs": int(sv[1])}
     lib.surfel_set_option(b"bwd_variant", 2)
     tr.pipe.debug = 0
-    cam = tr.cams[0]
-    W, H = int(cam.image_width), int(cam.image_height)
     tiles = ((W + 15) // 16) * ((H + 15) // 16)
-    R = int(dsr.last_num_rendered)
-    Rs = dsr.staged_instances(W, H)
-    V = int((tr.last["radii"] > 0).sum().item())
+    R, Rs, V = cen["R"], cen["Rs"], cen["V"]
     from bench import roofline_object
     n_pass = -(-(32 + max(1, (tiles - 1).bit_length())) // 8)
     roof = roofline_object({k: v[0] / v[1] for k, v in st.items()}, workload or "?", int(tr.model.P), V, R, Rs, W, H, n_pass)
-    return {"roofline": roof, "instances_staged": Rs, "ms_per_step": round(dt / steps * 1e3, 4), "iters_per_s": round(steps / dt, 2), "steps": steps, "P": int(tr.model.P),
-            "visible": int((tr.last["radii"] > 0).sum().item()), "instances_R": R, "inst_per_tile": round(R / tiles, 1),
+    if roof:
+        roof["window"] = cen
+    return {"roofline": roof, "instances_staged": round(Rs, 1), "ms_per_step": round(dt / steps * 1e3, 4), "iters_per_s": round(steps / dt, 2), "steps": steps, "P": int(tr.model.P),
+            "visible": round(V, 1), "instances_R": round(R, 1), "inst_per_tile": round(R / tiles, 1),
             "inst_per_surfel": round(R / max(1, int(tr.model.P)), 2), "loss": round(float(tr.last["loss"]), 5),
             "kernels_ms": {k: round(v[0] / v[1], 4) for k, v in st.items()}, "blend_bwd_ms_by_walk": ab, "blend_bwd_lanes_by_walk": lanes,
             "lazy_overflows": int(getattr(tr, "lazy_overflows", 0)), "timed_window": alloc}
 
 
-def config_leg(dev, workload, steps=20, warmup=5):
+def config_leg(dev, workload, steps=20, warmup=5, prime=15, walks=True):
     """One more synthetic configuration through the same full training iteration (C4 = BASELINE configs[3] per-GPU shape,
     C2H = heavy footprints)."""
     import torch
@@ -211,7 +302,7 @@ def config_leg(dev, workload, steps=20, warmup=5):
     import diff_surfel_rasterization as dsr
     P, W, H, zf = synthetic.CONFIGS[workload]
     tr = make_trainer(dev, workload, n_views=8)
-    out = time_trainer(tr, steps, warmup, workload=workload)
+    out = time_trainer(tr, steps, warmup, prime=prime, workload=workload, walks=walks)
     out["workload"] = ("%s-synthetic: %d random surfels, %dx%d, median 1-sigma radius %.1f px, full iteration as the headline leg"
                        % (workload, P, W, H, synthetic.PX_RADIUS.get(workload) or max(4.0 * W / 1920.0, 1.5)))
     del tr
@@ -269,7 +360,9 @@ def trained_state(dev, preset="trained", state=None):
         pcd.colors = rng.random((c["n_init"], 3)).astype(np.float32)
         model.create_from_pcd(pcd, spatial_lr_scale=extent)
         opt = TR.optimization_params(iterations=c["train_iters"], lambda_dist=100.0, position_lr_max_steps=c["train_iters"])
-        tr = TR.Trainer(model, train_cams, opt, TR.pipeline_params(depth_ratio=1.0), extent=extent)
+        # (solo: under torch.distributed every rank prepares the SAME state by itself — seeded capture and points, bit-reproducible
+        # gradients —; trained_trainer checks that and falls back to rank 0's state)
+        tr = TR.Trainer(model, train_cams, opt, TR.pipeline_params(depth_ratio=1.0), extent=extent, solo=True)
         p0 = tr.evaluate(train_cams[:8])[0]
         torch.cuda.synchronize(); t0 = time.perf_counter()
         for _ in range(c["train_iters"] - 1):       # the schedule's last iteration takes no optimiser step (train.py:136)
@@ -288,10 +381,38 @@ def trained_state(dev, preset="trained", state=None):
     return model, train_cams, test_cams, extent, info
 
 
+def _adopt_rank0_state(model, extent):
+    """N > 1: if the ranks' independently prepared states differ in size, every rank takes rank 0's parameters (fresh optimiser state)."""
+    import torch
+    import torch.distributed as dist
+    import surfel_model
+    if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
+        return model
+    dev = model.device
+    p = torch.tensor([model.P], dtype=torch.int64, device=dev)
+    lo, hi = p.clone(), p.clone()
+    dist.all_reduce(lo, op=dist.ReduceOp.MIN); dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+    if int(lo) == int(hi):
+        return model
+    dist.broadcast(p, src=0)
+    if dist.get_rank() != 0:
+        fresh = surfel_model.GaussianModel(3, device=dev)
+        fresh._alloc(int(p))
+        fresh.max_radii2D = torch.zeros((int(p),), device=dev)
+        fresh.active_sh_degree, fresh.spatial_lr_scale = 3, extent
+        model = fresh
+    else:
+        model.grad = model.m = model.v = None      # every rank starts the timed Trainer with fresh moments
+    dist.broadcast(model.theta, src=0)
+    model.refresh_activations()
+    return model
+
+
 def trained_trainer(dev, preset="trained", state=None):
     """A Trainer on the steady-state iteration (every loss term on, no densification inside the timed window) of a trained state."""
     import surfel_trainer as TR
     model, train_cams, test_cams, extent, info = trained_state(dev, preset, state)
+    model = _adopt_rank0_state(model, extent)
     tr = TR.Trainer(model, train_cams, _frozen_schedule(TR), TR.pipeline_params(depth_ratio=1.0), extent=extent)
     tr.iteration = TRAINED_PRESETS[preset]["train_iters"]
     return tr, info
@@ -442,7 +563,7 @@ def cpu_dense_c1(max_seconds=25.0):
     sc = synthetic.make_scene(P, W, H, seed=0, z_far=zf)
     a = scene_args(sc)
     _, _, _, radii, st = oracle_forward(Oracle("f64"), a)
-    return da.time_dense_forward(sc, st, max_seconds)
+    return da.time_dense_forward(sc, st, max_seconds, cores=CPU_THREADS)
 
 
 def train_iter(dev, workload="C2", iters=60, warmup=15, n_views=8):
@@ -506,41 +627,17 @@ def raster_fwd_bwd(dev, workload="C2", iters=40, warmup=10):
 
 def fwd_1080p_sweep(dev, sizes=(300_000, 1_000_000, 2_000_000, 5_000_000, 10_000_000), iters=8, warmup=3):
     """forward-only throughput at 1920x1080 over P in {0.3, 1, 2, 5, 10} M random surfels (the 1 M point is
-    fwd_1080p's workload): Msplats/s and M tile instances/s per size."""
-    import torch
+    fwd_1080p's workload): Msplats/s, M tile instances/s and the forward's HBM roofline fraction per size."""
     import synthetic
-    import diff_surfel_rasterization as dsr
-    from diff_surfel_rasterization import GaussianRasterizationSettings, GaussianRasterizer
     W, H = 1920, 1080
+    zf = synthetic.CONFIGS["1080p_1M"][3]
     out = []
     for P in sizes:
-        zf = synthetic.CONFIGS["1080p_1M"][3]
-        sc = synthetic.make_scene(int(P), W, H, seed=0, z_far=zf)
-        t = lambda x: torch.as_tensor(np.ascontiguousarray(x)).to(dev)
-        rs = GaussianRasterizationSettings(image_height=H, image_width=W, tanfovx=sc["tanfovx"], tanfovy=sc["tanfovy"], bg=t(sc["bg"]),
-                                           scale_modifier=1.0, viewmatrix=t(sc["viewmatrix"]), projmatrix=t(sc["projmatrix"]),
-                                           sh_degree=3, campos=t(sc["campos"]), prefiltered=False, debug=False)
-        rast = GaussianRasterizer(raster_settings=rs)
-        means3D, shs, opac, scales, rots = (t(sc[k]) for k in ("means3D", "shs", "opacities", "scales", "rotations"))
-        del sc
-        means2D = torch.zeros_like(means3D)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        ms = []
-        with torch.no_grad():
-            for i in range(warmup + iters):
-                e0.record()
-                rast(means3D=means3D, means2D=means2D, shs=shs, colors_precomp=None, opacities=opac, scales=scales, rotations=rots, cov3D_precomp=None)
-                e1.record()
-                torch.cuda.synchronize()
-                if i >= warmup:
-                    ms.append(e0.elapsed_time(e1))
-        med = float(np.median(ms))
-        R = int(dsr.last_num_rendered)
-        out.append({"P": int(P), "ms_median": round(med, 4), "Msplats_per_s": round(P / (med * 1e-3) / 1e6, 1), "instances_R": R,
-                    "Minst_per_s": round(R / (med * 1e-3) / 1e6, 1)})
-        del means3D, shs, opac, scales, rots, means2D, rast
-        torch.cuda.empty_cache()
-    return {"workload": "forward only (preprocess .. blend incl. sort) at 1920x1080, random surfels (synthetic.make_scene), median of %d calls" % iters, "sizes": out}
+        med, R, Rs = _forward_only(dev, int(P), W, H, zf, iters, warmup)
+        rf = fwd_roofline(int(P), R, Rs, W, H, med)
+        out.append({"P": int(P), "ms_median": round(med, 4), "Msplats_per_s": round(P / (med * 1e-3) / 1e6, 1), "instances_R": R, "instances_staged": Rs,
+                    "Minst_per_s": round(R / (med * 1e-3) / 1e6, 1), "hbm_frac": rf["frac"], "hbm_frac_survey_R": rf["survey_R"]["frac"]})
+    return {"workload": "forward only (preprocess .. blend incl. sort) at 1920x1080 under no_grad, random surfels (synthetic.make_scene), median of %d calls" % iters, "sizes": out}
 
 
 def full_train_leg(dev, iterations=30_000, res=(800, 600), n_views=49, n_gt=60_000, n_init=40_000, max_seconds=240.0):

@@ -175,7 +175,7 @@ def render_dense(means3D, scales, rotations, opacities, shs, colors_precomp, tra
     return color, allmap
 
 
-def time_dense_forward(sc, st, max_seconds=25.0, rows_per_chunk=4):
+def time_dense_forward(sc, st, max_seconds=25.0, rows_per_chunk=4, cores=None):
     """CPU baseline leg of bench.py (BASELINE configs[0]): forward of the dense rasterizer above in fp32 under no_grad on all host
     cores, over as many 4-row chunks of the image as fit into `max_seconds`, extrapolated linearly to the full image.
     sc = synthetic scene dict, st = the C oracle's preprocess state (radii / tile rects / depth keys: the non-differentiable
@@ -184,7 +184,7 @@ def time_dense_forward(sc, st, max_seconds=25.0, rows_per_chunk=4):
     import time
     import numpy as np
     W, H, P = int(sc["W"]), int(sc["H"]), sc["means3D"].shape[0]
-    cores = min(os.cpu_count() or 1, 32)      # intra-op threads actually used: more than ~32 slows these broadcast-heavy ops down
+    cores = cores or min(os.cpu_count() or 1, 32)      # intra-op threads actually used: more than ~32 slows these broadcast-heavy ops down
     torch.set_num_threads(cores)
     t = lambda x: torch.tensor(np.asarray(x, np.float32))
     gx, gy = (W + 15) // 16, (H + 15) // 16
