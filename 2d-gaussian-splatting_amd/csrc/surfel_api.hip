@@ -428,6 +428,7 @@ int64_t surfel_rasterize_forward(surfel_alloc_fn geom_alloc, void* geom_user, su
     const int opt_tile_sort = ((debug >> 9) & 3) ? ((debug >> 9) & 3) - 1 : g_opt_tile_sort;
     const int opt_capacity = (debug & SURFEL_OPT_EXACT_BINNING) ? 0 : g_opt_capacity;
     const int opt_tile_order = ((debug >> 19) & 3) ? ((debug >> 19) & 3) - 1 : g_opt_tile_order;
+    const bool opt_stream = !(debug & SURFEL_OPT_NO_STREAM);      // (the caller knows no backward follows: render.py-style inference, no_grad re-renders)
     const int map_len = tile_map_len((width + TILE - 1) / TILE, (height + TILE - 1) / TILE);
     debug &= 0xff;
     g_last_binning = 0;
@@ -511,7 +512,7 @@ int64_t surfel_rasterize_forward(surfel_alloc_fn geom_alloc, void* geom_user, su
         if (cap > 0) {      // the binning buffers exist before preprocess runs: it clears the tile sort's head on the way
             const size_t sort_bytes = capacity_sort_scratch_bytes((size_t)cap, end_bit);
             size_t bin_bytes = 0;
-            const bool strm = BinState::wants_stream((size_t)cap);
+            const bool strm = opt_stream && BinState::wants_stream((size_t)cap);
             BinState::carve(nullptr, (size_t)cap, sort_bytes, &bin_bytes, strm);
             void* bin_base = binning_alloc(binning_user, bin_bytes);
             if (!bin_base) return fail(SURFEL_E_ALLOC, "binning buffer allocation failed");
@@ -617,7 +618,7 @@ int64_t surfel_rasterize_forward(surfel_alloc_fn geom_alloc, void* geom_user, su
 
             const size_t sort_bytes = radix_sort_scratch_bytes((size_t)R);
             size_t bin_bytes = 0;
-            const bool strm = BinState::wants_stream((size_t)R);
+            const bool strm = opt_stream && BinState::wants_stream((size_t)R);
             BinState::carve(nullptr, (size_t)R, sort_bytes, &bin_bytes, strm);
             void* bin_base = binning_alloc(binning_user, bin_bytes > 0 ? bin_bytes : 256);
             if (!bin_base) return fail(SURFEL_E_ALLOC, "binning buffer allocation failed");

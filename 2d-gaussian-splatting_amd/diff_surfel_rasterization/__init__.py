@@ -108,6 +108,11 @@ def finish_count():
 
 
 def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, raster_settings):
+    # no backward can follow (torch.no_grad(), or nothing requires a gradient: the reference's render.py / training_report renders,
+    # /root/reference/render.py:57, train.py:211): the forward leaves no tile stream behind (include/surfel_hip.h: SURFEL_OPT_NO_STREAM)
+    if not (torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in
+                                            (means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp))):
+        raster_settings = raster_settings._replace(debug=int(raster_settings.debug) | _n.OPT_NO_STREAM)
     return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
                                      raster_settings)
 

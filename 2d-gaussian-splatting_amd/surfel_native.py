@@ -37,6 +37,7 @@ OPT_ZERO_RECORDS = 1 << 18     # backward: zero gradient records behind a tile's
 OPT_LAZY_COUNT = 1 << 21       # forward: do not wait for the instance count; forward_count() collects it (include/surfel_hip.h)
 E_OVERFLOW = -5
 OPT_BWD_GATHER = 1 << 22       # backward: ignore the forward's tile stream, gather by surfel id (bit-identical)
+OPT_NO_STREAM = 1 << 23        # forward: no backward follows (inference / no_grad): leave no tile stream behind
 OPT_BWD_SCAN = 1 << 15         # scan walk (lanes = instances); deterministic, not bit-identical to rows / quad
 
 

@@ -51,6 +51,7 @@ extern "C" {
 #define SURFEL_OPT_TILE_ORDER(m)  ((((m) + 1) & 3) << 19)  /* forward: "tile_order" = m (0, 1, 2) for this call (the matching backward follows the forward) */
 #define SURFEL_OPT_LAZY_COUNT     (1 << 21)            /* forward: do not wait for the instance count (see surfel_forward_count) */
 #define SURFEL_OPT_BWD_GATHER     (1 << 22)            /* backward: ignore the forward's tile stream ("tile_stream") and gather the records by surfel id; bit-identical */
+#define SURFEL_OPT_NO_STREAM      (1 << 23)            /* forward: no backward will follow this call (inference, no_grad renders): leave no tile stream behind (saves 84 B per instance of stores and memory); a backward handed such a frame gathers by surfel id, same bits */
 #define SURFEL_OPT_BWD_SCAN       (1 << 15)            /* backward: scan walk ("bwd_variant" = 3) for this call; deterministic, NOT bit-identical to rows / quad */
 
 /* Allocator callback: return a device pointer to `bytes` bytes, 256-byte aligned, valid until the

@@ -29,7 +29,56 @@
 #include <stdlib.h>
 #include <string.h>
 
-#ifdef ORACLE_F32
+#ifdef ORACLE_MCA
+/* Monte Carlo arithmetic build (tests only; compiled as C++ by oracle/Makefile -> liboracle_mca.so): `real` carries a double whose
+ * value is multiplied by (1 + 2^-24 r), r uniform in [-1, 1), after EVERY arithmetic operation — the rounding error of an fp32
+ * evaluation (round to nearest: relative error <= 2^-24), drawn at random instead of determined by the operand bits.  One run
+ * is one plausible fp32 evaluation of this very algorithm (decisions included); N runs with different seeds show which output
+ * elements fp32 arithmetic DETERMINES to a given tolerance and which it does not (a decision sitting on its threshold, a
+ * cancelling sum).  Parker, "Monte Carlo arithmetic", 1997.  The draws are a function of (seed, work item): reproducible. */
+#include <cmath>
+static uint64_t g_mca_seed = 1;
+static thread_local uint64_t t_mca_state = 0x9E3779B97F4A7C15ull;
+static inline void mca_reseed(uint64_t item) {
+    uint64_t z = (g_mca_seed * 0xD1342543DE82EF95ull) ^ (item + 0x9E3779B97F4A7C15ull) * 0xBF58476D1CE4E5B9ull;
+    z ^= z >> 31; z *= 0x94D049BB133111EBull; z ^= z >> 29;
+    t_mca_state = z | 1ull;
+}
+static inline double mca_round(double x) {
+    uint64_t s = t_mca_state;
+    s ^= s << 13; s ^= s >> 7; s ^= s << 17;
+    t_mca_state = s;
+    const double r = (double)(int64_t)(s >> 11) * (1.0 / 4503599627370496.0) - 1.0;      /* [-1, 1) */
+    return x * (1.0 + 5.9604644775390625e-8 * r);
+}
+struct real {
+    double v;
+    real() {}
+    real(double x) : v(x) {}
+    explicit operator double() const { return v; }
+    explicit operator float() const { return (float)v; }
+    explicit operator int() const { return (int)v; }
+};
+static inline real operator+(real a, real b) { return real(mca_round(a.v + b.v)); }
+static inline real operator-(real a, real b) { return real(mca_round(a.v - b.v)); }
+static inline real operator*(real a, real b) { return real(mca_round(a.v * b.v)); }
+static inline real operator/(real a, real b) { return real(mca_round(a.v / b.v)); }
+static inline real operator-(real a) { return real(-a.v); }
+static inline real& operator+=(real& a, real b) { a = a + b; return a; }
+static inline real& operator-=(real& a, real b) { a = a - b; return a; }
+static inline real& operator*=(real& a, real b) { a = a * b; return a; }
+static inline bool operator<(real a, real b) { return a.v < b.v; }
+static inline bool operator<=(real a, real b) { return a.v <= b.v; }
+static inline bool operator>(real a, real b) { return a.v > b.v; }
+static inline bool operator>=(real a, real b) { return a.v >= b.v; }
+static inline bool operator==(real a, real b) { return a.v == b.v; }
+static inline bool operator!=(real a, real b) { return a.v != b.v; }
+static inline real R_EXP(real a) { return real(mca_round(mca_round(std::exp(a.v)))); }      /* (hardware exp: one more ulp) */
+static inline real R_SQRT(real a) { return real(mca_round(std::sqrt(a.v))); }
+static inline real R_CEIL(real a) { return real(std::ceil(a.v)); }
+#define MCA_RESEED(item) mca_reseed((uint64_t)(item))
+#define ATOMIC_ADD(dst, val) do { const double t_ = (val).v; double* p_ = &(dst).v; _Pragma("omp atomic") *p_ += t_; } while (0)
+#elif defined(ORACLE_F32)
 typedef float real;
 #define R_EXP expf
 #define R_SQRT sqrtf
@@ -39,6 +88,13 @@ typedef double real;
 #define R_EXP exp
 #define R_SQRT sqrt
 #define R_CEIL ceil
+#endif
+#ifndef ORACLE_MCA
+#define MCA_RESEED(item) ((void)0)
+#define ATOMIC_ADD(dst, val) do { _Pragma("omp atomic") (dst) += (val); } while (0)
+#endif
+#ifdef __cplusplus
+extern "C" {
 #endif
 
 /* [UPSTREAM-RECALL] constants of the rasterizer */
@@ -71,13 +127,41 @@ typedef struct {
 } oracle_params;
 
 int oracle_real_size(void) { return (int)sizeof(real); }
+#ifdef ORACLE_MCA
+void oracle_set_mca_seed(uint64_t seed) { g_mca_seed = seed ? seed : 1; }
+#endif
+
+/* Decision signatures (tests only).  With buffers registered, the forward blend leaves one 64-bit word per pixel and per surfel
+ * that identifies the DECISIONS taken there: which (pixel, surfel) pairs were composited, on which branch (rho3d <= rho2d) each
+ * one ran, which surfel carries the pixel's median depth.  Two runs whose words agree took the same decisions; a word that
+ * differs between the fp64 run and a Monte-Carlo-arithmetic run marks a threshold crossing ("threshold-crossing
+ * pixels exempt, count reported"). */
+static uint64_t* g_sig_pix = NULL;
+static uint64_t* g_sig_surf = NULL;
+static double* g_extent = NULL;      /* [P]: the AABB half-extent BEFORE ceil() (0 for culled surfels): how far the radius is from flipping */
+void oracle_set_signature_buffers(uint64_t* pix, uint64_t* surf, double* extent) { g_sig_pix = pix; g_sig_surf = surf; g_extent = extent; }
+static inline uint64_t sig_mix(uint64_t x) {
+    x += 0x9E3779B97F4A7C15ull; x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull; x = (x ^ (x >> 27)) * 0x94D049BB133111EBull; return x ^ (x >> 31);
+}
 
 static inline int imin(int a, int b) { return a < b ? a : b; }
 static inline int imax(int a, int b) { return a > b ? a : b; }
 
 /* Tile rectangle touched by a disc of integer radius r centred at (px,py).
  * [UPSTREAM-RECALL] float division then truncation, clamped to the tile grid. */
-static void tile_rect(real px, real py, int r, int gx, int gy, int* x0, int* y0, int* x1, int* y1) {
+#ifdef ORACLE_MCA
+#define RAW(x) ((x).v)      /* (no noise here: preprocess and binning must derive the SAME rectangle from the same centre and radius) */
+#else
+#define RAW(x) (x)
+#endif
+static void tile_rect(real px_, real py_, int r, int gx, int gy, int* x0, int* y0, int* x1, int* y1) {
+    const
+#ifdef ORACLE_F32
+        float
+#else
+        double
+#endif
+        px = RAW(px_), py = RAW(py_);
     *x0 = imin(gx, imax(0, (int)((px - r) / TILE)));
     *y0 = imin(gy, imax(0, (int)((py - r) / TILE)));
     *x1 = imin(gx, imax(0, (int)((px + r + TILE - 1) / TILE)));
@@ -127,8 +211,10 @@ int64_t oracle_preprocess(const oracle_params* prm, const float* means3D, const 
 
 #pragma omp parallel for schedule(static) reduction(+ : total)
     for (int i = 0; i < P; i++) {
+        MCA_RESEED(i);
         radii[i] = 0;
         tiles_touched[i] = 0;
+        if (g_extent) g_extent[i] = 0;
         depths[i] = 0;
         xy[2 * i] = xy[2 * i + 1] = 0;
         for (int k = 0; k < 4; k++) normal_opacity[4 * i + k] = 0;
@@ -185,6 +271,7 @@ int64_t oracle_preprocess(const oracle_params* prm, const float* means3D, const 
         const real ey = R_SQRT(hy > (real)1e-4 ? hy : (real)1e-4);
         real rad = ex > ey ? ex : ey;
         if (!(rad > CUTOFF * FILTER_SIZE)) rad = CUTOFF * FILTER_SIZE;
+        if (g_extent) g_extent[i] = (double)rad;
         rad = R_CEIL(rad);
         const int irad = (int)rad;
         int x0, y0, x1, y1;
@@ -345,12 +432,15 @@ void oracle_blend_forward(const oracle_params* prm, const uint32_t* ranges, cons
     for (int tile = 0; tile < gx * gy; tile++) {
         const uint32_t r0 = ranges[2 * tile], r1 = ranges[2 * tile + 1];
         const int bx = (tile % gx) * TILE, by = (tile / gx) * TILE;
+        MCA_RESEED(0x100000000ull + (uint64_t)tile);
         for (int ty = 0; ty < TILE; ty++)
             for (int tx = 0; tx < TILE; tx++) {
                 const int pxi = bx + tx, pyi = by + ty;
                 if (pxi >= W || pyi >= H) continue;
                 const size_t pix = (size_t)pyi * W + pxi;
                 const real pxf = (real)pxi, pyf = (real)pyi;
+                uint64_t sigp = 0;
+                uint32_t med_id = 0xffffffffu;
                 real T = 1, C[3] = {0, 0, 0}, N[3] = {0, 0, 0}, D = 0, M1 = 0, M2 = 0, dist = 0, med = 0;
                 uint32_t contributor = 0, last = 0, medc = 0;
                 for (uint32_t k = r0; k < r1; k++) {
@@ -370,7 +460,14 @@ void oracle_blend_forward(const oracle_params* prm, const uint32_t* ranges, cons
                     D += h.depth * w;
                     M1 += m * w;
                     M2 += m * m * w;
-                    if (T > (real)0.5) { med = h.depth; medc = contributor; }
+                    if (T > (real)0.5) { med = h.depth; medc = contributor; med_id = id; }
+                    if (g_sig_pix) {
+                        const uint64_t br = (h.rho3d <= h.rho2d) ? 1u : 0u;
+                        sigp += sig_mix(((uint64_t)id << 1) | br);
+                        const uint64_t ss = sig_mix(((uint64_t)pix << 1) | br);
+#pragma omp atomic
+                        g_sig_surf[id] += ss;
+                    }
                     for (int c = 0; c < 3; c++) N[c] += normal_opacity[4 * (size_t)id + c] * w;
                     for (int c = 0; c < 3; c++) {
                         const real col = colors_precomp ? (real)colors_precomp[3 * (size_t)id + c] : rgb[3 * (size_t)id + c];
@@ -378,6 +475,14 @@ void oracle_blend_forward(const oracle_params* prm, const uint32_t* ranges, cons
                     }
                     T = testT;
                     last = contributor;
+                }
+                if (g_sig_pix) {
+                    g_sig_pix[pix] = sigp + (med_id != 0xffffffffu ? sig_mix(0x4D454400000000ull + med_id) : 0ull);
+                    if (med_id != 0xffffffffu) {
+                        const uint64_t ss = sig_mix(0x4D454400000000ull + (uint64_t)pix);
+#pragma omp atomic
+                        g_sig_surf[med_id] += ss;
+                    }
                 }
                 final_T[pix] = T; final_T[HW + pix] = M1; final_T[2 * HW + pix] = M2;
                 n_contrib[pix] = last; n_contrib[HW + pix] = medc;
@@ -411,6 +516,7 @@ void oracle_blend_backward(const oracle_params* prm, const uint32_t* ranges, con
     for (int tile = 0; tile < gx * gy; tile++) {
         const uint32_t r0 = ranges[2 * tile], r1 = ranges[2 * tile + 1];
         const int bx = (tile % gx) * TILE, by = (tile / gx) * TILE;
+        MCA_RESEED(0x200000000ull + (uint64_t)tile);
         for (int ty = 0; ty < TILE; ty++)
             for (int tx = 0; tx < TILE; tx++) {
                 const int pxi = bx + tx, pyi = by + ty;
@@ -505,22 +611,13 @@ void oracle_blend_backward(const oracle_params* prm, const uint32_t* ranges, con
                         gT[8] = dL_dz;
                     }
                     const real gop = G * dL_dalpha;
-                    for (int q = 0; q < 9; q++) if (gT[q] != 0) {
-#pragma omp atomic
-                        dL_dtransMat[9 * (size_t)id + q] += gT[q];
-                    }
-                    for (int q = 0; q < 2; q++) if (gxy[q] != 0) {
-#pragma omp atomic
-                        dL_dmean2D[3 * (size_t)id + q] += gxy[q];
-                    }
+                    for (int q = 0; q < 9; q++) if (gT[q] != 0) ATOMIC_ADD(dL_dtransMat[9 * (size_t)id + q], gT[q]);
+                    for (int q = 0; q < 2; q++) if (gxy[q] != 0) ATOMIC_ADD(dL_dmean2D[3 * (size_t)id + q], gxy[q]);
                     for (int q = 0; q < 3; q++) {
-#pragma omp atomic
-                        dL_dnormal[3 * (size_t)id + q] += gnor[q];
-#pragma omp atomic
-                        dL_dcolors[3 * (size_t)id + q] += gcol[q];
+                        ATOMIC_ADD(dL_dnormal[3 * (size_t)id + q], gnor[q]);
+                        ATOMIC_ADD(dL_dcolors[3 * (size_t)id + q], gcol[q]);
                     }
-#pragma omp atomic
-                    dL_dopacity[id] += gop;
+                    ATOMIC_ADD(dL_dopacity[id], gop);
                 }
             }
     }
@@ -546,6 +643,7 @@ void oracle_preprocess_backward(const oracle_params* prm, const float* means3D, 
     const float* vm = viewmatrix;
 #pragma omp parallel for schedule(static)
     for (int i = 0; i < P; i++) {
+        MCA_RESEED(0x300000000ull + (uint64_t)i);
         if (!(radii[i] > 0)) continue;
         real T[9];
         if (transMat_precomp) for (int k = 0; k < 9; k++) T[k] = transMat_precomp[9 * i + k];
@@ -718,3 +816,6 @@ void oracle_knn_dist2(int P, const float* pts, real* out) {
         out[i] = (best[0] + best[1] + best[2]) / 3;
     }
 }
+#ifdef __cplusplus
+}
+#endif

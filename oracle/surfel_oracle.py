@@ -24,7 +24,7 @@ class _Params(C.Structure):
 
 def build(force=False):
     """Compile liboracle_f64.so / liboracle_f32.so with gcc (oracle/Makefile)."""
-    libs = [os.path.join(_HERE, n) for n in ("liboracle_f64.so", "liboracle_f32.so")]
+    libs = [os.path.join(_HERE, n) for n in ("liboracle_f64.so", "liboracle_f32.so", "liboracle_mca.so")]
     src = os.path.join(_HERE, "surfel_oracle.c")
     if force or any((not os.path.exists(l)) or os.path.getmtime(l) < os.path.getmtime(src) for l in libs):
         subprocess.check_call(["make", "-C", _HERE, "-B" if force else "-s", "all"])
@@ -51,12 +51,18 @@ def _f32(a):
 
 
 class Oracle:
-    """precision: 'f64' (checker) or 'f32' (timed CPU port)."""
+    """precision: 'f64' (checker), 'f32' (timed CPU port) or 'mca' (Monte Carlo arithmetic: every operation of the algorithm carries a
+    random fp32-sized rounding error — surfel_oracle.c, ORACLE_MCA; set_seed() picks the draw)."""
 
     def __init__(self, precision="f64"):
         self.lib = _lib(precision)
-        self.real = np.float64 if precision == "f64" else np.float32
+        self.precision = precision
+        self.real = np.float32 if precision == "f32" else np.float64
         assert self.lib.oracle_real_size() == np.dtype(self.real).itemsize
+
+    def set_seed(self, seed):
+        assert self.precision == "mca"
+        self.lib.oracle_set_mca_seed(C.c_uint64(int(seed)))
 
     def _params(self, P, D, M, W, H, tanfovx, tanfovy, scale_modifier):
         return _Params(P, D, M, W, H, tanfovx, tanfovy, scale_modifier)
@@ -82,6 +88,9 @@ class Oracle:
         st.transMat = np.zeros((P, 9), real); st.normal_opacity = np.zeros((P, 4), real)
         st.rgb = np.zeros((P, 3), real); st.clamped = np.zeros((P, 3), np.uint8)
         st.tiles_touched = np.zeros(P, np.uint32)
+        # decision signatures: one word per pixel / surfel identifying the decisions taken there; the AABB extent in front of ceil()
+        st.sig_pix = np.zeros((H, W), np.uint64); st.sig_surf = np.zeros(P, np.uint64); st.extent = np.zeros(P, np.float64)
+        self.lib.oracle_set_signature_buffers(_p(st.sig_pix), _p(st.sig_surf), _p(st.extent))
         R = self.lib.oracle_preprocess(C.byref(prm), _p(means3D), _p(opacities), _p(scales), _p(rotations),
                                        _p(transMat_precomp), _p(colors_precomp), _p(sh), _p(viewmatrix),
                                        _p(projmatrix), _p(campos), _p(st.depths), _p(st.radii), _p(st.xy),
@@ -101,6 +110,7 @@ class Oracle:
         self.lib.oracle_blend_forward(C.byref(prm), _p(st.ranges), _p(st.point_list), _p(st.xy), _p(st.transMat),
                                       _p(transMat_precomp), _p(st.normal_opacity), _p(st.rgb), _p(colors_precomp),
                                       _p(bg), _p(st.out_color), _p(st.out_others), _p(st.final_T), _p(st.n_contrib))
+        self.lib.oracle_set_signature_buffers(None, None, None)
         return st.R, st.out_color, st.out_others, st.radii, st
 
     # ------------------------------------------------------------------ backward

@@ -1,0 +1,148 @@
+"""Which output elements does fp32 arithmetic DETERMINE?  (">= 99.9 % ... threshold-crossing pixels exempt, count reported")
+
+The algorithm takes hard decisions on computed quantities — alpha < 1/255, T (1 - alpha) < 1e-4, rho3d <= rho2d, depth < 0.2,
+T > 0.5 (median), ceil() of the AABB extent, the SH clamp — and its intersection k x l cancels to ~1e-4 relative, so ANY fp32
+implementation (the reference CUDA one included) lands on the other side of a decision for some pairs and carries ~1e-3 relative
+noise on some gradient sums.  Instead of lowering the bar until the measured fraction passes, the tests ask the oracle itself:
+
+  * N_DRAWS Monte-Carlo-arithmetic evaluations of the SAME algorithm (oracle/surfel_oracle.c -DORACLE_MCA: every operation carries
+    a random relative error of at most 2^-24, i.e. one fp32 rounding; same inputs, same sort keys) next to the fp64 evaluation;
+  * an element is DETERMINED if every draw agrees with the fp64 value to within DET_FRAC x the stated tolerance; otherwise it
+    is EXEMPT — fp32 arithmetic does not pin it to the tolerance, whoever implements it;
+  * exempt elements are split by the oracle's decision signatures (which pairs were composited, on which branch, which surfel
+    is the median; radius; SH clamp): FLIPPED (a threshold crossing in at least one draw) or ILL-CONDITIONED (same decisions,
+    cancelling sums);
+  * the device is held to the FULL tolerance on >= PASS_FRAC of the determined elements, cosine >= COS_MIN on them, radii exact
+    wherever the extent is further from an integer than RAD_K x the draws' largest deviation.
+
+The exempt fractions are printed and capped (EXEMPT_CAP), so that the exemption cannot silently swallow a tensor.
+"""
+import numpy as np
+
+from helpers import oracle_forward
+
+N_DRAWS = 3
+DET_FRAC = 0.5
+PASS_FRAC = 0.999
+COS_MIN = 0.9999
+RAD_K = 4.0                 # (8 with fewer than four draws: the largest deviation of two draws underestimates the spread)
+EXEMPT_CAP = 0.25
+IMG_ATOL, IMG_RTOL = 1e-4, 1e-4
+G_ATOL_MEAN, G_RTOL = 1e-4, 2e-3
+
+GRADS = (("means3D", "dL_dmeans3D"), ("scales", "dL_dscales"), ("rots", "dL_drots"), ("opacity", "dL_dopacity"), ("sh", "dL_dsh"), ("means2D", "dL_dmean2D"))
+
+
+def img_tol(ref):
+    return IMG_ATOL + IMG_RTOL * np.abs(ref)
+
+
+def grad_tol(ref):
+    return G_ATOL_MEAN * np.abs(ref).mean() + 1e-30 + G_RTOL * np.abs(ref)
+
+
+class Determinacy:
+    def __init__(self, a, depth_key, n_draws=N_DRAWS, **fw):
+        """a: scene arguments (helpers.scene_args); depth_key: the device's fp32 view depths (sort key of every run);
+        fw: colors_precomp / transMat_precomp / use_sh for oracle_forward."""
+        from oracle.surfel_oracle import Oracle
+        self.o64, self.om = Oracle("f64"), Oracle("mca")
+        self.a, self.dk, self.fw, self.n = a, depth_key, fw, n_draws
+        self.R, self.col, self.oth, self.radii, self.st = oracle_forward(self.o64, a, depth_key=depth_key, **fw)
+        self.draw_st = []
+        for k in range(n_draws):
+            self.om.set_seed(k + 1)
+            self.draw_st.append(oracle_forward(self.om, a, depth_key=depth_key, **fw)[4])
+        ref = self.st
+        self.flip_pix = np.zeros(ref.sig_pix.shape, bool)
+        self.flip_surf = np.zeros(ref.sig_surf.shape, bool)
+        dev = np.zeros(ref.extent.shape)
+        for d in self.draw_st:
+            self.flip_pix |= d.sig_pix != ref.sig_pix
+            self.flip_surf |= (d.sig_surf != ref.sig_surf) | (d.radii != ref.radii) | (d.clamped != ref.clamped).any(1)
+            dev = np.maximum(dev, np.abs(d.extent - ref.extent))
+        # radius = ceil(extent): pinned where the extent stays on its side of the integers under RAD_K x the draws' largest deviation
+        band = (RAD_K if n_draws >= 4 else 2.0 * RAD_K) * dev + 1e-12
+        self.radii_determined = (np.ceil(ref.extent - band) == np.ceil(ref.extent + band)) & np.all([d.radii == ref.radii for d in self.draw_st], 0)
+        self.grads, self.draw_grads = None, None
+
+    def backward(self, gC, gO):
+        self.grads = self.o64.rasterize_backward(self.st, gC, gO)
+        self.draw_grads = []
+        for k, d in enumerate(self.draw_st):
+            self.om.set_seed(1000 + k)
+            self.draw_grads.append(self.om.rasterize_backward(d, gC, gO))
+        return self.grads
+
+    # ---- classification
+    def _determined(self, ref, draws, tol):
+        ok = np.ones(ref.shape, bool)
+        for d in draws:
+            ok &= np.abs(np.asarray(d, np.float64) - ref) <= DET_FRAC * tol
+        return ok
+
+    def image_masks(self):
+        """{name: (ref, determined mask, flipped mask)} for colour and the seven allmap channels."""
+        out = {}
+        ref = self.col
+        out["color"] = (ref, self._determined(ref, [d.out_color for d in self.draw_st], img_tol(ref)), np.broadcast_to(self.flip_pix, ref.shape))
+        for ch in range(7):
+            ref = self.oth[ch]
+            out["others%d" % ch] = (ref, self._determined(ref, [d.out_others[ch] for d in self.draw_st], img_tol(ref)), self.flip_pix)
+        return out
+
+    def grad_masks(self, names=GRADS):
+        out = {}
+        for k, attr in names:
+            ref = getattr(self.grads, attr)
+            det = self._determined(ref, [getattr(g, attr) for g in self.draw_grads], grad_tol(ref))
+            out[k] = (ref, det, np.broadcast_to(self.flip_surf.reshape((-1,) + (1,) * (ref.ndim - 1)), ref.shape))
+        return out
+
+
+def judge(tag, name, x, ref, det, flip, tol, pass_frac=PASS_FRAC, cos_min=COS_MIN):
+    """Hold x to `tol` on the determined elements; print the accounting; returns the row."""
+    x = np.asarray(x, np.float64).reshape(ref.shape)
+    assert np.isfinite(x).all(), name
+    bad = np.abs(x - ref) > tol
+    n_det = int(det.sum())
+    exempt = 1.0 - n_det / det.size
+    flipped = float((~det & flip).sum()) / max(1, det.size - n_det)
+    f_det = 1.0 - float((bad & det).sum()) / max(1, n_det)
+    f_all = 1.0 - float(bad.mean())
+    xd, rd = x[det], ref[det]
+    den = np.sqrt((xd * xd).sum() * (rd * rd).sum())
+    cs = float((xd * rd).sum() / den) if den > 0 else 1.0
+    print("%s %-8s: determined %.5f pass (all elements %.5f) | exempt %.5f of elements, %.0f %% of them with a flipped decision | cosine %.7f"
+          % (tag, name, f_det, f_all, exempt, 100 * flipped, cs))
+    assert exempt <= EXEMPT_CAP, "%s %s: %.3f of the elements are exempt — the probe, not the device, needs a look" % (tag, name, exempt)
+    assert f_det >= pass_frac, "%s %s: only %.5f of the fp32-determined elements within tolerance" % (tag, name, f_det)
+    assert cs >= cos_min, "%s %s: cosine %.7f on the fp32-determined elements" % (tag, name, cs)
+    return dict(name=name, determined_pass=f_det, all_pass=f_all, exempt=exempt, exempt_flipped=flipped, cosine=cs)
+
+
+def judge_images(tag, det, color, others, pass_frac=PASS_FRAC):
+    m = det.image_masks()
+    rows = [judge(tag, "color", color, *m["color"], img_tol(m["color"][0]), pass_frac)]
+    for ch in range(7):
+        r = m["others%d" % ch]
+        rows.append(judge(tag, "others%d" % ch, others[ch], *r, img_tol(r[0]), pass_frac))
+    return rows
+
+
+def judge_grads(tag, det, g, names=GRADS, pass_frac=PASS_FRAC, cos_min=COS_MIN):
+    m = det.grad_masks(names)
+    return [judge(tag, k, g[k], *m[k], grad_tol(m[k][0]), pass_frac, cos_min) for k, _ in names]
+
+
+def judge_radii(tag, det, radii_dev, R_dev):
+    """Radii exact wherever fp32 pins the extent's ceil(); the device's instance count is the exact-cull subset of the rect count."""
+    got = np.asarray(radii_dev)
+    rd = det.radii_determined
+    diff = got != det.radii
+    print("%s radii   : %d of %d differ, %d of those on pinned extents | exempt (extent within fp32 noise of an integer) %.5f"
+          % (tag, int(diff.sum()), diff.size, int((diff & rd).sum()), 1.0 - rd.mean()))
+    assert not (diff & rd).any(), "%s: %d radii differ where fp32 determines them" % (tag, int((diff & rd).sum()))
+    assert 1.0 - rd.mean() <= EXEMPT_CAP
+    # a radius off by one grows the rect by at most one ring of tiles
+    assert R_dev <= det.R + 8 * int(diff.sum()), (R_dev, det.R)

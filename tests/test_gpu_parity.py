@@ -1,34 +1,33 @@
 """-m gpu parity tests: libsurfel_hip.so (through its C ABI) against the fp64 CPU oracle.
 
-Stated fp32 tolerance (device fp32 vs oracle fp64):
+Stated fp32 tolerance (device fp32 vs oracle fp64), the same in every test of this file:
   element test  : images |d| <= 1e-4 + 1e-4*|ref| ; grads |d| <= 1e-4*mean|ref| + 2e-3*|ref|
-  small scenes  : >= 99.9 % of pixels / gradient elements pass (or <= 3 surfels off), cosine >= 0.9999,
-                  radii and instance count exact
-  config sizes  : (C1 10k/256^2, C2 300k/800^2, C3 200k/800x600, C4 2M/1600x1060)  >= 99.8 % of pixels, >= 98.5 % of gradient elements,
-                  cosine >= 0.999, radii mismatch <= 0.5 %  — AND never worse than the SAME algorithm run in
-                  fp32 on the CPU (oracle -DORACLE_F32) by more than 0.2 % of elements.
-Why the config-size bars are looser: the algorithm itself (as upstream states it) is ill-conditioned in fp32 —
-the AABB half-extent is cx^2 - sum(f*Tu*Tu) (cancellation of ~1e5-sized terms, so ceil(radius) flips for ~0.1 % of
-surfels) and k = px*Tw - Tu cancels to ~1e-4 relative — so ANY fp32 implementation, including the reference CUDA
-one, differs from fp64 on the (pixel, surfel) pairs that sit on the 1/255, 1e-4 or rho3d<=rho2d thresholds.
-scripts/diag_precision.py prints both columns; measured deviation of the HIP path is <= the CPU-fp32 one.
-The device's float32 view depths are injected into the oracle as the sort key so both sides order
-near-ties identically.
+  bar           : >= 99.9 % of the fp32-DETERMINED elements pass (C5: >= 99.5 %), cosine >= 0.9999 on them, radii exact wherever
+                  fp32 pins the extent's ceil() — SURVEY.md 8d's formulation: "threshold-crossing pixels exempt, count reported".
+Which elements are exempt is not fitted to the device's results: tests/determinacy.py asks the ORACLE — N Monte-Carlo-arithmetic
+evaluations of the same algorithm (every operation with a random fp32-sized rounding error) next to the fp64 one; an element is
+determined if all of them agree with fp64 to within half the tolerance.  The exempt elements are counted per tensor and split
+into "a decision flipped in some draw" (alpha < 1/255, T(1-alpha) < 1e-4, rho3d <= rho2d, depth < 0.2, T > 0.5, ceil(extent), SH
+clamp — by the oracle's decision signatures) and "same decisions, ill-conditioned sums" (k = px*Tw - Tu cancels to ~1e-4 relative;
+cx^2 - sum(f*Tu*Tu) in the AABB).  Small scenes are additionally held on ALL elements (>= 99.9 % or <= 3 surfels off).  As a second
+yardstick the config-size tests print the same algorithm run in plain fp32 on the CPU (oracle -DORACLE_F32) and require the
+device's all-element fraction to be no more than 0.2 % below it.
+The device's float32 view depths are injected into every oracle run as the sort key so all sides order near-ties identically.
 """
 import numpy as np
 import pytest
 
+import determinacy as D
 from helpers import HipRun, cosine, frac_close, oracle_forward, scene_args
 
 pytestmark = pytest.mark.gpu
 
-IMG_ATOL, IMG_RTOL, IMG_FRAC = 1e-4, 1e-4, 0.999
+IMG_ATOL, IMG_RTOL, IMG_FRAC = D.IMG_ATOL, D.IMG_RTOL, D.PASS_FRAC
 LARGE_SORT_DEFAULT = 2          # surfel_set_option("large_sort") default of the library (profiles/r02_large_sort.md)
-G_RTOL, G_FRAC, G_COS = 2e-3, 0.999, 0.9999
-GOLDEN_IMG_FRAC, GOLDEN_G_FRAC, GOLDEN_G_COS = 0.9995, 0.997, 0.99999      # test_golden_fixture: measured 1.00000 / 1.00000 / 1.0000000 on every tensor (512 surfels, 64x48)
-DIST_G_FRAC = {1000.0: 0.995, 30000.0: 0.96}      # test_distortion_dominated_gradients: floors = the measured minima (0.99733 / 0.96570, C1 scan) - 0.3 / 0.6 %; the fp32 CPU run of the oracle scores 0.99617 / 0.94700 there
-DTU_G_FRAC = 0.993         # test_dtu_gradient_regime_parity: measured 0.99634 (means3D, scan) ... 0.99997 (sh); fp32 CPU run 0.99420 ... 0.99992
-TRAINED_G_FRAC = 0.992     # test_trained_state_parity: measured 0.99565 (means3D) ... 0.99963 (sh) on every walk, the fp32 CPU run of the oracle 0.99510 ... 0.99959
+G_RTOL, G_FRAC, G_COS = D.G_RTOL, D.PASS_FRAC, D.COS_MIN
+GOLDEN_IMG_FRAC, GOLDEN_G_FRAC, GOLDEN_G_COS = 0.9995, 0.999, 0.99999      # test_golden_fixture (512 surfels, 64x48): all elements, no exemption
+C5_PASS_FRAC = 0.995        # SURVEY 8d's bar at the 10 M-surfel stress size (2 draws there: fewer exempt elements found, a looser bar on the rest)
+STRESS_EXEMPT_CAP = 0.6     # scenes BUILT to be ill-conditioned (distortion gradient x 30 000, discs of hundreds of pixels): the probe may exempt more
 
 
 def _scene(name_or_dims, seed=0, **kw):
@@ -42,22 +41,10 @@ def _scene(name_or_dims, seed=0, **kw):
 
 
 def _check_binning(run, R, radii):
-    """fp32 device vs fp64 oracle: a surfel whose extent sits within fp32 noise of an integer may ceil() differently
-    (module doc), so allow <= 0.5 % of radii to differ by 1 (and the instance count to move accordingly)."""
+    """Small scenes: radii exact.  The device emits a (tile, surfel) instance only where the surfel's alpha >= 1/255 bbox reaches the
+    tile, so its instance count is a subset of the reference rect count the oracle reports.  (Config sizes: determinacy.judge_radii.)"""
     got = run.radii.cpu().numpy()
-    diff = got != radii
-    assert diff.mean() <= 5e-3, "radii mismatch fraction %.6f" % diff.mean()
-    if diff.any():
-        both = diff & (got > 0) & (radii > 0)
-        # (a radius of tens of thousands of pixels — a disc that all but touches the camera plane, seen on trained states — carries the
-        # fp32 error of its ill-conditioned projection: 2.5e-4 relative beyond 4096 px; its rect is the whole screen either way)
-        allow = np.where(radii[both] > 4096, np.ceil(2.5e-4 * radii[both]), 1)
-        assert (np.abs(got[both].astype(np.int64) - radii[both]) <= allow).all()
-    # The device emits a (tile, surfel) instance only where the surfel's alpha>=1/255 bbox reaches the tile, so its
-    # instance count is a subset of the reference rect count the oracle reports.
-    assert run.R <= R + 8 * int(diff.sum()), (run.R, R)
-    if got.size <= 4096:
-        assert not diff.any() and run.R <= R            # small scenes: radii exact
+    assert np.array_equal(got, radii) and run.R <= R, (int((got != radii).sum()), run.R, R)
 
 
 def _check_images(run, col, oth, st):
@@ -130,9 +117,17 @@ def test_golden_fixture(golden):
         assert fr >= GOLDEN_G_FRAC and cs >= GOLDEN_G_COS, "%s: frac %.5f cosine %.7f" % (k, fr, cs)
     # the reference's own in-tree transMat (gaussian_renderer/__init__.py:64-75) fed as cov3D_precomp must
     # render the same colour image as the native scale/rotation path (SURVEY.md §4 self-consistency)
+    # ... at the stated image tolerance, on the pixels fp32 determines, colour AND depth / alpha / median depth / distortion (the precomp
+    # path carries no normal: channels 2-4 differ by design): the reference's T (torch fp32) and the kernel's T differ by roundings
     run2 = HipRun(a, transMat_precomp=golden["ref_cov3D_precomp"]).forward()
-    c1, c2 = run.color.cpu().numpy(), run2.color.cpu().numpy()
-    assert frac_close(c2, c1, 2e-3, 2e-3) >= 0.99
+    det = D.Determinacy(a, run.depths(), n_draws=5)
+    D.judge_images("golden native", det, run.color.cpu().numpy(), run.others.cpu().numpy())
+    m = det.image_masks()
+    c2, o2 = run2.color.cpu().numpy(), run2.others.cpu().numpy()
+    D.judge("golden cov3D_precomp twin", "color", c2, *m["color"], D.img_tol(m["color"][0]))
+    for ch in (0, 1, 5, 6):
+        r = m["others%d" % ch]
+        D.judge("golden cov3D_precomp twin", "others%d" % ch, o2[ch], *r, D.img_tol(r[0]))
 
 
 def _check_depths(run, st, radii):
@@ -146,49 +141,49 @@ def _check_depths(run, st, radii):
     assert err.max() <= 4e-6 and np.median(err / st.depths[vis]) <= 1.2e-7, (err.max(), np.median(err / st.depths[vis]))
 
 
+CONFIG_DRAWS = {"C1": 5, "C2": 5, "C3": 5, "C4": 4}
+
+
+def _yardstick(tag, name, x, ref, r32, tol):
+    """All elements (no exemption) next to the same algorithm in plain fp32 on the CPU: the device is never worse by more than 0.2 %."""
+    x = np.asarray(x, np.float64).reshape(ref.shape)
+    f = float((np.abs(x - ref) <= tol).mean()); f32 = float((np.abs(np.asarray(r32, np.float64) - ref) <= tol).mean())
+    print("%s %-8s: all elements hip %.5f cpu-fp32 %.5f" % (tag, name, f, f32))
+    assert f >= f32 - 0.002, "%s %s: hip %.5f, cpu-fp32 %.5f" % (tag, name, f, f32)
+
+
 @pytest.mark.parametrize("name", ["C1", "C2", "C3", "C4"])
 def test_config_sizes(name):
     """BASELINE configs 1-4 shapes (10k/256^2, 300k/800^2, 200k/800x600 = DTU -r 2 /root/reference/scripts/dtu_eval.py:23,
-    2M/1600x1060 = the width-1600 cap of /root/reference/utils/camera_utils.py:25-33): fp64 oracle, with the fp32 CPU run of the
-    same algorithm as the yardstick for what fp32 arithmetic alone costs (module doc).  At C3 / C4 both binning paths are forced
-    and must agree bit for bit (C4 takes the > 1 M-item three-launch sort)."""
+    2M/1600x1060 = the width-1600 cap of /root/reference/utils/camera_utils.py:25-33) against the fp64 oracle under the module's bar:
+    >= 99.9 % of the fp32-determined elements, cosine >= 0.9999, radii exact where pinned, exempt fractions printed (determinacy.py);
+    the fp32 CPU run of the same algorithm as the all-element yardstick.  At C3 / C4 both binning paths are forced and must agree
+    bit for bit (C4 takes the > 1 M-item three-launch sort)."""
     import surfel_native as n
     from oracle.surfel_oracle import Oracle
     sc = _scene(name)
     a = scene_args(sc)
     run = HipRun(a).forward()
     dk = run.depths()
-    o64, o32 = Oracle("f64"), Oracle("f32")
-    R, col, oth, radii, st = oracle_forward(o64, a, depth_key=dk)
+    det = D.Determinacy(a, dk, n_draws=CONFIG_DRAWS[name])
+    R, col, oth, radii, st = det.R, det.col, det.oth, det.radii, det.st
+    o32 = Oracle("f32")
     R32, col32, oth32, radii32, st32 = oracle_forward(o32, a, depth_key=dk)
-    _check_binning(run, R, radii)
+    D.judge_radii(name, det, run.radii.cpu().numpy(), run.R)
     _check_depths(run, st, radii)
     c = run.color.cpu().numpy(); o = run.others.cpu().numpy()
-    assert np.isfinite(c).all() and np.isfinite(o).all()
+    D.judge_images(name, det, c, o)
     for nm, x, x32, ref in [("color", c, col32, col)] + [("others%d" % i, o[i], oth32[i], oth[i]) for i in range(7)]:
-        f, f32 = frac_close(x, ref, IMG_ATOL, IMG_RTOL), frac_close(x32, ref, IMG_ATOL, IMG_RTOL)
-        assert f >= 0.998 and f >= f32 - 0.002, "%s: hip %.5f, cpu-fp32 %.5f" % (nm, f, f32)
-        print("%s %s: pixel frac hip %.5f cpu-fp32 %.5f" % (name, nm, f, f32))
+        _yardstick(name, nm, x, ref, x32, D.img_tol(ref))
     rng = np.random.default_rng(9)
     gC = rng.normal(size=col.shape).astype(np.float32); gO = rng.normal(size=oth.shape).astype(np.float32)
     g = run.backward(gC, gO)
-    og, og32 = o64.rasterize_backward(st, gC, gO), o32.rasterize_backward(st32, gC, gO)
+    og, og32 = det.backward(gC, gO), o32.rasterize_backward(st32, gC, gO)
 
     def check(g, walk):
-        for k, ref, r32 in [("means3D", og.dL_dmeans3D, og32.dL_dmeans3D), ("scales", og.dL_dscales, og32.dL_dscales),
-                            ("rots", og.dL_drots, og32.dL_drots), ("opacity", og.dL_dopacity, og32.dL_dopacity),
-                            ("sh", og.dL_dsh, og32.dL_dsh), ("means2D", og.dL_dmean2D, og32.dL_dmean2D)]:
-            x = g[k].reshape(ref.shape)
-            assert np.isfinite(x).all(), k
-            scale = np.abs(ref).mean()
-            f, f32 = frac_close(x, ref, 1e-4 * scale, G_RTOL), frac_close(r32, ref, 1e-4 * scale, G_RTOL)
-            cs, cs32 = cosine(x, ref), cosine(r32, ref)
-            # (bar = the measured minimum — 0.99006, C2 dL/drots; C3 0.99172, C4 0.99602, C1 0.99727 — minus 0.3 %)
-            assert f >= 0.987 and f >= f32 - 0.002, "%s %s: hip %.5f, cpu-fp32 %.5f" % (walk, k, f, f32)
-            # the cosine of the ill-conditioned tensors (the means2D statistic above all) is dominated by a handful of edge-on
-            # surfels whose fp32 value swings with the last bit of T; like `f`, it is judged against the fp32 CPU run as well
-            assert cs >= 0.999 or cs >= cs32 - 1e-3, "%s %s cosine hip %.7f, cpu-fp32 %.7f" % (walk, k, cs, cs32)
-            print("%s %s %s: frac hip %.5f cpu-fp32 %.5f | cosine hip %.7f cpu-fp32 %.7f" % (name, walk, k, f, f32, cs, cs32))
+        D.judge_grads("%s %s" % (name, walk), det, g)
+        for k, attr in D.GRADS:
+            _yardstick("%s %s" % (name, walk), k, g[k], getattr(og, attr), getattr(og32, attr), D.grad_tol(getattr(og, attr)))
 
     check(g, "auto")
     run.debug = n.OPT_BWD_SCAN          # the scan walk is held to the same bars
@@ -240,21 +235,13 @@ def _trained_state(W, H, iters, lambda_dist, view=3, seed=0):
     return a, cam
 
 
-def _walk_table(tag, run, gC, gO, og, og32, bar):
+def _walk_table(tag, run, gC, gO, det, cap=D.EXEMPT_CAP):
+    """Every blend_bwd walk under the module's bar on the fp32-determined elements of `det` (its backward has been run on gC, gO)."""
     import surfel_native as n
     for walk, flag in (("rows", n.OPT_BWD_ROWS), ("quad", n.OPT_BWD_QUAD), ("scan", n.OPT_BWD_SCAN), ("auto", 0)):
         run.debug = flag
         g = run.backward(gC, gO)
-        for k, ref, r32 in [("means3D", og.dL_dmeans3D, og32.dL_dmeans3D), ("scales", og.dL_dscales, og32.dL_dscales), ("rots", og.dL_drots, og32.dL_drots),
-                            ("opacity", og.dL_dopacity, og32.dL_dopacity), ("sh", og.dL_dsh, og32.dL_dsh), ("means2D", og.dL_dmean2D, og32.dL_dmean2D)]:
-            x = g[k].reshape(ref.shape)
-            assert np.isfinite(x).all(), k
-            scale = np.abs(ref).mean()
-            fr, f32 = frac_close(x, ref, 1e-4 * scale, G_RTOL), frac_close(r32, ref, 1e-4 * scale, G_RTOL)
-            cs, cs32 = cosine(x, ref), cosine(r32, ref)
-            print("%s %s %s: frac hip %.5f cpu-fp32 %.5f | cosine hip %.7f cpu-fp32 %.7f" % (tag, walk, k, fr, f32, cs, cs32))
-            assert fr >= bar and fr >= f32 - 0.003, "%s %s: hip %.5f, cpu-fp32 %.5f" % (walk, k, fr, f32)
-            assert cs >= 0.999 or cs >= cs32 - 1e-3, "%s %s cosine hip %.7f, cpu-fp32 %.7f" % (walk, k, cs, cs32)
+        D.judge_grads("%s %s" % (tag, walk), det, g)
     run.debug = 0
 
 
@@ -262,8 +249,8 @@ def test_trained_state_parity():
     """The regime that dominates every realistic leg: a TRAINED state — wide faint discs, needles, early
     saturation, hundreds of instances on the centre tiles — at 800x800, not random surfels.  1 500 iterations of the reference
     schedule (densification from 500) on a synthetic capture, then one training view of that model: all ten channels and every
-    gradient of the rows / quad / scan walks against the fp64 oracle, with the fp32 CPU run of the same algorithm as the yardstick
-    (as test_config_sizes); the measured fractions are printed."""
+    gradient of the rows / quad / scan walks against the fp64 oracle under the module's bar (fp32-determined elements, exempt
+    fractions printed)."""
     import torch
     from oracle.surfel_oracle import Oracle
     W = H = 800
@@ -271,26 +258,20 @@ def test_trained_state_parity():
     P = a["means3D"].shape[0]
     run = HipRun(a).forward()
     dk = run.depths()
-    o64, o32 = Oracle("f64"), Oracle("f32")
-    R, col, oth, radii, st = oracle_forward(o64, a, depth_key=dk)
-    R32, col32, oth32, radii32, st32 = oracle_forward(o32, a, depth_key=dk)
+    det = D.Determinacy(a, dk, n_draws=4)
+    R, col, oth, radii, st = det.R, det.col, det.oth, det.radii, det.st
     gx, gy = (W + 15) // 16, (H + 15) // 16
     ranges = run.ia.last()[:gx * gy * 8].view(torch.int32).view(-1, 2).cpu().numpy()
     lens = ranges[:, 1] - ranges[:, 0]
     print("trained state: %d surfels, R %d (%.1f per surfel), longest tile list %d, empty tiles %d of %d" % (P, run.R, run.R / P, lens.max(), int((lens == 0).sum()), lens.size))
     assert P > 30_000 and run.R > 4 * P and lens.max() > 300      # the regime: many instances per surfel, long centre lists
-    _check_binning(run, R, radii)
+    D.judge_radii("trained", det, run.radii.cpu().numpy(), run.R)
     _check_depths(run, st, radii)
-    c = run.color.cpu().numpy(); o = run.others.cpu().numpy()
-    assert np.isfinite(c).all() and np.isfinite(o).all()
-    for nm, x, x32, ref in [("color", c, col32, col)] + [("others%d" % i, o[i], oth32[i], oth[i]) for i in range(7)]:
-        fr, f32 = frac_close(x, ref, IMG_ATOL, IMG_RTOL), frac_close(x32, ref, IMG_ATOL, IMG_RTOL)
-        print("trained %s: pixel frac hip %.5f cpu-fp32 %.5f" % (nm, fr, f32))
-        assert fr >= 0.998 and fr >= f32 - 0.002, "%s: hip %.5f, cpu-fp32 %.5f" % (nm, fr, f32)
+    D.judge_images("trained", det, run.color.cpu().numpy(), run.others.cpu().numpy())
     rg = np.random.default_rng(9)
     gC = rg.normal(size=col.shape).astype(np.float32); gO = rg.normal(size=oth.shape).astype(np.float32)
-    og, og32 = o64.rasterize_backward(st, gC, gO), o32.rasterize_backward(st32, gC, gO)
-    _walk_table("trained", run, gC, gO, og, og32, TRAINED_G_FRAC)
+    det.backward(gC, gO)
+    _walk_table("trained", run, gC, gO, det)
 
 
 def test_dtu_gradient_regime_parity():
@@ -299,7 +280,7 @@ def test_dtu_gradient_regime_parity():
     DTU -r 2 shape 800x600, and upstream gradients that are the REAL loss's (/root/reference/train.py:77-88: L1 + SSIM on the colour,
     lambda_normal x normal consistency and lambda_dist x distortion through the allmap post-processing), produced by the product's own
     fused loss launch on this frame — not N(0,1) on ten channels.  rows / quad / scan / auto against the fp64 oracle on those same
-    upstream gradients, the fp32 CPU run of the oracle as the yardstick; the ratio |g_dist| / |g_colour| is printed."""
+    upstream gradients under the module's bar; the ratio |g_dist| / |g_colour| is printed."""
     import torch
     import surfel_losses as L
     from oracle.surfel_oracle import Oracle
@@ -308,9 +289,8 @@ def test_dtu_gradient_regime_parity():
     P = a["means3D"].shape[0]
     run = HipRun(a).forward()
     dk = run.depths()
-    o64, o32 = Oracle("f64"), Oracle("f32")
-    R, col, oth, radii, st = oracle_forward(o64, a, depth_key=dk)
-    R32, col32, oth32, radii32, st32 = oracle_forward(o32, a, depth_key=dk)
+    det = D.Determinacy(a, dk, n_draws=4)
+    R, col, oth, radii, st = det.R, det.col, det.oth, det.radii, det.st
     assert P > 30_000 and run.R > 4 * P
     with torch.no_grad():
         lctx, total, scalars = L.train_loss_manual(run.color, run.others, cam.original_image, cam.post_consts(), 1.0, 0.2, 0.05, 1000.0, defer_scalars=False)
@@ -322,39 +302,27 @@ def test_dtu_gradient_regime_parity():
     print("DTU regime: %d surfels, R %d, loss terms %s, mean |g_dist| / mean |g_colour| = %.0f, |g_normal| / |g_colour| = %.2f" %
           (P, run.R, np.round(scalars.cpu().numpy(), 5).tolist(), ratio, float(np.abs(gO[2:5]).mean() / np.abs(gC).mean())))
     assert ratio > 300.0      # the regime: the distortion gradient dominates the colour gradient by orders of magnitude
-    og, og32 = o64.rasterize_backward(st, gC, gO), o32.rasterize_backward(st32, gC, gO)
-    _walk_table("DTU", run, gC, gO, og, og32, DTU_G_FRAC)
+    det.backward(gC, gO)
+    _walk_table("DTU", run, gC, gO, det)
 
 
 def test_config_c5_stress():
     """BASELINE config 5 (10 M surfels, 3840x2160, ~1e8 tile instances: 32-bit offsets, the > 1 M-item sort on both levels):
-    instance count, radii, depths, all ten image channels and every gradient against the fp64 oracle."""
-    from oracle.surfel_oracle import Oracle
+    instance count, radii, depths, all ten image channels and every gradient against the fp64 oracle: >= 99.5 % of the
+    fp32-determined elements (two Monte-Carlo-arithmetic draws at this size), cosine >= 0.9999."""
     sc = _scene("C5")
     a = scene_args(sc)
     run = HipRun(a).forward()
-    o64 = Oracle("f64")
-    R, col, oth, radii, st = oracle_forward(o64, a, depth_key=run.depths())
+    det = D.Determinacy(a, run.depths(), n_draws=2)
     assert run.R > 50_000_000
-    _check_binning(run, R, radii)
-    _check_depths(run, st, radii)
-    c = run.color.cpu().numpy(); o = run.others.cpu().numpy()
-    assert np.isfinite(c).all() and np.isfinite(o).all()
-    for nm, x, ref in [("color", c, col)] + [("others%d" % i, o[i], oth[i]) for i in range(7)]:
-        f = frac_close(x, ref, IMG_ATOL, IMG_RTOL)
-        print("C5 %s: pixel frac %.5f" % (nm, f))
-        assert f >= 0.995, "%s: %.5f" % (nm, f)
+    D.judge_radii("C5", det, run.radii.cpu().numpy(), run.R)
+    _check_depths(run, det.st, det.radii)
+    D.judge_images("C5", det, run.color.cpu().numpy(), run.others.cpu().numpy(), pass_frac=C5_PASS_FRAC)
     rng = np.random.default_rng(9)
-    gC = rng.normal(size=col.shape).astype(np.float32); gO = rng.normal(size=oth.shape).astype(np.float32)
+    gC = rng.normal(size=det.col.shape).astype(np.float32); gO = rng.normal(size=det.oth.shape).astype(np.float32)
     g = run.backward(gC, gO)
-    og = o64.rasterize_backward(st, gC, gO)
-    for k, ref in [("means3D", og.dL_dmeans3D), ("scales", og.dL_dscales), ("rots", og.dL_drots), ("opacity", og.dL_dopacity),
-                   ("sh", og.dL_dsh)]:
-        x = g[k].reshape(ref.shape)
-        assert np.isfinite(x).all(), k
-        f, cs = frac_close(x, ref, 1e-4 * np.abs(ref).mean(), G_RTOL), cosine(x, ref)
-        print("C5 %s: frac %.5f cosine %.7f" % (k, f, cs))
-        assert f >= 0.97 and cs >= 0.995, "%s: frac %.5f cosine %.7f" % (k, f, cs)
+    det.backward(gC, gO)
+    D.judge_grads("C5", det, g, pass_frac=C5_PASS_FRAC)
 
 
 def test_precomp_and_override_color():
@@ -568,16 +536,11 @@ def test_heavy_surfels_are_gathered_by_the_wave():
     for r in res[1:]:
         for k in res[0]:
             assert np.array_equal(res[0][k], r[k]), "dL/d%s differs between the gather / tail variants" % k
-    o = Oracle("f64")
-    R, col, oth, radii, st = oracle_forward(o, a, depth_key=run.depths())
-    _check_images(run, col, oth, st)
-    # discs of hundreds of pixels are the ill-conditioned end of the algorithm in fp32 (module doc): the config-size bars
-    og = o.rasterize_backward(st, gC, gO)
-    for k, ref in [("means3D", og.dL_dmeans3D), ("opacity", og.dL_dopacity), ("sh", og.dL_dsh), ("means2D", og.dL_dmean2D),
-                   ("scales", og.dL_dscales), ("rots", og.dL_drots)]:
-        x = res[0][k].reshape(ref.shape)
-        f, cs = frac_close(x, ref, 1e-4 * np.abs(ref).mean() + 1e-12, G_RTOL), cosine(x, ref)
-        assert f >= 0.985 and cs >= 0.99999, "%s: %.5f of elements within tolerance, cosine %.8f" % (k, f, cs)
+    # discs of hundreds of pixels are the ill-conditioned end of the algorithm in fp32: the module's bar on the fp32-determined elements
+    det = D.Determinacy(a, run.depths(), n_draws=5)
+    D.judge_images("heavy", det, run.color.cpu().numpy(), run.others.cpu().numpy())
+    det.backward(gC, gO)
+    D.judge_grads("heavy", det, res[0])
 
 
 def _clustered_scene(P=30000, W=400, H=304, seed=17, shrink=0.3):
@@ -902,7 +865,7 @@ def test_distortion_dominated_gradients(kind, gscale):
     (/root/reference/scripts/dtu_eval.py:23, loss at /root/reference/train.py:77-88) dL/d(distortion map) is thousands of times the
     colour gradient, and the distortion term of a pair's u — mm^2 A - 2 mm M1 + M2, a variance-like form whose large terms cancel —
     dominates dL/dalpha.  Every walk against the fp64 oracle with N(0,1) gradients on nine channels and N(0,1) x gscale on the
-    distortion channel; the yardstick is the same algorithm in fp32 on the CPU (oracle -DORACLE_F32), as in test_config_sizes."""
+    distortion channel, under the module's bar on the fp32-determined elements (determinacy.py)."""
     import surfel_native as n
     import synthetic
     from oracle.surfel_oracle import Oracle
@@ -916,24 +879,19 @@ def test_distortion_dominated_gradients(kind, gscale):
     gC = rng.normal(size=(3, a["H"], a["W"])).astype(np.float32); gO = rng.normal(size=(7, a["H"], a["W"])).astype(np.float32)
     gO[6] *= gscale
     run = HipRun(a).forward()
-    dk = run.depths()
-    o64, o32 = Oracle("f64"), Oracle("f32")
-    _, _, _, _, st = oracle_forward(o64, a, depth_key=dk)
-    _, _, _, _, st32 = oracle_forward(o32, a, depth_key=dk)
-    og, og32 = o64.rasterize_backward(st, gC, gO), o32.rasterize_backward(st32, gC, gO)
+    det = D.Determinacy(a, run.depths(), n_draws=5)
+    det.backward(gC, gO)
+    names = tuple(x for x in D.GRADS if x[0] != "means2D")
+    m = det.grad_masks(names)
     for walk, flag in (("rows", n.OPT_BWD_ROWS), ("quad", n.OPT_BWD_QUAD), ("scan", n.OPT_BWD_SCAN)):
         run.debug = flag
         g = run.backward(gC, gO)
-        for k, ref, r32 in [("means3D", og.dL_dmeans3D, og32.dL_dmeans3D), ("scales", og.dL_dscales, og32.dL_dscales), ("rots", og.dL_drots, og32.dL_drots),
-                            ("opacity", og.dL_dopacity, og32.dL_dopacity), ("sh", og.dL_dsh, og32.dL_dsh)]:
-            x = g[k].reshape(ref.shape)
-            assert np.isfinite(x).all(), k
-            scale = np.abs(ref).mean() + 1e-30
-            fr, f32 = frac_close(x, ref, 1e-4 * scale, G_RTOL), frac_close(r32, ref, 1e-4 * scale, G_RTOL)
-            cs, cs32 = cosine(x, ref), cosine(r32, ref)
-            print("g_dist x%g %s %s %s: frac hip %.5f cpu-fp32 %.5f | cosine hip %.7f cpu-fp32 %.7f" % (gscale, kind, walk, k, fr, f32, cs, cs32))
-            assert fr >= DIST_G_FRAC[gscale] and fr >= f32 - 0.005, "%s %s %s: hip %.5f, cpu-fp32 %.5f" % (kind, walk, k, fr, f32)
-            assert cs >= 0.9999 or cs >= cs32 - 1e-4, "%s %s %s cosine hip %.7f, cpu-fp32 %.7f" % (kind, walk, k, cs, cs32)
+        old_cap, D.EXEMPT_CAP = D.EXEMPT_CAP, STRESS_EXEMPT_CAP      # (built to be ill-conditioned: the probe may exempt more here)
+        try:
+            for k, _ in names:
+                D.judge("g_dist x%g %s %s" % (gscale, kind, walk), k, g[k], *m[k], D.grad_tol(m[k][0]))
+        finally:
+            D.EXEMPT_CAP = old_cap
 
 
 @pytest.mark.parametrize("kind", ["plain", "needles", "huge", "tiny", "opaque_faint", "huge_faint"])
@@ -1339,3 +1297,87 @@ def test_tile_band_sharding_on_device():
         acc = gb if acc is None else [x + y for x, y in zip(acc, gb)]
     for got, ref in zip(acc, g_full):
         assert cosine(got.cpu().numpy(), ref.cpu().numpy()) > 0.9999
+
+
+def test_interleaved_forwards_and_backwards():
+    """SURVEY 8b's threading convention: forward -> backward state travels with the call's own buffers, so several forwards may sit
+    between a forward and its backward (/root/reference/train.py:211: training_report re-renders under no_grad between iterations;
+    any caller may hold two graphs).  The library's process-wide state that could break this — the tile-stream registry, the lazy-count
+    word, the per-size capacity history, the backward-walk word in the image buffer — is exercised: forward A (800x800), forward B
+    (another size, on a side stream), a no_grad re-render of A and of B (no stream left behind: SURFEL_OPT_NO_STREAM), backward A,
+    backward B (side stream).  Images and every gradient must equal the un-interleaved run BIT FOR BIT, through the drop-in autograd
+    module and through the C ABI."""
+    import torch
+    import synthetic
+    from diff_surfel_rasterization import GaussianRasterizationSettings, GaussianRasterizer
+    dev = torch.device("cuda:0")
+    t = lambda x: torch.tensor(x, device=dev)
+    scenes = {"A": scene_args(synthetic.make_scene(40_000, 800, 800, seed=21, px_radius=5.0)),
+              "B": scene_args(synthetic.make_scene(9_000, 336, 208, seed=22, px_radius=6.0))}
+    rngs = np.random.default_rng(4)
+    ups = {k: (t(rngs.normal(size=(3, a["H"], a["W"])).astype(np.float32)), t(rngs.normal(size=(7, a["H"], a["W"])).astype(np.float32))) for k, a in scenes.items()}
+
+    def module_call(a, grad=True):
+        rs = GaussianRasterizationSettings(image_height=a["H"], image_width=a["W"], tanfovx=a["tanfovx"], tanfovy=a["tanfovy"], bg=t(a["bg"]),
+                                           scale_modifier=1.0, viewmatrix=t(a["viewmatrix"]), projmatrix=t(a["projmatrix"]), sh_degree=3,
+                                           campos=t(a["campos"]), prefiltered=False, debug=False)
+        p = {k: t(a[k]).requires_grad_(grad) for k in ("means3D", "shs", "opacities", "scales", "rotations")}
+        m2 = torch.zeros_like(p["means3D"], requires_grad=grad)
+        color, radii, allmap = GaussianRasterizer(raster_settings=rs)(means3D=p["means3D"], means2D=m2, shs=p["shs"], colors_precomp=None, opacities=p["opacities"],
+                                                                      scales=p["scales"], rotations=p["rotations"], cov3D_precomp=None)
+        p["means2D"] = m2
+        return p, color, radii, allmap
+
+    def finish(p, color, allmap, up):
+        torch.autograd.backward([color, allmap], [up[0], up[1]])
+        torch.cuda.synchronize()
+        return {k: v.grad.detach().cpu().numpy().copy() for k, v in p.items()}, color.detach().cpu().numpy().copy(), allmap.detach().cpu().numpy().copy()
+
+    # un-interleaved
+    base = {}
+    for k, a in scenes.items():
+        p, color, radii, allmap = module_call(a)
+        base[k] = finish(p, color, allmap, ups[k])
+    # interleaved
+    side = torch.cuda.Stream(device=dev)
+    pA, cA, rA, mA = module_call(scenes["A"])
+    side.wait_stream(torch.cuda.current_stream(dev))
+    with torch.cuda.stream(side):
+        pB, cB, rB, mB = module_call(scenes["B"])
+    with torch.no_grad():      # train.py:211-style re-renders between a forward and its backward
+        _, c2, _, m2_ = module_call(scenes["A"], grad=False)
+        _, c3, _, m3_ = module_call(scenes["B"], grad=False)
+    torch.cuda.synchronize()
+    assert np.array_equal(c2.cpu().numpy(), base["A"][1]) and np.array_equal(m3_.cpu().numpy(), base["B"][2])
+    gA = finish(pA, cA, mA, ups["A"])
+    with torch.cuda.stream(side):
+        gB = finish(pB, cB, mB, ups["B"])
+    for k, got in (("A", gA), ("B", gB)):
+        assert np.array_equal(got[1], base[k][1]) and np.array_equal(got[2], base[k][2]), "%s: images differ when interleaved" % k
+        for name in got[0]:
+            assert np.array_equal(got[0][name], base[k][0][name]), "%s: dL/d%s differs when interleaved" % (k, name)
+
+    # the same through the C ABI (HipRun keeps each call's three buffers), backward order swapped as well
+    gup = {k: (ups[k][0].cpu().numpy(), ups[k][1].cpu().numpy()) for k in ups}
+    ref = {}
+    for k, a in scenes.items():
+        r = HipRun(a).forward()
+        ref[k] = (r.color.cpu().numpy(), r.others.cpu().numpy(), r.backward(*gup[k]))
+    rA_, rB_ = HipRun(scenes["A"]).forward(), HipRun(scenes["B"]).forward()
+    rA2 = HipRun(scenes["A"], debug=n_opt("OPT_NO_STREAM")).forward()      # a render-only frame of A's size in between
+    gB2 = rB_.backward(*gup["B"])
+    gA2 = rA_.backward(*gup["A"])
+    assert np.array_equal(rA2.color.cpu().numpy(), ref["A"][0])
+    for k, r, g in (("A", rA_, gA2), ("B", rB_, gB2)):
+        assert np.array_equal(r.color.cpu().numpy(), ref[k][0]) and np.array_equal(r.others.cpu().numpy(), ref[k][1])
+        for name in g:
+            assert np.array_equal(g[name], ref[k][2][name]), "C ABI %s: dL/d%s differs when interleaved" % (k, name)
+    # a frame rendered WITHOUT a stream still has a correct backward (it gathers by surfel id): same bits
+    gA3 = rA2.backward(*gup["A"])
+    for name in gA3:
+        assert np.array_equal(gA3[name], ref["A"][2][name]), "no-stream frame: dL/d%s differs" % name
+
+
+def n_opt(name):
+    import surfel_native as n
+    return getattr(n, name)
