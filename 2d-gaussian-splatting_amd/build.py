@@ -16,7 +16,7 @@ SOURCES = ["surfel_preprocess.hip", "surfel_forward.hip", "surfel_backward.hip",
 # round identically per (pixel, surfel) pair
 EXTRA = {"surfel_forward.hip": ["-fno-slp-vectorize"], "surfel_backward.hip": ["-fno-slp-vectorize", "-ffp-contract=off"],
          "surfel_backward_scan.hip": ["-fno-slp-vectorize", "-ffp-contract=off"]}
-HEADERS = ["surfel_common.h", "surfel_kernels.h", "surfel_blend_bwd.h", "train_kernels.h", "train_loss_body.h", "train_post_body.h", os.path.join("..", "..", "include", "surfel_hip.h"),
+HEADERS = ["surfel_common.h", "surfel_kernels.h", "surfel_blend_bwd.h", "train_kernels.h", "train_loss_body.h", "train_post_body.h", os.path.join("..", "..", "include", "surfel_hip.h"), os.path.join("..", "..", "include", "surfel_debug.h"),
            os.path.join("..", "..", "include", "surfel_train.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast", "-Wall", "-Wno-unused-result"]
 

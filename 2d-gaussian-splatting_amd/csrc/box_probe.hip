@@ -9,7 +9,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-#include "../../include/surfel_hip.h"
+#include "../../include/surfel_debug.h"
 
 namespace surfel {
 int api_fail(int code, const char* what, hipError_t e);

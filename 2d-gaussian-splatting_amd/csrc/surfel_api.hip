@@ -9,7 +9,7 @@
 
 #include <hip/hip_runtime.h>
 
-#include "../../include/surfel_hip.h"
+#include "../../include/surfel_debug.h"
 #include "surfel_common.h"
 #include "surfel_kernels.h"
 #include "train_kernels.h"

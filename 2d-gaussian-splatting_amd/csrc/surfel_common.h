@@ -286,4 +286,21 @@ __device__ __forceinline__ void world2pix(const float* __restrict__ pm, int W, i
         Pm[3 * r + 2] = m3;
     }
 }
+// ---- LDS-DMA (global -> LDS without a VGPR, asynchronous, completion by vmcnt) ----
+__device__ __forceinline__ unsigned lds_offset(const void* p) {
+    return (unsigned)(uintptr_t)(const __attribute__((address_space(3))) void*)p;
+}
+// 16 B per lane, global -> LDS at (wave-uniform) lds_base + 16 * lane.  M0 carries the LDS base and is compiler-reserved: saved and
+// restored inside the statement.  hipcc does not count this load: the issuer waits with an explicit s_waitcnt vmcnt.
+__device__ __forceinline__ void dma16(const void* gsrc, unsigned lds_base) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_base) : "memory");
+}
+__device__ __forceinline__ void dma4(const void* gsrc, unsigned lds_base) {      // 4 B per lane -> lds_base + 4 * lane
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_base) : "memory");
+}
+
 }  // namespace surfel

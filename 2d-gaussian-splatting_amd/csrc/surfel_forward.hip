@@ -148,21 +148,6 @@ __global__ void __launch_bounds__(BLOCK) blend_fwd_kernel(BlendFwdArgs a) {
 constexpr int NB = 128;                 // instances per batch
 constexpr int PMSTRIDE = 4;             // a row's four mask words: one aligned 16-B read
 
-__device__ __forceinline__ unsigned lds_offset(const void* p) {
-    return (unsigned)(uintptr_t)(const __attribute__((address_space(3))) void*)p;
-}
-// 16 B per lane, global -> LDS at (wave-uniform) lds_base + 16 * lane.  M0 carries the LDS base and is compiler-reserved: saved and
-// restored inside the statement.  hipcc does not count this load: the issuer waits with an explicit s_waitcnt vmcnt.
-__device__ __forceinline__ void dma16(const void* gsrc, unsigned lds_base) {
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(gsrc), "s"(lds_base) : "memory");
-}
-__device__ __forceinline__ void dma4(const void* gsrc, unsigned lds_base) {      // 4 B per lane -> lds_base + 4 * lane
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(gsrc), "s"(lds_base) : "memory");
-}
 // sub-tile bits (id = 4 * by + bx) of the two 4-row strips by = 2 h, 2 h + 1
 __device__ __forceinline__ unsigned subtile_overlap_half(const Foot& f, int tile_x0, int tile_y0, int h) {
     unsigned ov = 0;

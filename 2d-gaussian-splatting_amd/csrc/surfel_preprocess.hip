@@ -28,7 +28,8 @@ __device__ __constant__ float SH_C3[7] = {-0.5900435899266435f, 2.89061144264055
 // HBM traffic per surfel: reads 40 B geometry (+192 B SH only when the surfel survives culling),
 // writes 112 B record + 21 B bookkeeping.
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ uint32_t preprocess_one(const PreprocessArgs& a, const int i) {
+// sh_lds: this surfel's 12 float4 of SH coefficients in LDS (the wave's block arrived by LDS-DMA: preprocess_fwd_kernel), or NULL
+__device__ __forceinline__ uint32_t preprocess_one(const PreprocessArgs& a, const int i, const float4* sh_lds = nullptr) {
     int rad_out = 0;
     uint32_t tiles = 0;
     uint32_t dkey = 0xffffffffu;      // culled surfels sort behind every visible one
@@ -131,7 +132,11 @@ __device__ __forceinline__ uint32_t preprocess_one(const PreprocessArgs& a, cons
                 float4 c4[12];
 #pragma unroll
                 for (int v = 0; v < 12; v++) c4[v] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (a.D > 2) {
+                if (sh_lds) {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the DMA is invisible to the compiler's own counting
+#pragma unroll
+                    for (int v = 0; v < 12; v++) c4[v] = sh_lds[v];
+                } else if (a.D > 2) {
 #pragma unroll
                     for (int v = 0; v < 12; v++) c4[v] = shq[v];
                 } else if (a.D == 2) {
@@ -264,13 +269,35 @@ __device__ __forceinline__ uint32_t preprocess_one(const PreprocessArgs& a, cons
 #ifndef PRE_FWD_MINWG
 #define PRE_FWD_MINWG 4
 #endif
+// DMA (large frames, launch_preprocess_fwd): the SH block is 83 % of this kernel's input bytes.  Read by its owner thread it is twelve
+// 16-B loads at a 192-B stride per lane: 64 cache lines per load instruction.  A wave's 64 surfels hold their coefficients in ONE
+// contiguous 12 KB span, so the wave fetches it as twelve fully coalesced 1 KB LDS-DMA instructions (global -> LDS, no VGPR, issued
+// before anything else) and every lane picks its own 192 B out of LDS when it gets to the colour (full degree only: lower degrees
+// read a prefix per surfel).  Same bits.  Measured (profiles/r06_ab_preprocess_dma.jsonl): 2.2 M surfels 0.220 -> 0.200 ms, 2 M random
+// 0.187 -> 0.181; at 300 k surfels the 48 KB of LDS (3 workgroups per CU instead of 4) cost 1 us -> small frames keep the direct loads.
+template <bool DMA>
 __global__ void __launch_bounds__(256, PRE_FWD_MINWG) preprocess_fwd_kernel(PreprocessArgs a) {
     __shared__ uint32_t s_tot[4], s_vis[4];
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    __shared__ float4 s_sh[DMA ? 4 : 1][DMA ? 64 * 12 : 1];      // DMA: 48 KB -> 3 workgroups per CU
+    const float4* sh_lds = nullptr;
+    if (DMA && a.shs != nullptr && a.colors_precomp == nullptr && a.M == 16 && a.D > 2) {
+        const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+        const int first = blockIdx.x * 256 + wave * 64;
+        const int npieces = 12 * min(64, a.P - first);
+        const float4* __restrict__ src = reinterpret_cast<const float4*>(a.shs) + (size_t)first * 12;
+        const unsigned base = __builtin_amdgcn_readfirstlane(lds_offset(&s_sh[wave][0]));      // (wave-uniform: M0 takes an SGPR)
+#pragma unroll
+        for (int v = 0; v < 12; v++) {
+            const int p = v * 64 + lane;
+            if (p < npieces) dma16(src + p, base + (unsigned)v * 1024u);
+        }
+        sh_lds = &s_sh[wave][lane * 12];
+    }
     for (uint32_t w = (uint32_t)i; w < a.zero_a_words; w += gridDim.x * blockDim.x) a.zero_a[w] = 0u;
     for (uint32_t w = (uint32_t)i; w < a.zero_b_words; w += gridDim.x * blockDim.x) a.zero_b[w] = 0u;
     for (uint32_t w = (uint32_t)i; w < a.zero_c_words; w += gridDim.x * blockDim.x) a.zero_c[w] = 0u;
-    uint32_t tiles = i < a.P ? preprocess_one(a, i) : 0u;
+    uint32_t tiles = i < a.P ? preprocess_one(a, i, sh_lds) : 0u;
     const uint32_t vis = (uint32_t)__popcll(__ballot(tiles != 0u));     // surfels that emit at least one instance
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) tiles += __shfl_xor(tiles, o);
@@ -926,7 +953,9 @@ __global__ void __launch_bounds__(256, PRE_BWD_MINWG) preprocess_bwd_kernel(Prep
 
 // ------------------------------------------------------------------------------- launchers
 void launch_preprocess_fwd(const PreprocessArgs& a, hipStream_t s) {
-    if (a.P > 0) hipLaunchKernelGGL(preprocess_fwd_kernel, dim3((a.P + 255) / 256), dim3(256), 0, s, a);
+    if (a.P <= 0) return;
+    if (a.P >= (1 << 19)) hipLaunchKernelGGL(preprocess_fwd_kernel<true>, dim3((a.P + 255) / 256), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(preprocess_fwd_kernel<false>, dim3((a.P + 255) / 256), dim3(256), 0, s, a);
 }
 void launch_emit_instances(int P, float* rec, const uint32_t* rects, const uint32_t* order, const uint32_t* offsets_sorted, uint32_t* keys,
                            uint32_t* vals, int gx, uint32_t* zero_ptr, uint32_t zero_words, hipStream_t s) {

@@ -30,6 +30,9 @@
 namespace surfel {
 
 constexpr size_t RS_ONESWEEP_MAX_ITEMS = (size_t)1 << 20;
+// largest input the one-launch-per-pass look-back passes take (above: histogram + scan + scatter per pass, or rocPRIM: use_rocprim).
+// [r6] raised to 2^22 for the 2.2 M-key depth sort of the garden state it LOST: 0.220 -> 0.248 ms (profiles/r06_ab_preprocess_dma.jsonl)
+constexpr size_t g_onesweep_max = RS_ONESWEEP_MAX_ITEMS;
 // Large inputs (n > RS_ONESWEEP_MAX: the P-sized depth sort at C4 / C5 and the R-sized tile sort of 1e7 - 1e8 instances) can be
 // handed to rocprim::radix_sort_pairs (the north star names rocPRIM for the global key sort) instead of the three-launch path
 // below: surfel_set_option("large_sort", 1).  Both are stable LSD sorts on [begin_bit, end_bit): results are identical.
@@ -45,7 +48,7 @@ static inline bool use_rocprim(size_t n, int begin_bit, int end_bit) {
     // bit 0 — all the hot path sorts on — are exact at every size tested)
     if (begin_bit != 0) return false;
     if (g_large_sort_impl == 3) return true;
-    if (n <= RS_ONESWEEP_MAX_ITEMS) return false;
+    if (n <= g_onesweep_max) return false;
     if (g_large_sort_impl != 2) return g_large_sort_impl == 1;
     return (end_bit - begin_bit) <= 16 || n >= ((size_t)4 << 20);
 }
@@ -68,8 +71,7 @@ constexpr int RS_THREADS = 256;
 // (512-item tiles were measured 2x SLOWER at 0.3-0.6 M items: 4x the tickets, status words and look-back depth.)
 constexpr int RS_IPT = 8;
 constexpr int RS_TILE = RS_THREADS * RS_IPT;
-constexpr size_t RS_ONESWEEP_MAX = RS_ONESWEEP_MAX_ITEMS;
-static inline bool rs_onesweep(size_t n) { return n <= RS_ONESWEEP_MAX; }
+static inline bool rs_onesweep(size_t n) { return n <= g_onesweep_max; }
 constexpr int RS_BITS = 8;
 constexpr int RS_RADIX = 1 << RS_BITS;
 constexpr int RS_MAX_PASSES = 4;

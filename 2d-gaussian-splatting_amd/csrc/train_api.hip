@@ -4,7 +4,7 @@
 
 #include <hip/hip_runtime.h>
 
-#include "../../include/surfel_hip.h"
+#include "../../include/surfel_debug.h"
 #include "../../include/surfel_train.h"
 #include "train_kernels.h"
 

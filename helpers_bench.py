@@ -312,7 +312,7 @@ def config_leg(dev, workload, steps=20, warmup=5, prime=15, walks=True):
 
 
 # (the knobs of the garden preset can be overridden from the environment: that is how it was tuned to settle above a million surfels)
-GARDEN_GT = int(os.environ.get("GARDEN_GT", 2_000_000)); GARDEN_INIT = int(os.environ.get("GARDEN_INIT", 2_600_000))
+GARDEN_GT = int(os.environ.get("GARDEN_GT", 4_000_000)); GARDEN_INIT = int(os.environ.get("GARDEN_INIT", 5_400_000))
 GARDEN_VIEWS = int(os.environ.get("GARDEN_VIEWS", 32)); GARDEN_ITERS = int(os.environ.get("GARDEN_ITERS", 2500)); GARDEN_PX = float(os.environ.get("GARDEN_PX", 0.010))
 TRAINED_PRESETS = {
     # name: ground-truth surfels, initial random points, views, (W, H), iterations of the reference schedule (untimed), gt disc scale

@@ -1,4 +1,4 @@
-"""CPU tests: the C-ABI library loads (no GPU needed for dlopen) and exports every symbol include/surfel_hip.h declares;
+"""CPU tests: the C-ABI library loads (no GPU needed for dlopen) and exports every symbol include/*.h declare;
 the Python boundary mirrors the reference's names and error behaviour without touching a device."""
 import os
 import re
@@ -10,7 +10,7 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def _declared_symbols():
     syms = set()
-    for hdr in ("surfel_hip.h", "surfel_train.h"):
+    for hdr in ("surfel_hip.h", "surfel_debug.h", "surfel_train.h"):
         src = open(os.path.join(REPO, "include", hdr)).read()
         src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
         syms |= set(re.findall(r"\b(surfel_[a-z0-9_]+)\s*\(", src))

@@ -1,6 +1,6 @@
 """CPU tests of the library's public surface and of the conventions round 5 introduced: the documented options are exactly the accepted
 ones, removed ones are refused, the tile stream's bit permutation matches the thread -> pixel map it serves, the bench's box-probe
-normalisation is the identity on its reference box, and the design document stays a design document."""
+model is the identity on its reference box, the product header stays the product surface, and the design document a design document."""
 import os
 import re
 
@@ -104,7 +104,20 @@ def test_box_probe_normalisation_is_the_identity_on_its_reference_box():
     assert abs(s - 1.0) < 1e-12
     src = open(os.path.join(REPO, "helpers_bench.py")).read()
     assert 'STEP_SPLIT["blend"] * r["blend_mix_Mvisits_per_s"]' in src and "slowdown_vs_reference_box_by_probes" in src
-    assert "ms_per_step_normalised" in open(os.path.join(REPO, "bench.py")).read()
+    # (round 6: the headline carries the raw step only — no normalisation by one of the product's own kernels)
+    assert "ms_per_step_normalised" not in open(os.path.join(REPO, "bench.py")).read()
+
+
+def test_the_product_header_is_the_product_surface():
+    """include/surfel_hip.h = entry points + options (<= 120 lines, no probes, no profile file names, no round history);
+    diagnostics live in include/surfel_debug.h"""
+    hdr = _header()
+    assert len(hdr.splitlines()) <= 120, len(hdr.splitlines())
+    for word in ("surfel_debug_", "profiles/", "round ", "surfel_last_stage_ms", "box_probe"):
+        assert word not in hdr, word
+    dbg = open(os.path.join(REPO, "include", "surfel_debug.h")).read()
+    for fn in ("surfel_debug_box_probe", "surfel_debug_latency_probe", "surfel_debug_set_blend_stats", "surfel_debug_sort_pairs", "surfel_collect_stage_ms"):
+        assert fn in dbg, fn
 
 
 def test_design_document_stays_a_design_document():
