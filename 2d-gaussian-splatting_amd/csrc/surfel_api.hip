@@ -24,8 +24,6 @@ int g_opt_tile_sort = 1;   // surfel_set_option("tile_depth_sort", .): 0 never, 
 int g_opt_bwd_variant = 2; // surfel_set_option("bwd_variant", .): 0 per-row walk, 1 per-quad walk (0 / 1 bit-identical), 2 auto = rows or scan by the device rule, 3 scan walk
 surfel_hook_fn g_colour_hook = nullptr;   // surfel_set_backward_hook
 void* g_colour_hook_user = nullptr;
-surfel_hook_fn g_fwd_hook = nullptr;      // surfel_set_forward_hook
-void* g_fwd_hook_user = nullptr;
 int g_opt_stream = 1;      // surfel_set_option("tile_stream", .): blend_fwd leaves the tile stream for blend_bwd (surfel_common.h); 0: blend_bwd gathers
 unsigned long long* g_blend_stats = nullptr;   // surfel_debug_set_blend_stats
 thread_local int64_t g_last_R = -1; thread_local int g_last_W = 0, g_last_H = 0;   // auto heuristic (speed only; results identical; a stale
@@ -57,8 +55,8 @@ thread_local int g_stage_n = 0;
 thread_local int g_stage_id[16];
 
 const char* kStageNames[] = {"preprocess_fwd", "depth_sort_scan", "emit_instances", "tile_sort", "tile_ranges", "blend_fwd",
-                             "zero_grec", "blend_bwd", "preprocess_bwd", "knn", "tile_depth_sort", "sh_colour"};
-enum Stage { ST_PRE = 0, ST_SCAN, ST_EMIT, ST_SORT, ST_RANGES, ST_BLEND, ST_ZERO, ST_BBWD, ST_PBWD, ST_KNN, ST_TSORT, ST_COLOUR };
+                             "zero_grec", "blend_bwd", "preprocess_bwd", "knn", "tile_depth_sort"};
+enum Stage { ST_PRE = 0, ST_SCAN, ST_EMIT, ST_SORT, ST_RANGES, ST_BLEND, ST_ZERO, ST_BBWD, ST_PBWD, ST_KNN, ST_TSORT };
 
 int fail(int code, const char* what, hipError_t e = hipSuccess) {
     g_err = what;
@@ -289,7 +287,7 @@ extern "C" {
 
 int surfel_abi_version(void) { return SURFEL_ABI_VERSION; }
 const char* surfel_last_error(void) { return g_err.c_str(); }
-const char* surfel_stage_name(int stage) { return (stage >= 0 && stage < 12) ? kStageNames[stage] : "?"; }
+const char* surfel_stage_name(int stage) { return (stage >= 0 && stage < 11) ? kStageNames[stage] : "?"; }
 int surfel_last_stage_ms(float* ms, int cap) {
     int n = g_stage_n < cap ? g_stage_n : cap;
     for (int i = 0; i < n; i++) ms[i] = g_stage_ms[i];
@@ -335,10 +333,6 @@ int surfel_set_option(const char* name, int value) {
     return fail(SURFEL_E_INVALID, "unknown option");
 }
 
-int surfel_set_forward_hook(surfel_hook_fn sh_needed, void* user) {
-    g_fwd_hook = sh_needed; g_fwd_hook_user = user;
-    return 0;
-}
 int surfel_set_backward_hook(surfel_hook_fn colour_ready, void* user) {
     g_colour_hook = colour_ready; g_colour_hook_user = user;
     return 0;
@@ -372,7 +366,7 @@ int surfel_collect_stage_ms(float* sum_ms, int* count, int cap) {
         (void)hipEventDestroy(p.e0); (void)hipEventDestroy(p.e1);
     }
     g_pending.clear();
-    return 12;
+    return 11;
 }
 
 // Lazily counted frames (SURFEL_OPT_LAZY_COUNT): a capacity-path forward that did not wait for its instance count.  The count is
@@ -434,7 +428,6 @@ int64_t surfel_rasterize_forward(surfel_alloc_fn geom_alloc, void* geom_user, su
     const int opt_tile_sort = ((debug >> 9) & 3) ? ((debug >> 9) & 3) - 1 : g_opt_tile_sort;
     const int opt_capacity = (debug & SURFEL_OPT_EXACT_BINNING) ? 0 : g_opt_capacity;
     const int opt_tile_order = ((debug >> 19) & 3) ? ((debug >> 19) & 3) - 1 : g_opt_tile_order;
-    const bool opt_late_colour = (debug & SURFEL_OPT_LATE_COLOUR) && shs != nullptr && colors_precomp == nullptr && P > 0;
     const bool opt_stream = !(debug & SURFEL_OPT_NO_STREAM);      // (the caller knows no backward follows: render.py-style inference, no_grad re-renders)
     const int map_len = tile_map_len((width + TILE - 1) / TILE, (height + TILE - 1) / TILE);
     debug &= 0xff;
@@ -467,17 +460,6 @@ int64_t surfel_rasterize_forward(surfel_alloc_fn geom_alloc, void* geom_user, su
     int64_t R = 0;
     GeomState geom{};
     BinState bin{};
-    PreprocessArgs pa{};
-    // late-colour frames: the caller's hook (it makes `stream` wait for whatever still writes the SH coefficients), then the colours
-#define LATE_COLOUR()                                                                      \
-    do {                                                                                   \
-        if (opt_late_colour) {                                                             \
-            if (g_fwd_hook) g_fwd_hook(g_fwd_hook_user);                                   \
-            tm.begin();                                                                    \
-            launch_sh_colour(pa, s);                                                       \
-            STAGE_END(tm, ST_COLOUR);                                                      \
-        }                                                                                  \
-    } while (0)
     CapEntry* tile_ce = cap_entry(width, height, true);      // per-size history (capacity, tile-order verdicts) of this host thread
     if (tile_ce->frames == ~0u) {      // a (re-)used slot must not inherit the previous size's tile-order verdict
         tile_ce->frames = 0;
@@ -495,8 +477,9 @@ int64_t surfel_rasterize_forward(surfel_alloc_fn geom_alloc, void* geom_user, su
         if (!geom_base) return fail(SURFEL_E_ALLOC, "geometry buffer allocation failed");
         geom = GeomState::carve(geom_base, P, temp_bytes, nullptr);
 
+        PreprocessArgs pa{};
         pa.P = P; pa.D = D; pa.M = M; pa.W = width; pa.H = height; pa.gx = gx; pa.gy = gy; pa.scale_modifier = scale_modifier;
-        pa.cull = opt_cull; pa.late_colour = opt_late_colour ? 1 : 0;
+        pa.cull = opt_cull;
         pa.means3D = means3D; pa.opacities = opacities; pa.scales = scales; pa.rotations = rotations;
         pa.transMat_precomp = transMat_precomp; pa.colors_precomp = colors_precomp; pa.shs = shs;
         pa.viewmatrix = viewmatrix; pa.projmatrix = projmatrix; pa.campos = cam_pos;
@@ -576,7 +559,6 @@ int64_t surfel_rasterize_forward(surfel_alloc_fn geom_alloc, void* geom_user, su
             launch_tile_depth_sort(gx * gy, ce->maxR, img.ranges, bin.point_list, geom.dkey_a, bin.vals_alt, bin.keys_a, bin.keys_b, fused_ranges, s);
             STAGE_END(tm, ST_TSORT);
             run_tile_order(tile_ce, img.ranges, gx, gy, img.tile_map, img.total + 2 * R_SLOTS + 1, opt_tile_order, s);
-            LATE_COLOUR();
             BlendFwdArgs ba{};
             ba.W = width; ba.H = height; ba.gx = gx; ba.gy = gy;
             ba.ranges = img.ranges; ba.point_list = bin.point_list; ba.rec = geom.rec; ba.bg = background;
@@ -680,7 +662,6 @@ int64_t surfel_rasterize_forward(surfel_alloc_fn geom_alloc, void* geom_user, su
     }
 
     run_tile_order(tile_ce, img.ranges, gx, gy, img.tile_map, img.total + 2 * R_SLOTS + 1, opt_tile_order, s);
-    LATE_COLOUR();
     BlendFwdArgs ba{};
     ba.W = width; ba.H = height; ba.gx = gx; ba.gy = gy;
     ba.ranges = img.ranges; ba.point_list = bin.point_list; ba.rec = geom.rec; ba.bg = background;

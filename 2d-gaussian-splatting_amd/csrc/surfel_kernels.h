@@ -8,7 +8,6 @@ namespace surfel {
 struct PreprocessArgs {
     int P, D, M, W, H, gx, gy;
     int cull;                 // 0: emit the full reference rect, footprints unbounded (test switch)
-    int late_colour;          // 1: preprocess_fwd leaves the SH colour (record floats 15-17, clamp bits) to sh_colour_kernel (SURFEL_OPT_LATE_COLOUR)
     float scale_modifier;
     const float* means3D; const float* opacities; const float* scales; const float* rotations;
     const float* transMat_precomp; const float* colors_precomp; const float* shs;
@@ -69,7 +68,6 @@ struct PreprocessBwdArgs {
 };
 
 void launch_preprocess_fwd(const PreprocessArgs& a, hipStream_t s);
-void launch_sh_colour(const PreprocessArgs& a, hipStream_t s);      // the SH colours of a late_colour frame, right before the blend
 void launch_emit_instances(int P, float* rec, const uint32_t* rects, const uint32_t* order, const uint32_t* offsets_sorted, uint32_t* keys,
                            uint32_t* vals, int gx, uint32_t* zero_ptr, uint32_t zero_words, hipStream_t s);
 void launch_tile_ranges(int64_t R, const uint32_t* keys, uint2* ranges, hipStream_t s);

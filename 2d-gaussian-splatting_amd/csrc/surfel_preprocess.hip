@@ -28,85 +28,6 @@ __device__ __constant__ float SH_C3[7] = {-0.5900435899266435f, 2.89061144264055
 // HBM traffic per surfel: reads 40 B geometry (+192 B SH only when the surfel survives culling),
 // writes 112 B record + 21 B bookkeeping.
 // ---------------------------------------------------------------------------------------------
-// SH -> RGB of surfel i (utils/sh_utils.py:57-112, +0.5, clamp_min 0: gaussian_renderer/__init__.py:88-91) — ONE definition for
-// preprocess_fwd and for sh_colour_kernel (late-colour frames): same statements, same bits.
-// sh_lds: this surfel's 12 float4 of coefficients in LDS (the wave's block arrived by LDS-DMA), or NULL.
-__device__ __forceinline__ void sh_colour(const PreprocessArgs& a, const int i, const float px, const float py, const float pz, const float4* sh_lds,
-                                          float& r, float& g, float& b, uint8_t& clampbits) {
-        const float4* __restrict__ shq = reinterpret_cast<const float4*>(a.shs + (size_t)i * a.M * 3);
-        float dx = px - a.campos[0], dy = py - a.campos[1], dz = pz - a.campos[2];
-        const float il = rsqrtf(dx * dx + dy * dy + dz * dz);
-        dx *= il; dy *= il; dz *= il;
-        // basis values for the active degree (zero above it)
-        float B[16];
-#pragma unroll
-        for (int k = 1; k < 16; k++) B[k] = 0.f;
-        B[0] = SH_C0;
-        int nb = 1;
-        if (a.D > 0) {
-            B[1] = -SH_C1 * dy; B[2] = SH_C1 * dz; B[3] = -SH_C1 * dx; nb = 4;
-            if (a.D > 1) {
-                const float xx = dx * dx, yy = dy * dy, zz = dz * dz, xy = dx * dy, yz = dy * dz, xz = dx * dz;
-                B[4] = SH_C2[0] * xy; B[5] = SH_C2[1] * yz; B[6] = SH_C2[2] * (2.f * zz - xx - yy);
-                B[7] = SH_C2[3] * xz; B[8] = SH_C2[4] * (xx - yy); nb = 9;
-                if (a.D > 2) {
-                    B[9] = SH_C3[0] * dy * (3.f * xx - yy); B[10] = SH_C3[1] * xy * dz;
-                    B[11] = SH_C3[2] * dy * (4.f * zz - xx - yy); B[12] = SH_C3[3] * dz * (2.f * zz - 3.f * xx - 3.f * yy);
-                    B[13] = SH_C3[4] * dx * (4.f * zz - xx - yy); B[14] = SH_C3[5] * dz * (xx - yy);
-                    B[15] = SH_C3[6] * dx * (xx - 3.f * yy); nb = 16;
-                }
-            }
-        }
-        // coefficients are [M][3] floats = 12 float4 for M = 16.  ALL loads of the surfel are issued back to back before any
-        // use (one round trip, and each 128-B line is consumed while it is still in L2): with the loads interleaved with the
-        // FMAs the compiler serialised 12 dependent round trips and the kernel fetched 2.6x its algorithmic bytes.
-        // Only the float4s holding active coefficients are read (wave-uniform degree): 1 / 3 / 7 / 12.
-        if (a.M == 16) {
-            float4 c4[12];
-#pragma unroll
-            for (int v = 0; v < 12; v++) c4[v] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (sh_lds) {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the DMA is invisible to the compiler's own counting
-#pragma unroll
-                for (int v = 0; v < 12; v++) c4[v] = sh_lds[v];
-            } else if (a.D > 2) {
-#pragma unroll
-                for (int v = 0; v < 12; v++) c4[v] = shq[v];
-            } else if (a.D == 2) {
-#pragma unroll
-                for (int v = 0; v < 7; v++) c4[v] = shq[v];
-            } else if (a.D == 1) {
-#pragma unroll
-                for (int v = 0; v < 3; v++) c4[v] = shq[v];
-            } else {
-                c4[0] = shq[0];
-            }
-            float acc[3] = {0.f, 0.f, 0.f};
-#pragma unroll
-            for (int v = 0; v < 12; v++) {
-                const float cv[4] = {c4[v].x, c4[v].y, c4[v].z, c4[v].w};
-#pragma unroll
-                for (int e = 0; e < 4; e++) {
-                    const int flat = 4 * v + e;          // = 3*coef + channel; B is zero above the active degree
-                    acc[flat % 3] += B[flat / 3] * cv[e];
-                }
-            }
-            r = acc[0]; g = acc[1]; b = acc[2];
-        } else {
-            const float* __restrict__ sh = a.shs + (size_t)i * a.M * 3;
-            r = SH_C0 * sh[0]; g = SH_C0 * sh[1]; b = SH_C0 * sh[2];
-            if (nb > 1) {
-#pragma unroll
-                for (int k = 1; k < 16; k++) {
-                    if (k < nb && k < a.M) { r += B[k] * sh[3 * k]; g += B[k] * sh[3 * k + 1]; b += B[k] * sh[3 * k + 2]; }
-                }
-            }
-        }
-        r += 0.5f; g += 0.5f; b += 0.5f;
-        clampbits = (r < 0.f ? 1 : 0) | (g < 0.f ? 2 : 0) | (b < 0.f ? 4 : 0);
-        r = fmaxf(r, 0.f); g = fmaxf(g, 0.f); b = fmaxf(b, 0.f);
-}
-
 // sh_lds: this surfel's 12 float4 of SH coefficients in LDS (the wave's block arrived by LDS-DMA: preprocess_fwd_kernel), or NULL
 __device__ __forceinline__ uint32_t preprocess_one(const PreprocessArgs& a, const int i, const float4* sh_lds = nullptr) {
     int rad_out = 0;
@@ -179,7 +100,78 @@ __device__ __forceinline__ uint32_t preprocess_one(const PreprocessArgs& a, cons
         float r = 0.f, g = 0.f, b = 0.f;
         uint8_t clampbits = 0;
         if (a.colors_precomp == nullptr) {
-            if (!a.late_colour) sh_colour(a, i, px, py, pz, sh_lds, r, g, b, clampbits);
+            const float4* __restrict__ shq = reinterpret_cast<const float4*>(a.shs + (size_t)i * a.M * 3);
+            float dx = px - a.campos[0], dy = py - a.campos[1], dz = pz - a.campos[2];
+            const float il = rsqrtf(dx * dx + dy * dy + dz * dz);
+            dx *= il; dy *= il; dz *= il;
+            // basis values for the active degree (zero above it)
+            float B[16];
+#pragma unroll
+            for (int k = 1; k < 16; k++) B[k] = 0.f;
+            B[0] = SH_C0;
+            int nb = 1;
+            if (a.D > 0) {
+                B[1] = -SH_C1 * dy; B[2] = SH_C1 * dz; B[3] = -SH_C1 * dx; nb = 4;
+                if (a.D > 1) {
+                    const float xx = dx * dx, yy = dy * dy, zz = dz * dz, xy = dx * dy, yz = dy * dz, xz = dx * dz;
+                    B[4] = SH_C2[0] * xy; B[5] = SH_C2[1] * yz; B[6] = SH_C2[2] * (2.f * zz - xx - yy);
+                    B[7] = SH_C2[3] * xz; B[8] = SH_C2[4] * (xx - yy); nb = 9;
+                    if (a.D > 2) {
+                        B[9] = SH_C3[0] * dy * (3.f * xx - yy); B[10] = SH_C3[1] * xy * dz;
+                        B[11] = SH_C3[2] * dy * (4.f * zz - xx - yy); B[12] = SH_C3[3] * dz * (2.f * zz - 3.f * xx - 3.f * yy);
+                        B[13] = SH_C3[4] * dx * (4.f * zz - xx - yy); B[14] = SH_C3[5] * dz * (xx - yy);
+                        B[15] = SH_C3[6] * dx * (xx - 3.f * yy); nb = 16;
+                    }
+                }
+            }
+            // coefficients are [M][3] floats = 12 float4 for M = 16.  ALL loads of the surfel are issued back to back before any
+            // use (one round trip, and each 128-B line is consumed while it is still in L2): with the loads interleaved with the
+            // FMAs the compiler serialised 12 dependent round trips and the kernel fetched 2.6x its algorithmic bytes.
+            // Only the float4s holding active coefficients are read (wave-uniform degree): 1 / 3 / 7 / 12.
+            if (a.M == 16) {
+                float4 c4[12];
+#pragma unroll
+                for (int v = 0; v < 12; v++) c4[v] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (sh_lds) {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the DMA is invisible to the compiler's own counting
+#pragma unroll
+                    for (int v = 0; v < 12; v++) c4[v] = sh_lds[v];
+                } else if (a.D > 2) {
+#pragma unroll
+                    for (int v = 0; v < 12; v++) c4[v] = shq[v];
+                } else if (a.D == 2) {
+#pragma unroll
+                    for (int v = 0; v < 7; v++) c4[v] = shq[v];
+                } else if (a.D == 1) {
+#pragma unroll
+                    for (int v = 0; v < 3; v++) c4[v] = shq[v];
+                } else {
+                    c4[0] = shq[0];
+                }
+                float acc[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+                for (int v = 0; v < 12; v++) {
+                    const float cv[4] = {c4[v].x, c4[v].y, c4[v].z, c4[v].w};
+#pragma unroll
+                    for (int e = 0; e < 4; e++) {
+                        const int flat = 4 * v + e;          // = 3*coef + channel; B is zero above the active degree
+                        acc[flat % 3] += B[flat / 3] * cv[e];
+                    }
+                }
+                r = acc[0]; g = acc[1]; b = acc[2];
+            } else {
+                const float* __restrict__ sh = a.shs + (size_t)i * a.M * 3;
+                r = SH_C0 * sh[0]; g = SH_C0 * sh[1]; b = SH_C0 * sh[2];
+                if (nb > 1) {
+#pragma unroll
+                    for (int k = 1; k < 16; k++) {
+                        if (k < nb && k < a.M) { r += B[k] * sh[3 * k]; g += B[k] * sh[3 * k + 1]; b += B[k] * sh[3 * k + 2]; }
+                    }
+                }
+            }
+            r += 0.5f; g += 0.5f; b += 0.5f;
+            clampbits = (r < 0.f ? 1 : 0) | (g < 0.f ? 2 : 0) | (b < 0.f ? 4 : 0);
+            r = fmaxf(r, 0.f); g = fmaxf(g, 0.f); b = fmaxf(b, 0.f);
         } else {
             r = a.colors_precomp[3 * (size_t)i]; g = a.colors_precomp[3 * (size_t)i + 1]; b = a.colors_precomp[3 * (size_t)i + 2];
         }
@@ -270,23 +262,6 @@ __device__ __forceinline__ uint32_t preprocess_one(const PreprocessArgs& a, cons
     return tiles;
 }
 
-// The wave's 64 surfels hold their SH coefficients in ONE contiguous 12 KB span: twelve fully coalesced 1 KB LDS-DMA instructions
-// (global -> LDS, no VGPR); returns where this lane's surfel will find its 12 float4 (after s_waitcnt vmcnt(0): sh_colour).
-__device__ __forceinline__ const float4* sh_dma_issue(const PreprocessArgs& a, float4* s_sh /* [4][64 * 12] */) {
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int first = blockIdx.x * 256 + wave * 64;
-    const int npieces = 12 * min(64, a.P - first);
-    const float4* __restrict__ src = reinterpret_cast<const float4*>(a.shs) + (size_t)first * 12;
-    float4* const mine = s_sh + wave * (64 * 12);
-    const unsigned base = __builtin_amdgcn_readfirstlane(lds_offset(mine));      // (wave-uniform: M0 takes an SGPR)
-#pragma unroll
-    for (int v = 0; v < 12; v++) {
-        const int p = v * 64 + lane;
-        if (p < npieces) dma16(src + p, base + (unsigned)v * 1024u);
-    }
-    return mine + lane * 12;
-}
-
 // The instance total R = sum(tiles_touched) sizes the binning buffers, so it has to reach the host.  It is summed
 // here so the small D2H copy can be issued right after this kernel and the host wakes up, allocates and enqueues
 // the rest of the forward WHILE the device is still depth-sorting.  One atomic per workgroup, spread over
@@ -306,7 +281,19 @@ __global__ void __launch_bounds__(256, PRE_FWD_MINWG) preprocess_fwd_kernel(Prep
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     __shared__ float4 s_sh[DMA ? 4 : 1][DMA ? 64 * 12 : 1];      // DMA: 48 KB -> 3 workgroups per CU
     const float4* sh_lds = nullptr;
-    if (DMA && !a.late_colour && a.shs != nullptr && a.colors_precomp == nullptr && a.M == 16 && a.D > 2) sh_lds = sh_dma_issue(a, &s_sh[0][0]);
+    if (DMA && a.shs != nullptr && a.colors_precomp == nullptr && a.M == 16 && a.D > 2) {
+        const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+        const int first = blockIdx.x * 256 + wave * 64;
+        const int npieces = 12 * min(64, a.P - first);
+        const float4* __restrict__ src = reinterpret_cast<const float4*>(a.shs) + (size_t)first * 12;
+        const unsigned base = __builtin_amdgcn_readfirstlane(lds_offset(&s_sh[wave][0]));      // (wave-uniform: M0 takes an SGPR)
+#pragma unroll
+        for (int v = 0; v < 12; v++) {
+            const int p = v * 64 + lane;
+            if (p < npieces) dma16(src + p, base + (unsigned)v * 1024u);
+        }
+        sh_lds = &s_sh[wave][lane * 12];
+    }
     for (uint32_t w = (uint32_t)i; w < a.zero_a_words; w += gridDim.x * blockDim.x) a.zero_a[w] = 0u;
     for (uint32_t w = (uint32_t)i; w < a.zero_b_words; w += gridDim.x * blockDim.x) a.zero_b[w] = 0u;
     for (uint32_t w = (uint32_t)i; w < a.zero_c_words; w += gridDim.x * blockDim.x) a.zero_c[w] = 0u;
@@ -325,26 +312,6 @@ __global__ void __launch_bounds__(256, PRE_FWD_MINWG) preprocess_fwd_kernel(Prep
             atomicAdd(a.total_instances + R_SLOTS + (blockIdx.x % R_SLOTS), s_vis[0] + s_vis[1] + s_vis[2] + s_vis[3]);
         }
     }
-}
-
-// Late-colour frames (SURFEL_OPT_LATE_COLOUR): the SH colours of the surfels preprocess_fwd kept (radii > 0), written into the
-// records (floats 15-17) and the clamp bits right before the blend — the trainer's SH-block Adam step of the PREVIOUS iteration may
-// still be running on another stream while preprocess and the binning of this one execute (surfel_set_forward_hook).
-template <bool DMA>
-__global__ void __launch_bounds__(256) sh_colour_kernel(PreprocessArgs a) {
-    __shared__ float4 s_sh[DMA ? 4 : 1][DMA ? 64 * 12 : 1];
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    const float4* sh_lds = nullptr;
-    if (DMA && a.M == 16 && a.D > 2) sh_lds = sh_dma_issue(a, &s_sh[0][0]);
-    if (i >= a.P || a.radii[i] <= 0) return;
-    const float px = a.means3D[3 * i], py = a.means3D[3 * i + 1], pz = a.means3D[3 * i + 2];
-    float r = 0.f, g = 0.f, b = 0.f;
-    uint8_t clampbits = 0;
-    sh_colour(a, i, px, py, pz, sh_lds, r, g, b, clampbits);
-    float* __restrict__ rec = a.rec + (size_t)i * REC_F;
-    rec[15] = r;
-    *reinterpret_cast<float2*>(rec + 16) = make_float2(g, b);
-    a.clamped[i] = clampbits;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -989,11 +956,6 @@ void launch_preprocess_fwd(const PreprocessArgs& a, hipStream_t s) {
     if (a.P <= 0) return;
     if (a.P >= (1 << 19)) hipLaunchKernelGGL(preprocess_fwd_kernel<true>, dim3((a.P + 255) / 256), dim3(256), 0, s, a);
     else hipLaunchKernelGGL(preprocess_fwd_kernel<false>, dim3((a.P + 255) / 256), dim3(256), 0, s, a);
-}
-void launch_sh_colour(const PreprocessArgs& a, hipStream_t s) {
-    if (a.P <= 0 || a.shs == nullptr) return;
-    if (a.P >= (1 << 19)) hipLaunchKernelGGL(sh_colour_kernel<true>, dim3((a.P + 255) / 256), dim3(256), 0, s, a);
-    else hipLaunchKernelGGL(sh_colour_kernel<false>, dim3((a.P + 255) / 256), dim3(256), 0, s, a);
 }
 void launch_emit_instances(int P, float* rec, const uint32_t* rects, const uint32_t* order, const uint32_t* offsets_sorted, uint32_t* keys,
                            uint32_t* vals, int gx, uint32_t* zero_ptr, uint32_t zero_words, hipStream_t s) {

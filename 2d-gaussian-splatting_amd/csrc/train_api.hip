@@ -129,22 +129,6 @@ int surfel_train_update(int P, float* theta, const float* grad, float* m, float*
     return launched("train_update_kernel");
 }
 
-int surfel_train_update_part(int part, int P, float* theta, const float* grad, float* m, float* v, float* act, const float* lr, float beta1, float beta2,
-                             float eps, int t, float grad_scale, int D, int N, const float* campos_all, const float* gcol_all, const float* dL_dmeans2D,
-                             const int* radii, float* grad_accum, float* denom, float* max_radii, float* xyz_fwd, void* stream) {
-    if (part != 1 && part != 2) return api_fail(SURFEL_E_INVALID, "train_update_part: part must be 2 (statistics + geometry) or 1 (SH block)");
-    if (P < 0 || t < 1 || !lr || (P > 0 && (!theta || !m || !v || !xyz_fwd))) return api_fail(SURFEL_E_INVALID, "train_update_part: bad arguments");
-    if (P == 0) return 0;
-    if (part == 2 && (!grad || !act)) return api_fail(SURFEL_E_INVALID, "train_update_part: the geometry part needs grad and act");
-    if (part == 2 && dL_dmeans2D && (!radii || !grad_accum || !denom || !max_radii)) return api_fail(SURFEL_E_INVALID, "train_update_part: bad statistics arguments");
-    if (part == 1 && (!gcol_all || !campos_all || N < 1 || D < 0 || D > 3)) return api_fail(SURFEL_E_INVALID, "train_update_part: the SH part needs the colour gradients");
-    const float bc1 = (float)(1.0 - std::pow((double)beta1, (double)t));
-    const float bc2s = (float)std::sqrt(1.0 - std::pow((double)beta2, (double)t));
-    launch_train_update_part(part, P, theta, grad, m, v, act, lr, beta1, beta2, eps, bc1, bc2s, grad_scale, D, N, campos_all, gcol_all, dL_dmeans2D, radii,
-                             grad_accum, denom, max_radii, xyz_fwd, static_cast<hipStream_t>(stream));
-    return launched(part == 2 ? "train_update_geom_kernel" : "adam_sh_kernel");
-}
-
 int surfel_sh_grad_gather(int P, int D, int N, const float* means3D, const float* campos_all, const float* gcol_all, float* dL_dsh, void* stream) {
     if (P < 0 || D < 0 || D > 3 || N < 1 || (P > 0 && (!means3D || !campos_all || !gcol_all || !dL_dsh)))
         return api_fail(SURFEL_E_INVALID, "sh_grad_gather: bad arguments");

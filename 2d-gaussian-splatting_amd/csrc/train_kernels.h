@@ -40,9 +40,6 @@ void launch_train_update(int P, float* theta, const float* grad, float* m, float
                          const float* g2d, const int* radii, float* accum, float* denom, float* maxr, hipStream_t s);
 void launch_sh_grad_gather(int P, int D, int N, const float* means3D, const float* campos_all, const float* gcol_all, float* dL_dsh,
                            hipStream_t s);
-void launch_train_update_part(int part, int P, float* theta, const float* grad, float* m, float* v, float* act, const float* lr, float beta1, float beta2,
-                              float eps, float bc1, float bc2_sqrt, float grad_scale, int D, int N, const float* campos_all, const float* gcol_all,
-                              const float* g2d, const int* radii, float* accum, float* denom, float* maxr, float* xyz_fwd, hipStream_t s);
 void launch_densify_stats(int P, const float* g2d, const int* radii, float* accum, float* denom, float* maxr, hipStream_t s);
 
 // error plumbing shared with surfel_api.hip (thread-local message behind surfel_last_error())

@@ -210,10 +210,8 @@ __global__ __launch_bounds__(256) void sh_grad_gather_kernel(int P, int D, int N
 // Adam on the SH block with the gradients rebuilt in registers from the colour gradients: the 192 B/surfel SH gradient never
 // exists in HBM (the rasterizer's backward skips writing it, this kernel skips reading it).  Must run BEFORE the xyz update
 // (the view directions use the positions the forward saw).
-// pos: the positions the forward saw — theta's xyz section (this kernel runs before the geometry update), or a copy of it
-// (surfel_train_update_part: the geometry part ran first and left the copy, this part overlaps the next forward on another stream).
 __global__ __launch_bounds__(256) void adam_sh_kernel(int P, int D, int N, float* __restrict__ theta, float* __restrict__ m, float* __restrict__ v,
-                                                      const float* __restrict__ campos_all, const float* __restrict__ gcol_all, const float* __restrict__ pos, AdamK k) {
+                                                      const float* __restrict__ campos_all, const float* __restrict__ gcol_all, AdamK k) {
     // one workgroup = 64 surfels: wave 0 rebuilds their 48 SH gradients into LDS, then all 256 threads run Adam over the
     // 64 x 48 contiguous floats of theta / m / v (coalesced)
     __shared__ float s_g[64 * 49];
@@ -223,7 +221,7 @@ __global__ __launch_bounds__(256) void adam_sh_kernel(int P, int D, int N, float
         const int i = i0 + tid;
         if (i < P) {
             float acc[48];
-            sh_grad_rebuild(i, P, D, N, pos[3 * (size_t)i], pos[3 * (size_t)i + 1], pos[3 * (size_t)i + 2], campos_all, gcol_all, acc);
+            sh_grad_rebuild(i, P, D, N, theta[3 * (size_t)i], theta[3 * (size_t)i + 1], theta[3 * (size_t)i + 2], campos_all, gcol_all, acc);
 #pragma unroll
             for (int q = 0; q < 48; q++) s_g[tid * 49 + q] = acc[q] * k.grad_scale;
         }
@@ -282,34 +280,7 @@ __global__ __launch_bounds__(256) void train_update_kernel(int P, int D, int N, 
     }
 }
 
-// The geometry half of a split update (surfel_train_update_part, part 2): statistics + xyz / opacity / scaling / rotation Adam + next
-// activations per surfel — adam_act_kernel with the statistics in front — and a copy of the positions it replaces, for the SH half.
-__global__ __launch_bounds__(256) void train_update_geom_kernel(int P, float* __restrict__ theta, const float* __restrict__ grad, float* __restrict__ m,
-                                                                float* __restrict__ v, float* __restrict__ act, const float* __restrict__ g2d,
-                                                                const int* __restrict__ radii, float* __restrict__ accum, float* __restrict__ denom,
-                                                                float* __restrict__ maxr, float* __restrict__ xyz_fwd, AdamK k) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= P) return;
-    if (g2d) densify_surfel(i, g2d, radii, accum, denom, maxr);
-    if (xyz_fwd) {
-        xyz_fwd[3 * (size_t)i] = theta[3 * (size_t)i]; xyz_fwd[3 * (size_t)i + 1] = theta[3 * (size_t)i + 1]; xyz_fwd[3 * (size_t)i + 2] = theta[3 * (size_t)i + 2];
-    }
-    adam_act_surfel(i, P, theta, grad, m, v, act, k);
-}
-
 }  // namespace
-
-void launch_train_update_part(int part, int P, float* theta, const float* grad, float* m, float* v, float* act, const float* lr, float beta1, float beta2,
-                              float eps, float bc1, float bc2_sqrt, float grad_scale, int D, int N, const float* campos_all, const float* gcol_all,
-                              const float* g2d, const int* radii, float* accum, float* denom, float* maxr, float* xyz_fwd, hipStream_t s) {
-    AdamK k;
-    for (int i = 0; i < 6; i++) k.lr[i] = lr[i];
-    k.beta1 = beta1; k.beta2 = beta2; k.eps = eps; k.bc1 = bc1; k.bc2_sqrt = bc2_sqrt; k.grad_scale = grad_scale;
-    if (part == 2)
-        hipLaunchKernelGGL(train_update_geom_kernel, dim3((P + 255) / 256), dim3(256), 0, s, P, theta, grad, m, v, act, g2d, radii, accum, denom, maxr, xyz_fwd, k);
-    else
-        hipLaunchKernelGGL(adam_sh_kernel, dim3((P + 63) / 64), dim3(256), 0, s, P, D, N, theta, m, v, campos_all, gcol_all, (const float*)xyz_fwd, k);
-}
 
 void launch_train_update(int P, float* theta, const float* grad, float* m, float* v, float* act, const float* lr, float beta1, float beta2,
                          float eps, float bc1, float bc2_sqrt, float grad_scale, int D, int N, const float* campos_all, const float* gcol_all,
@@ -340,7 +311,7 @@ void launch_adam(int P, float* theta, const float* grad, float* m, float* v, flo
     // elementwise kernel.  Geometry sections (parts & 2): xyz + the activated sections, one per-surfel kernel.
     if (parts & 1) {
         if (gcol_all) {
-            hipLaunchKernelGGL(adam_sh_kernel, dim3((P + 63) / 64), dim3(256), 0, s, P, D, N, theta, m, v, campos_all, gcol_all, (const float*)theta, k);
+            hipLaunchKernelGGL(adam_sh_kernel, dim3((P + 63) / 64), dim3(256), 0, s, P, D, N, theta, m, v, campos_all, gcol_all, k);
         } else {
             size_t nsh = (size_t)48 * P, blocks_sh = (nsh + 256 * 4 - 1) / (256 * 4);
             if (blocks_sh > 65536) blocks_sh = 65536;

@@ -123,21 +123,6 @@ def exchange_collectives(grad, gcol, P, group=None, async_op=False):
     return (gall, wg, wr) if async_op else gall
 
 
-# Events behind SH-block optimiser steps that run on a side stream (GaussianModel.update_step_split): whoever touches the parameter
-# store next on another stream waits for them first.  The rasterizer's late-colour forward does so through its hook
-# (surfel_native.set_forward_hook(join_side_work)); every other reader goes through GaussianModel.theta / get_features.
-_PENDING_SIDE = []
-
-
-def join_side_work():
-    """Make the current stream wait for every pending side-stream update (a stream-level wait: the host does not block)."""
-    if _PENDING_SIDE:
-        s = torch.cuda.current_stream()
-        for ev in _PENDING_SIDE:
-            s.wait_event(ev)
-        _PENDING_SIDE.clear()
-
-
 class GaussianModel:
     def __init__(self, sh_degree: int, device="cuda"):
         self.active_sh_degree = 0
@@ -149,9 +134,7 @@ class GaussianModel:
         self.n_coef = (sh_degree + 1) ** 2
         self.device = torch.device(device)
         self.P = 0
-        self._theta = None
-        self.act = self.grad = self.m = self.v = None
-        self.xyz_fwd = None
+        self.theta = self.act = self.grad = self.m = self.v = None
         self.max_radii2D = torch.empty(0)
         self.xyz_gradient_accum = torch.empty(0)
         self.denom = torch.empty(0)
@@ -164,17 +147,6 @@ class GaussianModel:
         self._lr_args = None
 
     # ------------------------------------------------------------------ store
-    @property
-    def theta(self):
-        """The flat parameter store.  Reading it orders the current stream behind a pending side-stream SH update (join_side_work)."""
-        join_side_work()
-        return self._theta
-
-    @theta.setter
-    def theta(self, t):
-        join_side_work()
-        self._theta = t
-
     def _alloc(self, P):
         dev = self.device
         self.P = P
@@ -246,9 +218,7 @@ class GaussianModel:
     @property
     def get_xyz(self): return self._gate(self._pv["xyz"])
     @property
-    def get_features(self):
-        join_side_work()
-        return self._gate(self._pv["sh"].view(self.P, 16, 3))
+    def get_features(self): return self._gate(self._pv["sh"].view(self.P, 16, 3))
     @property
     def get_opacity(self): return self._gate(self._av["opacity"])
     @property
@@ -328,7 +298,7 @@ class GaussianModel:
         else:
             self.gcol = self._gcol_alias()
         dsr.set_grad_arena(dict(means3D=gv["xyz"], sh=gv["sh"].view(self.P, 16, 3) if sh_grad else None, opacities=gv["opacity"],
-                                scales=gv["scaling"], rotations=gv["rotation"], colors=self.gcol, _owner=self._theta))
+                                scales=gv["scaling"], rotations=gv["rotation"], colors=self.gcol, _owner=self.theta))
 
     def update_learning_rate(self, iteration):
         lr = expon_lr(iteration, **self._lr_args)
@@ -372,38 +342,6 @@ class GaussianModel:
                                                _n.current_stream_ptr(self.device))
         if rc < 0:
             raise RuntimeError("surfel_train_update failed: %s" % _n.last_error())
-
-    def update_step_split(self, colour_grads, stats=None, grad_scale=1.0, side_stream=None):
-        """update_step as TWO launches (surfel_train_update_part; same bits): statistics + geometry Adam + activations on the current
-        stream — it leaves the positions the forward saw in self.xyz_fwd — and the SH block's Adam (83 % of the update's bytes) on
-        `side_stream`, ordered behind the first by an event.  Returns the event recorded behind the SH part: whoever reads the SH
-        coefficients next must wait for it (Trainer: the next forward's late-colour hook)."""
-        self.step_count += 1
-        lr = (C.c_float * 6)(*self.lr)
-        cam, gc = colour_grads[0].contiguous().float(), colour_grads[1].contiguous().float()
-        g = r = None
-        if stats is not None:
-            g, r = stats[0].contiguous().float(), stats[1].contiguous().to(torch.int32)
-        if getattr(self, "xyz_fwd", None) is None or self.xyz_fwd.shape[0] != self.P:
-            self.xyz_fwd = torch.empty((self.P, 3), dtype=torch.float32, device=self.device)
-        lib = _n.load()
-        args = lambda part, stream: (part, self.P, _n.ptr(self.theta), _n.ptr(self.grad), _n.ptr(self.m), _n.ptr(self.v), _n.ptr(self.act), lr,
-                                     self.betas[0], self.betas[1], self.eps, self.step_count, float(grad_scale), int(self.active_sh_degree),
-                                     int(gc.shape[0]), _n.ptr(cam), _n.ptr(gc), _n.ptr(g), _n.ptr(r), _n.ptr(self.xyz_gradient_accum),
-                                     _n.ptr(self.denom), _n.ptr(self.max_radii2D), _n.ptr(self.xyz_fwd), stream)
-        with torch.cuda.device(self.device):
-            main = torch.cuda.current_stream(self.device)
-            rc = lib.surfel_train_update_part(*args(2, _n.current_stream_ptr(self.device)))
-            if rc >= 0:
-                side = side_stream if side_stream is not None else main
-                if side is not main:
-                    side.wait_stream(main)
-                rc = lib.surfel_train_update_part(*args(1, C.c_void_p(side.cuda_stream)))
-                done = torch.cuda.Event()
-                done.record(side)
-        if rc < 0:
-            raise RuntimeError("surfel_train_update_part failed: %s" % _n.last_error())
-        return done
 
     def exchange_gradients(self, campos_all, group=None):
         """View-parallel step: make self.grad the SUM over ranks of the per-view gradients with

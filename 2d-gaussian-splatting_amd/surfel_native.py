@@ -20,10 +20,10 @@ HOOK_FN = C.CFUNCTYPE(None, C.c_void_p)
 
 EXPORTS = ["surfel_abi_version", "surfel_last_error", "surfel_rasterize_forward", "surfel_rasterize_backward",
            "surfel_mark_visible", "surfel_knn_dist2", "surfel_last_stage_ms", "surfel_last_stage_ids", "surfel_stage_name",
-           "surfel_collect_stage_ms", "surfel_set_option", "surfel_debug_sort_pairs", "surfel_debug_set_blend_stats", "surfel_debug_last_binning", "surfel_debug_capacity_evictions", "surfel_debug_image_layout", "surfel_debug_box_probe", "surfel_debug_latency_probe", "surfel_set_backward_hook", "surfel_set_forward_hook", "surfel_forward_count",
+           "surfel_collect_stage_ms", "surfel_set_option", "surfel_debug_sort_pairs", "surfel_debug_set_blend_stats", "surfel_debug_last_binning", "surfel_debug_capacity_evictions", "surfel_debug_image_layout", "surfel_debug_box_probe", "surfel_debug_latency_probe", "surfel_set_backward_hook", "surfel_forward_count",
            # include/surfel_train.h
            "surfel_l1_ssim_forward", "surfel_l1_ssim_backward", "surfel_l1_ssim_forward_w", "surfel_l1_ssim_backward_w", "surfel_render_post_forward", "surfel_render_post_backward", "surfel_train_loss_forward", "surfel_train_loss_backward",
-           "surfel_reduce_partials", "surfel_loss_finalize", "surfel_activate", "surfel_adam_step", "surfel_train_update", "surfel_train_update_part", "surfel_sh_grad_gather", "surfel_densify_stats"]
+           "surfel_reduce_partials", "surfel_loss_finalize", "surfel_activate", "surfel_adam_step", "surfel_train_update", "surfel_sh_grad_gather", "surfel_densify_stats"]
 
 # per-call option overrides carried in the upper bits of the `debug` argument (include/surfel_hip.h)
 OPT_NO_CULL = 1 << 8
@@ -38,7 +38,6 @@ OPT_LAZY_COUNT = 1 << 21       # forward: do not wait for the instance count; fo
 E_OVERFLOW = -5
 OPT_BWD_GATHER = 1 << 22       # backward: ignore the forward's tile stream, gather by surfel id (bit-identical)
 OPT_NO_STREAM = 1 << 23        # forward: no backward follows (inference / no_grad): leave no tile stream behind
-OPT_LATE_COLOUR = 1 << 24      # forward: SH colours by a kernel of their own right before the blend (set_forward_hook)
 OPT_BWD_SCAN = 1 << 15         # scan walk (lanes = instances); deterministic, not bit-identical to rows / quad
 
 
@@ -98,8 +97,6 @@ def load():
         lib.surfel_debug_latency_probe.argtypes = [vp, i64, i, C.POINTER(C.c_float), vp]
         lib.surfel_set_backward_hook.restype = i
         lib.surfel_set_backward_hook.argtypes = [HOOK_FN, vp]
-        lib.surfel_set_forward_hook.restype = i
-        lib.surfel_set_forward_hook.argtypes = [HOOK_FN, vp]
         lib.surfel_forward_count.restype = i64
         lib.surfel_forward_count.argtypes = []
         lib.surfel_set_option.restype = i
@@ -119,7 +116,6 @@ def load():
                            ("surfel_activate", [i, vp, vp, vp]),
                            ("surfel_adam_step", [i, vp, vp, vp, vp, vp, fp, f, f, f, i, f, i, i, vp, vp, i, vp]),
                            ("surfel_train_update", [i, vp, vp, vp, vp, vp, fp, f, f, f, i, f, i, i, vp, vp, vp, vp, vp, vp, vp, vp]),
-                           ("surfel_train_update_part", [i, i, vp, vp, vp, vp, vp, fp, f, f, f, i, f, i, i, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
                            ("surfel_sh_grad_gather", [i, i, i, vp, vp, vp, vp, vp]),
                            ("surfel_densify_stats", [i, vp, vp, vp, vp, vp, vp])):
             fn = getattr(lib, name)
@@ -151,23 +147,6 @@ def set_backward_hook(fn):
     thunk = HOOK_FN(lambda user: fn())
     lib.surfel_set_backward_hook(thunk, None)
     _hook_keepalive = thunk
-
-
-def set_forward_hook(fn):
-    """surfel_set_forward_hook: fn() is called inside every OPT_LATE_COLOUR forward right before the kernel that reads the SH
-    coefficients is enqueued (None removes the hook)."""
-    global _fwd_hook_keepalive
-    lib = load()
-    if fn is None:
-        lib.surfel_set_forward_hook(HOOK_FN(), None)
-        _fwd_hook_keepalive = None
-        return
-    thunk = HOOK_FN(lambda user: fn())
-    lib.surfel_set_forward_hook(thunk, None)
-    _fwd_hook_keepalive = thunk
-
-
-_fwd_hook_keepalive = None
 
 
 class CapacityOverflow(RuntimeError):

@@ -199,14 +199,6 @@ class Trainer:
         # from the 12 B/surfel colour gradients.  Always on under view-parallel training (that is how the gradients are exchanged).
         self.fused_sh = self._exchange or os.environ.get("SURFEL_SH_FUSED", "1") != "0"
         self.fused_update = os.environ.get("SURFEL_FUSED_UPDATE", "1") != "0"      # surfel_train_update (statistics + Adam in one launch)
-        # The SH block's Adam step is 83 % of the update's bytes (HBM-bound) and nothing of the NEXT iteration needs its result before the
-        # blend: it runs on a side stream underneath the next iteration's preprocess and binning (latency-bound sorts), and the rasterizer
-        # reads the SH coefficients late (OPT_LATE_COLOUR; its hook joins the side stream).  Same kernels' arithmetic, same bits.
-        self.overlap_sh = os.environ.get("SURFEL_OVERLAP_SH", "1") != "0" and model.device.type == "cuda"
-        self._side = None
-        if self.overlap_sh:
-            import surfel_model as _sm
-            _n.set_forward_hook(_sm.join_side_work)
         if model.grad is None:
             model.training_setup(self.opt)
         if self.world > 1:
@@ -308,8 +300,7 @@ class Trainer:
         # parameter gates — with the same kernels and bits; compute_cov3D_python trains through PyTorch code and needs autograd.
         manual = self.manual_chain and not bands and not getattr(self.pipe, "compute_cov3D_python", False)
         g2d = None
-        late = _n.OPT_LATE_COLOUR if (self.overlap_sh and manual) else 0
-        for bits in ((_n.OPT_LAZY_COUNT | late, _n.OPT_EXACT_BINNING | late) if lazy else (late,)):
+        for bits in ((_n.OPT_LAZY_COUNT, _n.OPT_EXACT_BINNING) if lazy else (0,)):
             if manual:
                 with torch.no_grad():
                     rctx, image, radii, allmap = rasterize_manual(cam, m, self.pipe, self.background, debug_bits=bits)
@@ -369,14 +360,7 @@ class Trainer:
             # statistics + optimiser step as ONE launch where nothing can come between them (single GPU, SH block rebuilt in the kernel,
             # no densification / opacity reset this iteration): two launch boundaries and the statistics' latency-bound kernel fewer
             one_launch = self.fused_update and self.fused_sh and not bands and not self._exchange and it < opt.iterations and not self._is_event_iteration(it)
-            if one_launch and self.overlap_sh and manual:
-                import surfel_model as _sm
-                if self._side is None:
-                    self._side = torch.cuda.Stream(device=m.device)
-                ev = m.update_step_split((cam.camera_center[None], m.gcol[None]), stats=(g2d, radii) if stats_live else None, side_stream=self._side)
-                _sm._PENDING_SIDE.append(ev)
-                rebuilt = True
-            elif one_launch:
+            if one_launch:
                 m.update_step((cam.camera_center[None], m.gcol[None]), stats=((g2d if manual else means2D.grad), radii) if stats_live else None)
                 rebuilt = True      # (nothing left to do below)
             elif stats_live:

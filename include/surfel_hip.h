@@ -47,9 +47,9 @@ extern "C" {
 #define SURFEL_OPT_LAZY_COUNT     (1 << 21)            /* forward: do not wait for the instance count (surfel_forward_count) */
 #define SURFEL_OPT_BWD_GATHER     (1 << 22)            /* backward: ignore the forward's tile stream, gather the records by surfel id */
 #define SURFEL_OPT_NO_STREAM      (1 << 23)            /* forward: no backward will follow (inference, no_grad): leave no tile stream behind */
-#define SURFEL_OPT_LATE_COLOUR    (1 << 24)            /* forward: the SH coefficients are read by a kernel of their own right before the blend (surfel_set_forward_hook) */
 /* Allocator callback: `bytes` bytes of device memory, 256-byte aligned, valid until the caller frees it (SURVEY.md 8b "ownership"). */
 typedef void* (*surfel_alloc_fn)(void* user, size_t bytes);
+
 int surfel_abi_version(void);
 const char* surfel_last_error(void);
 /* Forward.  Replaces `_C.rasterize_gaussians` (call site /root/reference/gaussian_renderer/__init__.py:97-106).
@@ -99,13 +99,11 @@ int surfel_knn_dist2(surfel_alloc_fn scratch_alloc, void* scratch_user, int P, c
  */
 int surfel_set_option(const char* name, int value);
 
-/* Overlap hooks (process-wide; NULL removes one; results unchanged; no reference counterpart).  Backward: dL_dcolors is finalised right behind the
- * blend backward, colour_ready(user) is called on the calling thread (a view-parallel trainer launches its all-gather there), then the chain rule. */
+/* Multi-GPU overlap hook (process-wide; NULL removes it): surfel_rasterize_backward finalises dL_dcolors right behind the blend backward,
+ * calls colour_ready(user) on the calling thread (the caller launches its all-gather of dL_dcolors there), then enqueues the per-surfel
+ * chain rule.  All outputs unchanged.  No reference counterpart (the reference trains on one GPU). */
 typedef void (*surfel_hook_fn)(void* user);
 int surfel_set_backward_hook(surfel_hook_fn colour_ready, void* user);
-/* Forward: with SURFEL_OPT_LATE_COLOUR `shs` is read by ONE kernel enqueued right before the blend; sh_needed(user) is called just before it is
- * enqueued (a trainer whose SH-block optimiser step runs on another stream makes `stream` wait for it there: it overlaps preprocess + binning). */
-int surfel_set_forward_hook(surfel_hook_fn sh_needed, void* user);
 
 /* Lazily counted frames (SURFEL_OPT_LAZY_COUNT): a capacity-path forward returns at once with its CAPACITY (pass it to the backward as R);
  * the caller owes one surfel_forward_count() on the same thread before the frame's results take effect: the exact count, or

@@ -163,19 +163,6 @@ int surfel_train_update(int P, float* theta, const float* grad, float* m, float*
                         const float* dL_dmeans2D, const int* radii, float* grad_accum, float* denom, float* max_radii, void* stream);
 
 /*
- * surfel_train_update in TWO launches that may run on two streams (same results to the bit):
- *   part 2 — statistics + Adam of the geometry sections + next activations; leaves the positions it replaced in xyz_fwd [P,3];
- *   part 1 — Adam of the SH block (48 of the 58 floats: 83 % of the update's bytes), view directions from xyz_fwd; reads no `grad`.
- * Part 1 must come after part 2 (it reads xyz_fwd), and nothing else orders them: a trainer enqueues part 1 on a second stream and lets it
- * overlap the NEXT iteration's preprocess and binning — the rasterizer reads the SH coefficients late on request (include/surfel_hip.h:
- * SURFEL_OPT_LATE_COLOUR, surfel_set_forward_hook).  Same t in both calls = one optimiser step.
- */
-int surfel_train_update_part(int part, int P, float* theta, const float* grad, float* m, float* v, float* act, const float* lr,
-                             float beta1, float beta2, float eps, int t, float grad_scale,
-                             int D, int N, const float* campos_all, const float* gcol_all,
-                             const float* dL_dmeans2D, const int* radii, float* grad_accum, float* denom, float* max_radii,
-                             float* xyz_fwd, void* stream);
-/*
  * View-parallel training (new; the reference is single-GPU): the SH gradient of the summed loss rebuilt from every
  * rank's clamp-masked dL/dcolour instead of all-reducing 192 B/surfel:
  *   dL_dsh[P,16,3] = sum_{r<N} basis(normalize(means3D - campos_all[r])) (x) gcol_all[r, :, :]      (rank order, D = active degree)

@@ -1381,47 +1381,3 @@ def test_interleaved_forwards_and_backwards():
 def n_opt(name):
     import surfel_native as n
     return getattr(n, name)
-
-
-@pytest.mark.parametrize("kind", ["plain", "needles", "huge", "grazing", "crowded", "C1", "large"])
-def test_late_colour_forward_is_identical(kind):
-    """SURFEL_OPT_LATE_COLOUR: the SH colours by a kernel of their own right before the blend (the trainer's SH-block optimiser step
-    overlaps preprocess and binning) instead of inside preprocess_fwd — ONE device function, so images, radii, the count and every
-    gradient are the plain forward's bit for bit; `large` (600 k surfels) takes the LDS-DMA variants of both kernels, and the hook is
-    called exactly once per late-colour forward, never otherwise."""
-    import surfel_native as n
-    import synthetic
-    if kind == "large":
-        sc = synthetic.make_scene(600_000, 320, 208, seed=31, px_radius=1.5)
-    elif kind == "C1":
-        sc = _scene("C1")
-    else:
-        sc = _walk_scene(kind)
-    a = scene_args(sc)
-    rng = np.random.default_rng(6)
-    gC = rng.normal(size=(3, a["H"], a["W"])).astype(np.float32); gO = rng.normal(size=(7, a["H"], a["W"])).astype(np.float32)
-    calls = []
-    n.set_forward_hook(lambda: calls.append(1))
-    try:
-        base = HipRun(a).forward()
-        assert not calls
-        gb = base.backward(gC, gO)
-        for deg in (3, 1):
-            a2 = dict(a, sh_degree=deg)
-            ref = base if deg == 3 else HipRun(a2).forward()
-            gref = gb if deg == 3 else ref.backward(gC, gO)
-            del calls[:]
-            late = HipRun(a2, debug=n.OPT_LATE_COLOUR).forward()
-            assert len(calls) == 1
-            assert late.R == ref.R and np.array_equal(late.radii.cpu().numpy(), ref.radii.cpu().numpy())
-            assert np.array_equal(late.color.cpu().numpy(), ref.color.cpu().numpy()) and np.array_equal(late.others.cpu().numpy(), ref.others.cpu().numpy())
-            gl = late.backward(gC, gO)
-            for k in gl:
-                assert np.array_equal(gl[k], gref[k]), "%s degree %d: dL/d%s differs with late colours" % (kind, deg, k)
-        # precomputed colours: the flag is ignored (no SH to read), no hook call
-        cols = rng.uniform(0, 1, (a["means3D"].shape[0], 3)).astype(np.float32)
-        del calls[:]
-        r1 = HipRun(a, colors_precomp=cols).forward(); r2 = HipRun(a, colors_precomp=cols, debug=n.OPT_LATE_COLOUR).forward()
-        assert not calls and np.array_equal(r1.color.cpu().numpy(), r2.color.cpu().numpy())
-    finally:
-        n.set_forward_hook(None)

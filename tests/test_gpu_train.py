@@ -507,59 +507,20 @@ def test_fused_update_equals_the_three_launches():
     gt_model = TR.synthetic_object(2500, d, seed=4, px_scale=0.06)
     cams = TR.capture_views(gt_model, TR.orbit_cameras(4, 128, 96, device=d), bg)
     out = []
-    # [r6] a third form: the update as TWO launches on two streams (surfel_train_update_part: statistics + geometry on the iteration's
-    # stream, the SH block on a side stream underneath the next iteration's preprocess and binning, the rasterizer reading the SH
-    # coefficients late: OPT_LATE_COLOUR + forward hook) — the default of a single-GPU trainer
-    for fused, overlap in ((True, True), (True, False), (False, False)):
+    for fused in (True, False):
         torch.manual_seed(77)      # (the split samples of densify_and_split come from the global generator)
         m = TR.synthetic_object(2500, d, seed=5, px_scale=0.05)
         m.spatial_lr_scale = 1.0
         tr = TR.Trainer(m, cams, TR.optimization_params(dist_from_iter=2, normal_from_iter=0, lambda_dist=10.0, densify_from_iter=3, densification_interval=4,
                                                         densify_until_iter=12, opacity_reset_interval=10), TR.pipeline_params(depth_ratio=1.0))
-        assert tr.overlap_sh      # the default
-        tr.fused_update, tr.overlap_sh = fused, overlap
+        tr.fused_update = fused
         for _ in range(15):      # densifies at 4 and 8, resets the opacities at 10, statistics off from 12
             tr.step()
         torch.cuda.synchronize()
         out.append((m.P, m.theta.clone(), m.m.clone(), m.v.clone(), m.act.clone(), m.xyz_gradient_accum.clone(), m.denom.clone(), m.max_radii2D.clone()))
-    assert out[0][0] == out[1][0] == out[2][0] and out[0][0] > 1000
-    for other in out[1:]:
-        for a, b in zip(out[0][1:], other[1:]):
-            assert torch.equal(a, b)
-
-
-def test_side_stream_update_is_joined_by_every_reader():
-    """The SH block's Adam step of iteration k runs on a side stream while iteration k + 1 preprocesses and bins.  Whoever reads the
-    parameters in between must be ordered behind it WITHOUT a device synchronisation: model.theta / get_features (evaluation renders,
-    densification, saving) join the side stream on the reader's stream.  A trainer stepped with and without the overlap, read through
-    theta.clone() right after every step() — no torch.cuda.synchronize() — gives the same bits; so does an evaluation render between
-    two training steps (/root/reference/train.py:211)."""
-    import torch
-    import surfel_model as SM
-    import surfel_trainer as TR
-    d = dev()
-    bg = torch.zeros(3, device=d)
-    gt_model = TR.synthetic_object(60_000, d, seed=4, px_scale=0.03)
-    cams = TR.capture_views(gt_model, TR.orbit_cameras(4, 320, 240, device=d), bg)
-    snaps = []
-    for overlap in (True, False):
-        m = TR.synthetic_object(60_000, d, seed=5, px_scale=0.03)
-        m.spatial_lr_scale = 1.0
-        tr = TR.Trainer(m, cams, TR.optimization_params(dist_from_iter=0, normal_from_iter=0, lambda_dist=10.0, densify_from_iter=10 ** 9), TR.pipeline_params(depth_ratio=1.0))
-        tr.overlap_sh = overlap
-        got = []
-        for k in range(6):
-            tr.step()
-            if overlap and k < 5:
-                assert len(SM._PENDING_SIDE) == 1      # the SH part of this step is in flight (or done) on the side stream, unjoined
-            got.append(m.theta.clone())                # (the property joins; the clone is ordered behind the SH part)
-            assert not SM._PENDING_SIDE
-            if k == 2:
-                got.append(tr.evaluate(cams[:2])[0])   # a no_grad render between two steps
-        snaps.append(got)
-    torch.cuda.synchronize()
-    for a, b in zip(*snaps):
-        assert (torch.equal(a, b) if torch.is_tensor(a) else a == b)
+    assert out[0][0] == out[1][0] and out[0][0] > 1000
+    for a, b in zip(out[0][1:], out[1][1:]):
+        assert torch.equal(a, b)
 
 
 def test_trainer_redoes_a_lazily_counted_frame_that_really_overflowed():
