@@ -9,6 +9,7 @@
 #include <hip/hip_runtime.h>
 
 #include "../../include/surfel_hip.h"
+#include "../../include/surfel_debug.h"      // (one white-box check below: how the forward sized its buffers)
 #include "../../include/surfel_train.h"
 
 #define CHECK(x) do { if (!(x)) { std::printf("FAILED: %s (line %d): %s\n", #x, __LINE__, surfel_last_error()); return 1; } } while (0)
