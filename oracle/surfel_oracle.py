@@ -113,6 +113,29 @@ class Oracle:
         self.lib.oracle_set_signature_buffers(None, None, None)
         return st.R, st.out_color, st.out_others, st.radii, st
 
+    def preprocess_extents(self, means3D, colors_precomp, opacities, scales, rotations, scale_modifier, transMat_precomp, viewmatrix,
+                           projmatrix, tanfovx, tanfovy, H, W, sh, degree, campos):
+        """Stage 1 alone (oracle_preprocess): (radii, AABB half-extent in front of ceil()) of every surfel.  Tests use extra
+        Monte-Carlo-arithmetic draws of this cheap stage to pin which radii fp32 determines (tests/determinacy.py)."""
+        real = self.real
+        means3D = _f32(means3D); P = means3D.shape[0]
+        opacities = _f32(opacities).reshape(-1)
+        scales = _f32(scales); rotations = _f32(rotations); transMat_precomp = _f32(transMat_precomp)
+        colors_precomp = _f32(colors_precomp); sh = _f32(sh)
+        viewmatrix = _f32(viewmatrix); projmatrix = _f32(projmatrix); campos = _f32(campos)
+        M = sh.shape[1] if sh is not None else 0
+        prm = self._params(P, int(degree), M, int(W), int(H), tanfovx, tanfovy, scale_modifier)
+        depths = np.zeros(P, real); radii = np.zeros(P, np.int32); xy = np.zeros((P, 2), real)
+        transMat = np.zeros((P, 9), real); normal_opacity = np.zeros((P, 4), real)
+        rgb = np.zeros((P, 3), real); clamped = np.zeros((P, 3), np.uint8); tiles_touched = np.zeros(P, np.uint32)
+        extent = np.zeros(P, np.float64)
+        self.lib.oracle_set_signature_buffers(None, None, _p(extent))
+        self.lib.oracle_preprocess(C.byref(prm), _p(means3D), _p(opacities), _p(scales), _p(rotations), _p(transMat_precomp),
+                                   _p(colors_precomp), _p(sh), _p(viewmatrix), _p(projmatrix), _p(campos), _p(depths), _p(radii), _p(xy),
+                                   _p(transMat), _p(normal_opacity), _p(rgb), _p(clamped), _p(tiles_touched))
+        self.lib.oracle_set_signature_buffers(None, None, None)
+        return radii, extent
+
     # ------------------------------------------------------------------ backward
     def rasterize_backward(self, st, dL_dout_color, dL_dout_others):
         real = self.real

@@ -25,7 +25,8 @@ N_DRAWS = 3
 DET_FRAC = 0.5
 PASS_FRAC = 0.999
 COS_MIN = 0.9999
-RAD_K = 4.0                 # (8 with fewer than four draws: the largest deviation of two draws underestimates the spread)
+RAD_K = 4.0
+EXTENT_DRAWS = 8            # preprocess-only draws behind the radii pin (cheap: stage 1 alone)
 EXEMPT_CAP = 0.25
 IMG_ATOL, IMG_RTOL = 1e-4, 1e-4
 G_ATOL_MEAN, G_RTOL = 1e-4, 2e-3
@@ -61,9 +62,21 @@ class Determinacy:
             self.flip_pix |= d.sig_pix != ref.sig_pix
             self.flip_surf |= (d.sig_surf != ref.sig_surf) | (d.radii != ref.radii) | (d.clamped != ref.clamped).any(1)
             dev = np.maximum(dev, np.abs(d.extent - ref.extent))
-        # radius = ceil(extent): pinned where the extent stays on its side of the integers under RAD_K x the draws' largest deviation
-        band = (RAD_K if n_draws >= 4 else 2.0 * RAD_K) * dev + 1e-12
-        self.radii_determined = (np.ceil(ref.extent - band) == np.ceil(ref.extent + band)) & np.all([d.radii == ref.radii for d in self.draw_st], 0)
+        # radius = ceil(extent): pinned where the extent stays on its side of the integers under RAD_K x the draws' largest deviation.
+        # The extent comes out of stage 1 alone, so its spread is sampled with EXTENT_DRAWS preprocess-only draws whatever n_draws is
+        # (two draws underestimate a surfel's spread by 8x in ~1e-5 of 1e7 surfels: C5 showed 83 such "pinned" radii).
+        same_radii = np.all([d.radii == ref.radii for d in self.draw_st], 0)
+        for k in range(n_draws, EXTENT_DRAWS):
+            self.om.set_seed(100 + k)
+            r_k, e_k = self.om.preprocess_extents(a["means3D"], fw.get("colors_precomp"), a["opacities"],
+                                                  None if fw.get("transMat_precomp") is not None else a["scales"],
+                                                  None if fw.get("transMat_precomp") is not None else a["rotations"], a["scale_modifier"],
+                                                  fw.get("transMat_precomp"), a["viewmatrix"], a["projmatrix"], a["tanfovx"], a["tanfovy"], a["H"], a["W"],
+                                                  a["shs"] if (fw.get("use_sh", True) and fw.get("colors_precomp") is None) else None, a["sh_degree"], a["campos"])
+            dev = np.maximum(dev, np.abs(e_k - ref.extent))
+            same_radii &= r_k == ref.radii
+        band = RAD_K * dev + 1e-12
+        self.radii_determined = (np.ceil(ref.extent - band) == np.ceil(ref.extent + band)) & same_radii
         self.grads, self.draw_grads = None, None
 
     def backward(self, gC, gO):

@@ -145,6 +145,27 @@ def test_f32_port_matches_f64():
     assert np.mean(np.abs(col - col32) < 1e-4) > 0.999
 
 
+def test_radii_pin_uses_stage_one_alone():
+    """determinacy.py pins radii with preprocess-only Monte-Carlo-arithmetic draws: the stage-1 entry reproduces the full forward's
+    radii / extents exactly (fp64), a draw moves extents by fp32-sized amounts only, and the pinned set covers most surfels."""
+    import synthetic
+    import determinacy as D
+    from helpers import oracle_forward, scene_args
+    from oracle.surfel_oracle import Oracle
+    sc = synthetic.make_scene(2000, 128, 96, seed=1, px_radius=5.0)
+    a = scene_args(sc)
+    args = (a["means3D"], None, a["opacities"], a["scales"], a["rotations"], a["scale_modifier"], None, a["viewmatrix"], a["projmatrix"],
+            a["tanfovx"], a["tanfovy"], a["H"], a["W"], a["shs"], a["sh_degree"], a["campos"])
+    R, col, oth, radii, st = oracle_forward(Oracle("f64"), a)
+    r, e = Oracle("f64").preprocess_extents(*args)
+    assert np.array_equal(r, radii) and np.array_equal(e, st.extent)
+    om = Oracle("mca"); om.set_seed(7)
+    rm, em = om.preprocess_extents(*args)
+    assert np.abs(em - e).max() < 1e-2 and (rm != r).mean() < 0.01
+    det = D.Determinacy(a, None, n_draws=1)
+    assert det.radii_determined.mean() > 0.9 and np.array_equal(det.radii, radii)
+
+
 def test_knn_oracle_known_answer():
     from oracle.surfel_oracle import Oracle
     pts = np.array([[0, 0, 0], [1, 0, 0], [0, 2, 0], [0, 0, 3], [10, 10, 10]], np.float32)
