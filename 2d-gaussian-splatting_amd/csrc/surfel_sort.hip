@@ -6,18 +6,22 @@
 //   os_hist   : digit histograms of ALL passes in one sweep over the keys (the multiset of digits of a pass does not
 //               depend on the order earlier passes leave behind); also clears the look-back state.  Callers that
 //               produce the keys themselves can fill the histogram on the fly and skip this launch.
-//   os_pass   : one launch per pass.  A workgroup takes the next 2048-item tile (ticket order = input order), ranks
+//   os_pass   : one launch per pass.  A 1024-thread workgroup takes the next 4096-item tile (ticket order = input order), ranks
 //               its items with wave64 match-by-ballot (no atomics, order-preserving => stable), publishes its digit
 //               counts, and obtains the counts of all earlier tiles by decoupled look-back over their published
 //               (aggregate | inclusive-prefix) words — one 32-bit word per (tile, digit) carrying flag and value, stored
 //               and loaded at agent scope, so there is no separate payload to order.  Predecessor tiles hold smaller
 //               tickets, i.e. they are already running, so the spin always terminates.
-// Items are then scattered with coalesced same-digit runs.  Traffic per pass: 16 B/item + 1 KB of status per tile.
+// The tile's items pass through LDS in tile-local sorted order and leave as same-digit runs written by consecutive lanes.
+// Traffic per pass: 16 B/item + 1 KB of status per tile.
 // The look-back form is used while the whole grid is (nearly) resident (n <= RS_ONESWEEP_MAX): there a pass costs
-// 16 us instead of 30 us for three launches.  Beyond that, the number of in-flight tiles exceeds what one look-back
-// round (RS_LB words, ~1 us of agent-scope latency) can absorb and the chain throttles the scatter (measured 190 us
-// per pass at 10 M items vs 125 us), so large inputs take the classic three launches per pass:
-//   rs_hist (per-tile digit counts) -> rs_scan (one workgroup per digit over the tiles) -> the same scatter.
+// 16 us instead of 30 us for three launches.  Beyond that every tile is resident and publishing at once, a tile's look-back reads
+// O(tiles) words per digit and the chain throttles the scatter (measured at 2.2 M and 10 M items, both rounds 2 and 6), so
+// large inputs take three launches per pass:
+//   rs_hist_fat (digit counts per tile) -> rs_scan (one workgroup per digit over the tiles) -> the same tile body (os_pass_fat<false>).
+// [r6] Until round 6 the large path scattered from registers (2048-item tiles, a digit's 8 items per tile stored by whichever lanes
+// ranked them: 64 lines per store instruction, 1.2 TB/s per pass) and lost to rocPRIM on tile-id sorts; through LDS it reaches
+// 2.0 TB/s per pass at 8 M items (profiles/r06_sort_ab.jsonl: C4 depth sort + scan 196 -> 157 us, tile sort 169 (rocPRIM) -> 130 us).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -36,12 +40,11 @@ constexpr size_t g_onesweep_max = RS_ONESWEEP_MAX_ITEMS;
 // Large inputs (n > RS_ONESWEEP_MAX: the P-sized depth sort at C4 / C5 and the R-sized tile sort of 1e7 - 1e8 instances) can be
 // handed to rocprim::radix_sort_pairs (the north star names rocPRIM for the global key sort) instead of the three-launch path
 // below: surfel_set_option("large_sort", 1).  Both are stable LSD sorts on [begin_bit, end_bit): results are identical.
-// Measured choice: profiles/r02_large_sort.md.
 int g_large_sort_impl = 2;      // 0 own, 1 rocPRIM, 2 auto
 void set_large_sort_impl(int v) { g_large_sort_impl = v < 0 ? 0 : (v > 3 ? 2 : v); }      // 3: rocPRIM for every size (measurement only)
-// auto (measured on MI355X, profiles/r02_large_sort.md): rocPRIM for the R-sized tile-id sorts (<= 16 key bits: 2.1 vs 1.2 TB/s per
-// pass at 1.3e8 items, 1.5 vs 1.3 at 8e6) and for 32-bit sorts of >= 4 M items (10 M surfels: 0.66 vs 0.76 ms); the library's
-// own passes for 32-bit sorts below that (2 M surfels: 0.19 vs 0.22 ms).
+// auto (measured on MI355X, profiles/r06_sort_ab.jsonl): the library's own passes up to 2^25 items (8.1 M tile-id pairs: 130 vs
+// 168 us; 2 M / 10 M depth keys: 0.157 vs 0.216 / 0.584 vs 0.651 ms incl. the scan), rocPRIM above (1.3e8 tile-id pairs: 2.04 vs
+// 2.44 ms — at that size 8192-item tiles draw level, 2.02, but lose below).
 static inline bool use_rocprim(size_t n, int begin_bit, int end_bit) {
     // key fields that do not start at bit 0 always take the library's own passes: rocprim::radix_sort_pairs of this ROCm returned
     // wrongly ordered values for [24, 32), [30, 32) and [31, 32) at >= 4096 items (scripts/dbg/rocprim_small.py; fields starting at
@@ -50,7 +53,7 @@ static inline bool use_rocprim(size_t n, int begin_bit, int end_bit) {
     if (g_large_sort_impl == 3) return true;
     if (n <= g_onesweep_max) return false;
     if (g_large_sort_impl != 2) return g_large_sort_impl == 1;
-    return (end_bit - begin_bit) <= 16 || n >= ((size_t)4 << 20);
+    return n > ((size_t)1 << 25);
 }
 static size_t rocprim_sort_temp_bytes(size_t n) {
     // (queried for the full 32-bit key: an upper bound for every [begin_bit, end_bit) the library sorts on; the host-side query is
@@ -75,7 +78,6 @@ static inline bool rs_onesweep(size_t n) { return n <= g_onesweep_max; }
 constexpr int RS_BITS = 8;
 constexpr int RS_RADIX = 1 << RS_BITS;
 constexpr int RS_MAX_PASSES = 4;
-constexpr int RS_LB = 16;                       // look-back window (tiles per round)
 constexpr uint32_t ST_AGG = 1u << 30, ST_PREFIX = 2u << 30, ST_VALUE = (1u << 30) - 1u;
 
 // scratch layout (u32 words): ghist[RS_MAX_PASSES][256] | ticket[RS_MAX_PASSES] (+pad to 64) | status[passes][nblocks][256]
@@ -134,20 +136,22 @@ __global__ void __launch_bounds__(RS_THREADS) os_hist_kernel(const uint32_t* __r
     }
 }
 
-// ---- large-n path: per-tile digit counts -> hist[digit][tile], then one workgroup per digit scans its row
-__global__ void __launch_bounds__(RS_THREADS) rs_hist_kernel(const uint32_t* __restrict__ keys, uint32_t n, int shift, uint32_t mask,
-                                                             uint32_t* __restrict__ hist, uint32_t nblocks) {
+// ---- large-n path: digit counts per 4096-item tile -> hist[digit][tile] (rs_hist_fat_kernel), then one workgroup per digit scans its row
+constexpr int FTH_THREADS = 1024;
+template <int FTH_IPT>
+__global__ void __launch_bounds__(FTH_THREADS) rs_hist_fat_kernel(const uint32_t* __restrict__ keys, uint32_t n, int shift, uint32_t mask,
+                                                                  uint32_t* __restrict__ hist, uint32_t nblocks) {
     __shared__ uint32_t s_h[RS_RADIX];
-    s_h[threadIdx.x] = 0;
+    if (threadIdx.x < RS_RADIX) s_h[threadIdx.x] = 0;
     __syncthreads();
-    const uint32_t base = blockIdx.x * RS_TILE;
+    const uint32_t base = blockIdx.x * (uint32_t)(FTH_THREADS * FTH_IPT);
 #pragma unroll
-    for (int it = 0; it < RS_IPT; it++) {
-        const uint32_t e = base + it * RS_THREADS + threadIdx.x;
+    for (int it = 0; it < FTH_IPT; it++) {
+        const uint32_t e = base + it * FTH_THREADS + threadIdx.x;
         if (e < n) atomicAdd(&s_h[(keys[e] >> shift) & mask], 1u);
     }
     __syncthreads();
-    hist[(size_t)threadIdx.x * nblocks + blockIdx.x] = s_h[threadIdx.x];
+    if (threadIdx.x < RS_RADIX) hist[(size_t)threadIdx.x * nblocks + blockIdx.x] = s_h[threadIdx.x];
 }
 __global__ void __launch_bounds__(RS_THREADS) rs_scan_kernel(uint32_t* __restrict__ hist, uint32_t nblocks, uint32_t* __restrict__ total) {
     __shared__ uint32_t s_w[4];
@@ -175,123 +179,6 @@ __global__ void __launch_bounds__(RS_THREADS) rs_scan_kernel(uint32_t* __restric
     if (threadIdx.x == 0) total[blockIdx.x] = s_carry;
 }
 
-// one pass: tile ticket -> local ranks -> look-back -> scatter
-// LOOKBACK: ghist = digit totals, status/ticket = look-back state.  !LOOKBACK: ghist = total[digit] from rs_scan,
-// status = hist[digit][tile] already exclusive-scanned over the tiles, tile = blockIdx.x.
-// n_dev != nullptr (capacity binning): the item count lives on the device — the grid covers the capacity `n`, tiles behind the
-// real count leave right after taking their ticket (no earlier tile ever looks at them).
-template <bool LOOKBACK>
-__global__ void __launch_bounds__(RS_THREADS) os_pass_kernel(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ vals,
-                                                             uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out, uint32_t n,
-                                                             int shift, uint32_t mask, const uint32_t* __restrict__ ghist,
-                                                             uint32_t* __restrict__ status, uint32_t* __restrict__ ticket, uint32_t nblocks,
-                                                             const uint32_t* __restrict__ n_dev, int hstride) {
-    __shared__ uint32_t s_cnt[4][RS_RADIX];      // per-wave digit counts -> then per-wave output offsets
-    __shared__ uint32_t s_w[4];
-    __shared__ uint32_t s_tile;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const uint32_t d_t = threadIdx.x;            // the digit this thread owns in the offset phases
-    if (LOOKBACK && threadIdx.x == 0) s_tile = atomicAdd(ticket, 1u);
-#pragma unroll
-    for (int w = 0; w < 4; w++) s_cnt[w][d_t] = 0;
-    __syncthreads();
-    const uint32_t tile = LOOKBACK ? s_tile : blockIdx.x;
-    if (n_dev) {
-        n = min(n, *n_dev);
-        if (tile * (uint32_t)(RS_THREADS * RS_IPT) >= n) return;
-    }
-    // phase A: wave w owns a contiguous quarter of the tile, RS_IPT sweeps of 64 consecutive items
-    const uint32_t wbase = tile * (RS_THREADS * RS_IPT) + wave * (64 * RS_IPT);
-    uint32_t k[RS_IPT], v[RS_IPT], rank[RS_IPT];
-#pragma unroll
-    for (int it = 0; it < RS_IPT; it++) {
-        const uint32_t e = wbase + it * 64 + lane;
-        const bool valid = e < n;
-        k[it] = valid ? keys[e] : 0xffffffffu;
-        v[it] = valid ? vals[e] : 0u;
-    }
-#pragma unroll
-    for (int it = 0; it < RS_IPT; it++) {
-        const uint32_t e = wbase + it * 64 + lane;
-        const bool valid = e < n;
-        const uint32_t d = (k[it] >> shift) & mask;
-        unsigned long long mm = __ballot(valid);
-#pragma unroll
-        for (int b = 0; b < RS_BITS; b++) {
-            const bool bit = (d >> b) & 1u;
-            const unsigned long long bal = __ballot(bit);
-            mm &= bit ? bal : ~bal;
-        }
-        if (!valid) mm = 0ull;                   // invalid lanes matched each other's padding digit: they own nothing
-        const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(mm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mm, 0u));
-        const uint32_t prev = valid ? s_cnt[wave][d] : 0u;   // same-wave LDS ops are program-ordered
-        rank[it] = prev + below;
-        if (valid && below == 0) s_cnt[wave][d] = prev + (uint32_t)__popcll(mm);
-    }
-    __syncthreads();
-    // tile count of this thread's digit; publish it, look back for the sum over earlier tiles
-    const uint32_t c0 = s_cnt[0][d_t], c1 = s_cnt[1][d_t], c2 = s_cnt[2][d_t], c3 = s_cnt[3][d_t];
-    const uint32_t cnt = c0 + c1 + c2 + c3;
-    uint32_t* my = status + (size_t)tile * RS_RADIX + d_t;
-    uint32_t excl = 0;
-    if (!LOOKBACK) {
-        excl = status[(size_t)d_t * nblocks + tile];
-    } else if (tile == 0) {
-        st_agent(my, cnt | ST_PREFIX);
-    } else {
-        st_agent(my, cnt | ST_AGG);
-        // Look back RS_LB tiles per round with independent loads.  When the whole grid is resident (small n) every tile
-        // publishes its aggregate at the same moment and a one-word-per-step walk would resolve in ~sqrt(2*tiles) dependent
-        // agent-scope loads (~0.7 us each); batching the window cuts the number of dependent rounds by sqrt(RS_LB).
-        int p = (int)tile - 1;                   // nearest tile not yet accounted for
-        bool done = false;
-        while (!done) {
-            uint32_t w[RS_LB];
-#pragma unroll
-            for (int i = 0; i < RS_LB; i++) w[i] = (p - i >= 0) ? ld_agent(status + (size_t)(p - i) * RS_RADIX + d_t) : ST_PREFIX;
-            int used = 0;
-#pragma unroll
-            for (int i = 0; i < RS_LB; i++) {
-                if (!done && used == i) {
-                    if ((w[i] >> 30) != 0u) {
-                        excl += w[i] & ST_VALUE;
-                        used = i + 1;
-                        if (w[i] & ST_PREFIX) done = true;
-                    }
-                }
-            }
-            p -= used;                           // a not-yet-published word stops the round; the next round re-reads from it
-            if (!done && used == 0) __builtin_amdgcn_s_sleep(1);
-        }
-        st_agent(my, (excl + cnt) | ST_PREFIX);
-    }
-    // global base of every digit = exclusive scan of the digit totals + everything earlier tiles hold of this digit
-    {
-        const uint32_t tot = ghist[(size_t)d_t * hstride];
-        uint32_t x = tot;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) { const uint32_t y = __shfl_up(x, o); if (lane >= o) x += y; }
-        if (lane == 63) s_w[wave] = x;
-        __syncthreads();
-        uint32_t off = x - tot + excl;
-        for (int w = 0; w < wave; w++) off += s_w[w];
-        // per-wave output offsets of this digit
-        s_cnt[0][d_t] = off; s_cnt[1][d_t] = off + c0; s_cnt[2][d_t] = off + c0 + c1; s_cnt[3][d_t] = off + c0 + c1 + c2;
-    }
-    __syncthreads();
-    // phase C: scatter
-#pragma unroll
-    for (int it = 0; it < RS_IPT; it++) {
-        const uint32_t e = wbase + it * 64 + lane;
-        if (e < n) {
-            const uint32_t d = (k[it] >> shift) & mask;
-            const uint32_t dst = s_cnt[wave][d] + rank[it];
-            keys_out[dst] = k[it];
-            vals_out[dst] = v[it];
-        }
-    }
-}
-
 // ---- the look-back pass for <= 2^20 items, fat tiles -------------------------------------------------------------------------
 // Same algorithm as os_pass_kernel<true>, 1024-thread workgroups with 4096-item tiles (8192 until round 5), and the tile's items go through LDS in
 // tile-local sorted order before they are stored.  Measured on the thin (2048-item) pass at 0.5 M items (r03g_C2_kernel_stats):
@@ -304,35 +191,41 @@ constexpr int FT_THREADS = 1024, FT_IPT = 4, FT_TILE = FT_THREADS * FT_IPT, FT_W
 constexpr int FT_LB = 32;      // look-back window: at most 256 tiles exist, all resident and publishing at about the same moment
 static inline uint32_t ft_nblocks(size_t n) { return (uint32_t)((n + FT_TILE - 1) / FT_TILE); }
 
+// LOOKBACK = false (inputs above 2^20 items, round 6): the same tile body behind the histogram + scan launches of the large-n path
+// (ghist = total[digit] from rs_scan, status = hist[digit][tile] exclusive-scanned over the 4096-item tiles, tile = blockIdx.x) — the
+// thin pass stores a digit's 8 items per tile from whichever lanes ranked them; here they leave LDS as 64-B runs.
+template <bool LOOKBACK, int IPT>
 __global__ void __launch_bounds__(FT_THREADS) os_pass_fat_kernel(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ vals,
                                                                  uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out, uint32_t n,
                                                                  int shift, uint32_t mask, const uint32_t* __restrict__ ghist,
                                                                  uint32_t* __restrict__ status, uint32_t* __restrict__ ticket,
-                                                                 const uint32_t* __restrict__ n_dev, int hstride, uint2* __restrict__ ranges) {
+                                                                 const uint32_t* __restrict__ n_dev, int hstride, uint2* __restrict__ ranges,
+                                                                 uint32_t nblocks) {
     __shared__ uint32_t s_cnt[FT_WAVES][RS_RADIX];      // per-wave digit counts -> then per-wave tile-local offsets
-    __shared__ uint2 s_item[FT_TILE];                   // (key, value) in tile-local sorted order
+    constexpr int TILE_ITEMS = FT_THREADS * IPT;
+    __shared__ uint2 s_item[TILE_ITEMS];                   // (key, value) in tile-local sorted order
     __shared__ uint32_t s_gbase[RS_RADIX];              // global slot of a digit's first item of this tile, minus its tile-local slot
     __shared__ uint32_t s_w[4][2];
     __shared__ uint32_t s_tile;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t d_t = threadIdx.x;                   // (threads < 256) the digit this thread owns in the offset phases
-    if (threadIdx.x == 0) s_tile = atomicAdd(ticket, 1u);
+    if (LOOKBACK && threadIdx.x == 0) s_tile = atomicAdd(ticket, 1u);
     for (int i = threadIdx.x; i < FT_WAVES * RS_RADIX; i += FT_THREADS) (&s_cnt[0][0])[i] = 0u;
     __syncthreads();
-    const uint32_t tile = s_tile;
+    const uint32_t tile = LOOKBACK ? s_tile : blockIdx.x;
     if (n_dev) n = min(n, *n_dev);
-    if (tile * (uint32_t)FT_TILE >= n) return;
-    const uint32_t wbase = tile * (uint32_t)FT_TILE + wave * (64 * FT_IPT);
-    uint32_t k[FT_IPT], v[FT_IPT], rank[FT_IPT];
+    if (tile * (uint32_t)TILE_ITEMS >= n) return;
+    const uint32_t wbase = tile * (uint32_t)TILE_ITEMS + wave * (64 * IPT);
+    uint32_t k[IPT], v[IPT], rank[IPT];
 #pragma unroll
-    for (int it = 0; it < FT_IPT; it++) {
+    for (int it = 0; it < IPT; it++) {
         const uint32_t e = wbase + it * 64 + lane;
         const bool valid = e < n;
         k[it] = valid ? keys[e] : 0xffffffffu;
         v[it] = valid ? vals[e] : 0u;
     }
 #pragma unroll
-    for (int it = 0; it < FT_IPT; it++) {
+    for (int it = 0; it < IPT; it++) {
         const uint32_t e = wbase + it * 64 + lane;
         const bool valid = e < n;
         const uint32_t d = (k[it] >> shift) & mask;
@@ -355,13 +248,19 @@ __global__ void __launch_bounds__(FT_THREADS) os_pass_fat_kernel(const uint32_t*
 #pragma unroll
         for (int w = 0; w < FT_WAVES; w++) { cw[w] = s_cnt[w][d_t]; cnt += cw[w]; }
         uint32_t* my = status + (size_t)tile * RS_RADIX + d_t;
-        if (tile == 0) {
+        if (!LOOKBACK) {
+            excl = status[(size_t)d_t * nblocks + tile];
+        } else if (tile == 0) {
             st_agent(my, cnt | ST_PREFIX);
         } else {
             st_agent(my, cnt | ST_AGG);
             int p = (int)tile - 1;
             bool done = false;
-            while (!done) {      // (see os_pass_kernel)
+            // Look back FT_LB tiles per round with independent loads.  When the whole grid is resident every tile publishes its
+            // aggregate at the same moment and a one-word-per-step walk would resolve in ~sqrt(2 * tiles) dependent agent-scope loads
+            // (~0.7 us each); batching the window cuts the number of dependent rounds.  A not-yet-published word stops the round; the
+            // next round re-reads from it.
+            while (!done) {
                 uint32_t w[FT_LB];
 #pragma unroll
                 for (int i = 0; i < FT_LB; i++) w[i] = (p - i >= 0) ? ld_agent(status + (size_t)(p - i) * RS_RADIX + d_t) : ST_PREFIX;
@@ -402,7 +301,7 @@ __global__ void __launch_bounds__(FT_THREADS) os_pass_fat_kernel(const uint32_t*
     }
     __syncthreads();
 #pragma unroll
-    for (int it = 0; it < FT_IPT; it++) {
+    for (int it = 0; it < IPT; it++) {
         const uint32_t e = wbase + it * 64 + lane;
         if (e < n) {
             const uint32_t d = (k[it] >> shift) & mask;
@@ -410,9 +309,9 @@ __global__ void __launch_bounds__(FT_THREADS) os_pass_fat_kernel(const uint32_t*
         }
     }
     __syncthreads();
-    const uint32_t items = min((uint32_t)FT_TILE, n - tile * (uint32_t)FT_TILE);
+    const uint32_t items = min((uint32_t)TILE_ITEMS, n - tile * (uint32_t)TILE_ITEMS);
 #pragma unroll
-    for (int it = 0; it < FT_IPT; it++) {
+    for (int it = 0; it < IPT; it++) {
         const uint32_t q = (uint32_t)it * FT_THREADS + threadIdx.x;
         if (q < items) {
             const uint2 kv = s_item[q];
@@ -658,10 +557,11 @@ int radix_sort_pairs_u32(uint32_t* keys_a, uint32_t* vals_a, uint32_t* keys_b, u
             const uint32_t mask = (1u << nb) - 1u;
             const uint32_t* kin = cur ? keys_b : keys_a; const uint32_t* vin = cur ? vals_b : vals_a;
             uint32_t* kout = cur ? keys_a : keys_b; uint32_t* vout = cur ? vals_a : vals_b;
-            hipLaunchKernelGGL(rs_hist_kernel, dim3(nblocks), dim3(RS_THREADS), 0, s, kin, (uint32_t)n, bit, mask, hist, nblocks);
-            hipLaunchKernelGGL(rs_scan_kernel, dim3(RS_RADIX), dim3(RS_THREADS), 0, s, hist, nblocks, total);
-            hipLaunchKernelGGL(os_pass_kernel<false>, dim3(nblocks), dim3(RS_THREADS), 0, s, kin, vin, kout, vout, (uint32_t)n, bit, mask, total, hist,
-                               (uint32_t*)nullptr, nblocks, (const uint32_t*)nullptr, 1);
+            const uint32_t fb = ft_nblocks(n);
+            hipLaunchKernelGGL(rs_hist_fat_kernel<FT_IPT>, dim3(fb), dim3(FTH_THREADS), 0, s, kin, (uint32_t)n, bit, mask, hist, fb);
+            hipLaunchKernelGGL(rs_scan_kernel, dim3(RS_RADIX), dim3(RS_THREADS), 0, s, hist, fb, total);
+            hipLaunchKernelGGL((os_pass_fat_kernel<false, FT_IPT>), dim3(fb), dim3(FT_THREADS), 0, s, kin, vin, kout, vout, (uint32_t)n, bit, mask, total, hist,
+                               (uint32_t*)nullptr, (const uint32_t*)nullptr, 1, (uint2*)nullptr, fb);
             cur ^= 1;
         }
         return cur;
@@ -677,8 +577,8 @@ int radix_sort_pairs_u32(uint32_t* keys_a, uint32_t* vals_a, uint32_t* keys_b, u
         const uint32_t mask = (1u << nb) - 1u;
         const uint32_t* kin = cur ? keys_b : keys_a; const uint32_t* vin = cur ? vals_b : vals_a;
         uint32_t* kout = cur ? keys_a : keys_b; uint32_t* vout = cur ? vals_a : vals_b;
-        hipLaunchKernelGGL(os_pass_fat_kernel, dim3(ft_nblocks(n)), dim3(FT_THREADS), 0, s, kin, vin, kout, vout, (uint32_t)n, bit, mask,
-                           ghist + p * RS_RADIX, status + (size_t)p * nblocks * RS_RADIX, ticket + p, (const uint32_t*)nullptr, 1, (uint2*)nullptr);
+        hipLaunchKernelGGL((os_pass_fat_kernel<true, FT_IPT>), dim3(ft_nblocks(n)), dim3(FT_THREADS), 0, s, kin, vin, kout, vout, (uint32_t)n, bit, mask,
+                           ghist + p * RS_RADIX, status + (size_t)p * nblocks * RS_RADIX, ticket + p, (const uint32_t*)nullptr, 1, (uint2*)nullptr, 0u);
         cur ^= 1;
     }
     return cur;
@@ -776,9 +676,9 @@ int radix_sort_pairs_u32_devn(uint32_t* keys_a, uint32_t* vals_a, uint32_t* keys
         const uint32_t mask = (1u << nb) - 1u;
         const uint32_t* kin = cur ? keys_b : keys_a; const uint32_t* vin = cur ? vals_b : vals_a;
         uint32_t* kout = cur ? keys_a : keys_b; uint32_t* vout = cur ? vals_a : vals_b;
-        hipLaunchKernelGGL(os_pass_fat_kernel, dim3(ft_nblocks(cap)), dim3(FT_THREADS), 0, s, kin, vin, kout, vout, (uint32_t)cap, bit, mask,
+        hipLaunchKernelGGL((os_pass_fat_kernel<true, FT_IPT>), dim3(ft_nblocks(cap)), dim3(FT_THREADS), 0, s, kin, vin, kout, vout, (uint32_t)cap, bit, mask,
                            ghist + (size_t)p * RS_RADIX * BE_HSTRIDE, status + (size_t)p * nblocks * RS_RADIX, ticket + p, n_dev, BE_HSTRIDE,
-                           p == passes - 1 ? ranges : (uint2*)nullptr);      // (the last pass leaves the tile ranges behind, start complemented)
+                           p == passes - 1 ? ranges : (uint2*)nullptr, 0u);      // (the last pass leaves the tile ranges behind, start complemented)
         cur ^= 1;
     }
     return cur;

@@ -91,7 +91,7 @@ int surfel_knn_dist2(surfel_alloc_fn scratch_alloc, void* scratch_user, int P, c
  *   "cull"             1   exact footprint culling (tile emission and per-sub-tile masks restricted to the alpha >= 1/255 footprint); 0: every pair of the reference's tile rectangles
  *   "tile_depth_sort"  1   binning path: 2 surfel-order emission + per-tile depth sort in LDS, 0 depth-presorted emission, 1 by the previous frame's instances per tile
  *   "capacity_binning" 1   frames of <= 2^20 instances size their binning buffers from recent frames' counts and never wait for this frame's count; an overflowing frame is redone
- *   "large_sort"       2   sorts of > 2^20 items: 0 own three-launch passes, 1 rocprim::radix_sort_pairs, 2 rocPRIM for <= 16 key bits or >= 4 M items
+ *   "large_sort"       2   sorts of > 2^20 items: 0 own three-launch passes, 1 rocprim::radix_sort_pairs, 2 rocPRIM above 2^25 items
  *   "tile_order"       0   which tile a blend workgroup takes: 1 XCD-contiguous runs, 2 longest lists first over the XCDs, 0 decided per frame on the device
  *   "fwd_pipe"         1   blend forward with LDS-DMA double-buffered staging (0: the batch-synchronous kernel, same bits)
  *   "tile_stream"      1   blend_fwd leaves the walked records + footprint bits in list order (84 B x binning capacity, frames <= 2^24 instances) for blend_bwd's staging
