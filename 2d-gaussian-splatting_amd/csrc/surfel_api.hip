@@ -757,6 +757,7 @@ int surfel_rasterize_backward(surfel_alloc_fn scratch_alloc, void* scratch_user,
     // record gather: per thread, or by the wave when a surfel holds many records AND the records (80 B each) overflow the 256 MB
     // Infinity Cache (measured: the cooperative form wins at C5 only, and loses 30 - 85 % on small frames); bit-identical sums
     pb.coop = (debug_in & SURFEL_OPT_PBWD_COOP) ? 1 : ((debug_in & SURFEL_OPT_PBWD_THREAD) ? 0 : ((R >= (int64_t)6 * P && R >= ((int64_t)32 << 20)) ? 1 : 0));
+    pb.dma = (debug_in & SURFEL_OPT_PBWD_NO_DMA) ? 0 : ((debug_in & SURFEL_OPT_PBWD_DMA) ? 1 : -1);
     pb.means3D = means3D; pb.radii = radii; pb.shs = shs; pb.clamped = geom.clamped; pb.scales = scales; pb.rotations = rotations;
     pb.transMat_precomp = transMat_precomp; pb.viewmatrix = viewmatrix; pb.projmatrix = projmatrix; pb.campos = cam_pos;
     pb.rec = geom.rec; pb.tiles_touched = geom.tiles_touched; pb.grec = grec; pb.cut = cut; pb.has_rec = has_rec; pb.depths = geom.depths; pb.gx = gx;

@@ -56,6 +56,7 @@ struct PreprocessBwdArgs {
     int P, D, M, W, H;
     int coop;                 // 1: wave-cooperative gather of the instance gradient records (many records per surfel)
     int keep_colors;          // 1: dL_dcolors was already written by launch_colour_gradients (and may be on the wire): leave it alone
+    int dma;                  // SH block by LDS-DMA: -1 default (when dL_dsh is written), 0 never, 1 always (per-thread gather only)
     float scale_modifier;
     const float* means3D; const int* radii; const float* shs; const uint8_t* clamped;
     const float* scales; const float* rotations; const float* transMat_precomp;

@@ -587,11 +587,32 @@ constexpr uint32_t HEAVY_MIN = 128;
 #ifndef PRE_BWD_MINWG
 #define PRE_BWD_MINWG 4
 #endif
-template <bool COOP, bool CUT>
+// DMA (per-thread record gather; round 6): the wave's 12 KB of SH coefficients — read here for the view direction's share of
+// dL/dmeans3D — arrive by LDS-DMA as in preprocess_fwd_kernel<true>, requested before the record gather.  Same bits.  Default
+// only where the caller wants dL/dsh (the drop-in autograd path: 192 B per surfel written here, the kernel is bandwidth-bound —
+// profiles/r06_pbwd_dma_ab.jsonl: 2 M surfels 630 -> 577 us, 300 k 89 -> 76 us); the trainer rebuilds the SH gradients in its
+// update launch and passes no dL/dsh: the kernel is then a latency-bound record gather and the 48 KB of LDS (3 workgroups per CU
+// instead of 4) cost more than the coalescing returns (C4 0.352 -> 0.412 ms, garden 0.305 -> 0.316).
+template <bool COOP, bool CUT, bool DMA>
 __global__ void __launch_bounds__(256, PRE_BWD_MINWG) preprocess_bwd_kernel(PreprocessBwdArgs a) {
     __shared__ float4 s_sum[COOP ? 256 * 5 : 1];
+    __shared__ float4 s_sh[DMA ? 4 : 1][DMA ? 64 * 12 : 1];      // DMA: 48 KB -> 3 workgroups per CU
     if (frame_overflowed(a.n_dev, a.n_cap)) return;      // (uniform: before any barrier)
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const float4* sh_lds = nullptr;
+    if (DMA && a.shs != nullptr && a.M == 16) {
+        const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+        const int first = blockIdx.x * 256 + wave * 64;
+        const int npieces = 12 * min(64, a.P - first);
+        const float4* __restrict__ src = reinterpret_cast<const float4*>(a.shs) + (size_t)first * 12;
+        const unsigned base = __builtin_amdgcn_readfirstlane(lds_offset(&s_sh[wave][0]));
+#pragma unroll
+        for (int v = 0; v < 12; v++) {
+            const int p = v * 64 + lane;
+            if (p < npieces) dma16(src + p, base + (unsigned)v * 1024u);
+        }
+        sh_lds = &s_sh[wave][lane * 12];
+    }
     float4 hs0 = make_float4(0.f, 0.f, 0.f, 0.f), hs1 = hs0, hs2 = hs0, hs3 = hs0, hs4 = hs0;
     bool heavy = false;
     {
@@ -913,9 +934,10 @@ __global__ void __launch_bounds__(256, PRE_BWD_MINWG) preprocess_bwd_kernel(Prep
         if (a.M == 16) {
             // one pass over the 48 coefficients as 12 float4: read sh (for the direction gradient), write dL/dsh
             const float4* __restrict__ shq = reinterpret_cast<const float4*>(a.shs + (size_t)i * 48);
+            if (DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (the DMA is invisible to the compiler's own counting)
 #pragma unroll
             for (int v = 0; v < 12; v++) {
-                const float4 c4 = shq[v];
+                const float4 c4 = DMA ? sh_lds[v] : shq[v];
                 const float cv[4] = {c4.x, c4.y, c4.z, c4.w};
                 float o[4];
 #pragma unroll
@@ -1025,12 +1047,16 @@ void launch_colour_gradients(const PreprocessBwdArgs& a, hipStream_t s) {
 void launch_preprocess_bwd(const PreprocessBwdArgs& a, hipStream_t s) {
     if (a.P <= 0) return;
     const dim3 grid((a.P + 255) / 256), block(256);
+    const bool dma = a.dma >= 0 ? a.dma != 0 : (a.shs != nullptr && a.M == 16 && a.dL_dsh != nullptr);
     if (a.coop) {
-        if (a.cut) hipLaunchKernelGGL((preprocess_bwd_kernel<true, true>), grid, block, 0, s, a);
-        else hipLaunchKernelGGL((preprocess_bwd_kernel<true, false>), grid, block, 0, s, a);
+        if (a.cut) hipLaunchKernelGGL((preprocess_bwd_kernel<true, true, false>), grid, block, 0, s, a);
+        else hipLaunchKernelGGL((preprocess_bwd_kernel<true, false, false>), grid, block, 0, s, a);
+    } else if (dma) {
+        if (a.cut) hipLaunchKernelGGL((preprocess_bwd_kernel<false, true, true>), grid, block, 0, s, a);
+        else hipLaunchKernelGGL((preprocess_bwd_kernel<false, false, true>), grid, block, 0, s, a);
     } else {
-        if (a.cut) hipLaunchKernelGGL((preprocess_bwd_kernel<false, true>), grid, block, 0, s, a);
-        else hipLaunchKernelGGL((preprocess_bwd_kernel<false, false>), grid, block, 0, s, a);
+        if (a.cut) hipLaunchKernelGGL((preprocess_bwd_kernel<false, true, false>), grid, block, 0, s, a);
+        else hipLaunchKernelGGL((preprocess_bwd_kernel<false, false, false>), grid, block, 0, s, a);
     }
 }
 

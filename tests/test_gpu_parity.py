@@ -507,6 +507,30 @@ def test_tile_cuts_equal_zero_records(kind):
                 assert np.array_equal(res[0][k], res[1][k]), "%s: dL/d%s differs between zero records and tile cuts (walk %x, gather %x)" % (kind, k, walk, gather)
 
 
+@pytest.mark.parametrize("shape", [(1500, 208, 136), (4099, 320, 240), (64, 96, 80)])
+def test_preprocess_bwd_sh_dma_is_identical(shape):
+    """preprocess_bwd reads the SH block for the view direction's share of dL/dmeans3D: per thread (small frames) or as the wave's
+    contiguous 12 KB by LDS-DMA (>= 2^19 surfels).  Forced both ways on surfel counts with a ragged last wave / last workgroup, with
+    culled surfels (whole waves that never look at their block), zero records and tile cuts: BIT-IDENTICAL gradients."""
+    import surfel_native as n
+    import synthetic
+    P, W, H = shape
+    sc = synthetic.make_scene(P, W, H, seed=P, px_radius=4.0)
+    a = scene_args(sc)
+    rng = np.random.default_rng(5)
+    gC = rng.normal(size=(3, H, W)).astype(np.float32); gO = rng.normal(size=(7, H, W)).astype(np.float32)
+    run = HipRun(a).forward()
+    for tail in (n.OPT_ZERO_RECORDS, n.OPT_TILE_CUTS):
+        res = []
+        for dma in (n.OPT_PBWD_NO_DMA, n.OPT_PBWD_DMA):
+            run.debug = n.OPT_PBWD_THREAD | tail | dma
+            res.append(run.backward(gC, gO))
+        for k in res[0]:
+            assert np.isfinite(res[1][k]).all(), k
+            assert np.array_equal(res[0][k], res[1][k]), "dL/d%s differs between per-thread SH loads and the LDS-DMA (tail %x)" % (k, tail)
+    assert np.abs(res[0]["means3D"]).max() > 0
+
+
 def test_heavy_surfels_are_gathered_by_the_wave():
     """Surfels with more than 128 instance records (background-sized discs covering hundreds of tiles) have their records summed by
     the whole wave in preprocess_bwd (lane-strided partial sums + butterfly) instead of by one thread walking them: gradients against
