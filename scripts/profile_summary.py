@@ -117,6 +117,7 @@ def main():
     merged = {k: v for k, v in merged.items() if k in STAGE_OF or k.startswith(ours) or "knn" in k}
     traffic = {}
     bwd_launches = -1
+    fwd_launches = -1
     for k, cs in merged.items():
         if "SQ_THREAD_CYCLES_VALU" in cs and cs.get("SQ_ACTIVE_INST_VALU"):
             cs["VALUUtilization_exec_lanes"] = round(cs["SQ_THREAD_CYCLES_VALU"] / (64.0 * cs["SQ_ACTIVE_INST_VALU"]), 4)
@@ -129,6 +130,10 @@ def main():
                 if st == "blend_bwd":
                     if cs.get("launches", 0) >= bwd_launches:
                         bwd_launches = cs.get("launches", 0)
+                        traffic[st] = cs["HBM_bytes_per_launch"]
+                elif st == "blend_fwd":      # (likewise: the pipelined kernel of the timed steps, not + the batch-synchronous one of evaluation renders)
+                    if cs.get("launches", 0) >= fwd_launches:
+                        fwd_launches = cs.get("launches", 0)
                         traffic[st] = cs["HBM_bytes_per_launch"]
                 else:
                     traffic[st] = traffic.get(st, 0) + cs["HBM_bytes_per_launch"]
