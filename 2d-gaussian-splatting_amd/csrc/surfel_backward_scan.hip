@@ -51,7 +51,35 @@ __device__ __forceinline__ float row_scan_add_excl(float x) {
     return e;
 }
 
+// index (0 .. 127) of set bit number k (0-based, k < popcount) of the 128-bit word (w1 : w0)
+__device__ __forceinline__ int select_bit128(unsigned long long w0, unsigned long long w1, int k) {
+    const int c0 = __popcll(w0);
+    unsigned long long w = k < c0 ? w0 : w1;
+    int idx = k < c0 ? 0 : 64;
+    k = k < c0 ? k : k - c0;
+#pragma unroll
+    for (int sh = 32; sh > 0; sh >>= 1) {
+        const unsigned long long lo = w & ((1ull << sh) - 1ull);
+        const int c = __popcll(lo);
+        if (k >= c) { k -= c; w >>= sh; idx += sh; } else w = lo;
+    }
+    return idx;
+}
+
 }  // namespace
+
+// [r6] BATCH TRUNCATION.  A batch lasts (chunks of its longest sub-tile list) rounds, and a round lasts one 16-step walk whatever it
+// holds — a workgroup's round is as long as ONE walk however many of its lanes and waves take part (profiles/r06_negative_results.md
+// section 6): a longest list of 50 costs four rounds, the fourth for two instances.  When the longest list ends 1 .. SCAN_TRUNC_REM
+// instances into a chunk, the batch is cut in front of the staged instance that opens that chunk (the deepest `keep` instances are
+// walked: full chunks on the longest list) and the next batch starts with the rest — staged again from there, nothing is carried.
+// Where a batch ends follows from the frame's lists alone, the same with and without the tile stream: same bits either way.
+// Measured (profiles/r06_ab_scan_trunc.jsonl): blend_bwd garden 1.345 -> 1.296 ms, C4 0.977 -> 0.944.
+// (The two staging paths are kept apart with `if constexpr`: an earlier form that shared a lambda between them cost the STREAM
+// instantiation 8 % — same instruction counts, another schedule.)
+#ifndef SCAN_TRUNC_REM
+#define SCAN_TRUNC_REM 8
+#endif
 
 // LDS records of a pixel, indexed by the pixel's owner thread (tid = 16 * sub-tile row + pixel of the sub-tile):
 //   s_pix  (read-only in the walk, 3 x float4): [0] gC0 gC1 gC2 g_depth   [1] gN0 gN1 gN2 g_med   [2] a2 a1 a0 last
@@ -129,6 +157,7 @@ __global__ void __launch_bounds__(BLOCK, SCAN_MIN_WG) blend_bwd_scan_kernel(Blen
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
     float4 pa = zero4, pb = zero4, pc = zero4, pd = zero4;
     uint32_t nid = 0;
+    constexpr bool TRUNC = SCAN_TRUNC_REM > 0;
     constexpr bool strm_on = STREAM;      // the host found the forward's tile stream for this frame (surfel_api.hip: stream_lookup)
     const float4* __restrict__ strm = a.strm_rec;
     const uint32_t* __restrict__ smask = a.strm_mask;
@@ -154,11 +183,12 @@ __global__ void __launch_bounds__(BLOCK, SCAN_MIN_WG) blend_bwd_scan_kernel(Blen
             if (a.has_rec && fh == 0) a.has_rec[id] = 1;      // every staged instance gets a record (finish_tail)
             if (fh == 0) { pa = src[0]; pb = src[1]; pc = src[3]; pd = src[4]; } else { pa = src[2]; pb = src[5]; pc = src[6]; }
         }
-        if (maxc - SB > 0 && ft < min(SB, maxc - SB)) nid = a.point_list[range.x + (maxc - SB - ft) - 1];
+        if (!TRUNC && maxc - SB > 0 && ft < min(SB, maxc - SB)) nid = a.point_list[range.x + (maxc - SB - ft) - 1];
     }
     bool pend = false;
     size_t pend_slot = 0;
-    for (int hi = maxc; hi > 0; hi -= SB) {
+    int step = SB;
+    for (int hi = maxc; hi > 0; hi -= step) {
         const int mb = min(SB, hi);
         __syncthreads();                      // previous batch written out: s_rec / s_list / s_rank reusable
         unsigned ovr = 0;
@@ -200,8 +230,8 @@ __global__ void __launch_bounds__(BLOCK, SCAN_MIN_WG) blend_bwd_scan_kernel(Blen
         }
         f0 = zero4; f1 = zero4; f2 = zero4;
         if (strm_on) {
-            if (hi - SB > 0) fetch(hi - SB);
-        } else if (hi - SB > 0) {             // next batch's records, and the ids of the one behind it
+            if (!TRUNC && hi - SB > 0) fetch(hi - SB);      // (TRUNC: behind the ballots, once this batch's length is known)
+        } else if (!TRUNC && hi - SB > 0) {   // next batch's records, and the ids of the one behind it
             const float4* __restrict__ recq = reinterpret_cast<const float4*>(a.rec);
             if (ft < min(SB, hi - SB)) {
                 const float4* __restrict__ src = recq + (size_t)nid * REC_Q;
@@ -218,6 +248,36 @@ __global__ void __launch_bounds__(BLOCK, SCAN_MIN_WG) blend_bwd_scan_kernel(Blen
             }
         }
         __syncthreads();
+        int keep = mb;                        // staged instances walked in this batch: the deepest `keep`
+        if (TRUNC) {
+            const unsigned long long w0 = s_bal[i16][0], w1 = s_bal[i16][1];
+            const int n = __popcll(w0) + __popcll(w1);
+            int nm = n;
+            nm = max(nm, __shfl_xor(nm, 1)); nm = max(nm, __shfl_xor(nm, 2)); nm = max(nm, __shfl_xor(nm, 4)); nm = max(nm, __shfl_xor(nm, 8));
+            const int full = nm & ~(CH - 1), rem = nm & (CH - 1);
+            if (full > 0 && rem > 0 && rem <= SCAN_TRUNC_REM) {
+                int ms = n > full ? select_bit128(w0, w1, full) : SB;      // the staged instance that opens this list's chunk behind the full ones
+                ms = min(ms, __shfl_xor(ms, 1)); ms = min(ms, __shfl_xor(ms, 2)); ms = min(ms, __shfl_xor(ms, 4)); ms = min(ms, __shfl_xor(ms, 8));
+                keep = ms;
+            }
+            keep = __builtin_amdgcn_readfirstlane(keep);
+            if constexpr (STREAM) {
+                if (hi - keep > 0) fetch(hi - keep);
+            } else {
+                // ids, then the half records of the next batch: two dependent round trips under this batch's walk (the ids can no longer
+                // be requested a batch ahead: where the next batch starts is only known here)
+                if (hi - keep > 0 && ft < min(SB, hi - keep)) {
+                    const float4* __restrict__ recq = reinterpret_cast<const float4*>(a.rec);
+                    const uint32_t id = a.point_list[range.x + (hi - keep - ft) - 1];
+                    const float4* __restrict__ src = recq + (size_t)id * REC_Q;
+                    if (a.has_rec && fh == 0) a.has_rec[id] = 1;
+                    if (fh == 0) { pa = src[0]; pb = src[1]; pc = src[3]; pd = src[4]; } else { pa = src[2]; pb = src[5]; pc = src[6]; }
+                }
+            }
+            if (ft >= keep) ovr = 0;
+        }
+        const unsigned long long km0 = keep >= 64 ? ~0ull : ((1ull << keep) - 1ull);
+        const unsigned long long km1 = keep >= 128 ? ~0ull : (keep > 64 ? ((1ull << (keep - 64)) - 1ull) : 0ull);
         if (fh == 1) {                        // (the threads that hold the footprints)
             // rank of this instance on every list it is on = instances ahead of it (staged order = back to front) on that list
             uint32_t rk[4] = {~0u, ~0u, ~0u, ~0u};
@@ -225,7 +285,7 @@ __global__ void __launch_bounds__(BLOCK, SCAN_MIN_WG) blend_bwd_scan_kernel(Blen
             const unsigned long long lt = (1ull << (ft & 63)) - 1ull;
 #pragma unroll
             for (int s = 0; s < 16; s++) {
-                const unsigned long long m0 = s_bal[s][0], m1 = s_bal[s][1];
+                const unsigned long long m0 = s_bal[s][0] & km0, m1 = s_bal[s][1] & km1;
                 const uint32_t r = ft < 64 ? (uint32_t)__popcll(m0 & lt) : (uint32_t)(__popcll(m0) + __popcll(m1 & lt));
                 if ((ovr >> s) & 1u) {
                     s_list[s][r] = (uint8_t)ft;
@@ -237,8 +297,8 @@ __global__ void __launch_bounds__(BLOCK, SCAN_MIN_WG) blend_bwd_scan_kernel(Blen
             s_cmm[ft] = cmin | (cmax << 8);      // an instance on no list: 255 | 0 -> takes part in no round
         }
         // list length of this row's sub-tile, and the number of rounds = chunks of the longest list (the same in every thread)
-        const int n_row = __popcll(s_bal[srow][0]) + __popcll(s_bal[srow][1]);
-        int nmax = __popcll(s_bal[i16][0]) + __popcll(s_bal[i16][1]);
+        const int n_row = __popcll(s_bal[srow][0] & km0) + __popcll(s_bal[srow][1] & km1);
+        int nmax = __popcll(s_bal[i16][0] & km0) + __popcll(s_bal[i16][1] & km1);
         nmax = max(nmax, __shfl_xor(nmax, 1)); nmax = max(nmax, __shfl_xor(nmax, 2)); nmax = max(nmax, __shfl_xor(nmax, 4)); nmax = max(nmax, __shfl_xor(nmax, 8));
         const int nrounds = (nmax + CH - 1) / CH;
         __syncthreads();
@@ -356,8 +416,9 @@ __global__ void __launch_bounds__(BLOCK, SCAN_MIN_WG) blend_bwd_scan_kernel(Blen
             __syncthreads();                  // slots reusable
         }
         // ---- the batch's gradient records: every staged instance gets one (zeros if no pixel took it)
-        pend = ft < mb;
+        pend = ft < keep;
         if (pend) pend_slot = grec_slot(s_rec[ft * 5 + 4], tx, ty);
+        step = keep;
     }
     if (pend) {
         float4* __restrict__ dst = reinterpret_cast<float4*>(a.grec + pend_slot * GREC_F);
