@@ -153,19 +153,21 @@ struct ImgState {    // per-pixel / per-tile state ("imgBuffer")
 // worker thread, possibly after other forwards), looks it up and stages from the stream if it finds one.  A buffer the registry no
 // longer knows (more than kStreamRegs forwards in between) is gathered by surfel id: always valid, same bits.  An address can only
 // be re-registered after its previous frame's buffers were freed, i.e. when no backward of that frame can come any more.
-struct StreamReg { const void* bin = nullptr; const float4* rec = nullptr; const uint32_t* mask = nullptr; };
+struct StreamReg { const void* bin = nullptr; const void* img = nullptr; const float4* rec = nullptr; const uint32_t* mask = nullptr; };
 constexpr int kStreamRegs = 64;
 StreamReg g_stream_regs[kStreamRegs];
 unsigned g_stream_next = 0;
 std::mutex g_stream_mu;
-void stream_register(const void* bin, const float4* rec, const uint32_t* mask) {
+// (keyed by the frame's binning AND image buffer: a caller that restores a saved binning buffer at an address still registered for
+// another, already freed frame hands the backward a different image buffer with it — no match, the backward gathers)
+void stream_register(const void* bin, const void* img, const float4* rec, const uint32_t* mask) {
     std::lock_guard<std::mutex> lk(g_stream_mu);
-    for (auto& r : g_stream_regs) if (r.bin == bin) { r.rec = rec; r.mask = mask; return; }
-    g_stream_regs[g_stream_next++ % kStreamRegs] = StreamReg{bin, rec, mask};
+    for (auto& r : g_stream_regs) if (r.bin == bin) { r.img = img; r.rec = rec; r.mask = mask; return; }
+    g_stream_regs[g_stream_next++ % kStreamRegs] = StreamReg{bin, img, rec, mask};
 }
-bool stream_lookup(const void* bin, const float4** rec, const uint32_t** mask) {
+bool stream_lookup(const void* bin, const void* img, const float4** rec, const uint32_t** mask) {
     std::lock_guard<std::mutex> lk(g_stream_mu);
-    for (auto& r : g_stream_regs) if (r.bin == bin && r.rec) { *rec = r.rec; *mask = r.mask; return true; }
+    for (auto& r : g_stream_regs) if (r.bin == bin && r.img == img && r.rec) { *rec = r.rec; *mask = r.mask; return true; }
     return false;
 }
 
@@ -566,7 +568,7 @@ int64_t surfel_rasterize_forward(surfel_alloc_fn geom_alloc, void* geom_user, su
             ba.tile_map = img.tile_map; ba.map_flag = img.total + 2 * R_SLOTS + 1; ba.map_len = map_len;
             ba.stats = g_blend_stats;
             ba.strm_rec = bin.strm_rec; ba.strm_mask = bin.strm_mask; ba.totals = img.total; ba.walk_word = img.total + 2 * R_SLOTS + 2;
-            stream_register(bin.point_list, launch_blend_fwd_writes_stream(ba) ? bin.strm_rec : nullptr, bin.strm_mask);
+            stream_register(bin.point_list, img_base, launch_blend_fwd_writes_stream(ba) ? bin.strm_rec : nullptr, bin.strm_mask);
             tm.begin();
             launch_blend_fwd(ba, s);
             STAGE_END(tm, ST_BLEND);
@@ -670,7 +672,7 @@ int64_t surfel_rasterize_forward(surfel_alloc_fn geom_alloc, void* geom_user, su
     ba.stats = g_blend_stats;
     ba.avg_list = (int)(R / ((int64_t)gx * gy));
     ba.strm_rec = bin.strm_rec; ba.strm_mask = bin.strm_mask; ba.totals = img.total; ba.walk_word = img.total + 2 * R_SLOTS + 2;
-    stream_register(bin.point_list, launch_blend_fwd_writes_stream(ba) ? bin.strm_rec : nullptr, bin.strm_mask);
+    stream_register(bin.point_list, img_base, launch_blend_fwd_writes_stream(ba) ? bin.strm_rec : nullptr, bin.strm_mask);
     tm.begin();
     launch_blend_fwd(ba, s);
     STAGE_END(tm, ST_BLEND);
@@ -729,7 +731,7 @@ int surfel_rasterize_backward(surfel_alloc_fn scratch_alloc, void* scratch_user,
     bb.grec = grec; bb.cut = cut; bb.has_rec = has_rec; bb.depths = geom.depths; bb.variant = opt_variant; bb.stats = g_blend_stats; bb.walk_word = img.total + 2 * R_SLOTS + 2;
     // num_rendered of a lazily counted frame is its CAPACITY: if the frame's real total (on the device since bin_emit_kernel; 0 on the
     // exact path) exceeds it, the lists are truncated and the first-instance slots run past `grec` — the kernels below return at once
-    if (!(debug_in & SURFEL_OPT_BWD_GATHER) && g_opt_stream) (void)stream_lookup(binning_buffer, &bb.strm_rec, &bb.strm_mask);      // (stays NULL: the walks gather)
+    if (!(debug_in & SURFEL_OPT_BWD_GATHER) && g_opt_stream) (void)stream_lookup(binning_buffer, image_buffer, &bb.strm_rec, &bb.strm_mask);      // (stays NULL: the walks gather)
     bb.n_dev = img.total + 2 * R_SLOTS; bb.n_cap = (uint32_t)(R < 0xffffffffll ? R : 0xffffffffll);
     if (R > 0) {
         // auto: rows or scan.  The scan walk takes the frames whose footprints span many tiles and the large ones — decided ON THE DEVICE

@@ -362,7 +362,7 @@ __global__ void __launch_bounds__(BLOCK, ROWS_WAVES) blend_bwd_rows_kernel(Blend
                 // waves per SIMD cover the LDS latency) and 1 - 2 % on the frames the scan walk takes anyway, for 21 registers.)
                 for (int v = 0; v < niter; v++) {
                     const bool actc = v < len;
-                    const int jc = (int)lrow[lpos + v];      // (past a shorter row's run: allocated, a valid index — the visit is masked)
+                    const int jc = (int)lrow[actc ? lpos + v : 0];      // (past a shorter row's run the visit is masked: it reads entry 0, inside the list)
                     const uint32_t infoc = s_info[jc];
                     const float4 c_q0 = s_rec[jc * 5 + 0], c_q1 = s_rec[jc * 5 + 1], c_q2 = s_rec[jc * 5 + 2], c_q3 = s_rec[jc * 5 + 3], c_q4 = s_rec[jc * 5 + 4];
                     Hit h;
