@@ -330,6 +330,12 @@ def main():
         roof = roofline_object(per_kernel, args.workload, P, V, R, Rs, W, H, n_pass)
         if roof:
             roof["window"] = census
+            if world == 1:
+                try:      # (an extra: what a useful (pixel, surfel) pair costs in wave-instructions — PMC instructions / pairs counted live)
+                    from helpers_bench import add_insts_per_pair, useful_pairs
+                    add_insts_per_pair(roof, useful_pairs(tr))
+                except Exception:      # noqa: BLE001
+                    pass
         if roof and roof.get("valu_issue") and probe and probe.get("valu_Ginst_per_s_in_kernel_span"):
             # against what THIS box's VALUs issue on independent v_fma_f32 streams (box_probe), not the 157.3 TFLOP/s / 128 yardstick that
             # non-packed fp32 code cannot reach
