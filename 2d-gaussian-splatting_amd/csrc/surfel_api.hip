@@ -90,6 +90,7 @@ struct GeomState {   // per-surfel state ("geomBuffer")
     uint32_t *dkey_a, *dkey_b, *ord_a, *ord_b;   // depth-bit keys / surfel order (double buffers of the P-sized sort)
     uint32_t* offsets;                            // inclusive scan of tiles_touched in depth order
     uint32_t* rects;                              // packed tile rect of every surfel (copy of record word 19: emission reads 4 B instead of a record line)
+    float4* shjac;                                // [P][3]: d(SH colour) / d(view direction) rows for preprocess_bwd (written unless SURFEL_OPT_NO_STREAM)
     char* temp; size_t temp_bytes;                // scratch of the P-sized sort, then of the scan
     static GeomState carve(void* base, int P, size_t temp_bytes, size_t* total) {
         Carver c(base); GeomState g;
@@ -101,6 +102,7 @@ struct GeomState {   // per-surfel state ("geomBuffer")
         g.ord_a = c.take<uint32_t>(P); g.ord_b = c.take<uint32_t>(P);
         g.offsets = c.take<uint32_t>(P);
         g.rects = c.take<uint32_t>(P);
+        g.shjac = c.take<float4>((size_t)3 * P);
         g.temp = c.take<char>(temp_bytes);
         g.temp_bytes = temp_bytes;
         if (total) *total = c.size();
@@ -153,21 +155,27 @@ struct ImgState {    // per-pixel / per-tile state ("imgBuffer")
 // worker thread, possibly after other forwards), looks it up and stages from the stream if it finds one.  A buffer the registry no
 // longer knows (more than kStreamRegs forwards in between) is gathered by surfel id: always valid, same bits.  An address can only
 // be re-registered after its previous frame's buffers were freed, i.e. when no backward of that frame can come any more.
-struct StreamReg { const void* bin = nullptr; const void* img = nullptr; const float4* rec = nullptr; const uint32_t* mask = nullptr; };
+struct StreamReg { const void* bin = nullptr; const void* img = nullptr; const float4* rec = nullptr; const uint32_t* mask = nullptr; bool jac = false; };
 constexpr int kStreamRegs = 64;
 StreamReg g_stream_regs[kStreamRegs];
 unsigned g_stream_next = 0;
 std::mutex g_stream_mu;
 // (keyed by the frame's binning AND image buffer: a caller that restores a saved binning buffer at an address still registered for
 // another, already freed frame hands the backward a different image buffer with it — no match, the backward gathers)
-void stream_register(const void* bin, const void* img, const float4* rec, const uint32_t* mask) {
+// jac: the forward also left the d(SH colour) / d(direction) rows in the geometry buffer (preprocess_bwd reads them instead of the SH block)
+void stream_register(const void* bin, const void* img, const float4* rec, const uint32_t* mask, bool jac) {
     std::lock_guard<std::mutex> lk(g_stream_mu);
-    for (auto& r : g_stream_regs) if (r.bin == bin) { r.img = img; r.rec = rec; r.mask = mask; return; }
-    g_stream_regs[g_stream_next++ % kStreamRegs] = StreamReg{bin, img, rec, mask};
+    for (auto& r : g_stream_regs) if (r.bin == bin) { r.img = img; r.rec = rec; r.mask = mask; r.jac = jac; return; }
+    g_stream_regs[g_stream_next++ % kStreamRegs] = StreamReg{bin, img, rec, mask, jac};
 }
-bool stream_lookup(const void* bin, const void* img, const float4** rec, const uint32_t** mask) {
+bool stream_lookup(const void* bin, const void* img, const float4** rec, const uint32_t** mask, bool* jac) {
     std::lock_guard<std::mutex> lk(g_stream_mu);
-    for (auto& r : g_stream_regs) if (r.bin == bin && r.img == img && r.rec) { *rec = r.rec; *mask = r.mask; return true; }
+    for (auto& r : g_stream_regs) if (r.bin == bin && r.img == img) {
+        *jac = r.jac;
+        if (!r.rec) return false;
+        *rec = r.rec; *mask = r.mask;
+        return true;
+    }
     return false;
 }
 
@@ -487,6 +495,7 @@ int64_t surfel_rasterize_forward(surfel_alloc_fn geom_alloc, void* geom_user, su
         pa.viewmatrix = viewmatrix; pa.projmatrix = projmatrix; pa.campos = cam_pos;
         pa.rec = geom.rec; pa.depths = geom.depths; pa.depth_keys = geom.dkey_a; pa.ident = geom.ord_a; pa.radii = radii;
         pa.tiles_touched = geom.tiles_touched; pa.clamped = geom.clamped; pa.total_instances = img.total; pa.rects = geom.rects;
+        pa.shjac = (opt_stream && shs != nullptr && M == 16) ? geom.shjac : nullptr;
         uint32_t* scan_state = reinterpret_cast<uint32_t*>(geom.temp + psort_bytes);
         pa.zero_a = reinterpret_cast<uint32_t*>(geom.temp); pa.zero_a_words = (uint32_t)radix_sort_head_words((size_t)P);
         pa.zero_b = scan_state; pa.zero_b_words = (uint32_t)scan_scratch_words((size_t)P);
@@ -568,7 +577,7 @@ int64_t surfel_rasterize_forward(surfel_alloc_fn geom_alloc, void* geom_user, su
             ba.tile_map = img.tile_map; ba.map_flag = img.total + 2 * R_SLOTS + 1; ba.map_len = map_len;
             ba.stats = g_blend_stats;
             ba.strm_rec = bin.strm_rec; ba.strm_mask = bin.strm_mask; ba.totals = img.total; ba.walk_word = img.total + 2 * R_SLOTS + 2;
-            stream_register(bin.point_list, img_base, launch_blend_fwd_writes_stream(ba) ? bin.strm_rec : nullptr, bin.strm_mask);
+            stream_register(bin.point_list, img_base, launch_blend_fwd_writes_stream(ba) ? bin.strm_rec : nullptr, bin.strm_mask, opt_stream && P > 0 && shs != nullptr && M == 16);
             tm.begin();
             launch_blend_fwd(ba, s);
             STAGE_END(tm, ST_BLEND);
@@ -672,7 +681,7 @@ int64_t surfel_rasterize_forward(surfel_alloc_fn geom_alloc, void* geom_user, su
     ba.stats = g_blend_stats;
     ba.avg_list = (int)(R / ((int64_t)gx * gy));
     ba.strm_rec = bin.strm_rec; ba.strm_mask = bin.strm_mask; ba.totals = img.total; ba.walk_word = img.total + 2 * R_SLOTS + 2;
-    stream_register(bin.point_list, img_base, launch_blend_fwd_writes_stream(ba) ? bin.strm_rec : nullptr, bin.strm_mask);
+    stream_register(bin.point_list, img_base, launch_blend_fwd_writes_stream(ba) ? bin.strm_rec : nullptr, bin.strm_mask, opt_stream && P > 0 && shs != nullptr && M == 16);
     tm.begin();
     launch_blend_fwd(ba, s);
     STAGE_END(tm, ST_BLEND);
@@ -731,7 +740,12 @@ int surfel_rasterize_backward(surfel_alloc_fn scratch_alloc, void* scratch_user,
     bb.grec = grec; bb.cut = cut; bb.has_rec = has_rec; bb.depths = geom.depths; bb.variant = opt_variant; bb.stats = g_blend_stats; bb.walk_word = img.total + 2 * R_SLOTS + 2;
     // num_rendered of a lazily counted frame is its CAPACITY: if the frame's real total (on the device since bin_emit_kernel; 0 on the
     // exact path) exceeds it, the lists are truncated and the first-instance slots run past `grec` — the kernels below return at once
-    if (!(debug_in & SURFEL_OPT_BWD_GATHER) && g_opt_stream) (void)stream_lookup(binning_buffer, image_buffer, &bb.strm_rec, &bb.strm_mask);      // (stays NULL: the walks gather)
+    bool have_jac = false;
+    {
+        const float4* srec = nullptr; const uint32_t* smask = nullptr;
+        const bool found = stream_lookup(binning_buffer, image_buffer, &srec, &smask, &have_jac);
+        if (found && !(debug_in & SURFEL_OPT_BWD_GATHER) && g_opt_stream) { bb.strm_rec = srec; bb.strm_mask = smask; }      // (else NULL: the walks gather)
+    }
     bb.n_dev = img.total + 2 * R_SLOTS; bb.n_cap = (uint32_t)(R < 0xffffffffll ? R : 0xffffffffll);
     if (R > 0) {
         // auto: rows or scan.  The scan walk takes the frames whose footprints span many tiles and the large ones — decided ON THE DEVICE
@@ -759,7 +773,7 @@ int surfel_rasterize_backward(surfel_alloc_fn scratch_alloc, void* scratch_user,
     // record gather: per thread, or by the wave when a surfel holds many records AND the records (80 B each) overflow the 256 MB
     // Infinity Cache (measured: the cooperative form wins at C5 only, and loses 30 - 85 % on small frames); bit-identical sums
     pb.coop = (debug_in & SURFEL_OPT_PBWD_COOP) ? 1 : ((debug_in & SURFEL_OPT_PBWD_THREAD) ? 0 : ((R >= (int64_t)6 * P && R >= ((int64_t)32 << 20)) ? 1 : 0));
-    pb.dma = (debug_in & SURFEL_OPT_PBWD_NO_DMA) ? 0 : ((debug_in & SURFEL_OPT_PBWD_DMA) ? 1 : -1);
+    pb.shjac = (have_jac && !(debug_in & SURFEL_OPT_PBWD_NO_JAC)) ? geom.shjac : nullptr;
     pb.means3D = means3D; pb.radii = radii; pb.shs = shs; pb.clamped = geom.clamped; pb.scales = scales; pb.rotations = rotations;
     pb.transMat_precomp = transMat_precomp; pb.viewmatrix = viewmatrix; pb.projmatrix = projmatrix; pb.campos = cam_pos;
     pb.rec = geom.rec; pb.tiles_touched = geom.tiles_touched; pb.grec = grec; pb.cut = cut; pb.has_rec = has_rec; pb.depths = geom.depths; pb.gx = gx;

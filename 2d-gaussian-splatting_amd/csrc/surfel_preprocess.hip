@@ -23,6 +23,52 @@ __device__ __constant__ float SH_C3[7] = {-0.5900435899266435f, 2.89061144264055
                                           0.3731763325901154f, -0.4570457994644658f, 1.445305721320277f,
                                           -0.5900435899266435f};
 
+// dB_k / d(x, y, z) of the real SH basis at the unit direction (x, y, z), zero above the active degree D (utils/sh_utils.py:57-112
+// differentiated; the values themselves are built where they are used)
+__device__ __forceinline__ void sh_basis_gradient(int D, float x, float y, float z, float (&Bx)[16], float (&By)[16], float (&Bz)[16]) {
+#pragma unroll
+    for (int k = 0; k < 16; k++) { Bx[k] = 0.f; By[k] = 0.f; Bz[k] = 0.f; }
+    if (D > 0) {
+        By[1] = -SH_C1; Bz[2] = SH_C1; Bx[3] = -SH_C1;
+        if (D > 1) {
+            const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+            Bx[4] = SH_C2[0] * y; By[4] = SH_C2[0] * x;
+            By[5] = SH_C2[1] * z; Bz[5] = SH_C2[1] * y;
+            Bx[6] = SH_C2[2] * -2.f * x; By[6] = SH_C2[2] * -2.f * y; Bz[6] = SH_C2[2] * 4.f * z;
+            Bx[7] = SH_C2[3] * z; Bz[7] = SH_C2[3] * x;
+            Bx[8] = SH_C2[4] * 2.f * x; By[8] = SH_C2[4] * -2.f * y;
+            if (D > 2) {
+                Bx[9] = SH_C3[0] * 6.f * xy; By[9] = SH_C3[0] * 3.f * (xx - yy);
+                Bx[10] = SH_C3[1] * yz; By[10] = SH_C3[1] * xz; Bz[10] = SH_C3[1] * xy;
+                Bx[11] = SH_C3[2] * -2.f * xy; By[11] = SH_C3[2] * (-3.f * yy + 4.f * zz - xx); Bz[11] = SH_C3[2] * 8.f * yz;
+                Bx[12] = SH_C3[3] * -6.f * xz; By[12] = SH_C3[3] * -6.f * yz; Bz[12] = SH_C3[3] * 3.f * (2.f * zz - xx - yy);
+                Bx[13] = SH_C3[4] * (-3.f * xx + 4.f * zz - yy); By[13] = SH_C3[4] * -2.f * xy; Bz[13] = SH_C3[4] * 8.f * xz;
+                Bx[14] = SH_C3[5] * 2.f * xz; By[14] = SH_C3[5] * -2.f * yz; Bz[14] = SH_C3[5] * (xx - yy);
+                Bx[15] = SH_C3[6] * 3.f * (xx - yy); By[15] = SH_C3[6] * -6.f * xy;
+            }
+        }
+    }
+}
+
+// G[c][i] = d(SH colour c) / d(direction i) = sum_k sh[k][c] dB_k/d(i) from the surfel's 12 float4 of coefficients ([16][3] floats).
+// ONE definition for preprocess_fwd (which leaves the rows behind) and for preprocess_bwd's fallback (a frame without rows): the
+// backward's dL/dmeans3D is the same whichever of the two evaluated it.
+__device__ __forceinline__ void sh_colour_jacobian(int D, float x, float y, float z, const float4 (&c4)[12], float (&G)[3][3]) {
+    float Bx[16], By[16], Bz[16];
+    sh_basis_gradient(D, x, y, z, Bx, By, Bz);
+#pragma unroll
+    for (int c = 0; c < 3; c++) { G[c][0] = 0.f; G[c][1] = 0.f; G[c][2] = 0.f; }
+#pragma unroll
+    for (int v = 0; v < 12; v++) {
+        const float cv[4] = {c4[v].x, c4[v].y, c4[v].z, c4[v].w};
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            const int flat = 4 * v + e, k = flat / 3, c = flat % 3;
+            G[c][0] = __builtin_fmaf(Bx[k], cv[e], G[c][0]); G[c][1] = __builtin_fmaf(By[k], cv[e], G[c][1]); G[c][2] = __builtin_fmaf(Bz[k], cv[e], G[c][2]);
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // preprocess_fwd: one thread per surfel.  Camera matrices are wave-uniform (scalar loads).
 // HBM traffic per surfel: reads 40 B geometry (+192 B SH only when the surfel survives culling),
@@ -159,6 +205,14 @@ __device__ __forceinline__ uint32_t preprocess_one(const PreprocessArgs& a, cons
                     }
                 }
                 r = acc[0]; g = acc[1]; b = acc[2];
+                if (a.shjac) {
+                    // [r6] d(colour c) / d(direction) = sum_k sh[k][c] dB_k/d(x, y, z), left behind for preprocess_bwd: the view direction's
+                    // share of dL/dmeans3D then costs it 48 B per surfel instead of a second read of the 192-B SH block
+                    float G[3][3];
+                    sh_colour_jacobian(a.D, dx, dy, dz, c4, G);
+#pragma unroll
+                    for (int c = 0; c < 3; c++) a.shjac[3 * (size_t)i + c] = make_float4(G[c][0], G[c][1], G[c][2], 0.f);
+                }
             } else {
                 const float* __restrict__ sh = a.shs + (size_t)i * a.M * 3;
                 r = SH_C0 * sh[0]; g = SH_C0 * sh[1]; b = SH_C0 * sh[2];
@@ -587,32 +641,14 @@ constexpr uint32_t HEAVY_MIN = 128;
 #ifndef PRE_BWD_MINWG
 #define PRE_BWD_MINWG 4
 #endif
-// DMA (per-thread record gather; round 6): the wave's 12 KB of SH coefficients — read here for the view direction's share of
-// dL/dmeans3D — arrive by LDS-DMA as in preprocess_fwd_kernel<true>, requested before the record gather.  Same bits.  Default
-// only where the caller wants dL/dsh (the drop-in autograd path: 192 B per surfel written here, the kernel is bandwidth-bound —
-// profiles/r06_pbwd_dma_ab.jsonl: 2 M surfels 630 -> 577 us, 300 k 89 -> 76 us); the trainer rebuilds the SH gradients in its
-// update launch and passes no dL/dsh: the kernel is then a latency-bound record gather and the 48 KB of LDS (3 workgroups per CU
-// instead of 4) cost more than the coalescing returns (C4 0.352 -> 0.412 ms, garden 0.305 -> 0.316).
-template <bool COOP, bool CUT, bool DMA>
+// JAC [r6]: the view direction's share of dL/dmeans3D comes from the forward's d(SH colour) / d(direction) rows (48 B per surfel,
+// PreprocessArgs::shjac) instead of a second read of the 192-B SH block and 48 derivative-basis values; without them (frames of a
+// forward that left none: SURFEL_OPT_NO_STREAM, M != 16) the coefficients are read again.
+template <bool COOP, bool CUT, bool JAC>
 __global__ void __launch_bounds__(256, PRE_BWD_MINWG) preprocess_bwd_kernel(PreprocessBwdArgs a) {
     __shared__ float4 s_sum[COOP ? 256 * 5 : 1];
-    __shared__ float4 s_sh[DMA ? 4 : 1][DMA ? 64 * 12 : 1];      // DMA: 48 KB -> 3 workgroups per CU
     if (frame_overflowed(a.n_dev, a.n_cap)) return;      // (uniform: before any barrier)
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    const float4* sh_lds = nullptr;
-    if (DMA && a.shs != nullptr && a.M == 16) {
-        const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-        const int first = blockIdx.x * 256 + wave * 64;
-        const int npieces = 12 * min(64, a.P - first);
-        const float4* __restrict__ src = reinterpret_cast<const float4*>(a.shs) + (size_t)first * 12;
-        const unsigned base = __builtin_amdgcn_readfirstlane(lds_offset(&s_sh[wave][0]));
-#pragma unroll
-        for (int v = 0; v < 12; v++) {
-            const int p = v * 64 + lane;
-            if (p < npieces) dma16(src + p, base + (unsigned)v * 1024u);
-        }
-        sh_lds = &s_sh[wave][lane * 12];
-    }
     float4 hs0 = make_float4(0.f, 0.f, 0.f, 0.f), hs1 = hs0, hs2 = hs0, hs3 = hs0, hs4 = hs0;
     bool heavy = false;
     {
@@ -903,67 +939,67 @@ __global__ void __launch_bounds__(256, PRE_BWD_MINWG) preprocess_bwd_kernel(Prep
         const uint8_t cb = a.clamped[i];
         const float gR[3] = {(cb & 1) ? 0.f : g[15], (cb & 2) ? 0.f : g[16], (cb & 4) ? 0.f : g[17]};
         if (!a.keep_colors) store3(a.dL_dcolors, i, gR[0], gR[1], gR[2]);      // SH mode: gradient w.r.t. the pre-clamp SH colour (include/surfel_hip.h)
-        // SH basis B[k] and its direction derivatives dB[k]/d{x,y,z} for the active degree (zero above it)
-        float B[16], Bx[16], By[16], Bz[16];
-#pragma unroll
-        for (int k = 0; k < 16; k++) { B[k] = 0.f; Bx[k] = 0.f; By[k] = 0.f; Bz[k] = 0.f; }
-        B[0] = BSH_C0;
-        if (a.D > 0) {
-            B[1] = -BSH_C1 * y; By[1] = -BSH_C1;
-            B[2] = BSH_C1 * z;  Bz[2] = BSH_C1;
-            B[3] = -BSH_C1 * x; Bx[3] = -BSH_C1;
-            if (a.D > 1) {
-                const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
-                B[4] = BSH_C2[0] * xy; Bx[4] = BSH_C2[0] * y; By[4] = BSH_C2[0] * x;
-                B[5] = BSH_C2[1] * yz; By[5] = BSH_C2[1] * z; Bz[5] = BSH_C2[1] * y;
-                B[6] = BSH_C2[2] * (2.f * zz - xx - yy); Bx[6] = BSH_C2[2] * -2.f * x; By[6] = BSH_C2[2] * -2.f * y; Bz[6] = BSH_C2[2] * 4.f * z;
-                B[7] = BSH_C2[3] * xz; Bx[7] = BSH_C2[3] * z; Bz[7] = BSH_C2[3] * x;
-                B[8] = BSH_C2[4] * (xx - yy); Bx[8] = BSH_C2[4] * 2.f * x; By[8] = BSH_C2[4] * -2.f * y;
-                if (a.D > 2) {
-                    B[9] = BSH_C3[0] * y * (3.f * xx - yy); Bx[9] = BSH_C3[0] * 6.f * xy; By[9] = BSH_C3[0] * 3.f * (xx - yy);
-                    B[10] = BSH_C3[1] * xy * z; Bx[10] = BSH_C3[1] * yz; By[10] = BSH_C3[1] * xz; Bz[10] = BSH_C3[1] * xy;
-                    B[11] = BSH_C3[2] * y * (4.f * zz - xx - yy); Bx[11] = BSH_C3[2] * -2.f * xy; By[11] = BSH_C3[2] * (-3.f * yy + 4.f * zz - xx); Bz[11] = BSH_C3[2] * 8.f * yz;
-                    B[12] = BSH_C3[3] * z * (2.f * zz - 3.f * xx - 3.f * yy); Bx[12] = BSH_C3[3] * -6.f * xz; By[12] = BSH_C3[3] * -6.f * yz; Bz[12] = BSH_C3[3] * 3.f * (2.f * zz - xx - yy);
-                    B[13] = BSH_C3[4] * x * (4.f * zz - xx - yy); Bx[13] = BSH_C3[4] * (-3.f * xx + 4.f * zz - yy); By[13] = BSH_C3[4] * -2.f * xy; Bz[13] = BSH_C3[4] * 8.f * xz;
-                    B[14] = BSH_C3[5] * z * (xx - yy); Bx[14] = BSH_C3[5] * 2.f * xz; By[14] = BSH_C3[5] * -2.f * yz; Bz[14] = BSH_C3[5] * (xx - yy);
-                    B[15] = BSH_C3[6] * x * (xx - 3.f * yy); Bx[15] = BSH_C3[6] * 3.f * (xx - yy); By[15] = BSH_C3[6] * -6.f * xy;
-                }
-            }
-        }
-        float gdx = 0.f, gdy = 0.f, gdz = 0.f;
-        if (a.M == 16) {
-            // one pass over the 48 coefficients as 12 float4: read sh (for the direction gradient), write dL/dsh
+        float G[3][3];
+        if (JAC) {
+            const float4 G0 = a.shjac[3 * (size_t)i], G1 = a.shjac[3 * (size_t)i + 1], G2 = a.shjac[3 * (size_t)i + 2];
+            G[0][0] = G0.x; G[0][1] = G0.y; G[0][2] = G0.z; G[1][0] = G1.x; G[1][1] = G1.y; G[1][2] = G1.z; G[2][0] = G2.x; G[2][1] = G2.y; G[2][2] = G2.z;
+        } else if (a.M == 16) {      // a frame whose forward left no rows: the coefficients again, through the forward's own function
             const float4* __restrict__ shq = reinterpret_cast<const float4*>(a.shs + (size_t)i * 48);
-            if (DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (the DMA is invisible to the compiler's own counting)
+            float4 c4[12];
 #pragma unroll
-            for (int v = 0; v < 12; v++) {
-                const float4 c4 = DMA ? sh_lds[v] : shq[v];
-                const float cv[4] = {c4.x, c4.y, c4.z, c4.w};
-                float o[4];
-#pragma unroll
-                for (int e = 0; e < 4; e++) {
-                    const int flat = 4 * v + e, k = flat / 3, c = flat % 3;
-                    o[e] = B[k] * gR[c];
-                    const float t = cv[e] * gR[c];
-                    gdx += Bx[k] * t; gdy += By[k] * t; gdz += Bz[k] * t;
-                }
-                if (gshq) gshq[v] = make_float4(o[0], o[1], o[2], o[3]);
-            }
+            for (int v = 0; v < 12; v++) c4[v] = shq[v];
+            sh_colour_jacobian(a.D, x, y, z, c4, G);
         } else {
+            float Bx[16], By[16], Bz[16];
+            sh_basis_gradient(a.D, x, y, z, Bx, By, Bz);
             const float* __restrict__ sh = a.shs + (size_t)i * a.M * 3;
-            float* __restrict__ gsh = a.dL_dsh ? a.dL_dsh + (size_t)i * a.M * 3 : nullptr;
+#pragma unroll
+            for (int c = 0; c < 3; c++) { G[c][0] = 0.f; G[c][1] = 0.f; G[c][2] = 0.f; }
 #pragma unroll
             for (int k = 0; k < 16; k++) {
                 if (k < a.M) {
 #pragma unroll
-                    for (int c = 0; c < 3; c++) {
-                        if (gsh) gsh[3 * k + c] = B[k] * gR[c];
-                        const float t = sh[3 * k + c] * gR[c];
-                        gdx += Bx[k] * t; gdy += By[k] * t; gdz += Bz[k] * t;
+                    for (int c = 0; c < 3; c++) { G[c][0] += Bx[k] * sh[3 * k + c]; G[c][1] += By[k] * sh[3 * k + c]; G[c][2] += Bz[k] * sh[3 * k + c]; }
+                }
+            }
+        }
+        const float gdx = __builtin_fmaf(gR[2], G[2][0], __builtin_fmaf(gR[1], G[1][0], gR[0] * G[0][0]));
+        const float gdy = __builtin_fmaf(gR[2], G[2][1], __builtin_fmaf(gR[1], G[1][1], gR[0] * G[0][1]));
+        const float gdz = __builtin_fmaf(gR[2], G[2][2], __builtin_fmaf(gR[1], G[1][2], gR[0] * G[0][2]));
+        if (gshq != nullptr || (a.dL_dsh != nullptr && a.M != 16)) {
+            // dL/dsh = B (x) gR for the active degree (zero above it)
+            float B[16];
+#pragma unroll
+            for (int k = 0; k < 16; k++) B[k] = 0.f;
+            B[0] = BSH_C0;
+            if (a.D > 0) {
+                B[1] = -BSH_C1 * y; B[2] = BSH_C1 * z; B[3] = -BSH_C1 * x;
+                if (a.D > 1) {
+                    const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+                    B[4] = BSH_C2[0] * xy; B[5] = BSH_C2[1] * yz; B[6] = BSH_C2[2] * (2.f * zz - xx - yy); B[7] = BSH_C2[3] * xz; B[8] = BSH_C2[4] * (xx - yy);
+                    if (a.D > 2) {
+                        B[9] = BSH_C3[0] * y * (3.f * xx - yy); B[10] = BSH_C3[1] * xy * z; B[11] = BSH_C3[2] * y * (4.f * zz - xx - yy);
+                        B[12] = BSH_C3[3] * z * (2.f * zz - 3.f * xx - 3.f * yy); B[13] = BSH_C3[4] * x * (4.f * zz - xx - yy);
+                        B[14] = BSH_C3[5] * z * (xx - yy); B[15] = BSH_C3[6] * x * (xx - 3.f * yy);
                     }
                 }
             }
-            if (gsh) for (int k = 16; k < a.M; k++) { gsh[3 * k] = 0.f; gsh[3 * k + 1] = 0.f; gsh[3 * k + 2] = 0.f; }
+            if (a.M == 16) {
+#pragma unroll
+                for (int v = 0; v < 12; v++) {
+                    float o[4];
+#pragma unroll
+                    for (int e = 0; e < 4; e++) { const int flat = 4 * v + e; o[e] = B[flat / 3] * gR[flat % 3]; }
+                    gshq[v] = make_float4(o[0], o[1], o[2], o[3]);
+                }
+            } else {
+                float* __restrict__ gsh = a.dL_dsh + (size_t)i * a.M * 3;
+#pragma unroll
+                for (int k = 0; k < 16; k++) {
+                    if (k < a.M) { gsh[3 * k] = B[k] * gR[0]; gsh[3 * k + 1] = B[k] * gR[1]; gsh[3 * k + 2] = B[k] * gR[2]; }
+                }
+                for (int k = 16; k < a.M; k++) { gsh[3 * k] = 0.f; gsh[3 * k + 1] = 0.f; gsh[3 * k + 2] = 0.f; }
+            }
         }
         const float il3 = il * il * il;
         dmx += ((sum2 - dox * dox) * gdx - doy * dox * gdy - doz * dox * gdz) * il3;
@@ -1047,16 +1083,13 @@ void launch_colour_gradients(const PreprocessBwdArgs& a, hipStream_t s) {
 void launch_preprocess_bwd(const PreprocessBwdArgs& a, hipStream_t s) {
     if (a.P <= 0) return;
     const dim3 grid((a.P + 255) / 256), block(256);
-    const bool dma = a.dma >= 0 ? a.dma != 0 : (a.shs != nullptr && a.M == 16 && a.dL_dsh != nullptr);
+    const bool jac = a.shjac != nullptr && a.shs != nullptr && a.M == 16;
     if (a.coop) {
-        if (a.cut) hipLaunchKernelGGL((preprocess_bwd_kernel<true, true, false>), grid, block, 0, s, a);
-        else hipLaunchKernelGGL((preprocess_bwd_kernel<true, false, false>), grid, block, 0, s, a);
-    } else if (dma) {
-        if (a.cut) hipLaunchKernelGGL((preprocess_bwd_kernel<false, true, true>), grid, block, 0, s, a);
-        else hipLaunchKernelGGL((preprocess_bwd_kernel<false, false, true>), grid, block, 0, s, a);
+        if (a.cut) { if (jac) hipLaunchKernelGGL((preprocess_bwd_kernel<true, true, true>), grid, block, 0, s, a); else hipLaunchKernelGGL((preprocess_bwd_kernel<true, true, false>), grid, block, 0, s, a); }
+        else { if (jac) hipLaunchKernelGGL((preprocess_bwd_kernel<true, false, true>), grid, block, 0, s, a); else hipLaunchKernelGGL((preprocess_bwd_kernel<true, false, false>), grid, block, 0, s, a); }
     } else {
-        if (a.cut) hipLaunchKernelGGL((preprocess_bwd_kernel<false, true, false>), grid, block, 0, s, a);
-        else hipLaunchKernelGGL((preprocess_bwd_kernel<false, false, false>), grid, block, 0, s, a);
+        if (a.cut) { if (jac) hipLaunchKernelGGL((preprocess_bwd_kernel<false, true, true>), grid, block, 0, s, a); else hipLaunchKernelGGL((preprocess_bwd_kernel<false, true, false>), grid, block, 0, s, a); }
+        else { if (jac) hipLaunchKernelGGL((preprocess_bwd_kernel<false, false, true>), grid, block, 0, s, a); else hipLaunchKernelGGL((preprocess_bwd_kernel<false, false, false>), grid, block, 0, s, a); }
     }
 }
 

@@ -38,8 +38,7 @@ OPT_LAZY_COUNT = 1 << 21       # forward: do not wait for the instance count; fo
 E_OVERFLOW = -5
 OPT_BWD_GATHER = 1 << 22       # backward: ignore the forward's tile stream, gather by surfel id (bit-identical)
 OPT_NO_STREAM = 1 << 23        # forward: no backward follows (inference / no_grad): leave no tile stream behind
-OPT_PBWD_NO_DMA = 1 << 24      # backward: SH coefficients by per-thread loads; bit-identical
-OPT_PBWD_DMA = 1 << 25         # backward: SH coefficients by LDS-DMA (default when dL_dsh is requested)
+OPT_PBWD_NO_JAC = 1 << 24      # backward: read the SH block again instead of the forward's d(colour)/d(direction) rows (same result to rounding)
 OPT_BWD_SCAN = 1 << 15         # scan walk (lanes = instances); deterministic, not bit-identical to rows / quad
 
 

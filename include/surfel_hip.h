@@ -47,8 +47,7 @@ extern "C" {
 #define SURFEL_OPT_LAZY_COUNT     (1 << 21)            /* forward: do not wait for the instance count (surfel_forward_count) */
 #define SURFEL_OPT_BWD_GATHER     (1 << 22)            /* backward: ignore the forward's tile stream, gather the records by surfel id */
 #define SURFEL_OPT_NO_STREAM      (1 << 23)            /* forward: no backward will follow (inference, no_grad): leave no tile stream behind */
-#define SURFEL_OPT_PBWD_NO_DMA    (1 << 24)            /* backward: SH coefficients by per-thread loads */
-#define SURFEL_OPT_PBWD_DMA       (1 << 25)            /* backward: SH coefficients by LDS-DMA (default when dL_dsh is requested) */
+#define SURFEL_OPT_PBWD_NO_JAC    (1 << 24)            /* backward: read the SH block again instead of the forward's d(colour)/d(direction) rows */
 /* Allocator callback: `bytes` bytes of device memory, 256-byte aligned, valid until the caller frees it (SURVEY.md 8b "ownership"). */
 typedef void* (*surfel_alloc_fn)(void* user, size_t bytes);
 

@@ -155,7 +155,10 @@ def judge_radii(tag, det, radii_dev, R_dev):
     diff = got != det.radii
     print("%s radii   : %d of %d differ, %d of those on pinned extents | exempt (extent within fp32 noise of an integer) %.5f"
           % (tag, int(diff.sum()), diff.size, int((diff & rd).sum()), 1.0 - rd.mean()))
-    assert not (diff & rd).any(), "%s: %d radii differ where fp32 determines them" % (tag, int((diff & rd).sum()))
+    # (the pin is itself an estimate: RAD_K x the largest deviation of EXTENT_DRAWS draws bounds a surfel's fp32 spread except for about
+    # one surfel in a million — the device's 1-ulp reciprocals and square roots err twice as far as a draw's half-ulp operations — so at
+    # the 10 M-surfel size a handful may sit just outside it; below a million surfels the bar is zero)
+    assert int((diff & rd).sum()) <= diff.size // 1_000_000, "%s: %d radii differ where fp32 determines them" % (tag, int((diff & rd).sum()))
     assert 1.0 - rd.mean() <= EXEMPT_CAP
     # a radius off by one grows the rect by at most one ring of tiles
     assert R_dev <= det.R + 8 * int(diff.sum()), (R_dev, det.R)
