@@ -45,6 +45,8 @@ def pmc_means(d):
     if not f:
         return {}
     for r in csv.DictReader(open(f)):
+        if re.search(r"blend_\w+_kernel<true", r["Kernel_Name"]):      # the instrumented (STATS) twins of bench.py's useful-pair census: spills, atomics
+            continue
         acc[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
     return {k: dict({c: sum(v) / len(v) for c, v in cs.items()}, launches=max(len(v) for v in cs.values())) for k, cs in acc.items()}
 
@@ -69,7 +71,7 @@ def eff_clock(d):
                 dur[r.get("Dispatch_Id", r.get("Correlation_Id"))] = float(r["End_Timestamp"]) - float(r["Start_Timestamp"])
     acc = collections.defaultdict(list)
     for r in rows:
-        if r["Counter_Name"] != "GRBM_GUI_ACTIVE" or r["Dispatch_Id"] not in dur or dur[r["Dispatch_Id"]] <= 0:
+        if r["Counter_Name"] != "GRBM_GUI_ACTIVE" or r["Dispatch_Id"] not in dur or dur[r["Dispatch_Id"]] <= 0 or re.search(r"blend_\w+_kernel<true", r["Kernel_Name"]):
             continue
         acc[short(r["Kernel_Name"])].append((float(r["Counter_Value"]), dur[r["Dispatch_Id"]]))
     out = {}
@@ -100,6 +102,8 @@ def main():
             w = csv.writer(fo)
             w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs", "StdDev"])
             for r in rows:
+                if re.search(r"blend_\w+_kernel<true", r["Name"]):      # (instrumented twins of the useful-pair census)
+                    continue
                 w.writerow([short(r["Name"]), r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"], r["MinNs"], r["MaxNs"], r["StdDev"]])
     log = os.path.join(src, "bench_kt.log")
     if os.path.exists(log):
