@@ -490,6 +490,7 @@ int64_t surfel_rasterize_forward(surfel_alloc_fn geom_alloc, void* geom_user, su
         PreprocessArgs pa{};
         pa.P = P; pa.D = D; pa.M = M; pa.W = width; pa.H = height; pa.gx = gx; pa.gy = gy; pa.scale_modifier = scale_modifier;
         pa.cull = opt_cull;
+        pa.pack_tiles = P < (1 << PACK_ID_BITS) ? 1 : 0;
         pa.means3D = means3D; pa.opacities = opacities; pa.scales = scales; pa.rotations = rotations;
         pa.transMat_precomp = transMat_precomp; pa.colors_precomp = colors_precomp; pa.shs = shs;
         pa.viewmatrix = viewmatrix; pa.projmatrix = projmatrix; pa.campos = cam_pos;
@@ -620,7 +621,7 @@ int64_t surfel_rasterize_forward(surfel_alloc_fn geom_alloc, void* geom_user, su
                 order = which ? geom.ord_b : geom.ord_a;
             }
             // (2) instance offsets in emission order: inclusive scan of tiles_touched[order[k]]
-            launch_scan_gather(geom.tiles_touched, order, geom.offsets, (size_t)P, scan_state, s);
+            launch_scan_gather(geom.tiles_touched, order, pa.pack_tiles, geom.offsets, (size_t)P, scan_state, s);
             STAGE_END(tm, ST_SCAN);
             if (!r_known) {
                 HIP_TRY(hipEventSynchronize(evR));
@@ -641,7 +642,7 @@ int64_t surfel_rasterize_forward(surfel_alloc_fn geom_alloc, void* geom_user, su
                 uint32_t* va = odd ? bin.vals_alt : bin.point_list;
                 uint32_t* vb = odd ? bin.point_list : bin.vals_alt;
                 tm.begin();
-                launch_emit_instances(P, geom.rec, geom.rects, order, geom.offsets, bin.keys_a, va, gx, reinterpret_cast<uint32_t*>(bin.sort_temp),
+                launch_emit_instances(P, geom.rec, geom.rects, order, pa.pack_tiles ? ((1u << PACK_ID_BITS) - 1u) : 0xffffffffu, geom.offsets, bin.keys_a, va, gx, reinterpret_cast<uint32_t*>(bin.sort_temp),
                                       (uint32_t)radix_sort_head_words((size_t)R), s);
                 STAGE_END(tm, ST_EMIT);
                 tm.begin();

@@ -10,6 +10,8 @@ constexpr int TILE = 16;            // tile edge in pixels (fixed by the referen
 constexpr int BLOCK = TILE * TILE;  // 256 threads = 4 waves
 constexpr int WAVE = 64;
 constexpr int R_SLOTS = 64;         // partial instance totals (summed on the host)
+constexpr int PACK_ID_BITS = 22;    // frames of < 2^22 surfels: the depth sort's value = surfel id | min(tiles_touched, PACK_TILES_MAX) << 22
+constexpr uint32_t PACK_TILES_MAX = 1023u;      // (this many or more: the scan looks the count up)
 
 // rasterizer constants (oracle/surfel_oracle.c holds the same list with provenance)
 constexpr float NEAR_N = 0.2f;

@@ -8,6 +8,7 @@ namespace surfel {
 struct PreprocessArgs {
     int P, D, M, W, H, gx, gy;
     int cull;                 // 0: emit the full reference rect, footprints unbounded (test switch)
+    int pack_tiles;           // 1 (P < 2^22): ident[i] = i | min(tiles_touched, 1023) << 22 — the depth-ordered scan then needs no gather by surfel id
     float scale_modifier;
     const float* means3D; const float* opacities; const float* scales; const float* rotations;
     const float* transMat_precomp; const float* colors_precomp; const float* shs;
@@ -70,7 +71,7 @@ struct PreprocessBwdArgs {
 };
 
 void launch_preprocess_fwd(const PreprocessArgs& a, hipStream_t s);
-void launch_emit_instances(int P, float* rec, const uint32_t* rects, const uint32_t* order, const uint32_t* offsets_sorted, uint32_t* keys,
+void launch_emit_instances(int P, float* rec, const uint32_t* rects, const uint32_t* order, uint32_t id_mask, const uint32_t* offsets_sorted, uint32_t* keys,
                            uint32_t* vals, int gx, uint32_t* zero_ptr, uint32_t zero_words, hipStream_t s);
 void launch_tile_ranges(int64_t R, const uint32_t* keys, uint2* ranges, hipStream_t s);
 int tile_map_len(int gx, int gy);
@@ -100,7 +101,7 @@ size_t scan_scratch_words(size_t n);          // zeroed scratch of launch_scan_g
 // decode: the ranges come from the sort's last pass (radix_sort_pairs_u32_devn) with complemented starts; the kernel turns them back
 void launch_tile_depth_sort(int ntiles, int64_t R, uint2* ranges, uint32_t* point_list, const uint32_t* depth_keys, uint32_t* tmp_ids,
                             uint32_t* tmp_keys, uint32_t* tmp_rank, bool decode, hipStream_t s);
-void launch_scan_gather(const uint32_t* vals, const uint32_t* order, uint32_t* out, size_t n, void* zeroed_scratch, hipStream_t s);
+void launch_scan_gather(const uint32_t* vals, const uint32_t* order, int packed, uint32_t* out, size_t n, void* zeroed_scratch, hipStream_t s);
 // capacity binning (surfel_sort.hip): scan + emission + tile-sort histograms in one launch, sort passes / ranges with the count on the device
 bool capacity_binning_ok(size_t cap, int end_bit);
 size_t capacity_sort_scratch_bytes(size_t cap, int end_bit);

@@ -341,7 +341,7 @@ size_t radix_sort_head_words(size_t n) { return rs_onesweep(n) ? RS_HEAD_WORDS :
 constexpr int SC_IPT = 8, SC_TILE = RS_THREADS * SC_IPT;
 size_t scan_scratch_words(size_t n) { return 64 + (n + SC_TILE - 1) / SC_TILE; }     // ticket (+pad) | status[tiles]; must be zero
 
-__global__ void __launch_bounds__(RS_THREADS) scan_gather_kernel(const uint32_t* __restrict__ vals, const uint32_t* __restrict__ order,
+__global__ void __launch_bounds__(RS_THREADS) scan_gather_kernel(const uint32_t* __restrict__ vals, const uint32_t* __restrict__ order, int packed,
                                                                  uint32_t* __restrict__ out, uint32_t n, uint32_t* __restrict__ scratch) {
     __shared__ uint32_t s_w[4];
     __shared__ uint32_t s_tile, s_excl;
@@ -356,7 +356,13 @@ __global__ void __launch_bounds__(RS_THREADS) scan_gather_kernel(const uint32_t*
 #pragma unroll
     for (int i = 0; i < SC_IPT; i++) {
         const uint32_t e = base + i;
-        v[i] = e < n ? vals[order[e]] : 0u;
+        uint32_t t = 0u;
+        if (e < n) {
+            const uint32_t ov = order[e];
+            if (packed) { t = ov >> PACK_ID_BITS; if (t == PACK_TILES_MAX) t = vals[ov & ((1u << PACK_ID_BITS) - 1u)]; }      // (the count rides in the sorted value)
+            else t = vals[ov];
+        }
+        v[i] = t;
         sum += v[i];
     }
     uint32_t x = sum;                              // inclusive scan of the per-thread sums over the workgroup
@@ -404,9 +410,9 @@ __global__ void __launch_bounds__(RS_THREADS) scan_gather_kernel(const uint32_t*
     }
 }
 
-void launch_scan_gather(const uint32_t* vals, const uint32_t* order, uint32_t* out, size_t n, void* zeroed_scratch, hipStream_t s) {
+void launch_scan_gather(const uint32_t* vals, const uint32_t* order, int packed, uint32_t* out, size_t n, void* zeroed_scratch, hipStream_t s) {
     if (n == 0) return;
-    hipLaunchKernelGGL(scan_gather_kernel, dim3((unsigned)((n + SC_TILE - 1) / SC_TILE)), dim3(RS_THREADS), 0, s, vals, order, out, (uint32_t)n,
+    hipLaunchKernelGGL(scan_gather_kernel, dim3((unsigned)((n + SC_TILE - 1) / SC_TILE)), dim3(RS_THREADS), 0, s, vals, order, packed, out, (uint32_t)n,
                        static_cast<uint32_t*>(zeroed_scratch));
 }
 

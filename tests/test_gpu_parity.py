@@ -419,16 +419,23 @@ def test_culling_is_exact(kind):
             assert R0 == Rref, (R0, Rref)
 
 
-@pytest.mark.parametrize("kind", ["plain", "huge", "ties", "crowded"])
+@pytest.mark.parametrize("kind", ["plain", "huge", "ties", "crowded", "giant"])
 def test_binning_paths_are_identical(kind):
     """The two binning paths — depth-presorted emission vs index-order emission + per-tile depth sort in LDS — must give
     BIT-IDENTICAL images and gradients (same per-tile order: depth bits, then surfel index).  'ties' holds many exactly equal
-    depths; 'crowded' piles > 4096 instances onto single tiles to take the rank-sort fallback."""
+    depths; 'crowded' piles > 4096 instances onto single tiles to take the rank-sort fallback; 'giant' holds discs that cover more
+    than 1023 tiles (the depth sort's value carries min(tile count, 1023) above the surfel id: such surfels take the look-up)."""
     import surfel_native as n
     import synthetic
     lib = n.load()
     if kind in ("plain", "huge"):
         sc = _stress_scene(kind, 21)
+    elif kind == "giant":
+        sc = synthetic.make_scene(2500, 656, 640, seed=8, px_radius=5.0, z_near=2.0, z_far=9.0)      # 41 x 40 = 1640 tiles
+        rng0 = np.random.default_rng(8)
+        big = rng0.random(sc["means3D"].shape[0]) < 0.004
+        sc["scales"][big] *= 30.0
+        sc["opacities"][big] = 0.03
     elif kind == "ties":
         sc = synthetic.make_scene(3000, 160, 120, seed=5, px_radius=6.0, z_near=2.0, z_far=6.0, tilt=False)
         # identity rotation camera: view depth = world z + const; quantise z so that hundreds of surfels share a depth bit pattern
@@ -446,6 +453,8 @@ def test_binning_paths_are_identical(kind):
         res.append((run.R, run.color.cpu().numpy(), run.others.cpu().numpy(), run.radii.cpu().numpy(), g))
     R0, c0, o0, r0, g0 = res[0]
     assert R0 > 0
+    if kind == "giant":
+        assert (r0 > 400).sum() >= 3, "no surfel large enough to cover 1023 tiles (largest radius %d px)" % r0.max()
     if kind == "crowded":
         tiles = ((a["W"] + 15) // 16) * ((a["H"] + 15) // 16)
         assert R0 > 4096 * tiles * 0.5, "scene not crowded enough to reach the fallback (%d instances on %d tiles)" % (R0, tiles)
