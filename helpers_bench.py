@@ -460,7 +460,7 @@ def trained_leg(dev, preset="trained", steps=30, warmup=5, state=None):
     import torch
     import diff_surfel_rasterization as dsr
     tr, info = trained_trainer(dev, preset, state)
-    out = time_trainer(tr, steps, warmup, prime=5, workload=preset)
+    out = time_trainer(tr, steps, warmup, prime=max(5, len(tr.cams)), workload=preset)      # (an epoch of the view stack: every view's buffer sizes seen before the window)
     out.update(info)
     model = tr.model
     del tr, model
