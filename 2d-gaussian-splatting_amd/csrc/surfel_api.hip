@@ -90,7 +90,7 @@ struct GeomState {   // per-surfel state ("geomBuffer")
     uint32_t *dkey_a, *dkey_b, *ord_a, *ord_b;   // depth-bit keys / surfel order (double buffers of the P-sized sort)
     uint32_t* offsets;                            // inclusive scan of tiles_touched in depth order
     uint32_t* rects;                              // packed tile rect of every surfel (copy of record word 19: emission reads 4 B instead of a record line)
-    float4* shjac;                                // [P][3]: d(SH colour) / d(view direction) rows for preprocess_bwd (written unless SURFEL_OPT_NO_STREAM)
+    float* shjac;                                 // [9][P]: d(SH colour) / d(view direction) planes for preprocess_bwd (written unless SURFEL_OPT_NO_STREAM)
     char* temp; size_t temp_bytes;                // scratch of the P-sized sort, then of the scan
     static GeomState carve(void* base, int P, size_t temp_bytes, size_t* total) {
         Carver c(base); GeomState g;
@@ -102,7 +102,7 @@ struct GeomState {   // per-surfel state ("geomBuffer")
         g.ord_a = c.take<uint32_t>(P); g.ord_b = c.take<uint32_t>(P);
         g.offsets = c.take<uint32_t>(P);
         g.rects = c.take<uint32_t>(P);
-        g.shjac = c.take<float4>((size_t)3 * P);
+        g.shjac = c.take<float>((size_t)9 * P);
         g.temp = c.take<char>(temp_bytes);
         g.temp_bytes = temp_bytes;
         if (total) *total = c.size();

@@ -15,7 +15,7 @@ struct PreprocessArgs {
     const float* viewmatrix; const float* projmatrix; const float* campos;
     float* rec; float* depths; uint32_t* depth_keys; uint32_t* ident; int* radii; uint32_t* tiles_touched; uint8_t* clamped;
     uint32_t* rects;          // packed emission rect per surfel (x0 | y0 << 10 | width << 20), a compact copy of record word 19
-    float4* shjac;            // [P][3] or NULL: d(SH colour c) / d(view direction) of every visible surfel (row c; .w unused) for preprocess_bwd
+    float* shjac;             // [9][P] or NULL: d(SH colour c) / d(view direction q) of every visible surfel (plane 3 c + q) for preprocess_bwd
     uint32_t* total_instances;     // [2 * R_SLOTS], zeroed by the caller: partial sums of tiles_touched | of (tiles_touched > 0)
     uint32_t* block_totals;        // [workgroups] instances emitted by every workgroup's 256 surfels (bin_emit_kernel's scan), or NULL
     uint32_t* zero_a; uint32_t zero_a_words;   // scratch words this kernel clears for the launches that follow
@@ -58,7 +58,7 @@ struct PreprocessBwdArgs {
     int P, D, M, W, H;
     int coop;                 // 1: wave-cooperative gather of the instance gradient records (many records per surfel)
     int keep_colors;          // 1: dL_dcolors was already written by launch_colour_gradients (and may be on the wire): leave it alone
-    const float4* shjac;      // the forward's d(SH colour) / d(view direction) rows, or NULL: read the SH coefficients again
+    const float* shjac;       // the forward's d(SH colour) / d(view direction) planes [9][P], or NULL: read the SH coefficients again
     float scale_modifier;
     const float* means3D; const int* radii; const float* shs; const uint8_t* clamped;
     const float* scales; const float* rotations; const float* transMat_precomp;

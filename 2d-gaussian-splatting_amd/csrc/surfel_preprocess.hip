@@ -211,7 +211,10 @@ __device__ __forceinline__ uint32_t preprocess_one(const PreprocessArgs& a, cons
                     float G[3][3];
                     sh_colour_jacobian(a.D, dx, dy, dz, c4, G);
 #pragma unroll
-                    for (int c = 0; c < 3; c++) a.shjac[3 * (size_t)i + c] = make_float4(G[c][0], G[c][1], G[c][2], 0.f);
+                    for (int c = 0; c < 3; c++) {      // nine planes of P floats: every store (and the backward's load) is coalesced
+#pragma unroll
+                        for (int q = 0; q < 3; q++) a.shjac[(size_t)(3 * c + q) * a.P + i] = G[c][q];
+                    }
                 }
             } else {
                 const float* __restrict__ sh = a.shs + (size_t)i * a.M * 3;
@@ -643,7 +646,7 @@ constexpr uint32_t HEAVY_MIN = 128;
 #ifndef PRE_BWD_MINWG
 #define PRE_BWD_MINWG 4
 #endif
-// JAC [r6]: the view direction's share of dL/dmeans3D comes from the forward's d(SH colour) / d(direction) rows (48 B per surfel,
+// JAC [r6]: the view direction's share of dL/dmeans3D comes from the forward's d(SH colour) / d(direction) rows (36 B per surfel,
 // PreprocessArgs::shjac) instead of a second read of the 192-B SH block and 48 derivative-basis values; without them (frames of a
 // forward that left none: SURFEL_OPT_NO_STREAM, M != 16) the coefficients are read again.
 template <bool COOP, bool CUT, bool JAC>
@@ -943,8 +946,11 @@ __global__ void __launch_bounds__(256, PRE_BWD_MINWG) preprocess_bwd_kernel(Prep
         if (!a.keep_colors) store3(a.dL_dcolors, i, gR[0], gR[1], gR[2]);      // SH mode: gradient w.r.t. the pre-clamp SH colour (include/surfel_hip.h)
         float G[3][3];
         if (JAC) {
-            const float4 G0 = a.shjac[3 * (size_t)i], G1 = a.shjac[3 * (size_t)i + 1], G2 = a.shjac[3 * (size_t)i + 2];
-            G[0][0] = G0.x; G[0][1] = G0.y; G[0][2] = G0.z; G[1][0] = G1.x; G[1][1] = G1.y; G[1][2] = G1.z; G[2][0] = G2.x; G[2][1] = G2.y; G[2][2] = G2.z;
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+#pragma unroll
+                for (int q = 0; q < 3; q++) G[c][q] = a.shjac[(size_t)(3 * c + q) * a.P + i];
+            }
         } else if (a.M == 16) {      // a frame whose forward left no rows: the coefficients again, through the forward's own function
             const float4* __restrict__ shq = reinterpret_cast<const float4*>(a.shs + (size_t)i * 48);
             float4 c4[12];
