@@ -70,15 +70,17 @@ __device__ __forceinline__ int select_bit128(unsigned long long w0, unsigned lon
 
 // [r6] BATCH TRUNCATION.  A batch lasts (chunks of its longest sub-tile list) rounds, and a round lasts one 16-step walk whatever it
 // holds — a workgroup's round is as long as ONE walk however many of its lanes and waves take part (profiles/r06_negative_results.md
-// section 6): a longest list of 50 costs four rounds, the fourth for two instances.  When the longest list ends 1 .. SCAN_TRUNC_REM
-// instances into a chunk, the batch is cut in front of the staged instance that opens that chunk (the deepest `keep` instances are
-// walked: full chunks on the longest list) and the next batch starts with the rest — staged again from there, nothing is carried.
+// section 6): a longest list of 50 costs four rounds, the fourth for two instances.  Where that pays (rounds + half a round of fixed
+// cost per staged instance gets smaller) the batch is cut in front of the staged instance that opens the longest list's last, partial
+// chunk (the deepest `keep` instances are walked: full chunks on the longest list) and the next batch starts with the rest — staged
+// again from there, nothing is carried.
 // Where a batch ends follows from the frame's lists alone, the same with and without the tile stream: same bits either way.
-// Measured (profiles/r06_ab_scan_trunc.jsonl): blend_bwd garden 1.345 -> 1.296 ms, C4 0.977 -> 0.944.
+// Measured (profiles/r06_ab_scan_trunc.jsonl): blend_bwd garden 1.345 -> 1.296 ms, C4 0.977 -> 0.944 with a fixed "1 .. 8 instances into
+// the chunk" rule; the cost rule above another 0.6 - 0.9 % (r06_ab_scan_trunc_policy.jsonl).
 // (The two staging paths are kept apart with `if constexpr`: an earlier form that shared a lambda between them cost the STREAM
 // instantiation 8 % — same instruction counts, another schedule.)
 #ifndef SCAN_TRUNC_REM
-#define SCAN_TRUNC_REM 8
+#define SCAN_TRUNC_REM 1      // 0: fixed 128-position batches
 #endif
 
 // LDS records of a pixel, indexed by the pixel's owner thread (tid = 16 * sub-tile row + pixel of the sub-tile):
@@ -255,10 +257,13 @@ __global__ void __launch_bounds__(BLOCK, SCAN_MIN_WG) blend_bwd_scan_kernel(Blen
             int nm = n;
             nm = max(nm, __shfl_xor(nm, 1)); nm = max(nm, __shfl_xor(nm, 2)); nm = max(nm, __shfl_xor(nm, 4)); nm = max(nm, __shfl_xor(nm, 8));
             const int full = nm & ~(CH - 1), rem = nm & (CH - 1);
-            if (full > 0 && rem > 0 && rem <= SCAN_TRUNC_REM) {
+            if (full > 0 && rem > 0) {
                 int ms = n > full ? select_bit128(w0, w1, full) : SB;      // the staged instance that opens this list's chunk behind the full ones
                 ms = min(ms, __shfl_xor(ms, 1)); ms = min(ms, __shfl_xor(ms, 2)); ms = min(ms, __shfl_xor(ms, 4)); ms = min(ms, __shfl_xor(ms, 8));
-                keep = ms;
+                // cut iff the batch then costs less per staged instance, a batch's fixed part taken as half a round:
+                // (r + 1/2) / ms < (r + 3/2) / mb   (r = full chunks of the longest list)
+                const int r = full / CH;
+                if (ms * (2 * r + 3) > mb * (2 * r + 1)) keep = ms;
             }
             keep = __builtin_amdgcn_readfirstlane(keep);
             if constexpr (STREAM) {
