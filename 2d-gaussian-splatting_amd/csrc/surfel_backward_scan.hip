@@ -363,9 +363,13 @@ __global__ void __launch_bounds__(BLOCK, SCAN_MIN_WG) blend_bwd_scan_kernel(Blen
 #pragma unroll
                 for (int v = 0; v < 18; v++) g[v] = 0.f;
 #if SCAN_PAIR
+                if constexpr (!STATS) {
                 // [r6] two pixel steps at a time: both steps' intersections first, then ONE joint transmittance scan whose two dependent
                 // DPP chains are interleaved (row_scan_mul2), then the two gradient halves — the same operations on the same values as
-                // the step-by-step form below (kept under SCAN_PAIR = 0), so the same bits
+                // the step-by-step form below (kept under SCAN_PAIR = 0, and for the instrumented STATS instantiation: its atomics put
+                // branches into the walk, and with them the paired form counted 3 - 18 % more composited pairs than the forward after an
+                // unrelated change of the register allocation — tests/test_gpu_parity.py::test_forward_and_backward_composite_the_same_pairs;
+                // the product instantiation is checked against the step-by-step build bit for bit, scripts/lib_identity.py)
                 constexpr float MC1 = FAR_N / (FAR_N - NEAR_N), MC2 = (FAR_N * NEAR_N) / (FAR_N - NEAR_N);
                 struct Half { float4 Cq, S; Hit h; bool ok; float alpha, depth, i1a; };
                 float4 Sn0 = srd[0], Sn1 = srd[1];
@@ -502,7 +506,9 @@ __global__ void __launch_bounds__(BLOCK, SCAN_MIN_WG) blend_bwd_scan_kernel(Blen
                     g[0] = u0; g[1] = u1; g[2] = u2; g[3] = v0; g[4] = v1; g[5] = v2; g[6] = w0; g[7] = w1; g[8] = w2;
                 }
 #endif
-#else
+                } else
+#endif
+                {
                 float4 Sn = srd[0];
                 constexpr float MC1 = FAR_N / (FAR_N - NEAR_N), MC2 = (FAR_N * NEAR_N) / (FAR_N - NEAR_N);
 #pragma unroll
@@ -566,7 +572,7 @@ __global__ void __launch_bounds__(BLOCK, SCAN_MIN_WG) blend_bwd_scan_kernel(Blen
                     g[9] = FMA(g2, h.dx, g[9]); g[10] = FMA(g2, h.dy, g[10]);
                 }
                 }
-#endif
+                }
                 s_slot[tid * 5 + 0] = make_float4(g[0], g[1], g[2], g[3]);
                 s_slot[tid * 5 + 1] = make_float4(g[4], g[5], g[6], g[7]);
                 s_slot[tid * 5 + 2] = make_float4(g[8], g[9], g[10], g[11]);

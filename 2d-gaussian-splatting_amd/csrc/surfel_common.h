@@ -48,10 +48,11 @@ constexpr int GREC_F = 20;
 // and libm-grade expf so that what the fast forms cost in parity can be measured (profiles/r02_fast_intrinsics_cost.md).
 #ifdef SURFEL_IEEE_MATH
 #define SURFEL_RCP(x) (1.0f / (x))
-#define SURFEL_EXP(x) expf(x)
+#define SURFEL_GAUSS(rho) expf(-0.5f * (rho))
 #else
 #define SURFEL_RCP(x) __builtin_amdgcn_rcpf(x)
-#define SURFEL_EXP(x) __expf(x)
+// exp(-rho / 2) = 2^(rho * -log2(e) / 2): ONE multiply in front of v_exp_f32 (round 6; -0.5f * rho through __expf took two)
+#define SURFEL_GAUSS(rho) __builtin_amdgcn_exp2f(-0.72134752044448170368f * (rho))
 #endif
 
 // ---- ray-splat intersection of one (pixel, surfel) pair --------------------------------------------
@@ -83,8 +84,8 @@ __device__ __forceinline__ bool pair_intersect(const float Twx, const float Twy,
     const float rho2d = FILTER_INV_SQUARE * SURFEL_FMA(h.dx, h.dx, h.dy * h.dy);
     h.use3d = rho3d <= rho2d;
     const float rho = fminf(rho3d, rho2d);
-    h.depth = h.use3d ? SURFEL_FMA(h.sx, Twx, h.sy * Twy) + Twz : Twz;
-    h.G = SURFEL_EXP(-0.5f * rho);
+    h.depth = h.use3d ? SURFEL_FMA(h.sx, Twx, SURFEL_FMA(h.sy, Twy, Twz)) : Twz;      // (round 6: two fused multiply-adds; sx Twx + sy Twy, + Twz took three operations)
+    h.G = SURFEL_GAUSS(rho);
     h.alpha = fminf(ALPHA_MAX, opa * h.G);
     return (p2 != 0.f) & (h.depth >= NEAR_N) & (h.alpha >= ALPHA_MIN);
 }
