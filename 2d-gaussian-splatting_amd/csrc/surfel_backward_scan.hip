@@ -41,24 +41,6 @@ __device__ __forceinline__ float row_scan_mul(float x) {
                  : "+v"(x));
     return x;
 }
-// the same scan of TWO independent values, the two dependent chains interleaved (a lone wave pays ~13 cycles per DEPENDENT DPP
-// instruction against ~5.5 per independent one: profiles/r05_issue_probe.md finding 3): same bits as two row_scan_mul calls
-__device__ __forceinline__ void row_scan_mul2(float& x, float& y) {
-    asm(
-                 "s_nop 1\n\t"
-                 "v_mul_f32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
-                 "v_mul_f32_dpp %1, %1, %1 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
-                 "s_nop 0\n\t"
-                 "v_mul_f32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
-                 "v_mul_f32_dpp %1, %1, %1 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
-                 "s_nop 0\n\t"
-                 "v_mul_f32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
-                 "v_mul_f32_dpp %1, %1, %1 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
-                 "s_nop 0\n\t"
-                 "v_mul_f32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
-                 "v_mul_f32_dpp %1, %1, %1 row_shr:8 row_mask:0xf bank_mask:0xf"
-                 : "+v"(x), "+v"(y));
-}
 template <int N>
 __device__ __forceinline__ float row_shr_add(float x) {      // x + (x shifted right by N lanes inside each row, zero fill): one v_add_f32_dpp
     return x + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x110 + N, 0xf, 0xf, true));
@@ -120,9 +102,6 @@ constexpr int STATE_SCRATCH = 49;      // float4s: 16 steps x 16 B + 64 lanes x 
 // conflict on every read of every step: 16.2 M of the kernel's LDS conflict cycles per launch at C2 against 1.4 M for the rows walk
 // (profiles/r03gscan_C2_pmc.json).  One float4 of padding per row moves the rows 4 banks apart.
 constexpr int PIX_ROW = 16 * 3 + 1, STATE_ROW = 16 + 1;
-#ifndef SCAN_PAIR
-#define SCAN_PAIR 1      // 0: one pixel step at a time (round 5)
-#endif
 #ifndef SCAN_INCL
 #define SCAN_INCL 1      // 1: inclusive sum scan (4 DPP adds) and one subtraction instead of the exclusive one (mov + 4 adds)
 #endif
@@ -362,110 +341,87 @@ __global__ void __launch_bounds__(BLOCK, SCAN_MIN_WG) blend_bwd_scan_kernel(Blen
                 float g[18];
 #pragma unroll
                 for (int v = 0; v < 18; v++) g[v] = 0.f;
-#if SCAN_PAIR
-                if constexpr (!STATS) {
-                // [r6] two pixel steps at a time: both steps' intersections first, then ONE joint transmittance scan whose two dependent
-                // DPP chains are interleaved (row_scan_mul2), then the two gradient halves — the same operations on the same values as
-                // the step-by-step form below (kept under SCAN_PAIR = 0, and for the instrumented STATS instantiation: its atomics put
-                // branches into the walk, and with them the paired form counted 3 - 18 % more composited pairs than the forward after an
-                // unrelated change of the register allocation — tests/test_gpu_parity.py::test_forward_and_backward_composite_the_same_pairs;
-                // the product instantiation is checked against the step-by-step build bit for bit, scripts/lib_identity.py)
-                constexpr float MC1 = FAR_N / (FAR_N - NEAR_N), MC2 = (FAR_N * NEAR_N) / (FAR_N - NEAR_N);
-                struct Half { float4 Cq, S; Hit h; bool ok; float alpha, depth, i1a; };
-                float4 Sn0 = srd[0], Sn1 = srd[1];
 #if SCAN_AFFINE
                 float M1[3] = {0.f, 0.f, 0.f}, M2[3] = {0.f, 0.f, 0.f};      // sums of (pixel column offset) dp and (pixel row offset) dp; g[0..2] holds the sum of dp
 #endif
+                {
+                float4 Sn = srd[0];
+                constexpr float MC1 = FAR_N / (FAR_N - NEAR_N), MC2 = (FAR_N * NEAR_N) / (FAR_N - NEAR_N);
 #pragma unroll
                 for (int cb = 0; cb < 4; cb++) {
                 Hit hr;
                 const float pyf = sy0 + (float)cb;
                 pair_planes(sx0, pyf, q0, q1, q2, hr);        // l and dy of this pixel row
 #pragma unroll
-                for (int cp = 0; cp < 4; cp += 2) {
-                    Half H[2];
-                    H[0].S = Sn0; H[1].S = Sn1;
-                    Sn0 = srd[(4 * cb + cp + 2) & 15]; Sn1 = srd[(4 * cb + cp + 3) & 15];      // the next two pixels' states, read ahead of this pair's writes
-#pragma unroll
-                    for (int e = 0; e < 2; e++) {
-                        const int ca = cp + e, p = 4 * cb + ca;
-                        Half& X = H[e];
-                        X.Cq = prow[p * 3 + 2];
-                        X.h.kx = K[ca][0]; X.h.ky = K[ca][1]; X.h.kz = K[ca][2]; X.h.lx = hr.lx; X.h.ly = hr.ly; X.h.lz = hr.lz;
-                        X.h.dx = DX[ca]; X.h.dy = hr.dy;
-                        const bool hit = pair_intersect(Twx, Twy, Twz, opa, X.h);
-                        X.ok = hit & (pos <= __float_as_int(X.Cq.w));
-                        // a pair that was not composited runs the same instructions with alpha = 0 and depth = 1: T x 1, X + 0
-                        X.alpha = X.ok ? X.h.alpha : 0.f; X.depth = X.ok ? X.h.depth : 1.f;
-                        X.i1a = SURFEL_RCP(1.f - X.alpha);
-                    }
-                    float sc0 = H[0].i1a, sc1 = H[1].i1a;
-                    row_scan_mul2(sc0, sc1);
-#pragma unroll
-                    for (int e = 0; e < 2; e++) {
-                        const int ca = cp + e, p = 4 * cb + ca;
-                        const float pxf = sx0 + (float)ca;
-                        const Half& X = H[e];
-                        const Hit& h = X.h;
-                        const float4 A = prow[p * 3 + 0], B = prow[p * 3 + 1], Cq = X.Cq, S = X.S;
-                        const bool ok = X.ok;
-                        const float alpha = X.alpha, depth = X.depth, i1a = X.i1a;
-                        const float T = S.x * (e == 0 ? sc0 : sc1);                // transmittance in front of this lane's instance
-                        const float w = alpha * T;
-                        const float inv_d = SURFEL_RCP(depth);
-                        const float mm = FMA(-(MC1 * NEAR_N), inv_d, MC1);
-                        float u = FMA(mm, FMA(mm, Cq.x, Cq.y), Cq.z);
-                        u = FMA(q3.w, A.x, u); u = FMA(q4.x, A.y, u); u = FMA(q4.y, A.z, u);
-                        u = FMA(depth, A.w, u);
-                        u = FMA(q3.x, B.x, u); u = FMA(q3.y, B.y, u); u = FMA(q3.z, B.z, u);
-                        const float wu = w * u;
+                for (int ca = 0; ca < 4; ca++) {
+                    const int p = 4 * cb + ca;
+                    const float pxf = sx0 + (float)ca;
+                    const float4 A = prow[p * 3 + 0], B = prow[p * 3 + 1], Cq = prow[p * 3 + 2];
+                    const float4 S = Sn;
+                    Sn = srd[(p + 1) & 15];                   // next pixel's state: read ahead of this step's write (the compiler cannot tell them apart)
+                    Hit h;
+                    h.kx = K[ca][0]; h.ky = K[ca][1]; h.kz = K[ca][2]; h.lx = hr.lx; h.ly = hr.ly; h.lz = hr.lz;
+                    h.dx = DX[ca]; h.dy = hr.dy;
+                    const bool hit = pair_intersect(Twx, Twy, Twz, opa, h);
+                    const bool ok = hit & (pos <= __float_as_int(Cq.w));      // (bitwise: `&&` would put a branch into the walk)
+                    // a pair that was not composited runs the same instructions with alpha = 0 and depth = 1: T x 1, X + 0
+                    const float alpha = ok ? h.alpha : 0.f, depth = ok ? h.depth : 1.f;
+                    const float i1a = SURFEL_RCP(1.f - alpha);
+                    const float T = S.x * row_scan_mul(i1a);                  // transmittance in front of this lane's instance
+                    const float w = alpha * T;
+                    const float inv_d = SURFEL_RCP(depth);
+                    const float mm = FMA(-(MC1 * NEAR_N), inv_d, MC1);
+                    float u = FMA(mm, FMA(mm, Cq.x, Cq.y), Cq.z);
+                    u = FMA(q3.w, A.x, u); u = FMA(q4.x, A.y, u); u = FMA(q4.y, A.z, u);
+                    u = FMA(depth, A.w, u);
+                    u = FMA(q3.x, B.x, u); u = FMA(q3.y, B.y, u); u = FMA(q3.z, B.z, u);
+                    const float wu = w * u;
 #if SCAN_INCL
-                        const float Xn = S.y + row_scan_add_incl(wu);             // suffix sum from this lane's instance on
-                        const float Xb = Xn - wu;                                 // ... and behind it
-                        const float dL_dalpha = ok ? FMA(T, u, -(Xb * i1a)) : 0.f;
-                        swr[p * 2] = make_float2(T, Xn);
+                    const float Xn = S.y + row_scan_add_incl(wu);             // suffix sum from this lane's instance on
+                    const float Xb = Xn - wu;                                 // ... and behind it
+                    const float dL_dalpha = ok ? FMA(T, u, -(Xb * i1a)) : 0.f;
+                    swr[p * 2] = make_float2(T, Xn);
 #else
-                        const float Xb = S.y + row_scan_add_excl(wu);             // suffix sum behind this lane's instance
-                        const float dL_dalpha = ok ? FMA(T, u, -(Xb * i1a)) : 0.f;
-                        swr[p * 2] = make_float2(T, Xb + wu);
+                    const float Xb = S.y + row_scan_add_excl(wu);             // suffix sum behind this lane's instance
+                    const float dL_dalpha = ok ? FMA(T, u, -(Xb * i1a)) : 0.f;
+                    swr[p * 2] = make_float2(T, Xb + wu);
 #endif
-                        if (STATS) {
-                            const unsigned long long okb = __ballot(ok), vb = __ballot(valid);
-                            if (lane == 0) {
-                                atomicAdd(&a.stats[0], 64ull); atomicAdd(&a.stats[1], (unsigned long long)__popcll(okb));
-                                atomicAdd(&a.stats[2], 1ull);
-                                if (p == 0) atomicAdd(&a.stats[3], (unsigned long long)__popcll(vb));
-                            }
+                    if (STATS) {
+                        const unsigned long long okb = __ballot(ok), vb = __ballot(valid);
+                        if (lane == 0) {
+                            atomicAdd(&a.stats[0], 64ull); atomicAdd(&a.stats[1], (unsigned long long)__popcll(okb));
+                            atomicAdd(&a.stats[2], 1ull);
+                            if (p == 0) atomicAdd(&a.stats[3], (unsigned long long)__popcll(vb));
                         }
-                        float dL_dz = w * FMA(FMA(mm + mm, Cq.x, Cq.y), (MC2 * inv_d) * inv_d, A.w);
-                        dL_dz += (ok & (pos == __float_as_int(S.z))) ? B.w : 0.f;
-                        g[15] = FMA(w, A.x, g[15]); g[16] = FMA(w, A.y, g[16]); g[17] = FMA(w, A.z, g[17]);
-                        g[11] = FMA(w, B.x, g[11]); g[12] = FMA(w, B.y, g[12]); g[13] = FMA(w, B.z, g[13]);
-                        g[14] = FMA(h.G, dL_dalpha, g[14]);
-                        const float nGG = -h.G * (opa * dL_dalpha);               // dL/dG * dG/drho * 2; the 0.99 clamp is pass-through
-                        // low-pass branch: no gradient reaches the intersection; the selects zero (s, 1/p2) themselves (they may be inf)
-                        const float sxg = h.use3d ? h.sx : 0.f, syg = h.use3d ? h.sy : 0.f, ipg = h.use3d ? h.ip : 0.f;
-                        const float g2 = h.use3d ? 0.f : nGG * FILTER_INV_SQUARE;
-                        const float ax = FMA(nGG, sxg, dL_dz * Twx) * ipg, ay = FMA(nGG, syg, dL_dz * Twy) * ipg;
-                        const float dp2 = -FMA(ax, sxg, ay * syg);
-#if SCAN_AFFINE
-                        // dp = dL/dp = (ax, ay, dp2): its moments over the chunk's pixels (offsets inside the sub-tile: small integers)
-                        (void)pxf;
-                        g[0] += ax; g[1] += ay; g[2] += dp2;
-                        if (ca > 0) { M1[0] = FMA((float)ca, ax, M1[0]); M1[1] = FMA((float)ca, ay, M1[1]); M1[2] = FMA((float)ca, dp2, M1[2]); }
-                        if (cb > 0) { M2[0] = FMA((float)cb, ax, M2[0]); M2[1] = FMA((float)cb, ay, M2[1]); M2[2] = FMA((float)cb, dp2, M2[2]); }
-                        g[6] = FMA(dL_dz, sxg, g[6]); g[7] = FMA(dL_dz, syg, g[7]); g[8] += dL_dz;
-#else
-                        // -dk = dp x l ,  -dl = k x dp
-                        const float nk0 = FMA(ay, h.lz, -(dp2 * h.ly)), nk1 = FMA(dp2, h.lx, -(ax * h.lz)), nk2 = FMA(ax, h.ly, -(ay * h.lx));
-                        const float nl0 = FMA(h.ky, dp2, -(h.kz * ay)), nl1 = FMA(h.kz, ax, -(h.kx * dp2)), nl2 = FMA(h.kx, ay, -(h.ky * ax));
-                        g[0] += nk0; g[1] += nk1; g[2] += nk2; g[3] += nl0; g[4] += nl1; g[5] += nl2;
-                        g[6] = FMA(dL_dz, sxg, g[6]); g[6] = FMA(-pxf, nk0, g[6]); g[6] = FMA(-pyf, nl0, g[6]);
-                        g[7] = FMA(dL_dz, syg, g[7]); g[7] = FMA(-pxf, nk1, g[7]); g[7] = FMA(-pyf, nl1, g[7]);
-                        g[8] += dL_dz; g[8] = FMA(-pxf, nk2, g[8]); g[8] = FMA(-pyf, nl2, g[8]);
-#endif
-                        g[9] = FMA(g2, h.dx, g[9]); g[10] = FMA(g2, h.dy, g[10]);
                     }
+                    float dL_dz = w * FMA(FMA(mm + mm, Cq.x, Cq.y), (MC2 * inv_d) * inv_d, A.w);
+                    dL_dz += (ok & (pos == __float_as_int(S.z))) ? B.w : 0.f;
+                    g[15] = FMA(w, A.x, g[15]); g[16] = FMA(w, A.y, g[16]); g[17] = FMA(w, A.z, g[17]);
+                    g[11] = FMA(w, B.x, g[11]); g[12] = FMA(w, B.y, g[12]); g[13] = FMA(w, B.z, g[13]);
+                    g[14] = FMA(h.G, dL_dalpha, g[14]);
+                    const float nGG = -h.G * (opa * dL_dalpha);               // dL/dG * dG/drho * 2; the 0.99 clamp is pass-through
+                    // low-pass branch: no gradient reaches the intersection; the selects zero (s, 1/p2) themselves (they may be inf)
+                    const float sxg = h.use3d ? h.sx : 0.f, syg = h.use3d ? h.sy : 0.f, ipg = h.use3d ? h.ip : 0.f;
+                    const float g2 = h.use3d ? 0.f : nGG * FILTER_INV_SQUARE;
+                    const float ax = FMA(nGG, sxg, dL_dz * Twx) * ipg, ay = FMA(nGG, syg, dL_dz * Twy) * ipg;
+                    const float dp2 = -FMA(ax, sxg, ay * syg);
+#if SCAN_AFFINE
+                    (void)pxf;
+                    g[0] += ax; g[1] += ay; g[2] += dp2;
+                    if (ca > 0) { M1[0] = FMA((float)ca, ax, M1[0]); M1[1] = FMA((float)ca, ay, M1[1]); M1[2] = FMA((float)ca, dp2, M1[2]); }
+                    if (cb > 0) { M2[0] = FMA((float)cb, ax, M2[0]); M2[1] = FMA((float)cb, ay, M2[1]); M2[2] = FMA((float)cb, dp2, M2[2]); }
+                    g[6] = FMA(dL_dz, sxg, g[6]); g[7] = FMA(dL_dz, syg, g[7]); g[8] += dL_dz;
+#else
+                    // -dk = dp x l ,  -dl = k x dp
+                    const float nk0 = FMA(ay, h.lz, -(dp2 * h.ly)), nk1 = FMA(dp2, h.lx, -(ax * h.lz)), nk2 = FMA(ax, h.ly, -(ay * h.lx));
+                    const float nl0 = FMA(h.ky, dp2, -(h.kz * ay)), nl1 = FMA(h.kz, ax, -(h.kx * dp2)), nl2 = FMA(h.kx, ay, -(h.ky * ax));
+                    g[0] += nk0; g[1] += nk1; g[2] += nk2; g[3] += nl0; g[4] += nl1; g[5] += nl2;
+                    g[6] = FMA(dL_dz, sxg, g[6]); g[6] = FMA(-pxf, nk0, g[6]); g[6] = FMA(-pyf, nl0, g[6]);
+                    g[7] = FMA(dL_dz, syg, g[7]); g[7] = FMA(-pxf, nk1, g[7]); g[7] = FMA(-pyf, nl1, g[7]);
+                    g[8] += dL_dz; g[8] = FMA(-pxf, nk2, g[8]); g[8] = FMA(-pyf, nl2, g[8]);
+#endif
+                    g[9] = FMA(g2, h.dx, g[9]); g[10] = FMA(g2, h.dy, g[10]);
+                }
                 }
                 }
 #if SCAN_AFFINE
@@ -506,73 +462,6 @@ __global__ void __launch_bounds__(BLOCK, SCAN_MIN_WG) blend_bwd_scan_kernel(Blen
                     g[0] = u0; g[1] = u1; g[2] = u2; g[3] = v0; g[4] = v1; g[5] = v2; g[6] = w0; g[7] = w1; g[8] = w2;
                 }
 #endif
-                } else
-#endif
-                {
-                float4 Sn = srd[0];
-                constexpr float MC1 = FAR_N / (FAR_N - NEAR_N), MC2 = (FAR_N * NEAR_N) / (FAR_N - NEAR_N);
-#pragma unroll
-                for (int cb = 0; cb < 4; cb++) {
-                Hit hr;
-                const float pyf = sy0 + (float)cb;
-                pair_planes(sx0, pyf, q0, q1, q2, hr);        // l and dy of this pixel row
-#pragma unroll
-                for (int ca = 0; ca < 4; ca++) {
-                    const int p = 4 * cb + ca;
-                    const float pxf = sx0 + (float)ca;
-                    const float4 A = prow[p * 3 + 0], B = prow[p * 3 + 1], Cq = prow[p * 3 + 2];
-                    const float4 S = Sn;
-                    Sn = srd[(p + 1) & 15];                   // next pixel's state: read ahead of this step's write (the compiler cannot tell them apart)
-                    Hit h;
-                    h.kx = K[ca][0]; h.ky = K[ca][1]; h.kz = K[ca][2]; h.lx = hr.lx; h.ly = hr.ly; h.lz = hr.lz;
-                    h.dx = DX[ca]; h.dy = hr.dy;
-                    const bool hit = pair_intersect(Twx, Twy, Twz, opa, h);
-                    const bool ok = hit && (pos <= __float_as_int(Cq.w));
-                    // a pair that was not composited runs the same instructions with alpha = 0 and depth = 1: T x 1, X + 0
-                    const float alpha = ok ? h.alpha : 0.f, depth = ok ? h.depth : 1.f;
-                    const float i1a = SURFEL_RCP(1.f - alpha);
-                    const float T = S.x * row_scan_mul(i1a);                  // transmittance in front of this lane's instance
-                    const float w = alpha * T;
-                    const float inv_d = SURFEL_RCP(depth);
-                    const float mm = FMA(-(MC1 * NEAR_N), inv_d, MC1);
-                    float u = FMA(mm, FMA(mm, Cq.x, Cq.y), Cq.z);
-                    u = FMA(q3.w, A.x, u); u = FMA(q4.x, A.y, u); u = FMA(q4.y, A.z, u);
-                    u = FMA(depth, A.w, u);
-                    u = FMA(q3.x, B.x, u); u = FMA(q3.y, B.y, u); u = FMA(q3.z, B.z, u);
-                    const float wu = w * u;
-                    const float Xb = S.y + row_scan_add_excl(wu);             // suffix sum behind this lane's instance
-                    const float dL_dalpha = ok ? FMA(T, u, -(Xb * i1a)) : 0.f;
-                    swr[p * 2] = make_float2(T, Xb + wu);
-                    if (STATS) {
-                        const unsigned long long okb = __ballot(ok), vb = __ballot(valid);
-                        if (lane == 0) {
-                            atomicAdd(&a.stats[0], 64ull); atomicAdd(&a.stats[1], (unsigned long long)__popcll(okb));
-                            atomicAdd(&a.stats[2], 1ull);
-                            if (p == 0) atomicAdd(&a.stats[3], (unsigned long long)__popcll(vb));
-                        }
-                    }
-                    float dL_dz = w * FMA(FMA(mm + mm, Cq.x, Cq.y), (MC2 * inv_d) * inv_d, A.w);
-                    dL_dz += (ok & (pos == __float_as_int(S.z))) ? B.w : 0.f;
-                    g[15] = FMA(w, A.x, g[15]); g[16] = FMA(w, A.y, g[16]); g[17] = FMA(w, A.z, g[17]);
-                    g[11] = FMA(w, B.x, g[11]); g[12] = FMA(w, B.y, g[12]); g[13] = FMA(w, B.z, g[13]);
-                    g[14] = FMA(h.G, dL_dalpha, g[14]);
-                    const float nGG = -h.G * (opa * dL_dalpha);               // dL/dG * dG/drho * 2; the 0.99 clamp is pass-through
-                    // low-pass branch: no gradient reaches the intersection; the selects zero (s, 1/p2) themselves (they may be inf)
-                    const float sxg = h.use3d ? h.sx : 0.f, syg = h.use3d ? h.sy : 0.f, ipg = h.use3d ? h.ip : 0.f;
-                    const float g2 = h.use3d ? 0.f : nGG * FILTER_INV_SQUARE;
-                    const float ax = FMA(nGG, sxg, dL_dz * Twx) * ipg, ay = FMA(nGG, syg, dL_dz * Twy) * ipg;
-                    const float dp2 = -FMA(ax, sxg, ay * syg);
-                    // -dk = dp x l ,  -dl = k x dp
-                    const float nk0 = FMA(ay, h.lz, -(dp2 * h.ly)), nk1 = FMA(dp2, h.lx, -(ax * h.lz)), nk2 = FMA(ax, h.ly, -(ay * h.lx));
-                    const float nl0 = FMA(h.ky, dp2, -(h.kz * ay)), nl1 = FMA(h.kz, ax, -(h.kx * dp2)), nl2 = FMA(h.kx, ay, -(h.ky * ax));
-                    g[0] += nk0; g[1] += nk1; g[2] += nk2; g[3] += nl0; g[4] += nl1; g[5] += nl2;
-                    g[6] = FMA(dL_dz, sxg, g[6]); g[6] = FMA(-pxf, nk0, g[6]); g[6] = FMA(-pyf, nl0, g[6]);
-                    g[7] = FMA(dL_dz, syg, g[7]); g[7] = FMA(-pxf, nk1, g[7]); g[7] = FMA(-pyf, nl1, g[7]);
-                    g[8] += dL_dz; g[8] = FMA(-pxf, nk2, g[8]); g[8] = FMA(-pyf, nl2, g[8]);
-                    g[9] = FMA(g2, h.dx, g[9]); g[10] = FMA(g2, h.dy, g[10]);
-                }
-                }
-                }
                 s_slot[tid * 5 + 0] = make_float4(g[0], g[1], g[2], g[3]);
                 s_slot[tid * 5 + 1] = make_float4(g[4], g[5], g[6], g[7]);
                 s_slot[tid * 5 + 2] = make_float4(g[8], g[9], g[10], g[11]);
