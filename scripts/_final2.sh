@@ -1,5 +1,6 @@
 cd /root/repo
 mkdir -p gpurun_out/final
-python scripts/lib_identity.py pairfinal - scan auto > gpurun_out/final/identity_nopair.txt 2>&1; tail -1 gpurun_out/final/identity_nopair.txt | cut -c1-300
-timeout 900 python -m pytest tests/test_gpu_parity.py -q -m gpu -k "scan or composite or dtu or trained or config_sizes" > gpurun_out/final/pytest_nopair.txt 2>&1; tail -2 gpurun_out/final/pytest_nopair.txt
-python scripts/ab_libs.py "garden,C4,trained" 3 pair=pairfinal step=- > gpurun_out/final/ab_nopair.jsonl 2> gpurun_out/final/ab_nopair.err; cut -c1-230 gpurun_out/final/ab_nopair.jsonl
+python bench.py > gpurun_out/final/bench_n1.json 2> gpurun_out/final/bench_n1.err; tail -c 300 gpurun_out/final/bench_n1.json
+bash scripts/profile_round.sh r06 "garden:3:full C2:0:short C4:3:short trained:3:short" > gpurun_out/final/profile_round.log 2>&1; tail -3 gpurun_out/final/profile_round.log
+timeout 1700 python -m pytest tests -q -m gpu > gpurun_out/final/gpu_tests.txt 2>&1; grep -n "passed\|failed" gpurun_out/final/gpu_tests.txt | tail -2
+python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > gpurun_out/final/smoke.txt 2>&1; tail -1 gpurun_out/final/smoke.txt
